@@ -1,0 +1,133 @@
+"""ctypes binding of libglorie_hip.so (the C ABI declared in include/glorie_hip.h).
+
+The product path has no CPU fallback: if the HIP library is missing or a call fails the
+caller gets an exception.  Only plumbing lives here -- device pointers come from
+``tensor.data_ptr()`` and the stream from ``torch.cuda.current_stream()``.
+"""
+import ctypes
+import os
+import threading
+
+import torch
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "lib", "libglorie_hip.so")
+
+GLORIE_F16, GLORIE_F32 = 0, 1
+_STATUS = {0: "GLORIE_OK", -1: "GLORIE_EINVAL", -2: "GLORIE_EHIP", -3: "GLORIE_ENOMEM",
+           -4: "GLORIE_EUNSUPPORTED"}
+
+_c_int, _c_f, _vp, _sz = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/glorie_hip.h one to one
+SIGNATURES = {
+    "glorie_version": (ctypes.c_char_p, []),
+    "glorie_last_hip_error": (_c_int, []),
+    "glorie_ctx_create": (_c_int, [ctypes.POINTER(_vp), _sz]),
+    "glorie_ctx_destroy": (_c_int, [_vp]),
+    "glorie_corr_index_fwd": (_c_int, [_vp, _vp, _vp] + [_c_int] * 7 + [_vp]),
+    "glorie_corr_lookup_pyramid": (_c_int, [_vp, _c_int, _vp, _vp] + [_c_int] * 7 + [_vp]),
+    "glorie_altcorr_fwd": (_c_int, [_vp] * 4 + [_c_int] * 8 + [_vp]),
+    "glorie_reproject": (_c_int, [_vp] * 7 + [_c_int] * 3 + [_vp]),
+    "glorie_frame_distance": (_c_int, [_vp] * 6 + [_c_int] * 3 + [_c_f, _vp]),
+    "glorie_iproj": (_c_int, [_vp] * 4 + [_c_int] * 3 + [_vp]),
+    "glorie_depth_filter": (_c_int, [_vp] * 6 + [_c_int] * 4 + [_vp]),
+    "glorie_cvx_upsample": (_c_int, [_vp] * 4 + [_c_int] * 5 + [_vp]),
+    "glorie_ba": (_c_int, [_vp] * 10 + [_c_int] * 8 + [_c_f, _c_f, _c_int, _c_int, _vp, _vp, _vp]),
+    "glorie_ba_status": (_c_int, [_vp, ctypes.POINTER(_c_int), _vp]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class GlorieError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the library (once).  Raises if it has not been built -- never falls back."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise GlorieError(
+                    f"{LIB_PATH} is missing: build it with `python glorie-slam_amd/build.py` "
+                    "(or __graft_entry__.build()); there is no CPU fallback for the hot path")
+            lib = ctypes.CDLL(LIB_PATH)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(lib, name)
+                fn.restype = res
+                fn.argtypes = args
+            _lib = lib
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        lib = load()
+        raise GlorieError(f"{what} failed: {_STATUS.get(status, status)} "
+                          f"(hipError {lib.glorie_last_hip_error()})")
+
+
+def stream_ptr(device=None):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def need_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise GlorieError("glorie_hip kernels take device tensors; got a CPU tensor "
+                              "(there is no CPU fallback on the product path)")
+
+
+def need_contiguous(**named):
+    # same contract as CHECK_CONTIGUOUS in the reference binding (src/lib/droid.cpp:85-86)
+    for k, t in named.items():
+        if t is not None and not t.is_contiguous():
+            raise RuntimeError(f"{k} must be contiguous")
+
+
+def dtype_code(t):
+    if t.dtype == torch.float16:
+        return GLORIE_F16
+    if t.dtype == torch.float32:
+        return GLORIE_F32
+    raise GlorieError(f"unsupported dtype {t.dtype}")
+
+
+class Context:
+    """Per-process/GPU scratch arena (glorie_ctx)."""
+
+    def __init__(self, scratch_bytes=64 << 20):
+        lib = load()
+        h = ctypes.c_void_p()
+        check(lib.glorie_ctx_create(ctypes.byref(h), scratch_bytes), "glorie_ctx_create")
+        self.handle = h
+
+    def ba_status(self):
+        out = (ctypes.c_int * 4)()
+        check(load().glorie_ba_status(self.handle, out, stream_ptr()), "glorie_ba_status")
+        return list(out)
+
+    def __del__(self):
+        try:
+            if self.handle and _lib is not None:
+                _lib.glorie_ctx_destroy(self.handle)
+        except Exception:
+            pass
+        self.handle = None
+
+
+_default_ctx = {}
+
+
+def default_context():
+    dev = torch.cuda.current_device()
+    if dev not in _default_ctx:
+        _default_ctx[dev] = Context()
+    return _default_ctx[dev]

@@ -1,0 +1,235 @@
+// Correlation-volume lookup for gfx950 (rows A2 of the scope table).
+//
+// Replaces droid_backends.corr_index_forward
+//   (/root/reference/src/lib/correlation_kernels.cu:19-70,126-155) and the 4-level loop +
+//   torch.cat of CorrBlock.__call__ (/root/reference/src/modules/droid_net/corr.py:43-53).
+//
+// Work decomposition (wave64 native, not a 16x16 CUDA block):
+//   one pixel of the source frame is served by 8 consecutive lanes; lane `row` (0..7) owns
+//   window row y1 = floor(y0)-r+row and fetches its 8 contiguous x-samples with ONE
+//   unaligned 16-byte load (global_load_dwordx4 on a 2-byte aligned address).  A wave thus
+//   serves 8 pixels and issues one wide load per level instead of 64 scalar loads per pixel.
+//   Row `row+1` is pulled from the neighbouring lane with DPP-style shuffles, after which
+//   lane `row` (<7) produces the 7 outputs (i, j=row), i=0..6, entirely in registers and
+//   stores them once -- no zero-fill pass and no read-modify-write of the output as in the
+//   reference (4 RMW per output there).
+//
+// Numerics: for fp16 the reference's rounding sequence is reproduced exactly:
+//   out = ((((+0 + h(s00*w00)) + h(s01*w01)) + h(s10*w10)) + h(s11*w11)), every product and
+//   every sum rounded to fp16 (c10::Half operators), w** = h(float weight).  Out-of-bounds
+//   samples are skipped in the reference; adding +0 instead is bit-identical because the
+//   accumulator can never be -0.  fp contraction is disabled in that block.
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include "../../include/glorie_hip.h"
+#include "common.hiph"
+
+namespace glorie {
+
+constexpr int kMaxLevels = 4;
+
+struct CorrLevels {
+  const void* vol[kMaxLevels];
+  int h2[kMaxLevels];
+  int w2[kMaxLevels];
+};
+
+template <typename T> struct Row8;
+template <> struct __attribute__((packed, aligned(2))) Row8<_Float16> { _Float16 v[8]; };
+template <> struct __attribute__((packed, aligned(4))) Row8<float> { float v[8]; };
+
+// bilinear blend of the 2x2 neighbourhood in the reference's accumulation order
+__device__ __forceinline__ _Float16 blend4(_Float16 s00, _Float16 s01, _Float16 s10, _Float16 s11,
+                                           _Float16 w00, _Float16 w01, _Float16 w10, _Float16 w11) {
+#pragma clang fp contract(off)
+  _Float16 acc = (_Float16)0.0f;
+  _Float16 t;
+  t = s00 * w00; acc = acc + t;
+  t = s01 * w01; acc = acc + t;
+  t = s10 * w10; acc = acc + t;
+  t = s11 * w11; acc = acc + t;
+  return acc;
+}
+// fp32: nvcc contracts `corr += s * w` into an FMA chain in the reference build
+__device__ __forceinline__ float blend4(float s00, float s01, float s10, float s11,
+                                        float w00, float w01, float w10, float w11) {
+  float acc = 0.0f;
+  acc = fmaf(s00, w00, acc);
+  acc = fmaf(s01, w01, acc);
+  acc = fmaf(s10, w10, acc);
+  acc = fmaf(s11, w11, acc);
+  return acc;
+}
+
+__device__ __forceinline__ _Float16 shfl_next(_Float16 v) {
+  // move one fp16 from lane+1; done on the 32-bit container
+  int x = (int)__builtin_bit_cast(unsigned short, v);
+  x = __shfl_down(x, 1, 64);
+  return __builtin_bit_cast(_Float16, (unsigned short)x);
+}
+__device__ __forceinline__ float shfl_next(float v) { return __shfl_down(v, 1, 64); }
+
+// 256 threads = 32 pixels x 8 window rows.  grid = (ceil(HW/32), N)
+template <typename T>
+__global__ __launch_bounds__(256) void corr_lookup_r3_kernel(
+    CorrLevels lv, int num_levels, int scale_coords,
+    const float* __restrict__ coords, T* __restrict__ out,
+    int HW, int out_channels) {
+  constexpr int R = 3, RD = 7, WIN = 8;
+  const int tid = threadIdx.x;
+  const int row = tid & 7;
+  const int p = blockIdx.x * 32 + (tid >> 3);
+  const int n = blockIdx.y;
+  const bool live = p < HW;
+  const int pc = live ? p : HW - 1;
+
+  const float x0 = coords[((size_t)n * 2 + 0) * HW + pc];
+  const float y0 = coords[((size_t)n * 2 + 1) * HW + pc];
+
+  float inv = 1.0f;
+  for (int l = 0; l < num_levels; ++l) {
+    const int h2 = lv.h2[l], w2 = lv.w2[l];
+    const float xs = scale_coords ? x0 * inv : x0;
+    const float ys = scale_coords ? y0 * inv : y0;
+    inv *= 0.5f;
+    const float fx = floorf(xs), fy = floorf(ys);
+    const float dx = xs - fx, dy = ys - fy;
+    const int ix0 = static_cast<int>(fx) - R;
+    const int y1 = static_cast<int>(fy) - R + row;
+
+    T s[WIN];
+#pragma unroll
+    for (int i = 0; i < WIN; ++i) s[i] = (T)0.0f;
+    if (y1 >= 0 && y1 < h2) {
+      const T* rowp = reinterpret_cast<const T*>(lv.vol[l]) +
+                      ((size_t)n * HW + pc) * ((size_t)h2 * w2) + (size_t)y1 * w2;
+      if (ix0 >= 0 && ix0 + WIN <= w2) {
+        Row8<T> r;
+        __builtin_memcpy(&r, rowp + ix0, sizeof(r));
+#pragma unroll
+        for (int i = 0; i < WIN; ++i) s[i] = r.v[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < WIN; ++i) {
+          const int x1 = ix0 + i;
+          if (x1 >= 0 && x1 < w2) s[i] = rowp[x1];
+        }
+      }
+    }
+    // window row j+1 lives in the next lane (same pixel for row < 7)
+    T nx[WIN];
+#pragma unroll
+    for (int i = 0; i < WIN; ++i) nx[i] = shfl_next(s[i]);
+
+    const T w00 = (T)((1.0f - dx) * (1.0f - dy));
+    const T w01 = (T)((1.0f - dx) * dy);
+    const T w10 = (T)(dx * (1.0f - dy));
+    const T w11 = (T)(dx * dy);
+
+    if (live && row < RD) {
+      T* o = out + ((size_t)n * out_channels + (size_t)l * RD * RD + row) * HW + p;
+#pragma unroll
+      for (int i = 0; i < RD; ++i) {
+        const T v = blend4(s[i], nx[i], s[i + 1], nx[i + 1], w00, w01, w10, w11);
+        o[(size_t)i * RD * HW] = v;
+      }
+    }
+  }
+}
+
+// generic-radius fallback: one thread per pixel, same arithmetic order.
+template <typename T>
+__global__ __launch_bounds__(256) void corr_lookup_generic_kernel(
+    CorrLevels lv, int num_levels, int scale_coords, int radius,
+    const float* __restrict__ coords, T* __restrict__ out, int HW, int out_channels) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = blockIdx.y;
+  if (p >= HW) return;
+  const int rd = 2 * radius + 1;
+  const float x0 = coords[((size_t)n * 2 + 0) * HW + p];
+  const float y0 = coords[((size_t)n * 2 + 1) * HW + p];
+  float inv = 1.0f;
+  for (int l = 0; l < num_levels; ++l) {
+    const int h2 = lv.h2[l], w2 = lv.w2[l];
+    const float xs = scale_coords ? x0 * inv : x0;
+    const float ys = scale_coords ? y0 * inv : y0;
+    inv *= 0.5f;
+    const float fx = floorf(xs), fy = floorf(ys);
+    const float dx = xs - fx, dy = ys - fy;
+    const int ix0 = static_cast<int>(fx) - radius;
+    const int iy0 = static_cast<int>(fy) - radius;
+    const T* plane = reinterpret_cast<const T*>(lv.vol[l]) + ((size_t)n * HW + p) * ((size_t)h2 * w2);
+    const T w00 = (T)((1.0f - dx) * (1.0f - dy));
+    const T w01 = (T)((1.0f - dx) * dy);
+    const T w10 = (T)(dx * (1.0f - dy));
+    const T w11 = (T)(dx * dy);
+    auto fetch = [&](int i, int j) -> T {
+      const int x1 = ix0 + i, y1 = iy0 + j;
+      return (x1 >= 0 && x1 < w2 && y1 >= 0 && y1 < h2) ? plane[(size_t)y1 * w2 + x1] : (T)0.0f;
+    };
+    for (int i = 0; i < rd; ++i)
+      for (int j = 0; j < rd; ++j) {
+        const T v = blend4(fetch(i, j), fetch(i, j + 1), fetch(i + 1, j), fetch(i + 1, j + 1),
+                           w00, w01, w10, w11);
+        out[((size_t)n * out_channels + (size_t)l * rd * rd + (size_t)i * rd + j) * HW + p] = v;
+      }
+  }
+}
+
+template <typename T>
+static int launch_lookup(const CorrLevels& lv, int L, int scale, const float* coords, void* out,
+                         int N, int HW, int radius, hipStream_t st) {
+  if (N == 0 || HW == 0) return GLORIE_OK;
+  const int chans = L * (2 * radius + 1) * (2 * radius + 1);
+  if (radius == 3) {
+    dim3 grid((HW + 31) / 32, N);
+    hipLaunchKernelGGL(corr_lookup_r3_kernel<T>, grid, dim3(256), 0, st, lv, L, scale, coords,
+                       reinterpret_cast<T*>(out), HW, chans);
+  } else {
+    dim3 grid((HW + 255) / 256, N);
+    hipLaunchKernelGGL(corr_lookup_generic_kernel<T>, grid, dim3(256), 0, st, lv, L, scale, radius,
+                       coords, reinterpret_cast<T*>(out), HW, chans);
+  }
+  return check_launch();
+}
+
+}  // namespace glorie
+
+using namespace glorie;
+
+extern "C" int glorie_corr_index_fwd(const void* volume, const float* coords, void* out, int N,
+                                     int h1, int w1, int h2, int w2, int radius, int dtype,
+                                     void* stream) {
+  if (N < 0 || h1 < 0 || w1 < 0 || h2 < 0 || w2 < 0 || radius < 0) return GLORIE_EINVAL;
+  if (N == 0 || h1 * w1 == 0) return GLORIE_OK;
+  if (!volume || !coords || !out) return GLORIE_EINVAL;
+  CorrLevels lv{};
+  lv.vol[0] = volume; lv.h2[0] = h2; lv.w2[0] = w2;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == GLORIE_F16) return launch_lookup<_Float16>(lv, 1, 0, coords, out, N, h1 * w1, radius, st);
+  if (dtype == GLORIE_F32) return launch_lookup<float>(lv, 1, 0, coords, out, N, h1 * w1, radius, st);
+  return GLORIE_EUNSUPPORTED;
+}
+
+extern "C" int glorie_corr_lookup_pyramid(const void* const* volumes, int num_levels,
+                                          const float* coords, void* out, int N, int h1, int w1,
+                                          int h2, int w2, int radius, int dtype, void* stream) {
+  if (num_levels < 1 || num_levels > kMaxLevels || N < 0 || h1 < 0 || w1 < 0 || radius < 0)
+    return GLORIE_EINVAL;
+  if (N == 0 || h1 * w1 == 0) return GLORIE_OK;
+  if (!volumes || !coords || !out) return GLORIE_EINVAL;
+  CorrLevels lv{};
+  for (int l = 0; l < num_levels; ++l) {
+    if (!volumes[l]) return GLORIE_EINVAL;
+    lv.vol[l] = volumes[l];
+    lv.h2[l] = h2 >> l;   // matches h2 // 2**l of corr.py:38
+    lv.w2[l] = w2 >> l;
+  }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == GLORIE_F16)
+    return launch_lookup<_Float16>(lv, num_levels, 1, coords, out, N, h1 * w1, radius, st);
+  if (dtype == GLORIE_F32)
+    return launch_lookup<float>(lv, num_levels, 1, coords, out, N, h1 * w1, radius, st);
+  return GLORIE_EUNSUPPORTED;
+}

@@ -1,0 +1,71 @@
+// Context, scratch arena and library identification for libglorie_hip.so
+#include <hip/hip_runtime.h>
+#include <new>
+#include "common.hiph"
+
+namespace glorie {
+
+int& last_hip_error() {
+  static thread_local int e = 0;
+  return e;
+}
+
+int ctx_reserve(Ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->scratch_bytes) return GLORIE_OK;
+  // growing re-allocates: only legal outside of stream capture (callers size the arena
+  // at context creation for captured loops).
+  size_t want = ctx->scratch_bytes ? ctx->scratch_bytes : (size_t)1 << 20;
+  while (want < bytes) want *= 2;
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, want);
+  if (e != hipSuccess) {
+    last_hip_error() = (int)e;
+    return GLORIE_ENOMEM;
+  }
+  if (ctx->scratch) {
+    // outstanding kernels may still use the old arena
+    (void)hipDeviceSynchronize();
+    (void)hipFree(ctx->scratch);
+  }
+  ctx->scratch = p;
+  ctx->scratch_bytes = want;
+  return GLORIE_OK;
+}
+
+}  // namespace glorie
+
+extern "C" const char* glorie_version(void) { return "glorie_hip 0.1.0 gfx950"; }
+
+extern "C" int glorie_last_hip_error(void) { return glorie::last_hip_error(); }
+
+extern "C" int glorie_ctx_create(glorie_ctx** out, size_t scratch_bytes) {
+  if (!out) return GLORIE_EINVAL;
+  glorie_ctx* c = new (std::nothrow) glorie_ctx();
+  if (!c) return GLORIE_ENOMEM;
+  if (glorie::check_hip(hipGetDevice(&c->device)) != GLORIE_OK) {
+    delete c;
+    return GLORIE_EHIP;
+  }
+  if (glorie::check_hip(hipMalloc(reinterpret_cast<void**>(&c->dstatus), 4 * sizeof(int))) != GLORIE_OK ||
+      glorie::check_hip(hipMemset(c->dstatus, 0, 4 * sizeof(int))) != GLORIE_OK) {
+    delete c;
+    return GLORIE_EHIP;
+  }
+  if (scratch_bytes) {
+    int s = glorie::ctx_reserve(c, scratch_bytes);
+    if (s != GLORIE_OK) {
+      delete c;
+      return s;
+    }
+  }
+  *out = c;
+  return GLORIE_OK;
+}
+
+extern "C" int glorie_ctx_destroy(glorie_ctx* ctx) {
+  if (!ctx) return GLORIE_EINVAL;
+  if (ctx->scratch) (void)hipFree(ctx->scratch);
+  if (ctx->dstatus) (void)hipFree(ctx->dstatus);
+  delete ctx;
+  return GLORIE_OK;
+}

@@ -1,0 +1,206 @@
+"""Drop-in for the reference's pybind11 extension ``droid_backends``
+(/root/reference/src/lib/droid.cpp:239-252) on top of the C ABI of libglorie_hip.so.
+
+Same function names, argument order, return shapes and error behaviour (non-contiguous
+input -> RuntimeError, like CHECK_CONTIGUOUS at droid.cpp:85-86).  ``ba`` mutates ``poses``
+and ``disps`` in place exactly like ``ba_cuda``.  The backward ops and ``projmap`` are not on
+the inference hot path and raise NotImplementedError.
+
+Extra entry points (fused forms the reference builds out of several torch ops):
+``corr_lookup_pyramid``, ``reproject``, ``cvx_upsample``.
+"""
+import ctypes
+
+import torch
+
+from . import _lib as L
+
+
+def _i64(t, name):
+    if t.dtype != torch.int64:
+        raise RuntimeError(f"{name} must be int64 (the reference kernels read `long`)")
+    return t
+
+
+# --------------------------------------------------------------------------------------
+# correlation
+# --------------------------------------------------------------------------------------
+def corr_index_forward(volume, coords, radius):
+    """volume [N,h1,w1,h2,w2] (f16|f32), coords [N,2,h1,w1] f32 -> [corr [N,2r+1,2r+1,h1,w1]]
+    reference: droid.cpp:172-180, correlation_kernels.cu:126-155"""
+    L.need_cuda(volume, coords)
+    L.need_contiguous(volume=volume, coords=coords)
+    if coords.dtype != torch.float32:
+        raise RuntimeError("coords must be float32")
+    N, h1, w1, h2, w2 = volume.shape
+    rd = 2 * radius + 1
+    out = torch.empty((N, rd, rd, h1, w1), dtype=volume.dtype, device=volume.device)
+    lib = L.load()
+    L.check(lib.glorie_corr_index_fwd(L.ptr(volume), L.ptr(coords), L.ptr(out), N, h1, w1, h2, w2,
+                                      radius, L.dtype_code(volume), L.stream_ptr()),
+            "glorie_corr_index_fwd")
+    return [out]
+
+
+def corr_lookup_pyramid(pyramid, coords, radius):
+    """Fused CorrBlock.__call__ body (corr.py:43-53): pyramid = list of level tensors
+    [N,h1,w1,h2>>l,w2>>l]; coords [N,2,h1,w1] f32 UNscaled -> [N, L*(2r+1)^2, h1, w1]."""
+    L.need_cuda(coords, *pyramid)
+    L.need_contiguous(coords=coords, **{f"level{i}": v for i, v in enumerate(pyramid)})
+    N, h1, w1, h2, w2 = pyramid[0].shape
+    nl = len(pyramid)
+    for l, v in enumerate(pyramid):
+        if tuple(v.shape) != (N, h1, w1, h2 >> l, w2 >> l) or v.dtype != pyramid[0].dtype:
+            raise RuntimeError(f"pyramid level {l} has shape {tuple(v.shape)}")
+    rd = 2 * radius + 1
+    out = torch.empty((N, nl * rd * rd, h1, w1), dtype=pyramid[0].dtype, device=coords.device)
+    arr = (ctypes.c_void_p * nl)(*[v.data_ptr() for v in pyramid])
+    lib = L.load()
+    L.check(lib.glorie_corr_lookup_pyramid(ctypes.cast(arr, ctypes.c_void_p), nl, L.ptr(coords),
+                                           L.ptr(out), N, h1, w1, h2, w2, radius,
+                                           L.dtype_code(pyramid[0]), L.stream_ptr()),
+            "glorie_corr_lookup_pyramid")
+    return out
+
+
+def corr_index_backward(volume, coords, corr_grad, radius):
+    raise NotImplementedError("corr_index_backward: training-only; the SLAM hot path runs under "
+                              "no_grad (factor_graph.py:213)")
+
+
+def altcorr_forward(fmap1, fmap2, coords, radius):
+    """fmap1 [B,H,W,C], fmap2 [B,H2,W2,C], coords [B,S,H,W,2] -> [corr [B,S,(2r+1)^2,H,W]] (f32)
+    reference: droid.cpp:195-205, altcorr_kernel.cu:290-319"""
+    L.need_cuda(fmap1, fmap2, coords)
+    L.need_contiguous(fmap1=fmap1, fmap2=fmap2, coords=coords)
+    if fmap1.dtype != torch.float32 or fmap2.dtype != torch.float32:
+        raise RuntimeError("altcorr_forward takes float32 feature maps (corr.py:125 casts)")
+    B, H, W, C = fmap1.shape
+    _, H2, W2, _ = fmap2.shape
+    S = coords.shape[1]
+    rd = 2 * radius + 1
+    out = torch.empty((B, S, rd * rd, H, W), dtype=torch.float32, device=fmap1.device)
+    lib = L.load()
+    L.check(lib.glorie_altcorr_fwd(L.ptr(fmap1), L.ptr(fmap2), L.ptr(coords), L.ptr(out), B, S, H,
+                                   W, H2, W2, C, radius, L.stream_ptr()), "glorie_altcorr_fwd")
+    return [out]
+
+
+def altcorr_backward(*args):
+    raise NotImplementedError("altcorr_backward: training-only, not on the SLAM hot path")
+
+
+# --------------------------------------------------------------------------------------
+# geometry
+# --------------------------------------------------------------------------------------
+def frame_distance(poses, disps, intrinsics, ii, jj, beta):
+    """reference: droid.cpp:122-138, droid_kernels.cu:1441-1463"""
+    L.need_cuda(poses, disps, intrinsics, ii, jj)
+    L.need_contiguous(poses=poses, disps=disps, intrinsics=intrinsics, ii=ii, jj=jj)
+    _i64(ii, "ii"), _i64(jj, "jj")
+    K = ii.shape[0]
+    h, w = disps.shape[1:]
+    dist = torch.empty((K,), dtype=torch.float32, device=poses.device)
+    L.check(L.load().glorie_frame_distance(L.ptr(poses), L.ptr(disps), L.ptr(intrinsics), L.ptr(ii),
+                                           L.ptr(jj), L.ptr(dist), K, h, w, float(beta),
+                                           L.stream_ptr()), "glorie_frame_distance")
+    return dist
+
+
+def projmap(*args):
+    raise NotImplementedError("projmap is exported by the reference but never called "
+                              "(SURVEY.md section 2.1)")
+
+
+def iproj(poses, disps, intrinsics):
+    """reference: droid.cpp:161-169, droid_kernels.cu:1521-1544"""
+    L.need_cuda(poses, disps, intrinsics)
+    L.need_contiguous(poses=poses, disps=disps, intrinsics=intrinsics)
+    num, h, w = disps.shape
+    pts = torch.empty((num, h, w, 3), dtype=torch.float32, device=disps.device)
+    L.check(L.load().glorie_iproj(L.ptr(poses), L.ptr(disps), L.ptr(intrinsics), L.ptr(pts), num, h,
+                                  w, L.stream_ptr()), "glorie_iproj")
+    return pts
+
+
+def depth_filter(poses, disps, intrinsics, ix, thresh):
+    """reference: droid.cpp:208-224, droid_kernels.cu:1494-1518"""
+    L.need_cuda(poses, disps, intrinsics, ix, thresh)
+    L.need_contiguous(poses=poses, disps=disps, intrinsics=intrinsics, ix=ix, thresh=thresh)
+    _i64(ix, "ix")
+    B, h, w = disps.shape
+    num = ix.shape[0]
+    count = torch.empty((num, h, w), dtype=torch.float32, device=disps.device)
+    L.check(L.load().glorie_depth_filter(L.ptr(poses), L.ptr(disps), L.ptr(intrinsics), L.ptr(ix),
+                                         L.ptr(thresh), L.ptr(count), B, num, h, w, L.stream_ptr()),
+            "glorie_depth_filter")
+    return count
+
+
+def reproject(poses, disps, intrinsics, ii, jj, return_valid=True):
+    """Fused pops.projective_transform(jacobian=False) (projective_ops.py:96-125).
+    poses [B,7], disps [B,h,w], intrinsics [B,4] -> coords [N,h,w,2], valid [N,h,w,1]"""
+    L.need_cuda(poses, disps, intrinsics, ii, jj)
+    L.need_contiguous(poses=poses, disps=disps, intrinsics=intrinsics, ii=ii, jj=jj)
+    _i64(ii, "ii"), _i64(jj, "jj")
+    N = ii.shape[0]
+    h, w = disps.shape[1:]
+    coords = torch.empty((N, h, w, 2), dtype=torch.float32, device=poses.device)
+    valid = torch.empty((N, h, w, 1), dtype=torch.float32, device=poses.device) if return_valid else None
+    L.check(L.load().glorie_reproject(L.ptr(poses), L.ptr(disps), L.ptr(intrinsics), L.ptr(ii),
+                                      L.ptr(jj), L.ptr(coords), L.ptr(valid), N, h, w,
+                                      L.stream_ptr()), "glorie_reproject")
+    return coords, valid
+
+
+def cvx_upsample(disps, ix, mask, disps_up, softmax_f32=False):
+    """disps_up[ix] = cvx_upsample(disps[ix], mask) in place (droid_net.py:9-23,
+    depth_video.py:140-144).  mask [M,576,h,w] f16|f32."""
+    L.need_cuda(disps, ix, mask, disps_up)
+    L.need_contiguous(disps=disps, ix=ix, mask=mask, disps_up=disps_up)
+    _i64(ix, "ix")
+    M = ix.shape[0]
+    h, w = disps.shape[1:]
+    if mask.numel() != M * 576 * h * w:
+        raise RuntimeError(f"mask has {mask.numel()} elements, expected {M}*576*{h}*{w}")
+    L.check(L.load().glorie_cvx_upsample(L.ptr(disps), L.ptr(ix), L.ptr(mask), L.ptr(disps_up), M, h,
+                                         w, L.dtype_code(mask), int(bool(softmax_f32)),
+                                         L.stream_ptr()), "glorie_cvx_upsample")
+    return disps_up
+
+
+# --------------------------------------------------------------------------------------
+# bundle adjustment
+# --------------------------------------------------------------------------------------
+def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, t1,
+       iterations, lm, ep, motion_only, depth_only=False, ctx=None):
+    """reference: droid.cpp:89-119, droid_kernels.cu:1314-1437.  Returns [dx, dz] of the last
+    iteration (the reference's return value, unused by its caller).  poses/disps updated in
+    place."""
+    L.need_cuda(poses, disps, intrinsics, targets, weights, ii, jj)
+    L.need_contiguous(targets=targets, weights=weights, poses=poses, disps=disps,
+                      intrinsics=intrinsics, disps_sens=disps_sens, ii=ii, jj=jj)
+    _i64(ii, "ii"), _i64(jj, "jj")
+    if eta is not None and not eta.is_contiguous():
+        eta = eta.contiguous()  # the reference does not check eta (droid.cpp:107-114)
+    B, h, w = disps.shape
+    N = ii.shape[0]
+    P = t1 - t0
+    M = eta.shape[0] if eta is not None else 0
+    if motion_only and eta is None:
+        M = 0
+    ctx = ctx or L.default_context()
+    dx = torch.zeros((max(P, 0), 6), dtype=torch.float32, device=poses.device)
+    dz = torch.zeros((M, h * w), dtype=torch.float32, device=poses.device)
+    if disps_sens is not None and (disps_sens.shape != disps.shape):
+        raise RuntimeError("disps_sens must have the shape of disps")
+    if motion_only and M == 0:
+        # the device still needs the slot count to carve its tables
+        M = int(torch.unique(torch.cat([torch.arange(t0, t1, device=ii.device), ii])).numel())
+    L.check(L.load().glorie_ba(ctx.handle, L.ptr(poses), L.ptr(disps), L.ptr(intrinsics),
+                               L.ptr(disps_sens), L.ptr(targets), L.ptr(weights), L.ptr(eta),
+                               L.ptr(ii), L.ptr(jj), B, N, M, h, w, int(t0), int(t1),
+                               int(iterations), float(lm), float(ep), int(bool(motion_only)),
+                               int(bool(depth_only)), L.ptr(dx), L.ptr(dz) if dz.numel() else None,
+                               L.stream_ptr()), "glorie_ba")
+    return [dx, dz]

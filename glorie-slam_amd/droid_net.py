@@ -1,0 +1,194 @@
+"""Host-side mirror of the reference's update operator and correlation blocks
+(/root/reference/src/modules/droid_net/{corr,gru,droid_net}.py) on top of the HIP kernels.
+
+Module / parameter names match the reference so that `droid.pth` loads with
+`load_state_dict` unchanged (src/slam.py:70-81): update.{corr_encoder,flow_encoder,weight,
+delta,gru,agg}.* .  The convolutions go through PyTorch-ROCm (MIOpen); the correlation
+lookup, the segment mean of GraphAgg and the convex upsampling are libglorie_hip kernels.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import droid_backends
+
+
+def _conv(cin, cout, k):
+    return nn.Conv2d(cin, cout, kernel_size=(k, k), padding=(k // 2, k // 2))
+
+
+class GradientClip(nn.Module):
+    """identity in the forward pass (clipping.py:7-26 only alters gradients)"""
+
+    def forward(self, x):
+        return x
+
+
+class ConvGRU(nn.Module):
+    """gru.py:5-33 -- gates see [net, inp] plus a global context vector"""
+
+    def __init__(self, h_planes=128, i_planes=128):
+        super().__init__()
+        self.do_checkpoint = False
+        for name in ("convz", "convr", "convq"):
+            setattr(self, name, _conv(h_planes + i_planes, h_planes, 3))
+        self.w = _conv(h_planes, h_planes, 1)
+        for name in ("convz_glo", "convr_glo", "convq_glo"):
+            setattr(self, name, _conv(h_planes, h_planes, 1))
+
+    def forward(self, net, *inputs):
+        inp = torch.cat(inputs, dim=1)
+        hx = torch.cat([net, inp], dim=1)
+        b, c, h, w = net.shape
+        glo = (torch.sigmoid(self.w(net)) * net).view(b, c, h * w).mean(-1).view(b, c, 1, 1)
+        z = torch.sigmoid(self.convz(hx) + self.convz_glo(glo))
+        r = torch.sigmoid(self.convr(hx) + self.convr_glo(glo))
+        q = torch.tanh(self.convq(torch.cat([r * net, inp], dim=1)) + self.convq_glo(glo))
+        return (1 - z) * net + z * q
+
+
+def segment_mean(x, ix, num):
+    """scatter_mean(x, ix, dim=1) of torch_scatter (droid_net.py:59): x [b,n,...] -> [b,num,...]"""
+    out = torch.zeros((x.shape[0], num) + tuple(x.shape[2:]), dtype=x.dtype, device=x.device)
+    out.index_add_(1, ix, x)
+    cnt = torch.bincount(ix, minlength=num).clamp_(min=1).to(x.dtype)
+    return out / cnt.view(1, num, *([1] * (x.dim() - 2)))
+
+
+class GraphAgg(nn.Module):
+    """droid_net.py:34-66"""
+
+    def __init__(self):
+        super().__init__()
+        self.conv1 = _conv(128, 128, 3)
+        self.conv2 = _conv(128, 128, 3)
+        self.relu = nn.ReLU(inplace=True)
+        self.eta = nn.Sequential(_conv(128, 1, 3), GradientClip(), nn.Softplus())
+        self.upmask = nn.Sequential(_conv(128, 8 * 8 * 9, 1))
+
+    def forward(self, net, ii):
+        batch, num, ch, ht, wd = net.shape
+        uniq, ix = torch.unique(ii, sorted=True, return_inverse=True)
+        groups = uniq.shape[0]
+        net = self.relu(self.conv1(net.view(batch * num, ch, ht, wd))).view(batch, num, 128, ht, wd)
+        net = segment_mean(net, ix, groups).view(-1, 128, ht, wd)
+        net = self.relu(self.conv2(net))
+        eta = self.eta(net).view(batch, -1, ht, wd)
+        upmask = self.upmask(net).view(batch, -1, 8 * 8 * 9, ht, wd)
+        return 0.01 * eta, upmask
+
+
+class UpdateModule(nn.Module):
+    """droid_net.py:69-139"""
+
+    def __init__(self):
+        super().__init__()
+        cor_planes = 4 * (2 * 3 + 1) ** 2
+        self.corr_encoder = nn.Sequential(_conv(cor_planes, 128, 1), nn.ReLU(inplace=True),
+                                          _conv(128, 128, 3), nn.ReLU(inplace=True))
+        self.flow_encoder = nn.Sequential(_conv(4, 128, 7), nn.ReLU(inplace=True),
+                                          _conv(128, 64, 3), nn.ReLU(inplace=True))
+        self.weight = nn.Sequential(_conv(128, 128, 3), nn.ReLU(inplace=True), _conv(128, 2, 3),
+                                    GradientClip(), nn.Sigmoid())
+        self.delta = nn.Sequential(_conv(128, 128, 3), nn.ReLU(inplace=True), _conv(128, 2, 3),
+                                   GradientClip())
+        self.gru = ConvGRU(128, 128 + 128 + 64)
+        self.agg = GraphAgg()
+
+    def forward(self, net, inp, corr, flow=None, ii=None, jj=None):
+        batch, num, ch, ht, wd = net.shape
+        if flow is None:
+            flow = torch.zeros(batch, num, 4, ht, wd, device=net.device)
+        flat = lambda t: t.view(batch * num, -1, ht, wd)
+        net = self.gru(flat(net), flat(inp), self.corr_encoder(flat(corr)),
+                       self.flow_encoder(flat(flow)))
+        delta = self.delta(net).view(batch, num, -1, ht, wd)
+        weight = self.weight(net).view(batch, num, -1, ht, wd)
+        delta = delta.permute(0, 1, 3, 4, 2)[..., :2].contiguous()
+        weight = weight.permute(0, 1, 3, 4, 2)[..., :2].contiguous()
+        net = net.view(batch, num, -1, ht, wd)
+        if ii is not None:
+            eta, upmask = self.agg(net, ii.to(net.device))
+            return net, delta, weight, eta, upmask
+        return net, delta, weight
+
+
+# --------------------------------------------------------------------------------------
+# correlation blocks
+# --------------------------------------------------------------------------------------
+class CorrBlock:
+    """All-pairs correlation pyramid + windowed lookup (corr.py:25-76).
+
+    The pyramid is built with torch (fp16 GEMM under autocast, like the reference) and kept
+    per edge; the lookup of all 4 levels + the channel concatenation is one HIP launch."""
+
+    def __init__(self, fmap1, fmap2, num_levels=4, radius=3):
+        self.num_levels = num_levels
+        self.radius = radius
+        corr = CorrBlock.corr(fmap1, fmap2)
+        batch, num, h1, w1, h2, w2 = corr.shape
+        corr = corr.reshape(batch * num * h1 * w1, 1, h2, w2)
+        self.corr_pyramid = []
+        for i in range(num_levels):
+            self.corr_pyramid.append(corr.view(batch * num, h1, w1, h2 // 2 ** i, w2 // 2 ** i))
+            if i + 1 < num_levels:
+                corr = F.avg_pool2d(corr, kernel_size=2, stride=2)
+
+    @staticmethod
+    def corr(fmap1, fmap2):
+        batch, num, dim, ht, wd = fmap1.shape
+        a = fmap1.reshape(batch * num, dim, ht * wd) / 4.0
+        b = fmap2.reshape(batch * num, dim, ht * wd) / 4.0
+        return torch.matmul(a.transpose(1, 2), b).view(batch, num, ht, wd, ht, wd)
+
+    def __call__(self, coords):
+        batch, num, ht, wd, _ = coords.shape
+        c = coords.permute(0, 1, 4, 2, 3).contiguous().view(batch * num, 2, ht, wd).float()
+        pyr = [v if v.is_contiguous() else v.contiguous() for v in self.corr_pyramid]
+        out = droid_backends.corr_lookup_pyramid(pyr, c, self.radius)
+        return out.view(batch, num, -1, ht, wd)
+
+    def cat(self, other):
+        self.corr_pyramid = [torch.cat([a, b], 0) for a, b in zip(self.corr_pyramid, other.corr_pyramid)]
+        return self
+
+    def __getitem__(self, index):
+        self.corr_pyramid = [v[index] for v in self.corr_pyramid]
+        return self
+
+
+class AltCorrBlock:
+    """Volume-free correlation for long graphs (corr.py:79-145)."""
+
+    def __init__(self, fmaps, num_levels=4, radius=3):
+        self.num_levels = num_levels
+        self.radius = radius
+        B, N, C, H, W = fmaps.shape
+        f = fmaps.view(B * N, C, H, W) / 4.0
+        self.pyramid = []
+        for i in range(num_levels):
+            self.pyramid.append(f.permute(0, 2, 3, 1).contiguous().view(B, N, H // 2 ** i, W // 2 ** i, C))
+            f = F.avg_pool2d(f, kernel_size=2, stride=2)
+
+    def corr_fn(self, coords, ii, jj):
+        B, N, H, W, S, _ = coords.shape
+        coords = coords.permute(0, 1, 4, 2, 3, 5)
+        outs = []
+        for i in range(self.num_levels):
+            f1 = self.pyramid[0][:, ii]
+            f2 = self.pyramid[i][:, jj]
+            c = (coords / 2 ** i).reshape(B * N, S, H, W, 2).contiguous()
+            f1 = f1.reshape((B * N,) + f1.shape[2:]).float().contiguous()
+            f2 = f2.reshape((B * N,) + f2.shape[2:]).float().contiguous()
+            corr, = droid_backends.altcorr_forward(f1, f2, c.float(), self.radius)
+            outs.append(corr.view(B, N, S, -1, H, W).permute(0, 1, 3, 4, 5, 2))
+        return torch.cat(outs, dim=2)
+
+    def __call__(self, coords, ii, jj):
+        squeeze = coords.dim() == 5
+        if squeeze:
+            coords = coords.unsqueeze(-2)
+        corr = self.corr_fn(coords, ii, jj)
+        if squeeze:
+            corr = corr.squeeze(-1)
+        return corr.contiguous()

@@ -1,0 +1,14 @@
+"""Import shim: the package directory is named ``glorie-slam_amd`` (not a valid Python
+identifier), so ``import glorie_slam_amd`` loads it from that directory under this name."""
+import importlib.util
+import os
+import sys
+
+_here = os.path.dirname(os.path.abspath(__file__))
+_pkg_dir = os.path.join(_here, "glorie-slam_amd")
+_spec = importlib.util.spec_from_file_location(
+    "glorie_slam_amd", os.path.join(_pkg_dir, "__init__.py"),
+    submodule_search_locations=[_pkg_dir])
+_mod = importlib.util.module_from_spec(_spec)
+sys.modules["glorie_slam_amd"] = _mod
+_spec.loader.exec_module(_mod)

@@ -1,0 +1,158 @@
+/*
+ * glorie_hip.h -- C ABI of libglorie_hip.so, the MI355X (gfx950) implementation of
+ * GlORIE-SLAM's dense hot path.
+ *
+ * This is the drop-in boundary.  It replaces the reference's pybind11 module
+ * `droid_backends` (/root/reference/src/lib/droid.cpp:239-252) and the three third-party
+ * boundaries the hot path crosses (lietorch SE3 retraction inside `ba`, faiss-gpu
+ * `IndexIVFFlat.search`, torch_scatter segment sums).  Every entry point
+ *
+ *   - is `extern "C"`, takes raw DEVICE pointers + explicit sizes, never a torch type;
+ *   - writes into CALLER-OWNED output buffers (allocation stays with the host framework);
+ *   - enqueues on the `hipStream_t` passed as the trailing `void* stream` (NULL = default
+ *     stream) and does not synchronise with the host;
+ *   - returns GLORIE_OK (0) or a negative glorie_status; no exception crosses the ABI.
+ *
+ * Index tensors are int64 (`long` in the reference kernels), images are row-major,
+ * poses are [tx ty tz qx qy qz qw], intrinsics are [fx fy cx cy].
+ *
+ * Each declaration cites the reference interface it replaces.
+ */
+#ifndef GLORIE_HIP_H
+#define GLORIE_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum glorie_status {
+  GLORIE_OK = 0,
+  GLORIE_EINVAL = -1,    /* bad argument (null pointer, negative size, unsupported dtype) */
+  GLORIE_EHIP = -2,      /* a HIP runtime call failed; see glorie_last_hip_error()         */
+  GLORIE_ENOMEM = -3,    /* scratch arena too small / allocation failed                    */
+  GLORIE_EUNSUPPORTED = -4
+} glorie_status;
+
+typedef enum glorie_dtype { GLORIE_F16 = 0, GLORIE_F32 = 1 } glorie_dtype;
+
+/* library identification: "glorie_hip <version> gfx950" */
+const char* glorie_version(void);
+/* hipError_t of the last failing HIP call on this thread (0 if none) */
+int glorie_last_hip_error(void);
+
+/* ------------------------------------------------------------------------------------ */
+/* Context: scratch arena + (optional) multi-GPU state.  One per process / GPU.          */
+/* ------------------------------------------------------------------------------------ */
+typedef struct glorie_ctx glorie_ctx;
+
+/* scratch_bytes: initial size of the device scratch arena (grown on demand outside of
+ * stream capture). */
+int glorie_ctx_create(glorie_ctx** out, size_t scratch_bytes);
+int glorie_ctx_destroy(glorie_ctx* ctx);
+
+/* ------------------------------------------------------------------------------------ */
+/* A. correlation lookup                                                                 */
+/* ------------------------------------------------------------------------------------ */
+
+/* droid_backends.corr_index_forward(volume, coords, radius)
+ *   reference: src/lib/droid.cpp:172-180, src/lib/correlation_kernels.cu:19-70,126-155
+ * volume [N,h1,w1,h2,w2] (dtype f16|f32), coords [N,2,h1,w1] f32 (already scaled to this
+ * level), out [N,2r+1,2r+1,h1,w1] same dtype as volume (fully overwritten; the reference
+ * zero-fills and accumulates).  Channel order: x-offset major (out[n][i][j], i<->x).
+ * f16 results are bit-identical to the reference's rounding sequence. */
+int glorie_corr_index_fwd(const void* volume, const float* coords, void* out,
+                          int N, int h1, int w1, int h2, int w2, int radius,
+                          int dtype, void* stream);
+
+/* Fused 4-level form of CorrBlock.__call__ (src/modules/droid_net/corr.py:43-53):
+ * volumes[l] is level l ([N,h1,w1,h2>>l,w2>>l]); coords [N,2,h1,w1] are UNscaled
+ * (the kernel applies /2^l, exact in fp32); out is the concatenated
+ * [N, L*(2r+1)^2, h1, w1] tensor the reference builds with torch.cat. */
+int glorie_corr_lookup_pyramid(const void* const* volumes, int num_levels,
+                               const float* coords, void* out,
+                               int N, int h1, int w1, int h2, int w2, int radius,
+                               int dtype, void* stream);
+
+/* droid_backends.altcorr_forward(fmap1, fmap2, coords, radius)
+ *   reference: src/lib/droid.cpp:195-205, src/lib/altcorr_kernel.cu:27-149,290-319
+ * fmap1 [B,H,W,C], fmap2 [B,H2,W2,C], coords [B,S,H,W,2] f32, out [B,S,(2r+1)^2,H,W].
+ * dtype f32 (the reference casts to float at the call site, corr.py:125). */
+int glorie_altcorr_fwd(const float* fmap1, const float* fmap2, const float* coords,
+                       float* out, int B, int S, int H, int W, int H2, int W2, int C,
+                       int radius, void* stream);
+
+/* ------------------------------------------------------------------------------------ */
+/* A/B. projective geometry                                                              */
+/* ------------------------------------------------------------------------------------ */
+
+/* pops.projective_transform(jacobian=False) via DepthVideo.reproject
+ *   reference: src/geom/projective_ops.py:96-125, src/depth_video.py:156-164
+ * poses [B,7], disps [B,h,w], intrinsics [B,4], ii/jj [N] int64.
+ * coords [N,h,w,2], valid [N,h,w] (1.0/0.0).  MIN_DEPTH 0.2, Z<0.1 -> 1 (python path). */
+int glorie_reproject(const float* poses, const float* disps, const float* intrinsics,
+                     const int64_t* ii, const int64_t* jj, float* coords, float* valid,
+                     int N, int h, int w, void* stream);
+
+/* droid_backends.frame_distance(poses, disps, intrinsics, ii, jj, beta)
+ *   reference: src/lib/droid.cpp:122-138, src/lib/droid_kernels.cu:518-657,1441-1463 */
+int glorie_frame_distance(const float* poses, const float* disps, const float* intrinsics,
+                          const int64_t* ii, const int64_t* jj, float* dist,
+                          int K, int h, int w, float beta, void* stream);
+
+/* droid_backends.iproj(poses, disps, intrinsics)
+ *   reference: src/lib/droid.cpp:161-169, src/lib/droid_kernels.cu:779-850,1521-1544
+ * points [num,h,w,3] */
+int glorie_iproj(const float* poses, const float* disps, const float* intrinsics,
+                 float* points, int num, int h, int w, void* stream);
+
+/* droid_backends.depth_filter(poses, disps, intrinsics, ix, thresh)
+ *   reference: src/lib/droid.cpp:208-224, src/lib/droid_kernels.cu:661-775,1494-1518
+ * disps [B,h,w]; ix [num] int64; thresh [num]; count [num,h,w] (overwritten). */
+int glorie_depth_filter(const float* poses, const float* disps, const float* intrinsics,
+                        const int64_t* ix, const float* thresh, float* count,
+                        int B, int num, int h, int w, void* stream);
+
+/* cvx_upsample(disps[ix,...,None], mask) via DepthVideo.upsample
+ *   reference: src/modules/droid_net/droid_net.py:9-23, src/depth_video.py:140-144
+ * disps [B,h,w] f32, ix [M] int64 (rows to read and rows of disps_up to write),
+ * mask [M,576,h,w] (dtype f16|f32), disps_up [B,8h,8w] f32.
+ * softmax_f32: 0 = round the softmax weights to the mask dtype (what torch.softmax does on
+ * an fp16 mask outside autocast, factor_graph.py:231-254); 1 = keep them in fp32 (softmax
+ * under autocast, factor_graph.py:286-291). */
+int glorie_cvx_upsample(const float* disps, const int64_t* ix, const void* mask,
+                        float* disps_up, int M, int h, int w, int mask_dtype,
+                        int softmax_f32, void* stream);
+
+/* ------------------------------------------------------------------------------------ */
+/* B. dense bundle adjustment                                                            */
+/* ------------------------------------------------------------------------------------ */
+
+/* droid_backends.ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj,
+ *                   t0, t1, iterations, lm, ep, motion_only, depth_only)
+ *   reference: src/lib/droid.cpp:89-119,241; src/lib/droid_kernels.cu:1314-1437
+ * poses [B,7] and disps [B,h,w] are updated IN PLACE.  targets/weights [N,2,h,w],
+ * eta [M,h,w] with M = #unique(cat(arange(t0,t1), ii)) (sorted order), disps_sens may be
+ * NULL (= all zeros, which is what the reference passes, depth_video.py:217).
+ * dx_out [t1-t0,6] / dz_out [M,h*w] receive the last iteration's updates (may be NULL).
+ * Whole Gauss-Newton loop runs on the device with no host synchronisation. */
+int glorie_ba(glorie_ctx* ctx, float* poses, float* disps, const float* intrinsics,
+              const float* disps_sens, const float* targets, const float* weights,
+              const float* eta, const int64_t* ii, const int64_t* jj,
+              int B, int N, int M, int h, int w, int t0, int t1, int iterations,
+              float lm, float ep, int motion_only, int depth_only,
+              float* dx_out, float* dz_out, void* stream);
+
+/* Diagnostic: waits for `stream`, then copies the 4-int device status of the last glorie_ba
+ * call on this context to host memory: [0] bit0 = M disagrees with the device-side count,
+ * bit2 = a Cholesky factorisation failed (update zeroed, as the reference's
+ * `solver.info() != Success` branch, droid_kernels.cu:1202-1210); [1] = M seen on the
+ * device; [2] = number of failed factorisations. */
+int glorie_ba_status(glorie_ctx* ctx, int* status_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GLORIE_HIP_H */

@@ -1,0 +1,165 @@
+"""Parity of the device-resident bundle adjustment with the oracle restatement of ba_cuda."""
+import numpy as np
+import pytest
+import torch
+
+import glorie_slam_amd.synth as synth
+from oracle import ba as oba, geom as ogeom, se3
+
+pytestmark = pytest.mark.gpu
+
+POSE_TOL = 1e-4   # poses 1e-4
+DISP_TOL = 2e-4
+
+
+def _t(x, dev):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+
+
+def make_problem(K, h, w, radius=2, noise=0.5, perturb=True, seed=7, extra_edges=()):
+    g = synth.keyframe_graph(K=K, h=h, w=w, radius=radius, seed=seed, noise_px=noise)
+    ii = np.concatenate([g["ii"], [e[0] for e in extra_edges]]).astype(np.int64)
+    jj = np.concatenate([g["jj"], [e[1] for e in extra_edges]]).astype(np.int64)
+    rng = np.random.default_rng(seed)
+    N = len(ii)
+    coords, _ = ogeom.reproject(g["poses"], g["disps"], g["intrinsics"], ii, jj)
+    noise_arr = rng.normal(0, noise, (N, 2, h, w)).astype(np.float32)
+    g["target"] = (coords.transpose(0, 3, 1, 2) + noise_arr).astype(np.float32)
+    g["weight"] = rng.uniform(0, 1, (N, 2, h, w)).astype(np.float32)
+    g["ii"], g["jj"] = ii, jj
+    if perturb:
+        for k in range(1, K):
+            g["poses"][k] = se3.retract((rng.standard_normal(6) * 0.005).astype(np.float32), g["poses"][k])
+        g["disps"] = (g["disps"] * (1 + 0.02 * rng.standard_normal(g["disps"].shape))).astype(np.float32)
+    return g
+
+
+def run_gpu(g, dev, t0, t1, iters, lm=1e-4, ep=0.1, motion_only=False, depth_only=False, eta=None):
+    from glorie_slam_amd import droid_backends as db
+    poses = _t(g["poses"], dev)
+    disps = _t(g["disps"], dev)
+    eta_t = _t(g["eta"] if eta is None else eta, dev)
+    dx, dz = db.ba(poses, disps, _t(g["intrinsics"][0], dev), None, _t(g["target"], dev),
+                   _t(g["weight"], dev), eta_t, _t(g["ii"], dev), _t(g["jj"], dev), t0, t1, iters,
+                   lm, ep, motion_only, depth_only)
+    torch.cuda.synchronize()
+    from glorie_slam_amd import _lib
+    st = _lib.default_context().ba_status()
+    return poses.cpu().numpy(), disps.cpu().numpy(), dx.cpu().numpy(), dz.cpu().numpy(), st
+
+
+@pytest.mark.parametrize("K,h,w,iters", [(4, 12, 16, 1), (5, 24, 32, 2), (8, 30, 40, 2)])
+def test_ba_matches_oracle(gpu, K, h, w, iters):
+    g = make_problem(K, h, w)
+    t0, t1 = 1, K
+    rp, rd, rdx, rdz, info = oba.ba(g["poses"], g["disps"], g["intrinsics"][0], g["target"], g["weight"],
+                                    g["eta"], g["ii"], g["jj"], t0, t1, iters, 1e-4, 0.1)
+    assert info["failed"] == 0
+    p, d, dx, dz, st = run_gpu(g, gpu, t0, t1, iters)
+    assert st[0] == 0 and st[1] == K
+    np.testing.assert_allclose(dx, rdx, rtol=2e-3, atol=2e-6)
+    np.testing.assert_allclose(p, rp, atol=POSE_TOL)
+    np.testing.assert_allclose(d, rd, atol=DISP_TOL)
+    np.testing.assert_allclose(dz, rdz, rtol=5e-3, atol=2e-5)
+    assert np.array_equal(p[0], g["poses"][0])  # pose 0 is fixed (t0 = 1)
+
+
+def test_ba_window_inside_graph(gpu):
+    """t0 > 1: frames below t0 are fixed but still own depth maps (kx = unique(cat(ts, ii)))"""
+    K = 7
+    g = make_problem(K, 16, 20, radius=3)
+    t0, t1 = 3, K
+    rp, rd, rdx, rdz, info = oba.ba(g["poses"], g["disps"], g["intrinsics"][0], g["target"], g["weight"],
+                                    g["eta"], g["ii"], g["jj"], t0, t1, 2, 1e-4, 0.1)
+    p, d, dx, dz, st = run_gpu(g, gpu, t0, t1, 2)
+    assert st[0] == 0
+    np.testing.assert_allclose(p, rp, atol=POSE_TOL)
+    np.testing.assert_allclose(d, rd, atol=DISP_TOL)
+    assert np.array_equal(p[:t0], g["poses"][:t0])
+
+
+def test_ba_motion_only_and_depth_only(gpu):
+    K = 5
+    g = make_problem(K, 16, 20)
+    rp, rd, rdx, _, _ = oba.ba(g["poses"], g["disps"], g["intrinsics"][0], g["target"], g["weight"],
+                               g["eta"], g["ii"], g["jj"], 1, K, 2, 1e-4, 0.1, motion_only=True)
+    p, d, dx, dz, st = run_gpu(g, gpu, 1, K, 2, motion_only=True)
+    np.testing.assert_allclose(p, rp, atol=POSE_TOL)
+    assert np.array_equal(d, g["disps"])
+    rp, rd, *_ = oba.ba(g["poses"], g["disps"], g["intrinsics"][0], g["target"], g["weight"],
+                        g["eta"], g["ii"], g["jj"], 1, K, 2, 1e-4, 0.1, depth_only=True)
+    p, d, dx, dz, st = run_gpu(g, gpu, 1, K, 2, depth_only=True)
+    assert np.array_equal(p, g["poses"])
+    np.testing.assert_allclose(d, rd, atol=DISP_TOL)
+
+
+def test_ba_stereo_edge_and_unordered_edges(gpu):
+    """ii == jj edges use the fixed baseline and only feed C, w; edge order must not matter"""
+    K = 5
+    g = make_problem(K, 12, 16, extra_edges=[(2, 2), (3, 3)])
+    rp, rd, *_ = oba.ba(g["poses"], g["disps"], g["intrinsics"][0], g["target"], g["weight"],
+                        g["eta"], g["ii"], g["jj"], 1, K, 1, 1e-4, 0.1)
+    p, d, dx, dz, st = run_gpu(g, gpu, 1, K, 1)
+    np.testing.assert_allclose(p, rp, atol=POSE_TOL)
+    np.testing.assert_allclose(d, rd, atol=DISP_TOL)
+    perm = np.random.default_rng(0).permutation(len(g["ii"]))
+    g2 = dict(g)
+    for k in ("ii", "jj", "target", "weight"):
+        g2[k] = g[k][perm]
+    p2, d2, *_ = run_gpu(g2, gpu, 1, K, 1)
+    np.testing.assert_allclose(p2, p, atol=2e-6)
+    np.testing.assert_allclose(d2, d, atol=2e-6)
+
+
+def test_ba_high_degree_frame(gpu):
+    """a hub frame with more than 8 outgoing edges exercises the grouped gram path"""
+    K = 14
+    g = make_problem(K, 12, 16, radius=2, extra_edges=[(6, j) for j in range(K) if abs(6 - j) > 2])
+    deg6 = int((g["ii"] == 6).sum())
+    assert deg6 > 8
+    rp, rd, *_ = oba.ba(g["poses"], g["disps"], g["intrinsics"][0], g["target"], g["weight"],
+                        g["eta"], g["ii"], g["jj"], 1, K, 1, 1e-4, 0.1)
+    p, d, dx, dz, st = run_gpu(g, gpu, 1, K, 1)
+    assert st[0] == 0
+    np.testing.assert_allclose(p, rp, atol=POSE_TOL)
+    np.testing.assert_allclose(d, rd, atol=DISP_TOL)
+
+
+def test_ba_cholesky_failure_gives_zero_update(gpu):
+    """non-PD reduced system -> zero pose update, like the reference's LLT failure branch"""
+    K = 4
+    g = make_problem(K, 12, 16)
+    p, d, dx, dz, st = run_gpu(g, gpu, 1, K, 1, lm=-3.0, ep=-1.0)
+    assert st[0] & 4 and st[2] == 1
+    assert np.all(dx == 0)
+    assert np.array_equal(p, g["poses"])
+
+
+def test_ba_large_window_uses_blocked_solver(gpu):
+    """6P > 192 switches to the blocked Cholesky in HBM"""
+    g = synth.loop_graph(K=40, h=12, w=16)
+    coords, _ = ogeom.reproject(g["poses"], g["disps"], g["intrinsics"], g["ii"], g["jj"])
+    g["target"] = (coords.transpose(0, 3, 1, 2) + g["noise"]).astype(np.float32)
+    K = g["K"]
+    rp, rd, rdx, *_ = oba.ba(g["poses"], g["disps"], g["intrinsics"][0], g["target"], g["weight"],
+                             g["eta"], g["ii"], g["jj"], 1, K, 1, 1e-5, 1e-2)
+    p, d, dx, dz, st = run_gpu(g, gpu, 1, K, 1, lm=1e-5, ep=1e-2)
+    assert st[0] == 0
+    np.testing.assert_allclose(dx, rdx, rtol=5e-3, atol=5e-6)
+    np.testing.assert_allclose(p, rp, atol=POSE_TOL)
+    np.testing.assert_allclose(d, rd, atol=DISP_TOL)
+
+
+def test_ba_full_size_fixed_point_and_descent(gpu):
+    """BASELINE size G8 (60x80, 36 edges): noise-free targets are a fixed point; from a
+    perturbed state two GN iterations cut the reprojection cost by > 5x."""
+    g = make_problem(8, 60, 80, radius=3, noise=0.0, perturb=False)
+    p, d, dx, dz, st = run_gpu(g, gpu, 1, 8, 2)
+    assert st[0] == 0
+    assert np.abs(dx).max() < 1e-4 and np.abs(dz).max() < 1e-4
+    g = make_problem(8, 60, 80, radius=3, noise=0.0, perturb=True)
+    intr = g["intrinsics"][0]
+    c0 = oba.reprojection_cost(g["poses"], g["disps"], intr, g["target"], g["weight"], g["ii"], g["jj"])
+    p, d, *_ = run_gpu(g, gpu, 1, 8, 2)
+    c1 = oba.reprojection_cost(p, d, intr, g["target"], g["weight"], g["ii"], g["jj"])
+    assert c1 < 0.2 * c0

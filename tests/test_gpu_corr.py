@@ -1,0 +1,108 @@
+"""Parity of the HIP correlation lookups with the oracle (through the C ABI)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import corr as ocorr
+
+pytestmark = pytest.mark.gpu
+
+
+def _vol(rng, N, h1, w1, h2, w2, dtype):
+    return rng.standard_normal((N, h1, w1, h2, w2)).astype(dtype)
+
+
+def _coords(rng, N, h1, w1, h2, w2, margin=5.0):
+    return np.stack([rng.uniform(-margin, w2 + margin, (N, h1, w1)),
+                     rng.uniform(-margin, h2 + margin, (N, h1, w1))], 1).astype(np.float32)
+
+
+@pytest.mark.parametrize("shape", [(2, 7, 9, 7, 9), (1, 30, 40, 30, 40), (3, 5, 33, 3, 5)])
+def test_corr_index_forward_fp16_bit_exact(gpu, shape):
+    from glorie_slam_amd import droid_backends as db
+    rng = np.random.default_rng(0)
+    vol = _vol(rng, *shape, np.float16)
+    coords = _coords(rng, *shape)
+    # include exact-integer coordinates and far out-of-bounds ones
+    coords[0, :, 0, 0] = (2.0, 1.0)
+    coords[0, :, 0, 1] = (-50.0, 400.0)
+    ref = ocorr.corr_index_forward(vol, coords, 3)
+    got, = db.corr_index_forward(torch.from_numpy(vol).to(gpu), torch.from_numpy(coords).to(gpu), 3)
+    got = got.cpu().numpy()
+    assert got.dtype == np.float16 and got.shape == ref.shape
+    assert np.array_equal(got.view(np.uint16), ref.view(np.uint16)), \
+        f"max abs diff {np.abs(got.astype(np.float32) - ref.astype(np.float32)).max()}"
+
+
+def test_corr_index_forward_fp32(gpu):
+    from glorie_slam_amd import droid_backends as db
+    rng = np.random.default_rng(1)
+    shape = (2, 6, 10, 12, 14)
+    vol = _vol(rng, *shape, np.float32)
+    coords = _coords(rng, *shape)
+    ref = ocorr.corr_index_forward(vol, coords, 3)
+    got, = db.corr_index_forward(torch.from_numpy(vol).to(gpu), torch.from_numpy(coords).to(gpu), 3)
+    np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-6, atol=1e-6)
+
+
+def test_corr_generic_radius(gpu):
+    from glorie_slam_amd import droid_backends as db
+    rng = np.random.default_rng(2)
+    shape = (1, 4, 5, 9, 9)
+    vol = _vol(rng, *shape, np.float16)
+    coords = _coords(rng, *shape, margin=2.0)
+    ref = ocorr.corr_index_forward(vol, coords, 2)
+    got, = db.corr_index_forward(torch.from_numpy(vol).to(gpu), torch.from_numpy(coords).to(gpu), 2)
+    assert np.array_equal(got.cpu().numpy().view(np.uint16), ref.view(np.uint16))
+
+
+def test_corr_lookup_pyramid_bit_exact(gpu):
+    """fused 4-level lookup == per-level reference path + cat (corr.py:43-53)"""
+    from glorie_slam_amd import droid_backends as db
+    rng = np.random.default_rng(3)
+    N, h, w = 2, 30, 40
+    levels = [rng.standard_normal((N, h, w, h >> l, w >> l)).astype(np.float16) for l in range(4)]
+    coords = _coords(rng, N, h, w, h, w)
+    ref = ocorr.corr_lookup_pyramid(levels, coords, 3)
+    got = db.corr_lookup_pyramid([torch.from_numpy(v).to(gpu) for v in levels],
+                                 torch.from_numpy(coords).to(gpu), 3).cpu().numpy()
+    assert got.shape == (N, 196, h, w)
+    assert np.array_equal(got.view(np.uint16), ref.view(np.uint16))
+
+
+def test_corr_empty_and_noncontiguous(gpu):
+    from glorie_slam_amd import droid_backends as db
+    vol = torch.zeros(0, 4, 4, 4, 4, dtype=torch.float16, device=gpu)
+    coords = torch.zeros(0, 2, 4, 4, device=gpu)
+    out, = db.corr_index_forward(vol, coords, 3)
+    assert out.shape == (0, 7, 7, 4, 4)
+    vol = torch.zeros(2, 4, 4, 4, 8, dtype=torch.float16, device=gpu)[..., ::2]
+    with pytest.raises(RuntimeError, match="contiguous"):
+        db.corr_index_forward(vol, torch.zeros(2, 2, 4, 4, device=gpu), 3)
+
+
+def test_corr_full_size_property(gpu):
+    """BASELINE size (60x80, 4 levels): a constant volume must return the constant for every
+    in-bounds window (weights sum to 1 up to fp16 rounding) and linearity in the volume."""
+    from glorie_slam_amd import droid_backends as db
+    N, h, w = 2, 60, 80
+    g = torch.Generator(device="cpu").manual_seed(0)
+    coords = torch.stack([torch.rand(N, h, w, generator=g) * (w - 20) + 10,
+                          torch.rand(N, h, w, generator=g) * (h - 20) + 10], 1).to(gpu)
+    levels = [torch.full((N, h, w, h >> l, w >> l), 2.0, dtype=torch.float16, device=gpu) for l in range(4)]
+    out = db.corr_lookup_pyramid(levels, coords, 3)
+    inner = out[:, :49]  # level 0 windows are fully in bounds for these coords
+    assert torch.allclose(inner.float(), torch.full_like(inner.float(), 2.0), atol=4e-3)
+
+
+def test_altcorr_forward(gpu):
+    from glorie_slam_amd import droid_backends as db
+    rng = np.random.default_rng(4)
+    B, H, W, C = 2, 9, 13, 128
+    f1 = (rng.standard_normal((B, H, W, C)) * 0.25).astype(np.float32)
+    f2 = (rng.standard_normal((B, H // 2, W // 2, C)) * 0.25).astype(np.float32)
+    coords = np.stack([rng.uniform(-3, W // 2 + 3, (B, 2, H, W)), rng.uniform(-3, H // 2 + 3, (B, 2, H, W))], -1).astype(np.float32)
+    ref = ocorr.altcorr_forward(f1, f2, coords, 3)
+    got, = db.altcorr_forward(torch.from_numpy(f1).to(gpu), torch.from_numpy(f2).to(gpu),
+                              torch.from_numpy(coords).to(gpu), 3)
+    np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=2e-5, atol=2e-5)
