@@ -62,6 +62,15 @@ __device__ __forceinline__ float blend4(float s00, float s01, float s10, float s
   return acc;
 }
 
+// float -> T weight.  The reference rounds the fp32 product to fp32 FIRST and then to fp16
+// (`scalar_t(dx * dy)`); hipcc would otherwise fuse mul+cvt into v_fma_mixlo_f16 (a single
+// rounding), which differs in rare near-tie cases.  The empty asm pins the fp32 value.
+template <typename T>
+__device__ __forceinline__ T weight_cast(float prod) {
+  asm volatile("" : "+v"(prod));
+  return (T)prod;
+}
+
 __device__ __forceinline__ _Float16 shfl_next(_Float16 v) {
   // move one fp16 from lane+1; done on the 32-bit container
   int x = (int)__builtin_bit_cast(unsigned short, v);
@@ -122,10 +131,10 @@ __global__ __launch_bounds__(256) void corr_lookup_r3_kernel(
 #pragma unroll
     for (int i = 0; i < WIN; ++i) nx[i] = shfl_next(s[i]);
 
-    const T w00 = (T)((1.0f - dx) * (1.0f - dy));
-    const T w01 = (T)((1.0f - dx) * dy);
-    const T w10 = (T)(dx * (1.0f - dy));
-    const T w11 = (T)(dx * dy);
+    const T w00 = weight_cast<T>((1.0f - dx) * (1.0f - dy));
+    const T w01 = weight_cast<T>((1.0f - dx) * dy);
+    const T w10 = weight_cast<T>(dx * (1.0f - dy));
+    const T w11 = weight_cast<T>(dx * dy);
 
     if (live && row < RD) {
       T* o = out + ((size_t)n * out_channels + (size_t)l * RD * RD + row) * HW + p;
@@ -160,10 +169,10 @@ __global__ __launch_bounds__(256) void corr_lookup_generic_kernel(
     const int ix0 = static_cast<int>(fx) - radius;
     const int iy0 = static_cast<int>(fy) - radius;
     const T* plane = reinterpret_cast<const T*>(lv.vol[l]) + ((size_t)n * HW + p) * ((size_t)h2 * w2);
-    const T w00 = (T)((1.0f - dx) * (1.0f - dy));
-    const T w01 = (T)((1.0f - dx) * dy);
-    const T w10 = (T)(dx * (1.0f - dy));
-    const T w11 = (T)(dx * dy);
+    const T w00 = weight_cast<T>((1.0f - dx) * (1.0f - dy));
+    const T w01 = weight_cast<T>((1.0f - dx) * dy);
+    const T w10 = weight_cast<T>(dx * (1.0f - dy));
+    const T w11 = weight_cast<T>(dx * dy);
     auto fetch = [&](int i, int j) -> T {
       const int x1 = ix0 + i, y1 = iy0 + j;
       return (x1 >= 0 && x1 < w2 && y1 >= 0 && y1 < h2) ? plane[(size_t)y1 * w2 + x1] : (T)0.0f;

@@ -1,0 +1,220 @@
+"""DepthVideo: shared keyframe state + the geometric operations of the hot path.
+
+Host-side mirror of /root/reference/src/depth_video.py (same attribute and method names, same
+argument meaning) whose native calls go through libglorie_hip:
+  reproject -> glorie_reproject          (fused pops.projective_transform, no lietorch)
+  distance  -> glorie_frame_distance
+  ba / dspo -> glorie_ba (stage 1)  /  glorie_dspo_scale_shift (stage 2)
+  upsample  -> glorie_cvx_upsample
+  update_valid_depth_mask -> glorie_depth_filter
+
+Deliberate difference, documented in DESIGN.md: DSPO stage 2 updates `disps`, `depth_scale`
+and `depth_shift` IN PLACE; the reference rebinds the attributes to new tensors
+(depth_video.py:278-282), which silently detaches the buffers shared with the mapper process.
+"""
+import numpy as np
+import torch
+from torch.multiprocessing import Value
+
+from . import droid_backends
+from . import _lib as L
+
+
+class DepthVideo:
+    def __init__(self, cfg, printer=None):
+        self.cfg = cfg
+        self.output = f"{cfg['data']['output']}/{cfg['setting']}/{cfg['scene']}" if 'data' in cfg else ''
+        ht = self.ht = cfg['cam']['H_out']
+        wd = self.wd = cfg['cam']['W_out']
+        self.counter = Value('i', 0)
+        buffer = cfg['tracking']['buffer']
+        self.BA_type = cfg['tracking']['backend']['BA_type']
+        self.mono_thres = cfg['tracking']['mono_thres']
+        self.device = cfg['device']
+        self.down_scale = s = 8
+        dev = self.device
+        f32 = dict(device=dev, dtype=torch.float)
+
+        def shared(t):
+            return t.share_memory_() if t.device.type == 'cpu' or True else t
+
+        self.timestamp = torch.zeros(buffer, **f32)
+        store_images = cfg['tracking'].get('store_images', True)
+        self.images = torch.zeros(buffer if store_images else 0, 3, ht, wd, device=dev, dtype=torch.uint8)
+        self.dirty = torch.zeros(buffer, device=dev, dtype=torch.bool)
+        self.npc_dirty = torch.zeros(buffer, device=dev, dtype=torch.bool)
+        self.poses = torch.zeros(buffer, 7, **f32)
+        self.disps = torch.ones(buffer, ht // s, wd // s, **f32)
+        self.disps_up = torch.zeros(buffer, ht, wd, **f32)
+        self.intrinsics = torch.zeros(buffer, 4, **f32)
+        self.mono_disps = torch.zeros(buffer, ht // s, wd // s, **f32)
+        self.depth_scale = torch.zeros(buffer, **f32)
+        self.depth_shift = torch.zeros(buffer, **f32)
+        self.valid_depth_mask = torch.zeros(buffer, ht, wd, device=dev, dtype=torch.bool)
+        self.valid_depth_mask_small = torch.zeros(buffer, ht // s, wd // s, device=dev, dtype=torch.bool)
+        self.fmaps = torch.zeros(buffer, 1, 128, ht // s, wd // s, dtype=torch.half, device=dev)
+        self.nets = torch.zeros(buffer, 128, ht // s, wd // s, dtype=torch.half, device=dev)
+        self.inps = torch.zeros(buffer, 128, ht // s, wd // s, dtype=torch.half, device=dev)
+        self.poses[:] = torch.as_tensor([0, 0, 0, 0, 0, 0, 1], **f32)
+        self.printer = printer
+        self._ctx = None
+
+    # ---- bookkeeping -----------------------------------------------------------------
+    def get_lock(self):
+        return self.counter.get_lock()
+
+    def _set(self, index, item):
+        if isinstance(index, int) and index >= self.counter.value:
+            self.counter.value = index + 1
+        elif isinstance(index, torch.Tensor) and index.max().item() > self.counter.value:
+            self.counter.value = index.max().item() + 1
+        self.timestamp[index] = item[0]
+        if self.images.shape[0]:
+            self.images[index] = item[1]
+        if item[2] is not None:
+            self.poses[index] = item[2]
+        if item[3] is not None:
+            self.disps[index] = item[3]
+        if item[4] is not None:
+            s = self.down_scale
+            mono = item[4][s // 2 - 1::s, s // 2 - 1::s]
+            self.mono_disps[index] = torch.where(mono > 0, 1.0 / mono, 0)
+        if item[5] is not None:
+            self.intrinsics[index] = item[5]
+        if len(item) > 6:
+            self.fmaps[index] = item[6]
+        if len(item) > 7:
+            self.nets[index] = item[7]
+        if len(item) > 8:
+            self.inps[index] = item[8]
+
+    def __setitem__(self, index, item):
+        with self.get_lock():
+            self._set(index, item)
+
+    def __getitem__(self, index):
+        with self.get_lock():
+            if isinstance(index, int) and index < 0:
+                index = self.counter.value + index
+            return (self.poses[index], self.disps[index], self.intrinsics[index],
+                    self.fmaps[index], self.nets[index], self.inps[index])
+
+    def append(self, *item):
+        with self.get_lock():
+            self._set(self.counter.value, item)
+
+    @staticmethod
+    def format_indicies(ii, jj, device="cuda"):
+        if not isinstance(ii, torch.Tensor):
+            ii = torch.as_tensor(ii)
+        if not isinstance(jj, torch.Tensor):
+            jj = torch.as_tensor(jj)
+        ii = ii.to(device=device, dtype=torch.long).reshape(-1)
+        jj = jj.to(device=device, dtype=torch.long).reshape(-1)
+        return ii, jj
+
+    def ctx(self):
+        if self._ctx is None:
+            self._ctx = L.Context()
+        return self._ctx
+
+    # ---- geometry --------------------------------------------------------------------
+    def upsample(self, ix, mask, softmax_f32=False):
+        """disps_up[ix] = cvx_upsample(disps[ix], mask)  (depth_video.py:140-144)"""
+        m = mask.reshape(-1, 576, mask.shape[-2], mask.shape[-1])
+        if not m.is_contiguous():
+            m = m.contiguous()
+        droid_backends.cvx_upsample(self.disps, ix.contiguous(), m, self.disps_up, softmax_f32=softmax_f32)
+
+    def normalize(self):
+        with self.get_lock():
+            n = self.counter.value
+            s = self.disps[:n].mean()
+            self.disps[:n] /= s
+            self.poses[:n, :3] *= s
+            self.set_dirty(0, n)
+
+    def reproject(self, ii, jj):
+        """coords [1,N,h,w,2], valid [1,N,h,w,1]  (depth_video.py:156-164)"""
+        ii, jj = DepthVideo.format_indicies(ii, jj, self.device)
+        coords, valid = droid_backends.reproject(self.poses, self.disps, self.intrinsics, ii, jj)
+        return coords[None], valid[None]
+
+    def distance(self, ii=None, jj=None, beta=0.3, bidirectional=True):
+        return_matrix = False
+        if ii is None:
+            return_matrix = True
+            N = self.counter.value
+            ii, jj = torch.meshgrid(torch.arange(N), torch.arange(N), indexing="ij")
+        ii, jj = DepthVideo.format_indicies(ii, jj, self.device)
+        intr0 = self.intrinsics[0].contiguous()
+        if bidirectional:
+            poses = self.poses[:self.counter.value].clone()
+            d1 = droid_backends.frame_distance(poses, self.disps, intr0, ii, jj, beta)
+            d2 = droid_backends.frame_distance(poses, self.disps, intr0, jj, ii, beta)
+            d = .5 * (d1 + d2)
+        else:
+            d = droid_backends.frame_distance(self.poses, self.disps, intr0, ii, jj, beta)
+        return d.reshape(N, N) if return_matrix else d
+
+    # ---- bundle adjustment -----------------------------------------------------------
+    def dspo(self, target, weight, eta, ii, jj, t0=1, t1=None, itrs=2, lm=1e-4, ep=0.1,
+             motion_only=False, opt_type="pose_depth"):
+        with self.get_lock():
+            if t1 is None:
+                t1 = max(ii.max().item(), jj.max().item()) + 1
+            h, w = self.ht // self.down_scale, self.wd // self.down_scale
+            if opt_type == "pose_depth":
+                target = target.view(-1, h, w, 2).permute(0, 3, 1, 2).contiguous()
+                weight = weight.view(-1, h, w, 2).permute(0, 3, 1, 2).contiguous()
+                droid_backends.ba(self.poses, self.disps, self.intrinsics[0].contiguous(), None,
+                                  target, weight, eta, ii, jj, t0, t1, itrs, lm, ep, motion_only,
+                                  False, ctx=self.ctx())
+                self.disps.clamp_(min=1e-5)
+                return True
+            elif opt_type == "depth_scale":
+                from . import dspo as _dspo
+                return _dspo.depth_scale_stage(self, target, weight, eta, ii, jj, itrs, lm, ep)
+            raise NotImplementedError(opt_type)
+
+    def ba(self, target, weight, eta, ii, jj, t0=1, t1=None, iters=2, lm=1e-4, ep=0.1,
+           motion_only=False, opt_type="pose_depth"):
+        if self.BA_type == "DSPO":
+            ok = self.dspo(target, weight, eta, ii, jj, t0, t1, iters, lm, ep, motion_only, opt_type)
+            if not ok:
+                self.dspo(target, weight, eta, ii, jj, t0, t1, iters, lm, ep, motion_only, "pose_depth")
+        elif self.BA_type == "DBA":
+            self.dspo(target, weight, eta, ii, jj, t0, t1, iters, lm, ep, motion_only, "pose_depth")
+        else:
+            raise NotImplementedError(self.BA_type)
+
+    # ---- masks -----------------------------------------------------------------------
+    @torch.no_grad()
+    def update_valid_depth_mask(self, up=True):
+        """two-view consistency mask (depth_video.py:326-361)"""
+        if up:
+            with self.get_lock():
+                dirty_index, = torch.where(self.dirty.clone())
+            if len(dirty_index) == 0:
+                return
+        else:
+            dirty_index = torch.arange(self.counter.value, device=self.device)
+        src = self.disps_up if up else self.disps
+        disps = torch.index_select(src, 0, dirty_index)
+        intr = (self.intrinsics[0].detach() * (self.down_scale if up else 1.0)).contiguous()
+        depths = 1.0 / disps
+        thresh = (self.cfg['tracking']['multiview_filter']['thresh'] * depths.mean(dim=[1, 2])).contiguous()
+        count = droid_backends.depth_filter(self.poses, src, intr, dirty_index.contiguous(), thresh)
+        visible = self.cfg['tracking']['multiview_filter']['visible_num']
+        depths[~(count >= visible)] = torch.nan
+        med = depths.view(depths.shape[0], -1).nanmedian(dim=1).values
+        masks = depths < 3 * med[:, None, None]
+        if up:
+            self.valid_depth_mask[dirty_index] = masks
+            self.dirty[dirty_index] = False
+        else:
+            self.valid_depth_mask_small[dirty_index] = masks
+
+    def set_dirty(self, index_start, index_end):
+        self.dirty[index_start:index_end] = True
+        self.npc_dirty[index_start:index_end] = True

@@ -1,0 +1,317 @@
+"""FactorGraph: edge store + one DSPO BA-update iteration (`update`, `update_lowmem`).
+
+Host-side mirror of /root/reference/src/factor_graph.py with the same public methods and
+arguments.  What changed underneath:
+  * edge lists are mirrored on the host, so `t0`, `unique(ii)` and the duplicate-edge filter
+    need no `.item()` / `.cpu()` round trips per call (factor_graph.py:42-53,229-230);
+  * reproject, the 4-level correlation lookup, BA and the convex upsampling are single HIP
+    launches (see droid_backends / depth_video);
+  * topology construction (`add_proximity_factors`, `add_backend_proximity_factors`) runs on
+    numpy copies of the distance matrix instead of per-element tensor indexing -- same
+    decisions, same edge order.
+"""
+import numpy as np
+import torch
+
+from .droid_net import CorrBlock, AltCorrBlock
+
+
+def coords_grid(ht, wd, device):
+    y, x = torch.meshgrid(torch.arange(ht, device=device).float(),
+                          torch.arange(wd, device=device).float(), indexing="ij")
+    return torch.stack([x, y], dim=-1)
+
+
+class FactorGraph:
+    def __init__(self, video, update_op, device="cuda:0", corr_impl="volume", max_factors=-1):
+        self.video = video
+        self.update_op = update_op
+        self.device = device
+        self.max_factors = max_factors
+        self.corr_impl = corr_impl
+        self.ht = ht = video.ht // video.down_scale
+        self.wd = wd = video.wd // video.down_scale
+        self.coords0 = coords_grid(ht, wd, device=device)
+        long0 = lambda: torch.as_tensor([], dtype=torch.long, device=device)
+        self.ii, self.jj, self.age = long0(), long0(), long0()
+        self.corr, self.net, self.inp = None, None, None
+        self.damping = 1e-6 * torch.ones_like(self.video.disps)
+        zero_tw = lambda: torch.zeros([1, 0, ht, wd, 2], device=device, dtype=torch.float)
+        self.target, self.weight = zero_tw(), zero_tw()
+        self.ii_inac, self.jj_inac = long0(), long0()
+        self.ii_bad, self.jj_bad = long0(), long0()
+        self.target_inac, self.weight_inac = zero_tw(), zero_tw()
+        self._uniq_cache = None
+
+    # ---- host mirrors ----------------------------------------------------------------
+    @staticmethod
+    def _host(t):
+        return t.detach().cpu().numpy().astype(np.int64) if t is not None and t.numel() else np.zeros(0, np.int64)
+
+    def _unique_ii(self):
+        """torch.unique(self.ii), cached until the edge set changes"""
+        if self._uniq_cache is None:
+            self._uniq_cache = (None, torch.unique(self.ii),
+                                int(self.ii.min().item()) if self.ii.numel() else 0)
+        return self._uniq_cache[1]
+
+    def _filter_repeated_edges(self, ii, jj):
+        have = set(zip(self._host(self.ii).tolist(), self._host(self.jj).tolist()))
+        have |= set(zip(self._host(self.ii_inac).tolist(), self._host(self.jj_inac).tolist()))
+        hi, hj = self._host(ii), self._host(jj)
+        keep = torch.as_tensor([(a, b) not in have for a, b in zip(hi.tolist(), hj.tolist())],
+                               dtype=torch.bool, device=ii.device)
+        return ii[keep], jj[keep]
+
+    def filter_edges(self):
+        conf = torch.mean(self.weight, dim=[0, 2, 3, 4])
+        mask = (torch.abs(self.ii - self.jj) > 2) & (conf < 0.001)
+        self.ii_bad = torch.cat([self.ii_bad, self.ii[mask]])
+        self.jj_bad = torch.cat([self.jj_bad, self.jj[mask]])
+        self.rm_factors(mask, store=False)
+
+    def clear_edges(self):
+        for k in ("ii", "jj", "age", "corr", "damping", "net", "inp", "target", "weight", "ii_inac",
+                  "jj_inac", "ii_bad", "jj_bad", "target_inac", "weight_inac"):
+            setattr(self, k, None)
+
+    # ---- edge management -------------------------------------------------------------
+    @torch.no_grad()
+    def add_factors(self, ii, jj, remove=False):
+        if not isinstance(ii, torch.Tensor):
+            ii = torch.as_tensor(ii, dtype=torch.long, device=self.device)
+        if not isinstance(jj, torch.Tensor):
+            jj = torch.as_tensor(jj, dtype=torch.long, device=self.device)
+        ii, jj = self._filter_repeated_edges(ii, jj)
+        if ii.shape[0] == 0:
+            return
+        if self.max_factors > 0 and self.ii.shape[0] + ii.shape[0] > self.max_factors \
+                and self.corr is not None and remove:
+            ix = torch.arange(len(self.age))[torch.argsort(self.age).cpu()]
+            self.rm_factors(ix >= self.max_factors - ii.shape[0], store=True)
+        net = self.video.nets[ii].to(self.device).unsqueeze(0)
+        if self.corr_impl == "volume":
+            c = (ii == jj).long()
+            fmap1 = self.video.fmaps[ii, 0].to(self.device).unsqueeze(0)
+            fmap2 = self.video.fmaps[jj, c].to(self.device).unsqueeze(0)
+            with torch.autocast("cuda", enabled=True):
+                corr = CorrBlock(fmap1, fmap2)
+            self.corr = corr if self.corr is None else self.corr.cat(corr)
+            inp = self.video.inps[ii].to(self.device).unsqueeze(0)
+            self.inp = inp if self.inp is None else torch.cat([self.inp, inp], 1)
+        target, _ = self.video.reproject(ii, jj)
+        weight = torch.zeros_like(target)
+        self._uniq_cache = None
+        self.ii = torch.cat([self.ii, ii], 0)
+        self.jj = torch.cat([self.jj, jj], 0)
+        self.age = torch.cat([self.age, torch.zeros_like(ii)], 0)
+        self.net = net if self.net is None else torch.cat([self.net, net], 1)
+        self.target = torch.cat([self.target, target], 1)
+        self.weight = torch.cat([self.weight, weight], 1)
+
+    def rm_factors(self, mask, store=False):
+        mask = mask.to(self.ii.device)
+        self._uniq_cache = None
+        if store:
+            self.ii_inac = torch.cat([self.ii_inac, self.ii[mask]], 0)
+            self.jj_inac = torch.cat([self.jj_inac, self.jj[mask]], 0)
+            self.target_inac = torch.cat([self.target_inac, self.target[:, mask]], 1)
+            self.weight_inac = torch.cat([self.weight_inac, self.weight[:, mask]], 1)
+        keep = ~mask
+        self.ii, self.jj, self.age = self.ii[keep], self.jj[keep], self.age[keep]
+        if self.corr_impl == "volume" and self.corr is not None:
+            self.corr = self.corr[keep]
+        if self.net is not None:
+            self.net = self.net[:, keep]
+        if self.inp is not None:
+            self.inp = self.inp[:, keep]
+        self.target = self.target[:, keep]
+        self.weight = self.weight[:, keep]
+
+    def rm_keyframe(self, ix):
+        v = self.video
+        with v.get_lock():
+            for name in ("timestamp", "images", "dirty", "npc_dirty", "poses", "disps", "disps_up",
+                         "intrinsics", "depth_scale", "depth_shift", "mono_disps", "valid_depth_mask",
+                         "valid_depth_mask_small", "nets", "inps", "fmaps"):
+                buf = getattr(v, name)
+                if buf.shape[0] > ix + 1:
+                    buf[ix] = buf[ix + 1]
+        m = (self.ii_inac == ix) | (self.jj_inac == ix)
+        self.ii_inac[self.ii_inac >= ix] -= 1
+        self.jj_inac[self.jj_inac >= ix] -= 1
+        if torch.any(m):
+            self.ii_inac, self.jj_inac = self.ii_inac[~m], self.jj_inac[~m]
+            self.target_inac, self.weight_inac = self.target_inac[:, ~m], self.weight_inac[:, ~m]
+        m = (self.ii == ix) | (self.jj == ix)
+        self.ii[self.ii >= ix] -= 1
+        self.jj[self.jj >= ix] -= 1
+        self.rm_factors(m, store=False)
+
+    # ---- one BA-update iteration -----------------------------------------------------
+    def _motion(self, coords1):
+        motn = torch.cat([coords1 - self.coords0, self.target - coords1], dim=-1)
+        return motn.permute(0, 1, 4, 2, 3).clamp(-64.0, 64.0)
+
+    @torch.no_grad()
+    def update(self, t0=None, t1=None, itrs=2, use_inactive=False, EP=1e-7, motion_only=False,
+               opt_type="pose_depth"):
+        """factor_graph.py:212-256"""
+        coords1, mask = self.video.reproject(self.ii, self.jj)
+        motn = self._motion(coords1)
+        corr = self.corr(coords1)
+        with torch.autocast("cuda", enabled=True):
+            self.net, delta, weight, damping, upmask = \
+                self.update_op(self.net, self.inp, corr, motn, self.ii, self.jj)
+        uniq = self._unique_ii()
+        if t0 is None:
+            t0 = max(1, self._uniq_cache[2] + 1)
+        self.target = coords1 + delta.to(dtype=torch.float)
+        self.weight = weight.to(dtype=torch.float)
+        self.damping[uniq] = damping
+        if use_inactive:
+            m = (self.ii_inac >= t0 - 3) & (self.jj_inac >= t0 - 3)
+            ii = torch.cat([self.ii_inac[m], self.ii], 0)
+            jj = torch.cat([self.jj_inac[m], self.jj], 0)
+            target = torch.cat([self.target_inac[:, m], self.target], 1)
+            weight = torch.cat([self.weight_inac[:, m], self.weight], 1)
+            uq = torch.unique(ii)
+        else:
+            ii, jj, target, weight, uq = self.ii, self.jj, self.target, self.weight, uniq
+        damping = .2 * self.damping[uq].contiguous() + EP
+        self.video.ba(target, weight, damping, ii, jj, t0, t1, iters=itrs, lm=1e-4, ep=0.1,
+                      motion_only=motion_only, opt_type=opt_type)
+        self.video.upsample(uniq, upmask)
+        self.age += 1
+
+    @torch.no_grad()
+    def update_lowmem(self, t0=None, t1=None, itrs=2, use_inactive=False, EP=1e-7, steps=8,
+                      enable_wq=True):
+        """factor_graph.py:259-309 -- alt-corr, 8 source frames per chunk"""
+        num, rig, ch, ht, wd = self.video.fmaps.shape
+        corr_op = AltCorrBlock(self.video.fmaps.view(1, num * rig, ch, ht, wd))
+        hjj = self._host(self.jj)
+        hii = self._host(self.ii)
+        for step in range(steps):
+            coords1, mask = self.video.reproject(self.ii, self.jj)
+            motn = self._motion(coords1)
+            s = 8
+            for i in range(0, int(hjj.max()) + 1, s):
+                vh = (hii >= i) & (hii < i + s)
+                if vh.sum() < 1:
+                    continue
+                v = torch.as_tensor(vh, device=self.device)
+                iis, jjs = self.ii[v], self.jj[v]
+                corr1 = corr_op(coords1[:, v], rig * iis, rig * jjs + (iis == jjs).long())
+                uq = torch.unique(iis)
+                with torch.autocast("cuda", enabled=True):
+                    net, delta, weight, damping, upmask = \
+                        self.update_op(self.net[:, v], self.video.inps[None, iis], corr1, motn[:, v], iis, jjs)
+                self.video.upsample(uq, upmask, softmax_f32=True)
+                self.net[:, v] = net
+                self.target[:, v] = coords1[:, v] + delta.float()
+                self.weight[:, v] = weight.float()
+                self.damping[uq] = damping
+            damping = .2 * self.damping[self._unique_ii()].contiguous() + EP
+            opt_type = ("pose_depth" if step % 2 == 0 else "depth_scale") if enable_wq else "pose_depth"
+            self.video.ba(self.target, self.weight, damping, self.ii, self.jj, t0, t1, iters=itrs,
+                          lm=1e-5, ep=1e-2, motion_only=False, opt_type=opt_type)
+
+    # ---- topology --------------------------------------------------------------------
+    def add_neighborhood_factors(self, t0, t1, r=3):
+        ii, jj = torch.meshgrid(torch.arange(t0, t1), torch.arange(t0, t1), indexing="ij")
+        ii = ii.reshape(-1).to(dtype=torch.long, device=self.device)
+        jj = jj.reshape(-1).to(dtype=torch.long, device=self.device)
+        keep = ((ii - jj).abs() > 0) & ((ii - jj).abs() <= r)
+        self.add_factors(ii[keep], jj[keep])
+
+    def add_proximity_factors(self, t0=0, t1=0, rad=2, nms=2, beta=0.25, thresh=16.0, remove=False):
+        """factor_graph.py:323-383 -- distance-sorted edge proposal with NMS suppression"""
+        t = self.video.counter.value
+        ii, jj = np.meshgrid(np.arange(t0, t), np.arange(t1, t), indexing="ij")
+        ii, jj = ii.reshape(-1), jj.reshape(-1)
+        d = self.video.distance(ii, jj, beta=beta).cpu().numpy().astype(np.float32)
+        d[ii - rad < jj] = np.inf
+        d[d > 100] = np.inf
+        wj = t - t1
+
+        def suppress(i, j):
+            lim = max(min(abs(i - j) - 2, nms), 0)
+            for di in range(-nms, nms + 1):
+                for dj in range(-nms, nms + 1):
+                    if abs(di) + abs(dj) <= lim:
+                        i1, j1 = i + di, j + dj
+                        if t0 <= i1 < t and t1 <= j1 < t:
+                            d[(i1 - t0) * wj + (j1 - t1)] = np.inf
+
+        ii1 = np.concatenate([self._host(self.ii), self._host(self.ii_bad), self._host(self.ii_inac)])
+        jj1 = np.concatenate([self._host(self.jj), self._host(self.jj_bad), self._host(self.jj_inac)])
+        for i, j in zip(ii1.tolist(), jj1.tolist()):
+            suppress(i, j)
+        es = []
+        for i in range(t0, t):
+            for j in range(max(i - rad - 1, 0), i):
+                es.append((i, j))
+                es.append((j, i))
+                d[(i - t0) * wj + (j - t1)] = np.inf
+        # torch.argsort on the device is not stable; ties are broken by index here
+        for k in np.argsort(d, kind="stable"):
+            if d[k] > thresh:
+                continue
+            if len(es) > self.max_factors:
+                break
+            i, j = int(ii[k]), int(jj[k])
+            es.append((i, j))
+            es.append((j, i))
+            suppress(i, j)
+        ei, ej = torch.as_tensor(es, device=self.device).unbind(dim=-1)
+        self.add_factors(ei, ej, remove)
+
+    def add_backend_proximity_factors(self, t_start, t_end, nms, radius, thresh, max_factors, beta,
+                                      t_start_loop=None, loop=False):
+        """factor_graph.py:386-462"""
+        if t_start_loop is None or not loop:
+            t_start_loop = t_start
+        assert t_start_loop >= t_start, f'short: {t_start_loop}, long: {t_start}.'
+        ilen, jlen = t_end - t_start_loop, t_end - t_start
+        ii, jj = np.meshgrid(np.arange(t_start_loop, t_end), np.arange(t_start, t_end), indexing="ij")
+        ii, jj = ii.reshape(-1), jj.reshape(-1)
+        d = self.video.distance(ii, jj, beta=beta).cpu().numpy().astype(np.float32)
+        rawd = d.copy().reshape(ilen, jlen)
+        d[ii - radius < jj] = np.inf
+        d[d > thresh] = np.inf
+        d = d.reshape(ilen, jlen)
+        es = []
+        for i in range(t_start_loop, t_end):
+            for j in range(max(i - radius - 1, 0), i):
+                es.append((i, j))
+                es.append((j, i))
+                d[i - t_start_loop, j - t_start] = np.inf
+        flat = d.reshape(-1)
+        order = np.argsort(flat, kind="stable")
+        order = order[flat[order] <= thresh]
+        loop_edges = 0
+        nn = 1
+        for k in order.tolist():
+            di, dj = k // jlen, k % jlen
+            if d[di, dj] > thresh:
+                continue
+            if len(es) > max_factors:
+                break
+            i, j = int(ii[k]), int(jj[k])
+            if loop:
+                sub = []
+                for si in range(max(i - nn, t_start_loop), min(i + nn + 1, t_end)):
+                    for sj in range(max(j - nn, t_start), min(j + nn + 1, t_end)):
+                        if rawd[si - t_start_loop, sj - t_start] <= thresh and si != sj and si - sj > 20:
+                            sub.append((si, sj))
+                es += sub
+                loop_edges += len(sub)
+            else:
+                es += [(i, j), (j, i)]
+            d[max(0, di - nms):min(ilen, di + nms + 1), max(0, dj - nms):min(jlen, dj + nms + 1)] = np.inf
+        if len(es) < 3 or (loop and loop_edges == 0):
+            return 0
+        ei, ej = torch.tensor(es, device=self.device).unbind(dim=-1)
+        self.add_factors(ei, ej, remove=True)
+        return len(self.ii)
