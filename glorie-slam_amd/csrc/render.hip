@@ -1,0 +1,134 @@
+// Neural-point renderer kernels (scope rows R2, R5) for gfx950: inverse-distance feature
+// interpolation over the k nearest neural points and per-ray alpha compositing.
+//
+// Reference behaviour restated from
+//   /root/reference/src/modules/conv_onet/models/decoder.py:130-173, 340-389  (get_feature_at_pos)
+//   /root/reference/src/utils/common.py:261-299                               (raw2outputs_nerf_color)
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <stdint.h>
+#include "common.hiph"
+
+namespace glorie {
+
+// ------------------------------------------------------------------------------------
+// IDW gather:  c[q] = sum_k w_k feats[I_k],  w = normalize_L1( [D<=r^2] / (D + 1e-10) )
+// One wave handles 2 samples: 32 lanes = the 32 feature channels of a 128-byte row, so
+// every neighbour row is one fully coalesced 128 B read (the gather unit SURVEY.md 8(d)
+// counts).  Lanes 0..7 of each half also carry the 8 (D, I) pairs.
+// ------------------------------------------------------------------------------------
+template <int K, int C>
+__global__ __launch_bounds__(256) void idw_gather_kernel(
+    const float* __restrict__ D, const int64_t* __restrict__ I, const int* __restrict__ nn,
+    const float* __restrict__ feats, int Q, float radius, const float* __restrict__ radius_ptr,
+    int min_nn, int expo_weighting, float* __restrict__ cout, float* __restrict__ wout,
+    uint8_t* __restrict__ has_out) {
+  static_assert(C == 32 && K <= 32, "layout assumes 32-channel features");
+  const int lane = threadIdx.x & 63;
+  const int half = lane >> 5, ch = lane & 31;
+  const int q = (blockIdx.x * 256 + threadIdx.x) / 32;
+  const bool live = q < Q;
+  const int qc = live ? q : Q - 1;
+  // lanes ch < K load one neighbour each
+  float d = FLT_MAX;
+  int idx = -1;
+  if (ch < K) {
+    d = D[(size_t)qc * K + ch];
+    idx = (int)I[(size_t)qc * K + ch];
+  }
+  const float r = radius_ptr ? radius_ptr[qc] : radius;
+  const float r2 = r * r;
+  float wgt = 0.0f;
+  if (ch < K && idx >= 0 && !(d > r2))
+    wgt = expo_weighting ? expf(-20.0f * sqrtf(d)) : 1.0f / (d + 1e-10f);
+  // L1 normalisation over the K lanes of this half (F.normalize(p=1, eps=1e-12))
+  float s = wgt;
+#pragma unroll
+  for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);  // stays inside the half
+  wgt = wgt / fmaxf(s, 1e-12f);
+  float acc = 0.0f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const float wk = __shfl(wgt, half * 32 + k, 64);
+    const int ik = __shfl(idx, half * 32 + k, 64);
+    if (wk != 0.0f) acc += wk * feats[(size_t)ik * C + ch];
+  }
+  if (!live) return;
+  const bool has = nn[q] > min_nn - 1;
+  // samples without enough neighbours get a N(0, 0.01) random feature in the reference
+  // (decoder.py:170-171); here they get zeros (their occupancy is forced to -100 anyway)
+  cout[(size_t)q * C + ch] = has ? acc : 0.0f;
+  if (wout && ch < K) wout[(size_t)q * K + ch] = wgt;
+  if (has_out && ch == 0) has_out[q] = has ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------
+// compositing: one lane per ray, S samples scanned in registers
+//   alpha = sigmoid(coef * occ), w_i = alpha_i * prod_{j<i} (1 - alpha_j + 1e-10)
+//   rgb = sum w rgb / (sum w + 1e-10), depth = sum w z / (sum w + 1e-10), var = sum w (z - depth)^2
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void composite_kernel(
+    const float* __restrict__ raw, const float* __restrict__ z_vals, int R, int S, float coef,
+    float* __restrict__ depth, float* __restrict__ var, float* __restrict__ rgb,
+    float* __restrict__ weights) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= R) return;
+  float T = 1.0f, wsum = 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f, dz = 0.0f;
+  for (int s = 0; s < S; ++s) {
+    const float4 v = reinterpret_cast<const float4*>(raw)[(size_t)r * S + s];
+    const float alpha = 1.0f / (1.0f + expf(-coef * v.w));
+    const float wgt = alpha * T;
+    T *= (1.0f - alpha + 1e-10f);
+    if (weights) weights[(size_t)r * S + s] = wgt;
+    wsum += wgt;
+    cr += wgt * v.x; cg += wgt * v.y; cb += wgt * v.z;
+    dz += wgt * z_vals[(size_t)r * S + s];
+  }
+  const float den = wsum + 1e-10f;
+  const float dm = dz / den;
+  rgb[(size_t)r * 3 + 0] = cr / den;
+  rgb[(size_t)r * 3 + 1] = cg / den;
+  rgb[(size_t)r * 3 + 2] = cb / den;
+  depth[r] = dm;
+  float vv = 0.0f;
+  T = 1.0f;
+  for (int s = 0; s < S; ++s) {
+    const float occ = raw[((size_t)r * S + s) * 4 + 3];
+    const float alpha = 1.0f / (1.0f + expf(-coef * occ));
+    const float wgt = alpha * T;
+    T *= (1.0f - alpha + 1e-10f);
+    const float t = z_vals[(size_t)r * S + s] - dm;
+    vv += wgt * t * t;
+  }
+  var[r] = vv;
+}
+
+}  // namespace glorie
+
+using namespace glorie;
+
+extern "C" int glorie_idw_gather(const float* D, const int64_t* I, const int* nn,
+                                 const float* feats, int Q, int k, int c_dim, float radius,
+                                 const float* radius_ptr, int min_nn, int expo_weighting,
+                                 float* c_out, float* w_out, uint8_t* has_out, void* stream) {
+  if (Q < 0) return GLORIE_EINVAL;
+  if (Q == 0) return GLORIE_OK;
+  if (!D || !I || !nn || !feats || !c_out) return GLORIE_EINVAL;
+  if (k != 8 || c_dim != 32) return GLORIE_EUNSUPPORTED;
+  const long threads = (long)Q * 32;
+  dim3 grid((unsigned)((threads + 255) / 256));
+  hipLaunchKernelGGL((idw_gather_kernel<8, 32>), grid, dim3(256), 0, (hipStream_t)stream, D, I, nn,
+                     feats, Q, radius, radius_ptr, min_nn, expo_weighting, c_out, w_out, has_out);
+  return check_launch();
+}
+
+extern "C" int glorie_composite(const float* raw, const float* z_vals, int R, int S, float coef,
+                                float* depth, float* var, float* rgb, float* weights,
+                                void* stream) {
+  if (R < 0 || S < 0) return GLORIE_EINVAL;
+  if (R == 0) return GLORIE_OK;
+  if (!raw || !z_vals || !depth || !var || !rgb) return GLORIE_EINVAL;
+  hipLaunchKernelGGL(composite_kernel, dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream, raw,
+                     z_vals, R, S, coef, depth, var, rgb, weights);
+  return check_launch();
+}

@@ -1,0 +1,266 @@
+"""Neural-point decoders (geometry + colour MLPs) -- host-side mirror of
+/root/reference/src/modules/conv_onet/models/decoder.py with identical module / parameter
+names (`geo_decoder.*`, `color_decoder.*`, so `middle_fine.pt` loads unchanged,
+mapper.py:105-121) and identical initialisation order under a fixed seed.
+
+What runs where: the neighbour search, the inverse-distance feature interpolation and the
+compositing are libglorie_hip kernels; ONE search serves both decoders (the reference runs
+the identical faiss query twice, decoder.py:136 and :346).  The dense layers are evaluated
+either by torch (autograd-capable path used by the mapper's optimisation loop) or by the
+fused MFMA kernel `point_ops.render_mlp` for inference.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+import torch.nn.init as init
+
+from . import point_ops
+
+
+class GaussianFourierFeatureTransform(nn.Module):
+    """decoder.py:8-37: x -> sin(2 pi x B) (optionally [sin, cos])"""
+
+    def __init__(self, num_input_channels, mapping_size=93, scale=25, learnable=False, concat=True):
+        super().__init__()
+        self.concat = concat
+        self.mapping_size = mapping_size
+        self.scale = scale
+        self.learnable = learnable
+        B = torch.randn((num_input_channels, mapping_size)) * scale
+        if learnable:
+            self._B = nn.Parameter(B)
+        else:
+            self._B = B  # plain attribute, like the reference (not part of the state dict)
+
+    def forward(self, x):
+        x = x.squeeze(0)
+        assert x.dim() == 2, f'Expected 2D input (got {x.dim()}D input)'
+        if self._B.device != x.device:
+            self._B = self._B.to(x.device) if not self.learnable else self._B
+        x = (2 * math.pi * x) @ self._B.to(x.device)
+        return torch.cat((torch.sin(x), torch.cos(x)), dim=-1) if self.concat else torch.sin(x)
+
+
+class DenseLayer(nn.Linear):
+    def __init__(self, in_dim, out_dim, activation="relu", *args, **kwargs):
+        self.activation = activation
+        super().__init__(in_dim, out_dim, *args, **kwargs)
+
+    def reset_parameters(self):
+        init.xavier_uniform_(self.weight, gain=init.calculate_gain(self.activation))
+        if self.bias is not None:
+            init.zeros_(self.bias)
+
+
+class Same(nn.Module):
+    def __init__(self, mapping_size=3):
+        super().__init__()
+        self.mapping_size = mapping_size
+
+    def forward(self, x):
+        return x.squeeze(0)
+
+
+class MLP_col_neighbor(nn.Module):
+    """F_theta of the paper (decoder.py:228-243)"""
+
+    def __init__(self, c_dim, embedding_size_rel, hidden_size):
+        super().__init__()
+        self.linear1 = nn.Linear(c_dim + embedding_size_rel, hidden_size)
+        self.linear2 = nn.Linear(hidden_size, c_dim)
+        self.act_fn = nn.Softplus(beta=100)
+        init.xavier_uniform_(self.linear1.weight)
+        init.xavier_uniform_(self.linear2.weight)
+
+    def forward(self, x):
+        return self.linear2(self.act_fn(self.linear1(x)))
+
+
+def _pts_linears(embedding_input, hidden, n_blocks, skips):
+    layers = [DenseLayer(embedding_input, hidden, activation="relu")]
+    for i in range(n_blocks - 1):
+        layers.append(DenseLayer(hidden + embedding_input if i in skips else hidden, hidden, activation="relu"))
+    return nn.ModuleList(layers)
+
+
+class _PointMLP(nn.Module):
+    """shared plumbing of the two decoders: neighbour lookup + IDW interpolation"""
+
+    def _neighbors(self, npc, p, dynamic_r_query, shared=None):
+        if shared is not None:
+            return shared
+        D, I, nn_num = npc.find_neighbors_faiss(p.detach().clone(), step='query',
+                                                dynamic_radius=dynamic_r_query)
+        return D, I, nn_num
+
+    def _weights(self, npc, D, neighbor_num, dynamic_r_query, is_tracker, cloud_pos, I, p):
+        bound = npc.get_radius_query() ** 2 if not self.use_dynamic_radius \
+            else dynamic_r_query.reshape(-1, 1) ** 2
+        if is_tracker:
+            D = torch.sum(torch.square(cloud_pos[I] - p.reshape(-1, 1, 3)), dim=-1)
+        has = neighbor_num > self.min_nn_num - 1
+        w = 1.0 / (D + 1e-10) if self.weighting == 'distance' else torch.exp(-20 * torch.sqrt(D))
+        w = torch.where(D > bound, torch.zeros_like(w), w)
+        return F.normalize(w, p=1, dim=1).unsqueeze(-1), has
+
+
+class MLP_geometry(_PointMLP):
+    """decoder.py:61-225"""
+
+    def __init__(self, cfg, c_dim=32, hidden_size=128, n_blocks=5, leaky=False, sample_mode='bilinear',
+                 skips=[2], pos_embedding_method='fourier', concat_feature=False,
+                 use_view_direction=False):
+        super().__init__()
+        self.feat_name = 'geometry_feat'
+        self.c_dim, self.concat_feature, self.n_blocks, self.skips = c_dim, concat_feature, n_blocks, skips
+        self.weighting = cfg['pointcloud']['nn_weighting']
+        self.use_dynamic_radius = cfg['pointcloud']['use_dynamic_radius']
+        self.min_nn_num = cfg['pointcloud']['min_nn_num']
+        self.N_surface = cfg['rendering']['N_surface']
+        self.use_view_direction = use_view_direction
+        if c_dim != 0:
+            self.fc_c = nn.ModuleList([nn.Linear(c_dim, hidden_size) for _ in range(n_blocks)])
+        embedding_size = 93
+        self.embedder = GaussianFourierFeatureTransform(3, mapping_size=embedding_size, scale=25,
+                                                        concat=False, learnable=True)
+        if self.use_view_direction:
+            self.embedder_view_direction = GaussianFourierFeatureTransform(3, mapping_size=embedding_size, scale=25)
+        self.embedder_rel_pos = GaussianFourierFeatureTransform(3, mapping_size=10, scale=32, learnable=True)
+        self.mlp_col_neighbor = MLP_col_neighbor(c_dim, 2 * self.embedder_rel_pos.mapping_size, hidden_size)
+        self.pts_linears = _pts_linears(embedding_size, hidden_size, n_blocks, skips)
+        self.output_linear = DenseLayer(hidden_size, 1, activation="relu")
+        self.actvn = nn.Softplus(beta=100) if not leaky else (lambda x: F.leaky_relu(x, 0.2))
+        self.sample_mode = sample_mode
+
+    def get_feature_at_pos(self, npc, p, npc_feats, is_tracker=False, cloud_pos=None,
+                           dynamic_r_query=None, shared=None):
+        p = p.reshape(-1, 3)
+        D, I, neighbor_num = self._neighbors(npc, p, dynamic_r_query, shared)
+        if D.is_cuda and not is_tracker and not npc_feats.requires_grad and self.weighting == 'distance':
+            radius = 0.0 if self.use_dynamic_radius else npc.get_radius_query()
+            c, has = point_ops.idw_gather(D, I, neighbor_num, npc_feats, radius=radius,
+                                          radius_per_query=dynamic_r_query if self.use_dynamic_radius else None,
+                                          min_nn=self.min_nn_num)
+            return c, has
+        w, has = self._weights(npc, D, neighbor_num, dynamic_r_query, is_tracker, cloud_pos, I, p)
+        c = (w * npc_feats[I]).sum(axis=1).reshape(-1, self.c_dim)
+        c = torch.where(has[:, None], c, torch.zeros_like(c))
+        return c, has
+
+    def forward(self, p, npc, npc_geo_feats, pts_num=16, is_tracker=False, cloud_pos=None,
+                pts_views_d=None, dynamic_r_query=None, shared=None):
+        c, has = self.get_feature_at_pos(npc, p, npc_geo_feats, is_tracker, cloud_pos,
+                                         dynamic_r_query=dynamic_r_query, shared=shared)
+        per_ray = torch.sum(has.view(-1, pts_num), 1)
+        valid_ray_mask = ~(per_ray < 3)
+        emb = self.embedder(p.float().reshape(1, -1, 3))
+        h = emb
+        for i, lin in enumerate(self.pts_linears):
+            h = F.relu(lin(h))
+            if self.c_dim != 0:
+                h = h + self.fc_c[i](c)
+            if i in self.skips:
+                h = torch.cat([emb, h], -1)
+        return self.output_linear(h).squeeze(-1), valid_ray_mask, has, per_ray
+
+
+class MLP_color(_PointMLP):
+    """decoder.py:265-433"""
+
+    def __init__(self, cfg, c_dim=32, hidden_size=128, n_blocks=5, leaky=False, sample_mode='bilinear',
+                 skips=[2], pos_embedding_method='fourier', concat_feature=False,
+                 use_view_direction=False):
+        super().__init__()
+        self.feat_name = 'color_feat'
+        self.c_dim, self.concat_feature, self.n_blocks, self.skips = c_dim, concat_feature, n_blocks, skips
+        self.weighting = cfg['pointcloud']['nn_weighting']
+        self.min_nn_num = cfg['pointcloud']['min_nn_num']
+        self.use_dynamic_radius = cfg['pointcloud']['use_dynamic_radius']
+        self.N_surface = cfg['rendering']['N_surface']
+        self.use_view_direction = use_view_direction
+        self.encode_rel_pos_in_col = cfg['model']['encode_rel_pos_in_col']
+        self.encode_viewd = cfg['model']['encode_viewd']
+        if c_dim != 0:
+            self.fc_c = nn.ModuleList([nn.Linear(c_dim, hidden_size) for _ in range(n_blocks)])
+        embedding_size = 20
+        self.embedder = GaussianFourierFeatureTransform(3, mapping_size=embedding_size, scale=32)
+        if self.use_view_direction:
+            if self.encode_viewd:
+                self.embedder_view_direction = GaussianFourierFeatureTransform(3, mapping_size=embedding_size, scale=32)
+            else:
+                self.embedder_view_direction = Same(mapping_size=3)
+        self.embedder_rel_pos = GaussianFourierFeatureTransform(3, mapping_size=10, scale=32, learnable=True)
+        self.mlp_col_neighbor = MLP_col_neighbor(c_dim, 2 * self.embedder_rel_pos.mapping_size, hidden_size)
+        embedding_input = 2 * embedding_size
+        if self.use_view_direction:
+            embedding_input += (2 if self.encode_viewd else 1) * self.embedder_view_direction.mapping_size
+        self.pts_linears = _pts_linears(embedding_input, hidden_size, n_blocks, skips)
+        self.output_linear = DenseLayer(hidden_size, 3, activation="linear")
+        self.actvn = nn.Softplus(beta=100) if not leaky else (lambda x: F.leaky_relu(x, 0.2))
+        self.sample_mode = sample_mode
+
+    def get_feature_at_pos(self, npc, p, npc_feats, is_tracker=False, cloud_pos=None,
+                           dynamic_r_query=None, shared=None):
+        p = p.reshape(-1, 3)
+        D, I, neighbor_num = self._neighbors(npc, p, dynamic_r_query, shared)
+        w, has = self._weights(npc, D, neighbor_num, dynamic_r_query, is_tracker, cloud_pos, I, p)
+        feats = npc_feats[I.clamp(min=0)]
+        if self.encode_rel_pos_in_col:
+            if cloud_pos is None:
+                cloud_pos = npc.cloud_pos()
+            rel = cloud_pos[I.clamp(min=0)] - p[:, None, :]
+            emb = self.embedder_rel_pos(rel.reshape(-1, 3)).reshape(rel.shape[0], -1, 2 * self.embedder_rel_pos.mapping_size)
+            feats = self.mlp_col_neighbor(torch.cat([emb, feats], dim=-1))
+        c = (w * feats).sum(axis=1).reshape(-1, self.c_dim)
+        c = torch.where(has[:, None], c, torch.zeros_like(c))
+        return c, has
+
+    def forward(self, p, npc, npc_col_feats, is_tracker=False, cloud_pos=None, pts_views_d=None,
+                dynamic_r_query=None, shared=None):
+        c, _ = self.get_feature_at_pos(npc, p, npc_col_feats, is_tracker, cloud_pos,
+                                       dynamic_r_query=dynamic_r_query, shared=shared)
+        emb = self.embedder(p.float().reshape(1, -1, 3))
+        if self.use_view_direction:
+            v = F.normalize(pts_views_d, p=2, dim=1)
+            emb = torch.cat([emb, self.embedder_view_direction(v)], -1)
+        h = emb
+        for i, lin in enumerate(self.pts_linears):
+            h = self.actvn(lin(h))
+            if self.c_dim != 0:
+                h = h + self.fc_c[i](c)
+            if i in self.skips:
+                h = torch.cat([emb, h], -1)
+        return torch.sigmoid(self.output_linear(h))
+
+
+class POINT(nn.Module):
+    """decoder.py:436-501.  `forward` keeps the reference signature and return values."""
+
+    def __init__(self, cfg, c_dim=32, hidden_size=128, pos_embedding_method='fourier',
+                 use_view_direction=False):
+        super().__init__()
+        self.geo_decoder = MLP_geometry(cfg=cfg, c_dim=c_dim, skips=[2], n_blocks=5, hidden_size=32,
+                                        pos_embedding_method=pos_embedding_method).eval()
+        self.color_decoder = MLP_color(cfg=cfg, c_dim=c_dim, skips=[2], n_blocks=5, hidden_size=hidden_size,
+                                       pos_embedding_method=pos_embedding_method,
+                                       use_view_direction=use_view_direction)
+
+    def forward(self, p, npc, stage, npc_geo_feats, npc_col_feats, pts_num=16, is_tracker=False,
+                cloud_pos=None, pts_views_d=None, dynamic_r_query=None):
+        pp = p.reshape(-1, 3)
+        # one neighbour search shared by both decoders
+        shared = npc.find_neighbors_faiss(pp.detach().clone(), step='query', dynamic_radius=dynamic_r_query)
+        geo_occ, ray_mask, point_mask, ray_counter = self.geo_decoder(
+            p, npc, npc_geo_feats, pts_num=pts_num, is_tracker=is_tracker, cloud_pos=cloud_pos,
+            dynamic_r_query=dynamic_r_query, shared=shared)
+        if stage == 'geometry':
+            raw = torch.zeros(geo_occ.shape[0], 4, device=p.device, dtype=torch.float)
+            raw[..., -1] = geo_occ
+            return raw, ray_mask, point_mask, ray_counter
+        if stage == 'color':
+            rgb = self.color_decoder(p, npc, npc_col_feats, is_tracker=is_tracker, cloud_pos=cloud_pos,
+                                     pts_views_d=pts_views_d, dynamic_r_query=dynamic_r_query, shared=shared)
+            return torch.cat([rgb, geo_occ.unsqueeze(-1)], dim=-1), ray_mask, point_mask, ray_counter
+        raise ValueError(stage)

@@ -1,0 +1,124 @@
+"""Renderer: per-ray sampling + decoder evaluation + compositing (scope rows R4-R7) -- mirror
+of /root/reference/src/utils/Renderer.py (`render_batch_ray`, `eval_points`, `render_img`).
+
+The reference evaluates 3000 rays per call to stay inside faiss limits (Renderer.py:7,267);
+here the whole image goes through in `ray_batch_size` = 65536-ray chunks by default.
+"""
+import warnings
+
+import torch
+
+from .common import get_rays, raw2outputs_nerf_color
+
+
+class Renderer(object):
+    def __init__(self, cfg, slam, points_batch_size=2 ** 22, ray_batch_size=65536):
+        self.ray_batch_size = ray_batch_size
+        self.points_batch_size = points_batch_size
+        r = cfg['rendering']
+        self.N_surface = r['N_surface']
+        self.near_end_surface = r['near_end_surface']
+        self.far_end_surface = r['far_end_surface']
+        self.sample_near_pcl = r['sample_near_pcl']
+        self.sigmoid_coefficient = r['sigmoid_coef']
+        self.near_end = r['near_end']
+        self.use_dynamic_radius = cfg['pointcloud']['use_dynamic_radius']
+        self.H, self.W, self.fx, self.fy, self.cx, self.cy = slam.H, slam.W, slam.fx, slam.fy, slam.cx, slam.cy
+
+    def eval_points(self, p, decoders, npc, stage='color', device=None, npc_geo_feats=None,
+                    npc_col_feats=None, is_tracker=False, cloud_pos=None, pts_views_d=None,
+                    ray_pts_num=None, dynamic_r_query=None):
+        rets, ray_masks, point_masks, counters = [], [], [], []
+        bs = self.points_batch_size - self.points_batch_size % max(ray_pts_num or 1, 1)
+        for s in range(0, p.shape[0], bs):
+            sl = slice(s, s + bs)
+            ret, vm, pm, cnt = decoders(p[sl].unsqueeze(0), npc, stage, npc_geo_feats, npc_col_feats,
+                                        ray_pts_num, is_tracker, cloud_pos,
+                                        pts_views_d[sl] if pts_views_d is not None else None,
+                                        dynamic_r_query[sl] if dynamic_r_query is not None else None)
+            ret = ret.squeeze(0)
+            if ret.dim() == 1 and ret.shape[0] == 4:
+                ret = ret.unsqueeze(0)
+            rets.append(ret); ray_masks.append(vm); point_masks.append(pm); counters.append(cnt)
+        return torch.cat(rets, 0), torch.cat(ray_masks, 0), torch.cat(point_masks, 0), torch.cat(counters)
+
+    def sample_z(self, npc, rays_o, rays_d, gt_depth, device):
+        """z_vals [R,S] and the near-cloud mask (Renderer.py:106-174)"""
+        S = self.N_surface
+        R = rays_o.shape[0]
+        if gt_depth is not None:
+            far = torch.minimum(5 * gt_depth.mean(), torch.max(gt_depth * 1.2)).repeat(R, 1).float()
+            if torch.numel(gt_depth) != 0:
+                gt_depth = gt_depth.reshape(-1, 1)
+            else:
+                warnings.warn('tensor gt_depth is empty')
+                gt_depth = torch.zeros(R, 1, device=device)
+        else:
+            far = 10 * torch.ones((R, 1), device=device).float()
+            gt_depth = torch.zeros(R, 1, device=device)
+        nz = (gt_depth > 0).squeeze(-1)
+        near_mask = torch.ones(R, device=device, dtype=torch.bool)
+        t = torch.linspace(0.0, 1.0, steps=S, device=device)
+        z = self.near_end_surface * gt_depth * (1. - t) + self.far_end_surface * gt_depth * t
+        z = torch.where(nz[:, None], z, torch.zeros_like(z))
+        if int(nz.sum()) < R:
+            if self.sample_near_pcl:
+                z0, not_near = npc.sample_near_pcl(rays_o[~nz].detach().clone(), rays_d[~nz].detach().clone(),
+                                                   self.near_end, torch.max(far), S)
+                if torch.sum(not_near.ravel()):
+                    near_mask[torch.nonzero(~nz, as_tuple=True)[0][not_near]] = False
+                z[~nz] = z0
+            else:
+                z[~nz] = torch.linspace(self.near_end, torch.max(far), steps=S, device=device).repeat((~nz).sum(), 1)
+        return z, near_mask, nz
+
+    def render_batch_ray(self, npc, decoders, rays_d, rays_o, device, stage, gt_depth=None,
+                         npc_geo_feats=None, npc_col_feats=None, is_tracker=False, cloud_pos=None,
+                         dynamic_r_query=None):
+        """Renderer.py:80-219 -> depth, uncertainty, color, valid_ray_mask, valid_ray_counts"""
+        S = self.N_surface
+        R = rays_o.shape[0]
+        z_vals, near_mask, nz = self.sample_z(npc, rays_o, rays_d, gt_depth, device)
+        pts = (rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]).reshape(-1, 3)
+        rays_d_pts = rays_d.repeat_interleave(S, dim=0).reshape(-1, 3)
+        if self.use_dynamic_radius:
+            dynamic_r_query = dynamic_r_query.reshape(-1, 1).repeat_interleave(S, dim=0)
+        raw, valid_ray_mask, point_mask, counts = self.eval_points(
+            pts, decoders, npc, stage, device, npc_geo_feats, npc_col_feats, is_tracker, cloud_pos,
+            rays_d_pts, ray_pts_num=S, dynamic_r_query=dynamic_r_query)
+        with torch.no_grad():
+            raw[torch.nonzero(~point_mask).flatten(), -1] = -100.0
+        raw = raw.reshape(R, S, -1)
+        depth, uncertainty, color, _ = raw2outputs_nerf_color(raw, z_vals, rays_d, device=device,
+                                                              coef=self.sigmoid_coefficient)
+        valid_ray_mask = valid_ray_mask & near_mask
+        if not self.sample_near_pcl:
+            depth[~nz] = 0
+        return depth, uncertainty, color, valid_ray_mask, counts
+
+    @torch.no_grad()
+    def render_img(self, npc, decoders, c2w, device, stage, gt_depth=None, npc_geo_feats=None,
+                   npc_col_feats=None, dynamic_r_query=None, cloud_pos=None):
+        """Renderer.py:221-306"""
+        H, W = self.H, self.W
+        rays_o, rays_d = get_rays(H, W, self.fx, self.fy, self.cx, self.cy, c2w, device)
+        rays_o, rays_d = rays_o.reshape(-1, 3), rays_d.reshape(-1, 3)
+        if self.use_dynamic_radius:
+            dynamic_r_query = dynamic_r_query.reshape(-1, 1)
+        gt = gt_depth.reshape(-1) if gt_depth is not None else None
+        outs = [[], [], [], [], []]
+        bs = self.ray_batch_size
+        for i in range(0, rays_d.shape[0], bs):
+            ret = self.render_batch_ray(
+                npc, decoders, rays_d[i:i + bs], rays_o[i:i + bs], device, stage,
+                gt_depth=gt[i:i + bs] if gt is not None else None, npc_geo_feats=npc_geo_feats,
+                npc_col_feats=npc_col_feats, cloud_pos=cloud_pos,
+                dynamic_r_query=dynamic_r_query[i:i + bs] if self.use_dynamic_radius else None)
+            for o, v in zip(outs, ret):
+                o.append(v)
+        depth = torch.cat(outs[0]).double().reshape(H, W)
+        unc = torch.cat(outs[1]).double().reshape(H, W)
+        color = torch.cat(outs[2]).reshape(H, W, 3)
+        vmask = torch.cat(outs[3]).double().reshape(H, W)
+        vcount = torch.cat(outs[4]).double().reshape(H, W)
+        return depth, unc, color, vmask, vcount

@@ -145,6 +145,49 @@ int glorie_ba(glorie_ctx* ctx, float* poses, float* disps, const float* intrinsi
               float lm, float ep, int motion_only, int depth_only,
               float* dx_out, float* dz_out, void* stream);
 
+/* ------------------------------------------------------------------------------------ */
+/* C. neural point cloud renderer                                                        */
+/* ------------------------------------------------------------------------------------ */
+
+/* Search structure replacing the faiss index of NeuralPointCloud
+ *   reference: src/neural_point.py:56-60 (IndexIVFFlat construction), :104-116
+ *   (index_train / index_reset / index_add), :254-259, :441-444 (re-train + add).
+ * Builds a uniform cell list over `points` [np,3] entirely on the device.
+ * Caller-owned outputs: sorted_pos [np,4] f32 (x,y,z, original index bit-cast to f32),
+ * cell_start [max_cells+1] int32, grid: 64 bytes (origin, cell size, dims).
+ * cell_size is a hint; it is enlarged on the device until the grid fits max_cells (< 2^22). */
+int glorie_knn_build(glorie_ctx* ctx, const float* points, int np, float cell_size,
+                     int max_cells, float* sorted_pos, int* cell_start, void* grid,
+                     void* stream);
+
+/* NeuralPointCloud.find_neighbors_faiss(pos, step, ..., dynamic_radius) -> (D, I, neighbor_num)
+ *   reference: src/neural_point.py:264-313 (faiss IndexIVFFlat.search, k = nn_num = 8)
+ * EXACT squared-L2 top-k ordered by (distance, index) -- the faiss index is approximate and
+ * not reproducible, see DESIGN.md.  queries [Q,3]; radius scalar, or radius_ptr [Q] (per-query
+ * `dynamic_radius`) when non-NULL.  D [Q,k] f32 ascending, I [Q,k] int64 (-1 / FLT_MAX when
+ * fewer than k points exist, like faiss), nn [Q] int32 = #(D < r^2) (may be NULL). k in {1,4,8,16} */
+int glorie_knn_query(const float* sorted_pos, const int* cell_start, const void* grid,
+                     const float* queries, int Q, int k, float radius, const float* radius_ptr,
+                     float* D, int64_t* I, int* nn, void* stream);
+
+/* Feature interpolation of MLP_geometry/MLP_color.get_feature_at_pos
+ *   reference: src/modules/conv_onet/models/decoder.py:130-173 (geometry), :340-389 (colour)
+ * w = L1-normalise( [D <= r^2] / (D + 1e-10) )  (or exp(-20 sqrt(D)) when expo_weighting),
+ * c[q] = sum_k w_k feats[I_k]; has[q] = nn[q] >= min_nn.  Samples without enough neighbours
+ * get c = 0 (the reference draws N(0,0.01) noise there, decoder.py:170-171).
+ * c_out [Q,c_dim], w_out [Q,k] (may be NULL), has_out [Q] uint8 (may be NULL). k=8, c_dim=32. */
+int glorie_idw_gather(const float* D, const int64_t* I, const int* nn, const float* feats,
+                      int Q, int k, int c_dim, float radius, const float* radius_ptr,
+                      int min_nn, int expo_weighting, float* c_out, float* w_out,
+                      uint8_t* has_out, void* stream);
+
+/* raw2outputs_nerf_color(raw, z_vals, rays_d, coef)
+ *   reference: src/utils/common.py:261-299
+ * raw [R,S,4] (rgb, occupancy), z_vals [R,S] -> depth [R], var [R], rgb [R,3],
+ * weights [R,S] (may be NULL). */
+int glorie_composite(const float* raw, const float* z_vals, int R, int S, float coef,
+                     float* depth, float* var, float* rgb, float* weights, void* stream);
+
 /* Diagnostic: waits for `stream`, then copies the 4-int device status of the last glorie_ba
  * call on this context to host memory: [0] bit0 = M disagrees with the device-side count,
  * bit2 = a Cholesky factorisation failed (update zeroed, as the reference's

@@ -1,0 +1,223 @@
+"""Generates the golden fixtures under tests/golden/ by IMPORTING the reference's pure-PyTorch
+modules on CPU (this container only; /root/reference never travels to the GPU box).
+
+    python tests/golden/make_golden.py
+
+Absent native dependencies are replaced by inert stand-ins at import time (they are never
+executed by the functions captured here, except `torch_scatter.scatter_mean`, restated with
+index_add_ -- a one-line, documented stand-in for the pinned torch_scatter 2.1.0):
+    droid_backends  -> empty module          lietorch -> dummy SE3 / Sim3 names
+    skimage         -> dummy                 torch_scatter -> scatter_sum / scatter_mean
+
+Fixtures store INPUT SEEDS/arrays and EXPECTED OUTPUTS only (data, no reference source).
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def install_stubs():
+    db = types.ModuleType("droid_backends")
+    sys.modules["droid_backends"] = db
+    lt = types.ModuleType("lietorch")
+
+    class SE3:  # names only
+        pass
+
+    class Sim3:
+        pass
+
+    lt.SE3, lt.Sim3 = SE3, Sim3
+    sys.modules["lietorch"] = lt
+    ts = types.ModuleType("torch_scatter")
+
+    def scatter_sum(src, index, dim=-1, out=None, dim_size=None):
+        size = list(src.shape)
+        size[dim] = int(index.max()) + 1 if dim_size is None else dim_size
+        o = torch.zeros(size, dtype=src.dtype)
+        return o.index_add_(dim, index, src)
+
+    def scatter_mean(src, index, dim=-1, out=None, dim_size=None):
+        s = scatter_sum(src, index, dim, None, dim_size)
+        cnt = torch.bincount(index, minlength=s.shape[dim]).clamp(min=1).to(src.dtype)
+        shape = [1] * s.dim()
+        shape[dim] = -1
+        return s / cnt.view(shape)
+
+    ts.scatter_sum, ts.scatter_mean = scatter_sum, scatter_mean
+    sys.modules["torch_scatter"] = ts
+    sk = types.ModuleType("skimage")
+    skc = types.ModuleType("skimage.color")
+    skc.rgb2gray = None
+    sk.color = skc
+    sk.filters = types.ModuleType("skimage.filters")
+    sys.modules["skimage"] = sk
+    sys.modules["skimage.color"] = skc
+    sys.modules["skimage.filters"] = sk.filters
+    sys.path.insert(0, REF)
+
+
+def decoder_cfg():
+    return {"pointcloud": {"nn_weighting": "distance", "use_dynamic_radius": True, "min_nn_num": 2,
+                           "nn_num": 8, "radius_query": 0.08},
+            "rendering": {"N_surface": 10},
+            "model": {"encode_rel_pos_in_col": True, "encode_viewd": True, "c_dim": 32}}
+
+
+class BruteNPC:
+    """fake npc: exact squared-L2 top-8 ordered by (distance, index) -- what the build's KNN returns"""
+
+    def __init__(self, pos, radius_query=0.08):
+        self.pos = pos
+        self.rq = radius_query
+
+    def get_radius_query(self):
+        return self.rq
+
+    def cloud_pos(self):
+        return self.pos
+
+    def find_neighbors_faiss(self, p, step='query', retrain=False, is_pts_grad=False, dynamic_radius=None):
+        d = p[:, None, :] - self.pos[None]
+        D = (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
+        Dn = D.numpy()
+        order = np.lexsort((np.broadcast_to(np.arange(Dn.shape[1]), Dn.shape), Dn), axis=1)[:, :8]
+        I = torch.from_numpy(order)
+        Dk = torch.gather(D, 1, I)
+        r2 = dynamic_radius.reshape(-1, 1) ** 2 if dynamic_radius is not None else self.rq ** 2
+        return Dk, I, (Dk < r2).sum(-1).int()
+
+
+def main():
+    install_stubs()
+    torch.set_num_threads(4)
+    from src.modules.droid_net.corr import CorrBlock
+    from src.modules.droid_net.droid_net import UpdateModule, cvx_upsample, GraphAgg
+    from src.modules.droid_net.gru import ConvGRU
+    from src.utils.common import raw2outputs_nerf_color, align_scale_and_shift, get_rays, get_rays_from_uv
+    from src.modules.conv_onet.models.decoder import POINT
+    from src.geom.chol import schur_solve, block_solve
+
+    # F4: CorrBlock pyramid (fp32 CPU) -- pins /4 scaling, pooling, layout
+    g = torch.Generator().manual_seed(1)
+    f1 = torch.randn(1, 2, 16, 8, 8, generator=g)
+    f2 = torch.randn(1, 2, 16, 8, 8, generator=g)
+    cb = CorrBlock(f1, f2, num_levels=3, radius=3)
+    np.savez_compressed(os.path.join(OUT, "corr_pyramid.npz"), fmap1=f1.numpy(), fmap2=f2.numpy(),
+                        **{f"level{i}": v.numpy() for i, v in enumerate(cb.corr_pyramid)})
+
+    # F5: cvx_upsample
+    g = torch.Generator().manual_seed(2)
+    data = torch.rand(2, 5, 7, 1, generator=g)
+    mask = torch.randn(2, 576, 5, 7, generator=g) * 2
+    up = cvx_upsample(data, mask)
+    np.savez_compressed(os.path.join(OUT, "cvx_upsample.npz"), data=data.numpy(), mask=mask.numpy(), up=up.numpy())
+
+    # F1-F3: update operator, seed 43 default init, 3 edges at 8x10 with a repeated source frame
+    torch.manual_seed(43)
+    net = UpdateModule().eval()
+    g = torch.Generator().manual_seed(3)
+    N, h, w = 3, 8, 10
+    inp = dict(net=torch.tanh(torch.randn(1, N, 128, h, w, generator=g)),
+               inp=torch.relu(torch.randn(1, N, 128, h, w, generator=g)),
+               corr=torch.randn(1, N, 196, h, w, generator=g),
+               flow=torch.randn(1, N, 4, h, w, generator=g) * 3)
+    ii = torch.tensor([0, 0, 1])
+    jj = torch.tensor([1, 2, 0])
+    with torch.no_grad():
+        o_net, o_delta, o_weight, o_eta, o_up = net(inp["net"], inp["inp"], inp["corr"], inp["flow"], ii, jj)
+        gru_only = net.gru(inp["net"][0], inp["inp"][0], inp["corr"][0, :, :128], inp["flow"][0, :, :1].repeat(1, 64, 1, 1))
+    psum = float(sum(p.double().abs().sum() for p in net.parameters()))
+    np.savez_compressed(os.path.join(OUT, "update_module.npz"), ii=ii.numpy(), jj=jj.numpy(),
+                        net=o_net.numpy().astype(np.float32), delta=o_delta.numpy(), weight=o_weight.numpy(),
+                        eta=o_eta.numpy(), upmask=o_up.numpy().astype(np.float16), gru=gru_only.numpy(),
+                        param_abs_sum=np.float64(psum),
+                        nparams=np.int64(sum(p.numel() for p in net.parameters())))
+
+    # F6: schur_solve / block_solve incl. a failing (non-PD) case
+    g = torch.Generator().manual_seed(4)
+    B, P, M, D, HW = 1, 3, 4, 2, 12
+    A = torch.randn(B, P * D, P * D + 6, generator=g)
+    H = (A @ A.transpose(1, 2) + 0.5 * torch.eye(P * D)).view(B, P, D, P, D).permute(0, 1, 3, 2, 4).contiguous()
+    E = torch.randn(B, P, M, D, HW, generator=g) * 0.1
+    C = torch.rand(B, M, HW, generator=g) + 1.0
+    v = torch.randn(B, P, D, generator=g)
+    wv = torch.randn(B, M, HW, generator=g)
+    dx, dz = schur_solve(H, E, C, v, wv, ep=0.1, lm=1e-4)
+    xb = block_solve(H, v, ep=0.1, lm=1e-4)
+    Hbad = -H
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        dx_bad, dz_bad = schur_solve(Hbad, E, C, v, wv, ep=0.1, lm=1e-4)
+    np.savez_compressed(os.path.join(OUT, "schur_solve.npz"), H=H.numpy(), E=E.numpy(), C=C.numpy(), v=v.numpy(),
+                        w=wv.numpy(), dx=dx.numpy(), dz=dz.numpy(), block_x=xb.numpy(),
+                        dx_bad=dx_bad.numpy(), dz_bad=dz_bad.numpy())
+
+    # F7: compositing
+    g = torch.Generator().manual_seed(5)
+    raw = torch.cat([torch.rand(40, 10, 3, generator=g), torch.randn(40, 10, 1, generator=g) * 30], -1)
+    raw[::7, :, -1] = -100.0
+    z = torch.sort(torch.rand(40, 10, generator=g) * 3 + 0.5, dim=-1).values
+    rd = torch.randn(40, 3, generator=g)
+    depth, var, rgb, wts = raw2outputs_nerf_color(raw.clone(), z, rd, device='cpu', coef=0.1)
+    np.savez_compressed(os.path.join(OUT, "raw2outputs.npz"), raw=raw.numpy(), z=z.numpy(), rays_d=rd.numpy(),
+                        depth=depth.numpy(), var=var.numpy(), rgb=rgb.numpy(), weights=wts.numpy())
+
+    # F8: align_scale_and_shift
+    g = torch.Generator().manual_seed(6)
+    pred = torch.rand(3, 9, 11, generator=g) + 0.2
+    tgt = pred * torch.tensor([1.5, 0.7, 2.0])[:, None, None] + torch.tensor([0.1, -0.05, 0.3])[:, None, None] \
+        + 0.01 * torch.randn(3, 9, 11, generator=g)
+    wts = (torch.rand(3, 9, 11, generator=g) > 0.3)
+    s, q, e = align_scale_and_shift(pred, tgt, wts)
+    np.savez_compressed(os.path.join(OUT, "align.npz"), pred=pred.numpy(), tgt=tgt.numpy(), wts=wts.numpy(),
+                        scale=s.numpy(), shift=q.numpy(), err=e.numpy())
+
+    # F10: rays
+    c2w = torch.eye(4)
+    c2w[:3, :3] = torch.tensor([[0.0, 0.0, -1.0], [-1.0, 0.0, 0.0], [0.0, 1.0, 0.0]])
+    c2w[:3, 3] = torch.tensor([0.3, -0.2, 1.0])
+    ro, rd = get_rays(6, 8, 10.0, 11.0, 3.5, 2.5, c2w, 'cpu')
+    uo, ud = get_rays_from_uv(torch.tensor([1.0, 5.0]), torch.tensor([2.0, 0.0]), c2w, 10.0, 11.0, 3.5, 2.5, 'cpu')
+    np.savez_compressed(os.path.join(OUT, "rays.npz"), c2w=c2w.numpy(), rays_o=ro.numpy(), rays_d=rd.numpy(),
+                        uv_o=uo.numpy(), uv_d=ud.numpy())
+
+    # F9: decoders (POINT, stage 'color') on a small cloud with the exact-KNN fake npc.
+    cfg = decoder_cfg()
+    torch.manual_seed(43)
+    dec = POINT(cfg, c_dim=32, hidden_size=128, use_view_direction=True).eval()
+    # POINT.forward builds f'cuda:{p.get_device()}'; on CPU get_device() is -1 -> patch torch.zeros device
+    g = torch.Generator().manual_seed(7)
+    cloud = torch.rand(600, 3, generator=g) * torch.tensor([1.0, 1.0, 0.05])
+    geo = torch.randn(600, 32, generator=g) * 0.1
+    col = torch.randn(600, 32, generator=g) * 0.1
+    R, S = 12, 10
+    p = torch.rand(R * S, 3, generator=g) * torch.tensor([1.0, 1.0, 0.08])
+    p[:S] += 5.0  # one ray far from the cloud -> no neighbours
+    views = torch.randn(R * S, 3, generator=g)
+    rad = torch.rand(R * S, 1, generator=g) * 0.08 + 0.06
+    npc = BruteNPC(cloud)
+    with torch.no_grad():
+        occ, ray_mask, point_mask, counter = dec.geo_decoder(p[None], npc, geo, pts_num=S, dynamic_r_query=rad)
+        torch.manual_seed(0)
+        rgb = dec.color_decoder(p[None], npc, col, cloud_pos=cloud, pts_views_d=views, dynamic_r_query=rad)
+    sd = {k: v.numpy() for k, v in dec.state_dict().items()}
+    np.savez_compressed(os.path.join(OUT, "decoders.npz"), cloud=cloud.numpy(), geo=geo.numpy(), col=col.numpy(),
+                        p=p.numpy(), views=views.numpy(), radius=rad.numpy(), occ=occ.numpy(), rgb=rgb.numpy(),
+                        ray_mask=ray_mask.numpy(), point_mask=point_mask.numpy(), counter=counter.numpy(),
+                        color_B_pos=dec.color_decoder.embedder._B.numpy(),
+                        color_B_view=dec.color_decoder.embedder_view_direction._B.numpy(),
+                        **{"sd__" + k: v for k, v in sd.items()})
+    for f in sorted(os.listdir(OUT)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KB")
+
+
+if __name__ == "__main__":
+    main()

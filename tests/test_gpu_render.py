@@ -1,0 +1,186 @@
+"""Parity of the renderer kernels (exact KNN, IDW gather, compositing, decoders) with the
+oracle and with the golden fixtures minted from the reference's decoder."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import knn as oknn
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _index(gpu, pts, cell=0.08, max_cells=1 << 18):
+    from glorie_slam_amd.point_ops import KnnIndex
+    idx = KnnIndex(gpu, cell_size=cell, max_cells=max_cells)
+    idx.set_points(torch.from_numpy(pts).to(gpu))
+    return idx
+
+
+def _check_knn(gpu, pts, q, cell=0.08, max_cells=1 << 18, radius=0.1):
+    idx = _index(gpu, pts, cell, max_cells)
+    D, I, nn = idx.search(torch.from_numpy(q).to(gpu), 8, radius=radius)
+    rD, rI = oknn.knn_bruteforce(pts, q, 8)
+    assert np.array_equal(I.cpu().numpy(), rI), "KNN indices differ from the exact oracle"
+    assert np.array_equal(D.cpu().numpy(), rD), "KNN distances differ"
+    assert np.array_equal(nn.cpu().numpy(), oknn.neighbor_count(rD, np.float32(radius)))
+    return idx
+
+
+def test_knn_uniform_cloud_bit_exact(gpu):
+    rng = np.random.default_rng(0)
+    pts = rng.uniform(-1, 1, (5000, 3)).astype(np.float32)
+    q = rng.uniform(-1.2, 1.2, (3000, 3)).astype(np.float32)
+    q[:5] = pts[:5]                      # exact hits (distance 0)
+    q[5:10] = (50.0, -30.0, 7.0)         # far outside the grid
+    _check_knn(gpu, pts, q)
+
+
+def test_knn_surface_cloud_and_dynamic_radius(gpu):
+    import glorie_slam_amd.synth as synth
+    pts, _, _ = synth.box_cloud(n_hits=4000)
+    rng = np.random.default_rng(1)
+    sel = rng.integers(0, len(pts), 2500)
+    q = (pts[sel] * rng.uniform(0.93, 1.07, (2500, 1))).astype(np.float32)
+    idx = _check_knn(gpu, pts, q, cell=0.1)
+    rad = rng.uniform(0.02, 0.3, 2500).astype(np.float32)
+    D, I, nn = idx.search(torch.from_numpy(q).to(gpu), 8, radius_per_query=torch.from_numpy(rad).to(gpu))
+    rD, rI = oknn.knn_bruteforce(pts, q, 8)
+    assert np.array_equal(nn.cpu().numpy(), oknn.neighbor_count(rD, rad))
+
+
+def test_knn_ties_duplicates_and_tiny_clouds(gpu):
+    rng = np.random.default_rng(2)
+    base = rng.uniform(0, 1, (40, 3)).astype(np.float32)
+    pts = np.concatenate([base, base, base[:10]])     # duplicated points -> equal distances
+    q = rng.uniform(0, 1, (200, 3)).astype(np.float32)
+    _check_knn(gpu, pts, q, cell=0.3)
+    # integer lattice: many exact ties
+    g = np.stack(np.meshgrid(*[np.arange(6)] * 3, indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    qq = (g[::3] + 0.5).astype(np.float32)
+    _check_knn(gpu, g, qq, cell=1.0)
+    # fewer points than k, and an empty cloud
+    idx = _index(gpu, base[:3])
+    D, I, nn = idx.search(torch.from_numpy(q[:7]).to(gpu), 8, radius=10.0)
+    rD, rI = oknn.knn_bruteforce(base[:3], q[:7], 8)
+    assert np.array_equal(I.cpu().numpy(), rI) and np.array_equal(D.cpu().numpy(), rD)
+    assert (I.cpu().numpy()[:, 3:] == -1).all() and (nn.cpu().numpy() == 3).all()
+    idx = _index(gpu, np.zeros((0, 3), np.float32))
+    D, I, nn = idx.search(torch.from_numpy(q[:4]).to(gpu), 8, radius=1.0)
+    assert (I.cpu().numpy() == -1).all() and (nn.cpu().numpy() == 0).all()
+
+
+def test_knn_coarse_grid_forced(gpu):
+    """max_cells tiny -> the device enlarges the cell size; results must not change"""
+    rng = np.random.default_rng(3)
+    pts = rng.normal(0, 1, (3000, 3)).astype(np.float32)
+    q = rng.normal(0, 1.5, (500, 3)).astype(np.float32)
+    _check_knn(gpu, pts, q, cell=0.01, max_cells=64)
+
+
+def test_knn_point_permutation_invariance(gpu):
+    rng = np.random.default_rng(4)
+    pts = rng.uniform(0, 1, (2000, 3)).astype(np.float32)
+    q = rng.uniform(0, 1, (300, 3)).astype(np.float32)
+    perm = rng.permutation(len(pts))
+    D1, I1, _ = _index(gpu, pts).search(torch.from_numpy(q).to(gpu), 8, radius=0.1)
+    D2, I2, _ = _index(gpu, pts[perm]).search(torch.from_numpy(q).to(gpu), 8, radius=0.1)
+    assert np.array_equal(D1.cpu().numpy(), D2.cpu().numpy())
+    assert np.array_equal(np.sort(I1.cpu().numpy(), 1), np.sort(perm[I2.cpu().numpy()], 1))
+
+
+def test_idw_gather(gpu):
+    from glorie_slam_amd import point_ops
+    rng = np.random.default_rng(5)
+    pts = rng.uniform(0, 1, (3000, 3)).astype(np.float32)
+    feats = rng.normal(0, 0.1, (3000, 32)).astype(np.float32)
+    q = rng.uniform(-0.1, 1.1, (1000, 3)).astype(np.float32)
+    rad = rng.uniform(0.02, 0.15, 1000).astype(np.float32)
+    idx = _index(gpu, pts)
+    D, I, nn = idx.search(torch.from_numpy(q).to(gpu), 8, radius_per_query=torch.from_numpy(rad).to(gpu))
+    c, has, w = point_ops.idw_gather(D, I, nn, torch.from_numpy(feats).to(gpu),
+                                     radius_per_query=torch.from_numpy(rad).to(gpu), return_weights=True)
+    rc, rhas, rw = oknn.idw_gather(D.cpu().numpy(), I.cpu().numpy(), nn.cpu().numpy(), feats, rad)
+    assert np.array_equal(has.cpu().numpy(), rhas) and 0 < rhas.sum() < len(rhas)
+    np.testing.assert_allclose(w.cpu().numpy(), rw, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(c.cpu().numpy(), rc, rtol=1e-4, atol=1e-6)
+
+
+def test_composite_matches_reference_fixture(gpu):
+    from glorie_slam_amd import point_ops
+    f = np.load(os.path.join(GOLD, "raw2outputs.npz"))
+    d, v, c, w = point_ops.composite(torch.from_numpy(f["raw"]).to(gpu), torch.from_numpy(f["z"]).to(gpu), 0.1)
+    np.testing.assert_allclose(d.cpu().numpy(), f["depth"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(v.cpu().numpy(), f["var"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(c.cpu().numpy(), f["rgb"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(w.cpu().numpy(), f["weights"], rtol=1e-5, atol=1e-7)
+
+
+def _cfg(dev):
+    return {"device": str(dev),
+            "pointcloud": {"nn_weighting": "distance", "use_dynamic_radius": True, "min_nn_num": 2,
+                           "nn_num": 8, "radius_query": 0.08, "radius_add": 0.04, "radius_min": 0.02},
+            "rendering": {"N_surface": 10, "near_end_surface": 0.95, "far_end_surface": 1.05,
+                          "sample_near_pcl": True, "sigmoid_coef": 0.1, "near_end": 0.3},
+            "model": {"encode_rel_pos_in_col": True, "encode_viewd": True, "c_dim": 32}}
+
+
+def test_decoders_on_gpu_match_reference_fixture(gpu):
+    """POINT.forward through the HIP KNN + IDW kernels == the reference decoder outputs"""
+    from glorie_slam_amd.decoder import POINT
+    from glorie_slam_amd.neural_point import NeuralPointCloud
+    f = np.load(os.path.join(GOLD, "decoders.npz"))
+    t = lambda k: torch.from_numpy(f[k]).to(gpu)
+    torch.manual_seed(43)
+    dec = POINT(_cfg(gpu), c_dim=32, hidden_size=128, use_view_direction=True).eval().to(gpu)
+    npc = NeuralPointCloud(_cfg(gpu))
+    npc.add_points(t("cloud"), t("geo"), t("col"))
+    with torch.no_grad():
+        raw, ray_mask, point_mask, counter = dec(t("p")[None], npc, "color", npc.geo_feats, npc.col_feats,
+                                                 pts_num=10, cloud_pos=npc.cloud_pos(),
+                                                 pts_views_d=t("views"), dynamic_r_query=t("radius"))
+    pm = f["point_mask"]
+    assert np.array_equal(point_mask.cpu().numpy(), pm)
+    assert np.array_equal(ray_mask.cpu().numpy(), f["ray_mask"])
+    assert np.array_equal(counter.cpu().numpy(), f["counter"])
+    raw = raw.cpu().numpy()
+    np.testing.assert_allclose(raw[pm, 3], f["occ"][pm], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(raw[pm, :3], f["rgb"][pm], rtol=1e-3, atol=1e-3)   # colours: 1e-3
+
+
+def test_render_batch_ray_end_to_end(gpu):
+    """render a small view of the synthetic box; rays that hit the cloud are valid, depth is
+    close to the surface depth, zero-depth rays go through sample_near_pcl"""
+    import glorie_slam_amd.synth as synth
+    from glorie_slam_amd.decoder import POINT
+    from glorie_slam_amd.neural_point import NeuralPointCloud
+    from glorie_slam_amd.renderer import Renderer
+    cfg = _cfg(gpu)
+    pts, geo, col = synth.box_cloud(n_hits=40000)
+    H, W = 24, 32
+    ro, rd, depth, radius, c2w = synth.box_rays(H, W, fx=16.0, fy=16.0, cx=15.5, cy=11.5)
+    t = lambda x: torch.from_numpy(x).to(gpu)
+    npc = NeuralPointCloud(cfg)
+    npc.add_points(t(pts), t(geo), t(col))
+    torch.manual_seed(43)
+    dec = POINT(cfg, use_view_direction=True).eval().to(gpu)
+
+    class Cam:
+        pass
+    cam = Cam()
+    cam.H, cam.W, cam.fx, cam.fy, cam.cx, cam.cy = H, W, 16.0, 16.0, 15.5, 11.5
+    ren = Renderer(cfg, cam)
+    gt = depth.copy()
+    gt[::9] = 0.0
+    with torch.no_grad():
+        d, u, c, vm, cnt = ren.render_batch_ray(npc, dec, t(rd), t(ro), gpu, "color", gt_depth=t(gt),
+                                                npc_geo_feats=npc.geo_feats, npc_col_feats=npc.col_feats,
+                                                cloud_pos=npc.cloud_pos(), dynamic_r_query=t(radius * 2.5))
+    assert d.shape == (H * W,) and c.shape == (H * W, 3) and vm.dtype == torch.bool
+    assert vm.float().mean() > 0.9
+    ok = vm.cpu().numpy() & (gt > 0)
+    assert np.all(np.isfinite(d.cpu().numpy()))
+    assert np.abs(d.cpu().numpy()[ok] - depth[ok]).max() < 0.06 * depth.max()
+    assert (c.cpu().numpy() >= 0).all() and (c.cpu().numpy() <= 1).all()
