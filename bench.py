@@ -60,6 +60,53 @@ def build_graph(device, K=8, h=60, w=80):
     return g, video, graph
 
 
+def render_cfg(device):
+    return {"device": str(device),
+            "pointcloud": {"nn_weighting": "distance", "use_dynamic_radius": True, "min_nn_num": 2,
+                           "nn_num": 8, "radius_query": 0.08, "radius_add": 0.04, "radius_min": 0.02},
+            "rendering": {"N_surface": 10, "near_end_surface": 0.95, "far_end_surface": 1.05,
+                          "sample_near_pcl": True, "sigmoid_coef": 0.1, "near_end": 0.3},
+            "model": {"encode_rel_pos_in_col": True, "encode_viewd": True, "c_dim": 32}}
+
+
+class _Cam:
+    H, W, fx, fy, cx, cy = 480, 640, 320.0, 320.0, 319.5, 239.5
+
+
+def build_renderer(device, rank=0, world=1):
+    """cloud PC (524,288 points) + one 640x480 view; rays are sharded over ranks by image rows"""
+    import glorie_slam_amd.synth as synth
+    from glorie_slam_amd.decoder import POINT
+    from glorie_slam_amd.neural_point import NeuralPointCloud
+    from glorie_slam_amd.renderer import Renderer
+    cfg = render_cfg(device)
+    pts, geo, col = synth.box_cloud()
+    pts, geo, col = pts[:524288], geo[:524288], col[:524288]
+    ro, rd, depth, radius, c2w = synth.box_rays()
+    R = ro.shape[0]
+    lo, hi = rank * R // world, (rank + 1) * R // world
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(device)
+    npc = NeuralPointCloud(cfg)
+    npc.add_points(t(pts), t(geo), t(col))
+    torch.manual_seed(43)
+    dec = POINT(cfg, use_view_direction=True).eval().to(device)
+    ren = Renderer(cfg, _Cam())
+    rays = dict(o=t(ro[lo:hi]), d=t(rd[lo:hi]), depth=t(depth[lo:hi]), radius=t(radius[lo:hi]))
+    return npc, dec, ren, rays
+
+
+def render_pass(npc, dec, ren, rays, device):
+    bs = ren.ray_batch_size
+    n = rays["o"].shape[0]
+    with torch.no_grad():
+        for i in range(0, n, bs):
+            ren.render_batch_ray(npc, dec, rays["d"][i:i + bs], rays["o"][i:i + bs], device, "color",
+                                 gt_depth=rays["depth"][i:i + bs], npc_geo_feats=npc.geo_feats,
+                                 npc_col_feats=npc.col_feats, cloud_pos=npc.cloud_pos(),
+                                 dynamic_r_query=rays["radius"][i:i + bs])
+    return n
+
+
 def cpu_baseline_step(g, n_edges=2):
     """Oracle ("port") timing of one step on a bounded sample: `n_edges` edges of the
     correlation lookup + update operator, and one BA call on a 4-keyframe 30x40 sub-problem;
@@ -166,6 +213,46 @@ def main():
     corr_ms = ev0.elapsed_time(ev1) / reps
     achieved = alg_bytes / (corr_ms * 1e-3) / 1e9
 
+    # ---- M2: rendered rays/sec (full 640x480 frame, rays sharded over ranks) ----------
+    npc, dec, ren, rays = build_renderer(device, rank, world)
+    render_pass(npc, dec, ren, rays, device)
+    barrier()
+    t_r = time.perf_counter()
+    n_r = 0
+    render_reps = 3
+    for _ in range(render_reps):
+        n_r += render_pass(npc, dec, ren, rays, device)
+    barrier()
+    t_r = time.perf_counter() - t_r
+    if world > 1:
+        tm = torch.tensor([t_r], device=device)
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        t_r = float(tm.item())
+    rays_per_s = world * n_r / t_r
+    # KNN + feature gather alone (HIP events), 2156 B per sample
+    S = ren.N_surface
+    nq = min(rays["o"].shape[0], 65536)
+    z = rays["depth"][:nq, None] * torch.linspace(0.95, 1.05, S, device=device)[None]
+    pq = (rays["o"][:nq, None] + rays["d"][:nq, None] * z[..., None]).reshape(-1, 3).contiguous()
+    rq = rays["radius"][:nq].repeat_interleave(S)
+    from glorie_slam_amd import point_ops
+
+    def knn_gather():
+        D, I, nn = npc.index.search(pq, 8, radius_per_query=rq)
+        point_ops.idw_gather(D, I, nn, npc.geo_feats, radius_per_query=rq)
+        point_ops.idw_gather(D, I, nn, npc.col_feats, radius_per_query=rq)
+
+    knn_gather()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        knn_gather()
+    e1.record()
+    torch.cuda.synchronize()
+    knn_ms = e0.elapsed_time(e1) / 5
+    knn_bytes = 2156.0 * pq.shape[0]
+    knn_gbs = knn_bytes / (knn_ms * 1e-3) / 1e9
+
     out = {
         "metric": "DSPO BA-update iters/sec + rendered rays/sec, 640x480 Replica keyframe graph",
         "value": world * args.steps / elapsed,
@@ -180,6 +267,13 @@ def main():
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "alg_bytes_per_launch": alg_bytes, "ms_per_launch": corr_ms},
+        "rays_per_sec": rays_per_s,
+        "render": {"rays": int(n_r // render_reps), "samples_per_ray": int(S), "cloud_points": int(npc.pts_num()),
+                   "ms_per_frame_shard": 1e3 * t_r / render_reps},
+        "roofline_knn": {"bound": "hbm", "kernel": "knn_query_kernel<8> + 2x idw_gather_kernel",
+                         "achieved": knn_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": knn_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "alg_bytes_per_launch": knn_bytes, "ms_per_launch": knn_ms},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_step(g)

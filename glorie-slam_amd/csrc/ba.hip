@@ -39,43 +39,9 @@
 #include <math.h>
 #include "common.hiph"
 #include "se3.hiph"
+#include "ba_common.hiph"
 
 namespace glorie {
-
-constexpr int kBaThreads = 256;
-constexpr int kMaxFramesLds = 4096;
-constexpr int kMaxEdgesLds = 16384;
-constexpr int kSolveMaxN = 192;  // single-workgroup Cholesky (packed fp64 in LDS)
-
-// status bits written to the device status word
-enum : int {
-  BA_ST_M_MISMATCH = 1,
-  BA_ST_DEG_TOO_LARGE = 2,
-  BA_ST_CHOL_FAILED = 4,
-  BA_ST_TOO_MANY = 8,
-};
-
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-
-struct BaWork {
-  // integer tables
-  int* slot_of_frame;  // [B]   frame -> slot or -1
-  int* kx;             // [M]   slot -> frame
-  int* csr_ptr;        // [M+1]
-  int* csr_edge;       // [N]
-  int* status;         // [4]   status word, Mdev, failures, -
-  // per edge
-  float* Ledge;  // [N][36]
-  float* Eij;    // [N][6][HW]
-  float* Hpart;  // [N][nchunks][27]
-  // per frame slot
-  float* Q;  // [M][HW]
-  float* W;  // [M][HW]
-  // dense reduced system
-  double* Hd;  // [n][n] (lower triangle used)
-  double* vd;  // [n]
-  float* dx;   // [P][6]
-};
 
 // ------------------------------------------------------------------------------------
 // prepare: one workgroup of 1024 threads; all tables are built in LDS and written once
@@ -822,7 +788,19 @@ __global__ __launch_bounds__(kBaThreads) void ba_update_kernel(
   if (dz_out) dz_out[(size_t)s * HW + px] = dz;
 }
 
-static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+int ba_prepare(const BaWork& wk, const int64_t* ii, int B, int N, int M, int t0, int t1,
+               hipStream_t st) {
+  const size_t prep_lds = sizeof(int) * ((size_t)3 * B + (size_t)N);
+  if (prep_lds > 150 * 1024) return GLORIE_EUNSUPPORTED;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ba_prepare_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(ba_prepare_kernel, dim3(1), dim3(1024), prep_lds, st, wk, ii, B, N, M, t0, t1);
+  return check_launch();
+}
 
 }  // namespace glorie
 
@@ -886,12 +864,8 @@ extern "C" int glorie_ba(glorie_ctx* ctx, float* poses, float* disps, const floa
   wk.vd = reinterpret_cast<double*>(base + o_vd);
   wk.dx = reinterpret_cast<float*>(base + o_dx);
 
-  const size_t prep_lds = sizeof(int) * ((size_t)3 * B + (size_t)N);
-  if (prep_lds > 150 * 1024) return GLORIE_EUNSUPPORTED;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ba_prepare_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ba_solve_lds_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_solve_kernel),
@@ -899,9 +873,7 @@ extern "C" int glorie_ba(glorie_ctx* ctx, float* poses, float* disps, const floa
     attr_set = true;
   }
 
-  hipLaunchKernelGGL(ba_prepare_kernel, dim3(1), dim3(1024), prep_lds, st, wk, ii, B, N, M, t0, t1);
-  GLORIE_TRY(check_launch());
-
+  GLORIE_TRY(ba_prepare(wk, ii, B, N, M, t0, t1, st));
 
   for (int it = 0; it < iterations; ++it) {
     GLORIE_TRY(check_hip(hipMemsetAsync(wk.Hd, 0, sizeof(double) * (size_t)n6 * n6, st)));

@@ -1,0 +1,57 @@
+"""DSPO stage 2 ("depth_scale"): host side of /root/reference/src/depth_video.py:222-285.
+
+Order of operations kept from the reference:
+  1. update_valid_depth_mask(up=False)           multiview consistency on the 1/8 maps
+  2. align_scale_and_shift(mono, est, valid)     initial per-frame scale/shift
+  3. mono_thres edge filtering                   -> an `edge_on` byte mask (no tensor compaction)
+  4. `itrs` x BA_with_scale_shift                -> one glorie_dspo_scale_shift call
+Differences: state is updated in place instead of rebinding attributes; the only
+host synchronisation is the scalar "are there any edges left" needed for the fallback decision
+of DepthVideo.ba (depth_video.py:290-294).
+"""
+import torch
+
+from . import _lib as L
+from .common import align_scale_and_shift
+
+
+def scale_shift_step(video, target, weight, eta, ii, jj, edge_on, itrs, lm, ep, alpha=0.01):
+    """glorie_dspo_scale_shift on the video buffers. target/weight [1,N,h,w,2] or [N,h,w,2]."""
+    h, w = video.ht // video.down_scale, video.wd // video.down_scale
+    target = target.reshape(-1, h, w, 2).contiguous().float()
+    weight = weight.reshape(-1, h, w, 2).contiguous().float()
+    eta = eta.reshape(-1, h, w).contiguous().float()
+    N, M, B = ii.shape[0], eta.shape[0], video.disps.shape[0]
+    vm = video.valid_depth_mask_small.to(torch.uint8).contiguous()
+    eo = edge_on.to(torch.uint8).contiguous() if edge_on is not None else None
+    L.check(L.load().glorie_dspo_scale_shift(
+        video.ctx().handle, L.ptr(video.poses), L.ptr(video.disps), L.ptr(video.intrinsics),
+        L.ptr(video.mono_disps), L.ptr(video.depth_scale), L.ptr(video.depth_shift), L.ptr(vm),
+        L.ptr(target), L.ptr(weight), L.ptr(eta), L.ptr(ii.contiguous()), L.ptr(jj.contiguous()),
+        L.ptr(eo), B, N, M, h, w, int(itrs), float(lm), float(ep), float(alpha), None,
+        L.stream_ptr()), "glorie_dspo_scale_shift")
+
+
+def depth_scale_stage(video, target, weight, eta, ii, jj, itrs, lm, ep):
+    """returns `success` like DepthVideo.dspo(opt_type='depth_scale')"""
+    video.update_valid_depth_mask(up=False)
+    n = video.counter.value
+    mono_d, est_d, valid_d = video.mono_disps[:n], video.disps[:n], video.valid_depth_mask_small[:n]
+    scale_t, shift_t, error_t = align_scale_and_shift(mono_d, est_d, valid_d)
+    video.depth_scale[:n] = scale_t
+    video.depth_shift[:n] = shift_t
+    edge_on = None
+    if video.mono_thres:
+        avg = est_d.mean(dim=[1, 2])
+        bad = (error_t / avg > video.mono_thres) | error_t.isnan() | (scale_t < 0) | \
+              (valid_d.sum(dim=[1, 2]) < valid_d.shape[1] * valid_d.shape[2] * 0.5)
+        bad_full = torch.zeros(video.disps.shape[0], dtype=torch.bool, device=bad.device)
+        bad_full[:n] = bad
+        edge_on = ~(bad_full[ii] | bad_full[jj])
+        if not bool(edge_on.any()):   # the one scalar sync: decides the stage-1 fallback
+            return False
+    if n <= 0 or ii.shape[0] == 0:
+        return False
+    scale_shift_step(video, target, weight, eta, ii, jj, edge_on, itrs, lm, ep, alpha=0.01)
+    video.disps.clamp_(min=1e-5)
+    return True

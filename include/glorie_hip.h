@@ -145,6 +145,25 @@ int glorie_ba(glorie_ctx* ctx, float* poses, float* disps, const float* intrinsi
               float lm, float ep, int motion_only, int depth_only,
               float* dx_out, float* dz_out, void* stream);
 
+/* DSPO stage 2, `BA_with_scale_shift(target, weight, eta, poses, disps, intrinsics, ii, jj,
+ *                mono_disps, scales, shifts, valid_depth_mask, ignore_frames=0, lm, ep, alpha)`
+ *   reference: src/geom/ba.py:127-216, src/geom/chol.py:58-85, call site
+ *   src/depth_video.py:262-276 (alpha = 0.01, `itrs` repetitions).
+ * Optimises disparities + per-frame scale/shift of the mono prior with poses fixed.
+ * disps [B,h,w], scales/shifts [B] are updated IN PLACE (the reference rebinds
+ * them).  target/weight are in the python layout [N,h,w,2]; intrinsics [B,4];
+ * valid_mask [B,h,w] uint8 (valid_depth_mask_small); eta [M,h,w], M = #unique(ii) in sorted
+ * order.  edge_on [N] uint8 (may be NULL = all on) replaces the reference's edge filtering by
+ * boolean-mask copies (depth_video.py:228-261); frames whose edges are all off are untouched
+ * and their eta rows ignored.  dz_out [M,h*w] may be NULL. */
+int glorie_dspo_scale_shift(glorie_ctx* ctx, const float* poses, float* disps,
+                            const float* intrinsics, const float* mono_disps, float* scales,
+                            float* shifts, const uint8_t* valid_mask, const float* target,
+                            const float* weight, const float* eta, const int64_t* ii,
+                            const int64_t* jj, const uint8_t* edge_on, int B, int N, int M, int h,
+                            int w, int iterations, float lm, float ep, float alpha, float* dz_out,
+                            void* stream);
+
 /* ------------------------------------------------------------------------------------ */
 /* C. neural point cloud renderer                                                        */
 /* ------------------------------------------------------------------------------------ */

@@ -142,3 +142,15 @@ def test_decoders_match_reference():
     # samples without neighbours get a random feature in the reference -> excluded
     np.testing.assert_allclose(raw[pm, 3].numpy(), f["occ"][pm], rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(raw[pm, :3].numpy(), f["rgb"][pm], rtol=1e-4, atol=1e-5)
+
+
+def test_schur_solve_oracle_matches_reference():
+    from oracle import dspo as odspo
+    f = gold("schur_solve.npz")
+    dx, dz = odspo.schur_solve(f["H"][0], f["E"][0], f["C"][0], f["v"][0], f["w"][0], 0.1, 1e-4)
+    np.testing.assert_allclose(dx, f["dx"][0], rtol=2e-4, atol=1e-5)
+    np.testing.assert_allclose(dz, f["dz"][0], rtol=2e-4, atol=1e-5)
+    np.testing.assert_allclose(odspo.block_solve(f["H"][0], f["v"][0]), f["block_x"][0], rtol=2e-4, atol=1e-5)
+    dxb, dzb = odspo.schur_solve(-f["H"][0], f["E"][0], f["C"][0], f["v"][0], f["w"][0], 0.1, 1e-4)
+    assert np.all(f["dx_bad"] == 0) and np.all(dxb == 0)      # non-PD -> zero update
+    np.testing.assert_allclose(dzb, f["dz_bad"][0], rtol=2e-4, atol=1e-5)

@@ -1,0 +1,94 @@
+"""Parity of DSPO stage 2 (disparity + scale/shift) with the dense oracle restatement."""
+import numpy as np
+import pytest
+import torch
+
+import glorie_slam_amd.synth as synth
+from oracle import dspo as odspo, geom as ogeom
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(x, dev):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+
+
+def problem(K=6, h=16, w=20, seed=3):
+    g = synth.keyframe_graph(K=K, h=h, w=w, radius=2, seed=seed)
+    rng = np.random.default_rng(seed)
+    coords, _ = ogeom.reproject(g["poses"], g["disps"], g["intrinsics"], g["ii"], g["jj"])
+    g["target"] = (coords + g["noise"].transpose(0, 2, 3, 1)).astype(np.float32)
+    g["weight_hw2"] = np.ascontiguousarray(g["weight"].transpose(0, 2, 3, 1))
+    s = rng.uniform(0.5, 2.0, K).astype(np.float32)
+    q = rng.uniform(-0.05, 0.05, K).astype(np.float32)
+    mono = ((g["disps"] - q[:, None, None]) / s[:, None, None] * (1 + 0.02 * rng.standard_normal(g["disps"].shape)))
+    mono[rng.uniform(size=mono.shape) < 0.1] = 0.0
+    g["mono"] = mono.astype(np.float32)
+    g["scales"] = (s * rng.uniform(0.9, 1.1, K)).astype(np.float32)
+    g["shifts"] = (q + rng.uniform(-0.01, 0.01, K)).astype(np.float32)
+    g["vmask"] = rng.uniform(size=g["disps"].shape) < 0.7
+    return g
+
+
+def run_gpu(g, dev, itrs, edge_on=None, lm=1e-4, ep=0.1, eta=None):
+    from glorie_slam_amd import _lib as L
+    ctx = L.default_context()
+    poses, disps = _t(g["poses"], dev), _t(g["disps"], dev)
+    sc, sh = _t(g["scales"], dev), _t(g["shifts"], dev)
+    eta_t = _t(g["eta"] if eta is None else eta, dev)
+    K, h, w = g["K"], g["h"], g["w"]
+    args = [_t(g["intrinsics"], dev), _t(g["mono"], dev), _t(g["vmask"].astype(np.uint8), dev),
+            _t(g["target"], dev), _t(g["weight_hw2"], dev), _t(g["ii"], dev), _t(g["jj"], dev)]
+    eo = _t(edge_on.astype(np.uint8), dev) if edge_on is not None else None
+    L.check(L.load().glorie_dspo_scale_shift(
+        ctx.handle, L.ptr(poses), L.ptr(disps), L.ptr(args[0]), L.ptr(args[1]), L.ptr(sc), L.ptr(sh),
+        L.ptr(args[2]), L.ptr(args[3]), L.ptr(args[4]), L.ptr(eta_t), L.ptr(args[5]), L.ptr(args[6]),
+        L.ptr(eo), K, len(g["ii"]), eta_t.shape[0], h, w, itrs, lm, ep, 0.01, None, L.stream_ptr()), "dspo")
+    torch.cuda.synchronize()
+    return disps.cpu().numpy(), sc.cpu().numpy(), sh.cpu().numpy(), ctx.ba_status()
+
+
+@pytest.mark.parametrize("itrs", [1, 2])
+def test_stage2_matches_dense_oracle(gpu, itrs):
+    g = problem()
+    d, s, q = g["disps"], g["scales"], g["shifts"]
+    for _ in range(itrs):
+        d, s, q, _ = odspo.ba_with_scale_shift(g["target"], g["weight_hw2"], g["eta"], g["poses"], d,
+                                               g["intrinsics"], g["ii"], g["jj"], g["mono"], s, q, g["vmask"])
+    gd, gs, gq, st = run_gpu(g, gpu, itrs)
+    assert st[0] == 0
+    np.testing.assert_allclose(gs, s, rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(gq, q, rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(gd, d, rtol=1e-4, atol=2e-5)
+
+
+def test_stage2_edge_mask_equals_filtered_graph(gpu):
+    """edge_on mask == physically removing the edges (and the eta rows of emptied frames)"""
+    g = problem(K=6)
+    bad = 2
+    keep = (g["ii"] != bad) & (g["jj"] != bad)
+    g2 = dict(g)
+    for k in ("ii", "jj", "target", "weight_hw2"):
+        g2[k] = g[k][keep]
+    kx_all = sorted(set(g["ii"].tolist()))
+    kx_f = sorted(set(g2["ii"].tolist()))
+    eta_f = g["eta"][[kx_all.index(f) for f in kx_f]]
+    d, s, q, _ = odspo.ba_with_scale_shift(g2["target"], g2["weight_hw2"], eta_f, g["poses"], g["disps"],
+                                           g["intrinsics"], g2["ii"], g2["jj"], g["mono"], g["scales"],
+                                           g["shifts"], g["vmask"])
+    gd, gs, gq, st = run_gpu(g, gpu, 1, edge_on=keep)
+    np.testing.assert_allclose(gd, d, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(gs, s, rtol=2e-4, atol=2e-5)
+    assert np.array_equal(gd[bad], g["disps"][bad]) and gs[bad] == g["scales"][bad]
+
+
+def test_stage2_failure_zeroes_all_scale_updates(gpu):
+    g = problem()
+    gd, gs, gq, st = run_gpu(g, gpu, 1, lm=-3.0, ep=-1.0)
+    assert st[0] & 4
+    assert np.array_equal(gs, g["scales"]) and np.array_equal(gq, g["shifts"])
+    assert not np.array_equal(gd, g["disps"])       # dz = Q w is still applied
+    d, s, q, _ = odspo.ba_with_scale_shift(g["target"], g["weight_hw2"], g["eta"], g["poses"], g["disps"],
+                                           g["intrinsics"], g["ii"], g["jj"], g["mono"], g["scales"],
+                                           g["shifts"], g["vmask"], lm=-3.0, ep=-1.0)
+    np.testing.assert_allclose(gd, d, rtol=1e-4, atol=2e-5)
