@@ -806,33 +806,29 @@ int ba_prepare(const BaWork& wk, const int64_t* ii, int B, int N, int M, int t0,
 
 using namespace glorie;
 
-extern "C" int glorie_ba(glorie_ctx* ctx, float* poses, float* disps, const float* intrinsics,
-                         const float* disps_sens, const float* targets, const float* weights,
-                         const float* eta, const int64_t* ii, const int64_t* jj, int B, int N,
-                         int M, int h, int w, int t0, int t1, int iterations, float lm, float ep,
-                         int motion_only, int depth_only, float* dx_out, float* dz_out,
-                         void* stream) {
-  if (!ctx || B < 0 || N < 0 || M < 0 || h < 0 || w < 0 || t1 < t0 || iterations < 0)
-    return GLORIE_EINVAL;
-  const int P = t1 - t0;
-  const int HW = h * w;
-  if (N == 0 || P == 0 || HW == 0 || iterations == 0) return GLORIE_OK;
-  if (!poses || !disps || !intrinsics || !targets || !weights || !ii || !jj) return GLORIE_EINVAL;
-  if (!motion_only && !eta) return GLORIE_EINVAL;
-  if (B > kMaxFramesLds || N > kMaxEdgesLds || t1 > B) return GLORIE_EUNSUPPORTED;
-  hipStream_t st = (hipStream_t)stream;
+namespace glorie {
 
+struct BaPlan {
+  BaWork wk;
+  int B, N, M, h, w, HW, t0, t1, P, n6, ppt, chunk_px, nchunks;
+};
+
+// validates sizes, carves the scratch arena (identical layout for identical sizes, so a
+// build_system call and the following solve_update call see the same buffers)
+static int ba_plan(glorie_ctx* ctx, int B, int N, int M, int h, int w, int t0, int t1,
+                   double* hv_ext, BaPlan& pl) {
+  if (!ctx || B < 0 || N < 0 || M < 0 || h < 0 || w < 0 || t1 < t0) return GLORIE_EINVAL;
+  if (B > kMaxFramesLds || N > kMaxEdgesLds || t1 > B) return GLORIE_EUNSUPPORTED;
+  pl.B = B; pl.N = N; pl.M = M; pl.h = h; pl.w = w; pl.HW = h * w; pl.t0 = t0; pl.t1 = t1;
+  pl.P = t1 - t0; pl.n6 = 6 * pl.P;
   // pixel chunking: enough workgroups to fill 256 CUs, at most 4 pixels per thread
   int ppt = 1;
-  {
-    const int per1 = (HW + kBaThreads - 1) / kBaThreads;
-    while (ppt < 4 && (long)M * ((per1 + ppt - 1) / ppt) > 1024) ++ppt;
-  }
-  const int chunk_px = kBaThreads * ppt;
-  const int nchunks = (HW + chunk_px - 1) / chunk_px;
-  const int n6 = 6 * P;
-
-  // scratch carve-up
+  const int per1 = (pl.HW + kBaThreads - 1) / kBaThreads;
+  while (ppt < 4 && (long)M * ((per1 + ppt - 1) / ppt) > 1024) ++ppt;
+  pl.ppt = ppt;
+  pl.chunk_px = kBaThreads * ppt;
+  pl.nchunks = (pl.HW + pl.chunk_px - 1) / pl.chunk_px;
+  const size_t HW = pl.HW, n6 = pl.n6;
   size_t off = 0;
   auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
   const size_t o_slot = carve(sizeof(int) * (size_t)B);
@@ -841,15 +837,14 @@ extern "C" int glorie_ba(glorie_ctx* ctx, float* poses, float* disps, const floa
   const size_t o_edge = carve(sizeof(int) * (size_t)N);
   const size_t o_L = carve(sizeof(float) * 36 * (size_t)N);
   const size_t o_E = carve(sizeof(float) * 6 * (size_t)N * HW);
-  const size_t o_Hp = carve(sizeof(float) * 27 * (size_t)N * nchunks);
+  const size_t o_Hp = carve(sizeof(float) * 27 * (size_t)N * pl.nchunks);
   const size_t o_Q = carve(sizeof(float) * (size_t)M * HW);
   const size_t o_W = carve(sizeof(float) * (size_t)M * HW);
-  const size_t o_Hd = carve(sizeof(double) * (size_t)n6 * n6);
-  const size_t o_vd = carve(sizeof(double) * (size_t)n6);
-  const size_t o_dx = carve(sizeof(float) * (size_t)n6);
+  const size_t o_Hd = carve(sizeof(double) * (n6 * n6 + n6));
+  const size_t o_dx = carve(sizeof(float) * n6);
   GLORIE_TRY(ctx_reserve(ctx, off));
   char* base = reinterpret_cast<char*>(ctx->scratch);
-  BaWork wk;
+  BaWork& wk = pl.wk;
   wk.slot_of_frame = reinterpret_cast<int*>(base + o_slot);
   wk.kx = reinterpret_cast<int*>(base + o_kx);
   wk.csr_ptr = reinterpret_cast<int*>(base + o_ptr);
@@ -860,10 +855,11 @@ extern "C" int glorie_ba(glorie_ctx* ctx, float* poses, float* disps, const floa
   wk.Hpart = reinterpret_cast<float*>(base + o_Hp);
   wk.Q = reinterpret_cast<float*>(base + o_Q);
   wk.W = reinterpret_cast<float*>(base + o_W);
-  wk.Hd = reinterpret_cast<double*>(base + o_Hd);
-  wk.vd = reinterpret_cast<double*>(base + o_vd);
+  // the dense system [H (n6 x n6) | v (n6)] is one contiguous fp64 buffer so that a
+  // multi-GPU caller can all-reduce it in a single collective
+  wk.Hd = hv_ext ? hv_ext : reinterpret_cast<double*>(base + o_Hd);
+  wk.vd = wk.Hd + n6 * n6;
   wk.dx = reinterpret_cast<float*>(base + o_dx);
-
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ba_solve_lds_kernel),
@@ -872,49 +868,119 @@ extern "C" int glorie_ba(glorie_ctx* ctx, float* poses, float* disps, const floa
                               hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     attr_set = true;
   }
+  return GLORIE_OK;
+}
 
-  GLORIE_TRY(ba_prepare(wk, ii, B, N, M, t0, t1, st));
+// Jacobians + Schur gram + pose blocks -> dense reduced system in wk.Hd / wk.vd
+static int ba_build_system(const BaPlan& pl, const float* poses, const float* disps,
+                           const float* intrinsics, const float* disps_sens, const float* targets,
+                           const float* weights, const float* eta, const int64_t* ii,
+                           const int64_t* jj, int motion_only, hipStream_t st) {
+  const BaWork& wk = pl.wk;
+  GLORIE_TRY(check_hip(hipMemsetAsync(wk.Hd, 0, sizeof(double) * ((size_t)pl.n6 * pl.n6 + pl.n6), st)));
+  hipLaunchKernelGGL(ba_jacobian_kernel, dim3(pl.nchunks, pl.M), dim3(kBaThreads), 0, st, wk, poses,
+                     disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, pl.HW, pl.w,
+                     pl.nchunks, pl.ppt, motion_only);
+  if (!motion_only)
+    hipLaunchKernelGGL(ba_gram_kernel, dim3(pl.nchunks, pl.M), dim3(kBaThreads), 0, st, wk, jj, pl.HW,
+                       pl.chunk_px, pl.t0, pl.t1);
+  hipLaunchKernelGGL(ba_assemble_kernel, dim3(pl.N), dim3(64), 0, st, wk, ii, jj, pl.nchunks, pl.t0, pl.t1);
+  return check_launch();
+}
 
-  for (int it = 0; it < iterations; ++it) {
-    GLORIE_TRY(check_hip(hipMemsetAsync(wk.Hd, 0, sizeof(double) * (size_t)n6 * n6, st)));
-    GLORIE_TRY(check_hip(hipMemsetAsync(wk.vd, 0, sizeof(double) * (size_t)n6, st)));
-    hipLaunchKernelGGL(ba_jacobian_kernel, dim3(nchunks, M), dim3(kBaThreads), 0, st, wk, poses,
-                       disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, HW, w, nchunks,
-                       ppt, motion_only);
-    GLORIE_TRY(check_launch());
-    if (!motion_only) {
-      hipLaunchKernelGGL(ba_gram_kernel, dim3(nchunks, M), dim3(kBaThreads), 0, st, wk,
-                         jj, HW, chunk_px, t0, t1);
-      GLORIE_TRY(check_launch());
-    }
-    hipLaunchKernelGGL(ba_assemble_kernel, dim3(N), dim3(64), 0, st, wk, ii, jj, nchunks, t0, t1);
-    GLORIE_TRY(check_launch());
-    if (n6 <= kSolveMaxN) {
-      const size_t lds = sizeof(double) * ((size_t)n6 * (n6 + 1) / 2 + n6);
-      hipLaunchKernelGGL(ba_solve_lds_kernel, dim3(1), dim3(256), lds, st, wk, n6, lm, ep);
-      GLORIE_TRY(check_launch());
-    } else {
-      if ((size_t)n6 * sizeof(double) > 128 * 1024) return GLORIE_EUNSUPPORTED;
-      hipLaunchKernelGGL(chol_damp_kernel, dim3((n6 + 255) / 256), dim3(256), 0, st, wk, n6, lm, ep);
-      for (int j0 = 0; j0 < n6; j0 += kNB) {
-        const int nb = (n6 - j0 < kNB) ? (n6 - j0) : kNB;
-        hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, st, wk, n6, j0, nb);
-        const int rem = n6 - j0 - nb;
-        if (rem > 0) {
-          hipLaunchKernelGGL(chol_panel_kernel, dim3((rem + 63) / 64), dim3(64), 0, st, wk, n6, j0, nb);
-          const int tl = (rem + 31) / 32;
-          hipLaunchKernelGGL(chol_trail_kernel, dim3(tl, tl), dim3(256), 0, st, wk, n6, j0, nb);
-        }
+// fp64 solve of the (all-reduced) system, then back-substitution + retraction
+static int ba_solve_update(const BaPlan& pl, float* poses, float* disps, const int64_t* ii,
+                           const int64_t* jj, float lm, float ep, int motion_only, int depth_only,
+                           float* dx_out, float* dz_out, hipStream_t st) {
+  const BaWork& wk = pl.wk;
+  const int n6 = pl.n6;
+  if (n6 <= kSolveMaxN) {
+    const size_t lds = sizeof(double) * ((size_t)n6 * (n6 + 1) / 2 + n6);
+    hipLaunchKernelGGL(ba_solve_lds_kernel, dim3(1), dim3(256), lds, st, wk, n6, lm, ep);
+  } else {
+    if ((size_t)n6 * sizeof(double) > 128 * 1024) return GLORIE_EUNSUPPORTED;
+    hipLaunchKernelGGL(chol_damp_kernel, dim3((n6 + 255) / 256), dim3(256), 0, st, wk, n6, lm, ep);
+    for (int j0 = 0; j0 < n6; j0 += kNB) {
+      const int nb = (n6 - j0 < kNB) ? (n6 - j0) : kNB;
+      hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, st, wk, n6, j0, nb);
+      const int rem = n6 - j0 - nb;
+      if (rem > 0) {
+        hipLaunchKernelGGL(chol_panel_kernel, dim3((rem + 63) / 64), dim3(64), 0, st, wk, n6, j0, nb);
+        const int tl = (rem + 31) / 32;
+        hipLaunchKernelGGL(chol_trail_kernel, dim3(tl, tl), dim3(256), 0, st, wk, n6, j0, nb);
       }
-      hipLaunchKernelGGL(chol_solve_kernel, dim3(1), dim3(1024), sizeof(double) * (size_t)n6, st, wk, n6);
-      GLORIE_TRY(check_launch());
     }
-    const int upd_chunks = (HW + kBaThreads - 1) / kBaThreads;
-    hipLaunchKernelGGL(ba_update_kernel, dim3(upd_chunks, M), dim3(kBaThreads), 0, st, wk, poses,
-                       disps, ii, jj, HW, t0, t1, motion_only, depth_only, dx_out, dz_out);
-    GLORIE_TRY(check_launch());
+    hipLaunchKernelGGL(chol_solve_kernel, dim3(1), dim3(1024), sizeof(double) * (size_t)n6, st, wk, n6);
+  }
+  const int upd_chunks = (pl.HW + kBaThreads - 1) / kBaThreads;
+  hipLaunchKernelGGL(ba_update_kernel, dim3(upd_chunks, pl.M), dim3(kBaThreads), 0, st, wk, poses,
+                     disps, ii, jj, pl.HW, pl.t0, pl.t1, motion_only, depth_only, dx_out, dz_out);
+  return check_launch();
+}
+
+}  // namespace glorie
+
+extern "C" int glorie_ba(glorie_ctx* ctx, float* poses, float* disps, const float* intrinsics,
+                         const float* disps_sens, const float* targets, const float* weights,
+                         const float* eta, const int64_t* ii, const int64_t* jj, int B, int N,
+                         int M, int h, int w, int t0, int t1, int iterations, float lm, float ep,
+                         int motion_only, int depth_only, float* dx_out, float* dz_out,
+                         void* stream) {
+  if (iterations < 0) return GLORIE_EINVAL;
+  BaPlan pl;
+  GLORIE_TRY(ba_plan(ctx, B, N, M, h, w, t0, t1, nullptr, pl));
+  if (N == 0 || pl.P == 0 || pl.HW == 0 || iterations == 0) return GLORIE_OK;
+  if (!poses || !disps || !intrinsics || !targets || !weights || !ii || !jj) return GLORIE_EINVAL;
+  if (!motion_only && !eta) return GLORIE_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  GLORIE_TRY(ba_prepare(pl.wk, ii, B, N, M, t0, t1, st));
+  for (int it = 0; it < iterations; ++it) {
+    GLORIE_TRY(ba_build_system(pl, poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj,
+                               motion_only, st));
+    GLORIE_TRY(ba_solve_update(pl, poses, disps, ii, jj, lm, ep, motion_only, depth_only, dx_out,
+                               dz_out, st));
   }
   return GLORIE_OK;
+}
+
+extern "C" int glorie_ba_build_system(glorie_ctx* ctx, const float* poses, const float* disps,
+                                      const float* intrinsics, const float* disps_sens,
+                                      const float* targets, const float* weights, const float* eta,
+                                      const int64_t* ii, const int64_t* jj, int B, int N, int M,
+                                      int h, int w, int t0, int t1, int motion_only, double* hv_out,
+                                      void* stream) {
+  BaPlan pl;
+  GLORIE_TRY(ba_plan(ctx, B, N, M, h, w, t0, t1, hv_out, pl));
+  if (!hv_out || pl.P == 0) return GLORIE_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (N == 0 || pl.HW == 0) {  // a rank without edges contributes a zero system
+    GLORIE_TRY(check_hip(hipMemsetAsync(ctx->dstatus, 0, 4 * sizeof(int), st)));
+    return check_hip(hipMemsetAsync(hv_out, 0, sizeof(double) * ((size_t)pl.n6 * pl.n6 + pl.n6), st));
+  }
+  if (!poses || !disps || !intrinsics || !targets || !weights || !ii || !jj) return GLORIE_EINVAL;
+  if (!motion_only && !eta) return GLORIE_EINVAL;
+  GLORIE_TRY(ba_prepare(pl.wk, ii, B, N, M, t0, t1, st));
+  return ba_build_system(pl, poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj,
+                         motion_only, st);
+}
+
+extern "C" int glorie_ba_solve_update(glorie_ctx* ctx, float* poses, float* disps,
+                                      const int64_t* ii, const int64_t* jj, int B, int N, int M,
+                                      int h, int w, int t0, int t1, float lm, float ep,
+                                      int motion_only, int depth_only, const double* hv,
+                                      float* dx_out, float* dz_out, void* stream) {
+  BaPlan pl;
+  GLORIE_TRY(ba_plan(ctx, B, N, M, h, w, t0, t1, const_cast<double*>(hv), pl));
+  if (!hv || !poses || !disps || pl.P == 0) return GLORIE_EINVAL;
+  if (N > 0 && (!ii || !jj)) return GLORIE_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (N == 0 || pl.HW == 0) {
+    // no local edges: still solve and retract the (replicated) poses; no depth frames to update
+    pl.M = 1;
+    return ba_solve_update(pl, poses, disps, ii, jj, lm, ep, /*motion_only=*/1, depth_only, dx_out,
+                           nullptr, st);
+  }
+  return ba_solve_update(pl, poses, disps, ii, jj, lm, ep, motion_only, depth_only, dx_out, dz_out, st);
 }
 
 // diagnostic: blocks until `stream` drains, then returns the device status word

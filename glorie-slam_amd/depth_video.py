@@ -58,6 +58,8 @@ class DepthVideo:
         self.poses[:] = torch.as_tensor([0, 0, 0, 0, 0, 0, 1], **f32)
         self.printer = printer
         self._ctx = None
+        # multi-GPU state (glorie_slam_amd.dist): None = single GPU
+        self.shard = None
 
     # ---- bookkeeping -----------------------------------------------------------------
     def get_lock(self):
@@ -113,6 +115,19 @@ class DepthVideo:
         jj = jj.to(device=device, dtype=torch.long).reshape(-1)
         return ii, jj
 
+    def enable_sharding(self, owner, rank, world, group=None):
+        """edges of this process' graphs are a source-keyframe shard (dist.shard_frames)"""
+        self.shard = dict(owner=owner, rank=rank, world=world, group=group)
+
+    def sync_owned(self, *names):
+        """all-gather the rows owned by each rank of the named per-keyframe buffers"""
+        if self.shard is None or self.shard["world"] <= 1:
+            return
+        from . import dist as gdist
+        for nme in names:
+            gdist.allgather_owned_rows(getattr(self, nme), self.shard["owner"], self.shard["rank"],
+                                       self.shard["world"], self.shard["group"])
+
     def ctx(self):
         if self._ctx is None:
             self._ctx = L.Context()
@@ -167,9 +182,15 @@ class DepthVideo:
             if opt_type == "pose_depth":
                 target = target.view(-1, h, w, 2).permute(0, 3, 1, 2).contiguous()
                 weight = weight.view(-1, h, w, 2).permute(0, 3, 1, 2).contiguous()
-                droid_backends.ba(self.poses, self.disps, self.intrinsics[0].contiguous(), None,
-                                  target, weight, eta, ii, jj, t0, t1, itrs, lm, ep, motion_only,
-                                  False, ctx=self.ctx())
+                if self.shard is not None and self.shard["world"] > 1:
+                    from . import dist as gdist
+                    gdist.ba_sharded(self.ctx(), self.poses, self.disps, self.intrinsics[0].contiguous(),
+                                     target, weight, eta.contiguous(), ii, jj, t0, t1, itrs, lm, ep,
+                                     motion_only, False, group=self.shard["group"])
+                else:
+                    droid_backends.ba(self.poses, self.disps, self.intrinsics[0].contiguous(), None,
+                                      target, weight, eta, ii, jj, t0, t1, itrs, lm, ep, motion_only,
+                                      False, ctx=self.ctx())
                 self.disps.clamp_(min=1e-5)
                 return True
             elif opt_type == "depth_scale":

@@ -1,0 +1,88 @@
+"""Multi-GPU execution of the hot path: one process per GPU, `torch.distributed` over RCCL
+(backend "nccl" on ROCm) -- SURVEY.md section 8(e).  The reference is single-GPU; this design is new.
+
+* Bundle adjustment: edges are partitioned by SOURCE keyframe (`shard_frames`).  Per GN iteration
+  the only exchange is ONE all-reduce(sum) of the packed fp64 system [H | v] (6P*6P + 6P doubles:
+  14 KB at P = 7, 26 MB at P = 300); every rank then solves the same system and retracts its
+  replica of the poses identically, and back-substitutes dz for the depth frames it owns.
+  After the last iteration the owned disparity maps are all-gathered.
+* Rendering: the cloud, its cell list and the decoder weights are replicated; rays are split in
+  contiguous blocks (`shard_range`), no collective in the forward pass.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib as L
+
+
+def shard_range(n, rank, world):
+    """contiguous block [lo, hi) of n items for `rank`"""
+    return rank * n // world, (rank + 1) * n // world
+
+
+def shard_frames(ii_host, world):
+    """Assign source keyframes to ranks in contiguous blocks with balanced edge counts.
+    Returns owner[frame] (int array over 0..max frame).  Deterministic, identical on all ranks."""
+    ii_host = np.asarray(ii_host, np.int64)
+    nf = int(ii_host.max()) + 1 if ii_host.size else 0
+    cnt = np.bincount(ii_host, minlength=nf).astype(np.float64)
+    csum = np.cumsum(cnt)
+    total = csum[-1] if nf else 0.0
+    owner = np.zeros(nf, np.int64)
+    for f in range(nf):
+        mid = csum[f] - 0.5 * cnt[f]          # centre of mass of this frame's edges
+        owner[f] = min(world - 1, int(mid * world / max(total, 1.0)))
+    return owner
+
+
+def local_edges(ii_host, owner, rank):
+    """boolean mask of the edges whose source frame is owned by `rank`"""
+    ii_host = np.asarray(ii_host, np.int64)
+    return owner[ii_host] == rank
+
+
+def allreduce_system(hv, group=None):
+    """sum the packed [H | v] buffer over ranks (RCCL all-reduce; gloo in the CPU tests)"""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(hv, op=dist.ReduceOp.SUM, group=group)
+    return hv
+
+
+def ba_sharded(ctx, poses, disps, intrinsics, targets, weights, eta, ii, jj, t0, t1, iterations,
+               lm, ep, motion_only=False, depth_only=False, group=None):
+    """Distributed droid_backends.ba: arguments are this rank's LOCAL edges (targets/weights
+    [N,2,h,w], eta rows of unique(cat(arange(t0,t1), ii_local))); poses/disps are full replicas,
+    updated in place (poses everywhere, disps for locally owned source frames)."""
+    B, h, w = disps.shape
+    N = int(ii.shape[0])
+    P = t1 - t0
+    n6 = 6 * P
+    M = int(eta.shape[0]) if eta is not None else 0
+    hv = torch.empty(n6 * n6 + n6, dtype=torch.float64, device=poses.device)
+    dx = torch.zeros(P, 6, dtype=torch.float32, device=poses.device)
+    lib = L.load()
+    for _ in range(iterations):
+        L.check(lib.glorie_ba_build_system(ctx.handle, L.ptr(poses), L.ptr(disps), L.ptr(intrinsics), None,
+                                           L.ptr(targets), L.ptr(weights), L.ptr(eta), L.ptr(ii), L.ptr(jj),
+                                           B, N, M, h, w, int(t0), int(t1), int(bool(motion_only)),
+                                           L.ptr(hv), L.stream_ptr()), "glorie_ba_build_system")
+        allreduce_system(hv, group)
+        L.check(lib.glorie_ba_solve_update(ctx.handle, L.ptr(poses), L.ptr(disps), L.ptr(ii), L.ptr(jj),
+                                           B, N, M, h, w, int(t0), int(t1), float(lm), float(ep),
+                                           int(bool(motion_only)), int(bool(depth_only)), L.ptr(hv),
+                                           L.ptr(dx), None, L.stream_ptr()), "glorie_ba_solve_update")
+    return dx
+
+
+def allgather_owned_rows(buf, owner, rank, world, group=None):
+    """make `buf[f]` consistent on all ranks: row f is taken from owner[f] (used for disps /
+    disps_up after a sharded BA-update).  Implemented as a masked all-reduce(sum)."""
+    if world <= 1:
+        return buf
+    nf = min(len(owner), buf.shape[0])
+    mine = torch.as_tensor(owner[:nf] == rank, device=buf.device)
+    contrib = torch.where(mine.view(-1, *([1] * (buf.dim() - 1))), buf[:nf], torch.zeros_like(buf[:nf]))
+    dist.all_reduce(contrib, op=dist.ReduceOp.SUM, group=group)
+    buf[:nf] = contrib
+    return buf

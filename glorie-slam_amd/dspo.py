@@ -48,9 +48,15 @@ def depth_scale_stage(video, target, weight, eta, ii, jj, itrs, lm, ep):
         bad_full = torch.zeros(video.disps.shape[0], dtype=torch.bool, device=bad.device)
         bad_full[:n] = bad
         edge_on = ~(bad_full[ii] | bad_full[jj])
-        if not bool(edge_on.any()):   # the one scalar sync: decides the stage-1 fallback
+        any_on = edge_on.any().to(torch.int32).reshape(1)
+        shard = getattr(video, "shard", None)
+        if shard is not None and shard["world"] > 1:
+            # the fallback decision must be identical on every rank (it selects a collective path)
+            import torch.distributed as dist
+            dist.all_reduce(any_on, op=dist.ReduceOp.MAX, group=shard["group"])
+        if not bool(any_on.item()):   # the one scalar sync: decides the stage-1 fallback
             return False
-    if n <= 0 or ii.shape[0] == 0:
+    if n <= 0:
         return False
     scale_shift_step(video, target, weight, eta, ii, jj, edge_on, itrs, lm, ep, alpha=0.01)
     video.disps.clamp_(min=1e-5)

@@ -169,6 +169,7 @@ class FactorGraph:
         self.target = coords1 + delta.to(dtype=torch.float)
         self.weight = weight.to(dtype=torch.float)
         self.damping[uniq] = damping
+        sharded = getattr(self.video, "shard", None) is not None and self.video.shard["world"] > 1
         if use_inactive:
             m = (self.ii_inac >= t0 - 3) & (self.jj_inac >= t0 - 3)
             ii = torch.cat([self.ii_inac[m], self.ii], 0)
@@ -178,10 +179,16 @@ class FactorGraph:
             uq = torch.unique(ii)
         else:
             ii, jj, target, weight, uq = self.ii, self.jj, self.target, self.weight, uniq
+        if sharded and opt_type == "pose_depth":
+            # a shard sees only its own source frames: the BA slots are unique(cat(arange(t0,t1), ii))
+            assert t1 is not None, "sharded BA needs an explicit (global) t1"
+            uq = torch.unique(torch.cat([torch.arange(t0, t1, device=ii.device), ii]))
         damping = .2 * self.damping[uq].contiguous() + EP
         self.video.ba(target, weight, damping, ii, jj, t0, t1, iters=itrs, lm=1e-4, ep=0.1,
                       motion_only=motion_only, opt_type=opt_type)
         self.video.upsample(uniq, upmask)
+        if sharded:
+            self.video.sync_owned("disps", "disps_up", "depth_scale", "depth_shift")
         self.age += 1
 
     @torch.no_grad()

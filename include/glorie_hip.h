@@ -145,6 +145,27 @@ int glorie_ba(glorie_ctx* ctx, float* poses, float* disps, const float* intrinsi
               float lm, float ep, int motion_only, int depth_only,
               float* dx_out, float* dz_out, void* stream);
 
+/* Multi-GPU form of glorie_ba: one Gauss-Newton iteration split at its
+ * single exchange step.  Edges are partitioned by SOURCE keyframe, so every per-edge term, the
+ * depth blocks C_k / w_k and every Schur product of frame k are local to the rank owning k;
+ * only the dense reduced system [H (6P x 6P, lower block triangle) | v (6P)] must be summed.
+ *   glorie_ba_build_system : local edges -> hv_out, (6P*6P + 6P) doubles, caller-owned
+ *   <caller: all-reduce(sum) of hv over RCCL>
+ *   glorie_ba_solve_update : damping + fp64 Cholesky of hv, pose retraction (replicated,
+ *                            identical on all ranks) and dz for the local depth frames.
+ * Both calls take the SAME local edge set / sizes on the same ctx, back to back; M counts
+ * unique(cat(arange(t0,t1), ii_local)) and eta holds those frames' rows.  A rank without
+ * edges passes N = 0.  With one rank the pair is equivalent to one iteration of glorie_ba. */
+int glorie_ba_build_system(glorie_ctx* ctx, const float* poses, const float* disps,
+                           const float* intrinsics, const float* disps_sens,
+                           const float* targets, const float* weights, const float* eta,
+                           const int64_t* ii, const int64_t* jj, int B, int N, int M, int h, int w,
+                           int t0, int t1, int motion_only, double* hv_out, void* stream);
+int glorie_ba_solve_update(glorie_ctx* ctx, float* poses, float* disps, const int64_t* ii,
+                           const int64_t* jj, int B, int N, int M, int h, int w, int t0, int t1,
+                           float lm, float ep, int motion_only, int depth_only, const double* hv,
+                           float* dx_out, float* dz_out, void* stream);
+
 /* DSPO stage 2, `BA_with_scale_shift(target, weight, eta, poses, disps, intrinsics, ii, jj,
  *                mono_disps, scales, shifts, valid_depth_mask, ignore_frames=0, lm, ep, alpha)`
  *   reference: src/geom/ba.py:127-216, src/geom/chol.py:58-85, call site

@@ -217,3 +217,51 @@ def reprojection_cost(poses, disps, intr, targets, weights, ii, jj):
         t = per_edge_terms(poses, disps, intr, targets[n], weights[n], int(ii[n]), int(jj[n]))
         c += float((t["w"].astype(np.float64) * t["r"].astype(np.float64) ** 2).sum())
     return c
+
+
+def reduced_system(poses, disps, intr, targets, weights, eta_by_frame, ii, jj, t0, t1):
+    """Dense reduced camera system (H = A - S, v = b - sb) BEFORE damping, for an arbitrary
+    subset of edges -- used to check that per-shard systems sum to the unsharded one
+    (edges partitioned by source frame).  eta_by_frame: [B,HW]."""
+    poses = np.asarray(poses, F)
+    disps = np.asarray(disps, F)
+    ii = [int(v) for v in ii]
+    jj = [int(v) for v in jj]
+    N = len(ii)
+    P = t1 - t0
+    B, h, w = disps.shape
+    HW = h * w
+    A = np.zeros((6 * P, 6 * P))
+    b = np.zeros(6 * P)
+    if N == 0:
+        return A, b
+    terms = [per_edge_terms(poses, disps, intr, targets[n], weights[n], ii[n], jj[n]) for n in range(N)]
+    for n in range(N):
+        i, j = ii[n] - t0, jj[n] - t0
+        Hs, vs = terms[n]["Hs"].astype(np.float64), terms[n]["vs"].astype(np.float64)
+        for (pa, pb, blk) in ((i, i, Hs[0]), (i, j, Hs[1]), (j, i, Hs[2]), (j, j, Hs[3])):
+            if 0 <= pa < P and 0 <= pb < P:
+                A[6 * pa:6 * pa + 6, 6 * pb:6 * pb + 6] += blk
+        if 0 <= i < P:
+            b[6 * i:6 * i + 6] += vs[0]
+        if 0 <= j < P:
+            b[6 * j:6 * j + 6] += vs[1]
+    # rows of the Schur system: self rows (pose k, depth k) for owned source frames in [t0,t1)
+    # and edge rows (pose jj, depth ii)
+    frames = sorted(set(ii))
+    for k in frames:
+        sel = [n for n in range(N) if ii[n] == k]
+        C = sum(terms[n]["Cii"].astype(np.float64) for n in sel) + np.asarray(eta_by_frame[k], np.float64).reshape(-1)
+        wv = sum(terms[n]["bz"].astype(np.float64) for n in sel)
+        Q = 1.0 / C
+        rows = []
+        if t0 <= k < t1:
+            rows.append((k - t0, sum(terms[n]["Eii"].astype(np.float64) for n in sel)))
+        for n in sel:
+            if t0 <= jj[n] < t1:
+                rows.append((jj[n] - t0, terms[n]["Eij"].astype(np.float64)))
+        for (pa, Ea) in rows:
+            b[6 * pa:6 * pa + 6] -= (Ea * (Q * wv)[None]).sum(1)
+            for (pb, Eb) in rows:
+                A[6 * pa:6 * pa + 6, 6 * pb:6 * pb + 6] -= (Ea * Q[None]) @ Eb.T
+    return A, b

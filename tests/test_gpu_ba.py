@@ -163,3 +163,44 @@ def test_ba_full_size_fixed_point_and_descent(gpu):
     p, d, *_ = run_gpu(g, gpu, 1, 8, 2)
     c1 = oba.reprojection_cost(p, d, intr, g["target"], g["weight"], g["ii"], g["jj"])
     assert c1 < 0.2 * c0
+
+
+def test_ba_sharded_equals_unsharded(gpu):
+    """build_system on two source-frame shards (two contexts on one GPU), summed like the RCCL
+    all-reduce would, then solve_update on each shard == glorie_ba on the whole graph."""
+    from glorie_slam_amd import _lib as L, dist as gdist
+    K = 7
+    g = make_problem(K, 16, 20, radius=3)
+    t0, t1, lm, ep = 1, K, 1e-4, 0.1
+    rp, rd, rdx, rdz, st = run_gpu(g, gpu, t0, t1, 1)
+    owner = gdist.shard_frames(g["ii"], 2)
+    B, h, w = g["disps"].shape
+    n6 = 6 * (t1 - t0)
+    lib = L.load()
+    shards = []
+    for r in range(2):
+        m = gdist.local_edges(g["ii"], owner, r)
+        ii_l, jj_l = g["ii"][m], g["jj"][m]
+        kx = sorted(set(list(range(t0, t1)) + ii_l.tolist()))
+        sh = dict(ctx=L.Context(), ii=_t(ii_l, gpu), jj=_t(jj_l, gpu), tgt=_t(g["target"][m], gpu),
+                  wgt=_t(g["weight"][m], gpu), eta=_t(g["eta"][kx], gpu), M=len(kx), N=int(m.sum()),
+                  poses=_t(g["poses"], gpu), disps=_t(g["disps"], gpu),
+                  hv=torch.empty(n6 * n6 + n6, dtype=torch.float64, device=gpu), owned=owner == r)
+        L.check(lib.glorie_ba_build_system(sh["ctx"].handle, L.ptr(sh["poses"]), L.ptr(sh["disps"]),
+                                           L.ptr(_t(g["intrinsics"][0], gpu)), None, L.ptr(sh["tgt"]),
+                                           L.ptr(sh["wgt"]), L.ptr(sh["eta"]), L.ptr(sh["ii"]), L.ptr(sh["jj"]),
+                                           B, sh["N"], sh["M"], h, w, t0, t1, 0, L.ptr(sh["hv"]),
+                                           L.stream_ptr()), "build")
+        shards.append(sh)
+    total = shards[0]["hv"] + shards[1]["hv"]
+    disps = g["disps"].copy()
+    for sh in shards:
+        sh["hv"].copy_(total)
+        L.check(lib.glorie_ba_solve_update(sh["ctx"].handle, L.ptr(sh["poses"]), L.ptr(sh["disps"]),
+                                           L.ptr(sh["ii"]), L.ptr(sh["jj"]), B, sh["N"], sh["M"], h, w, t0, t1,
+                                           lm, ep, 0, 0, L.ptr(sh["hv"]), None, None, L.stream_ptr()), "solve")
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(sh["poses"].cpu().numpy(), rp, atol=2e-6)
+        d = sh["disps"].cpu().numpy()
+        disps[:len(sh["owned"])][sh["owned"]] = d[:len(sh["owned"])][sh["owned"]]
+    np.testing.assert_allclose(disps, rd, atol=2e-6)
