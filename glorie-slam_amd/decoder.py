@@ -247,11 +247,39 @@ class POINT(nn.Module):
                                        pos_embedding_method=pos_embedding_method,
                                        use_view_direction=use_view_direction)
 
+    def _packed(self):
+        """parameter buffer of the fused kernels, rebuilt when any parameter was modified"""
+        ver = tuple(p._version for p in self.parameters()) + (str(next(self.parameters()).device),)
+        if getattr(self, "_pack_ver", None) != ver:
+            self._pack = point_ops.pack_decoders(self)
+            self._pack_ver = ver
+        return self._pack
+
+    def _fused_ok(self, p, npc_geo_feats, npc_col_feats, is_tracker, stage):
+        g, c = self.geo_decoder, self.color_decoder
+        return p.is_cuda and not is_tracker and not torch.is_grad_enabled() and \
+            g.weighting == 'distance' and c.weighting == 'distance' and g.c_dim == 32 and \
+            c.encode_rel_pos_in_col and c.use_view_direction and c.encode_viewd and \
+            getattr(self, "use_fused", True)
+
     def forward(self, p, npc, stage, npc_geo_feats, npc_col_feats, pts_num=16, is_tracker=False,
                 cloud_pos=None, pts_views_d=None, dynamic_r_query=None):
         pp = p.reshape(-1, 3)
         # one neighbour search shared by both decoders
         shared = npc.find_neighbors_faiss(pp.detach().clone(), step='query', dynamic_radius=dynamic_r_query)
+        if self._fused_ok(pp, npc_geo_feats, npc_col_feats, is_tracker, stage) and stage in ('geometry', 'color'):
+            # inference fast path: IDW gather + the three MFMA decoder kernels (csrc/mlp.hip)
+            D, I, nn_num = shared
+            g = self.geo_decoder
+            radius = 0.0 if g.use_dynamic_radius else npc.get_radius_query()
+            rq = dynamic_r_query if g.use_dynamic_radius else None
+            c_geo, has, w = point_ops.idw_gather(D, I, nn_num, npc_geo_feats, radius=radius,
+                                                 radius_per_query=rq, min_nn=g.min_nn_num, return_weights=True)
+            cp = cloud_pos if cloud_pos is not None else npc.cloud_pos()
+            raw = point_ops.render_mlp(self._packed(), pp, pts_views_d, cp, npc_col_feats, c_geo, I, w, has,
+                                       stage=stage)
+            per_ray = torch.sum(has.view(-1, pts_num), 1)
+            return raw, ~(per_ray < 3), has, per_ray
         geo_occ, ray_mask, point_mask, ray_counter = self.geo_decoder(
             p, npc, npc_geo_feats, pts_num=pts_num, is_tracker=is_tracker, cloud_pos=cloud_pos,
             dynamic_r_query=dynamic_r_query, shared=shared)

@@ -111,3 +111,94 @@ def composite(raw, z_vals, coef=0.1, return_weights=True):
                                       L.ptr(var), L.ptr(rgb), L.ptr(w), L.stream_ptr()),
             "glorie_composite")
     return depth, var, rgb, w
+
+
+# --------------------------------------------------------------------------------------
+# fused decoders (csrc/mlp.hip)
+# --------------------------------------------------------------------------------------
+def _t(w):
+    """nn.Linear weight [out,in] -> K-major [in,out] fp32"""
+    return w.detach().float().t().contiguous()
+
+
+def _pad_rows(m, rows):
+    out = torch.zeros(rows, m.shape[1], dtype=torch.float32, device=m.device)
+    out[:m.shape[0]] = m
+    return out
+
+
+def _pad_cols(m, cols):
+    out = torch.zeros(m.shape[0], cols, dtype=torch.float32, device=m.device)
+    out[:, :m.shape[1]] = m
+    return out
+
+
+def pack_decoders(decoders):
+    """Flatten a POINT module into the parameter buffer of glorie_render_mlp (layout mirrored in
+    csrc/mlp.hip: GeoParams | NbParams | ColParams)."""
+    g, c = decoders.geo_decoder, decoders.color_decoder
+    dev = next(decoders.parameters()).device
+    f = lambda t: t.detach().float().reshape(-1).to(dev)
+    parts = []
+    # geometry
+    parts.append(f(_pad_cols(g.embedder._B.detach().float().to(dev), 96)))
+    parts.append(f(_pad_rows(_t(g.pts_linears[0].weight), 96)))
+    parts.append(f(_t(g.pts_linears[1].weight)))
+    parts.append(f(_t(g.pts_linears[2].weight)))
+    w3 = _t(g.pts_linears[3].weight)                       # [125, 32]: rows 0..92 embedding, 93..124 hidden
+    parts.append(f(_pad_rows(w3[:93], 96)))
+    parts.append(f(w3[93:]))
+    parts.append(f(_t(g.pts_linears[4].weight)))
+    parts.append(f(_pad_cols(_t(g.output_linear.weight), 16)))
+    parts.append(torch.cat([f(_t(l.weight)) for l in g.fc_c]))
+    parts.append(torch.cat([f(l.bias) for l in g.pts_linears]))
+    parts.append(torch.cat([f(l.bias) for l in g.fc_c]))
+    parts.append(torch.cat([f(g.output_linear.bias), torch.zeros(3, device=dev)]))
+    # per-neighbour F_theta (of the colour decoder)
+    n = c.mlp_col_neighbor
+    parts.append(f(c.embedder_rel_pos._B))
+    parts.append(torch.zeros(2, device=dev))
+    parts.append(f(_t(n.linear1.weight)))
+    parts.append(f(n.linear1.bias))
+    parts.append(f(_t(n.linear2.weight)))
+    parts.append(f(n.linear2.bias))
+    # colour
+    parts.append(f(c.embedder._B.to(dev)))
+    parts.append(f(c.embedder_view_direction._B.to(dev)))
+    parts.append(f(_t(c.pts_linears[0].weight)))
+    parts.append(f(_t(c.pts_linears[1].weight)))
+    parts.append(f(_t(c.pts_linears[2].weight)))
+    w3 = _t(c.pts_linears[3].weight)                       # [208, 128]: rows 0..79 embedding
+    parts.append(f(w3[:80]))
+    parts.append(f(w3[80:]))
+    parts.append(f(_t(c.pts_linears[4].weight)))
+    parts.append(f(_pad_cols(_t(c.output_linear.weight), 16)))
+    parts.append(torch.cat([f(_t(l.weight)) for l in c.fc_c]))
+    parts.append(torch.cat([f(l.bias) for l in c.pts_linears]))
+    parts.append(torch.cat([f(l.bias) for l in c.fc_c]))
+    parts.append(torch.cat([f(c.output_linear.bias), torch.zeros(1, device=dev)]))
+    packed = torch.cat(parts).contiguous()
+    expect = int(L.load().glorie_decoder_pack_floats())
+    if packed.numel() != expect:
+        raise L.GlorieError(f"decoder pack has {packed.numel()} floats, library expects {expect}")
+    return packed
+
+
+def render_mlp(packed, pts, views, cloud_pos, col_feats, c_geo, I, weights, has, stage="color"):
+    """raw [Q,4] = (rgb, occ) for samples `pts` given their neighbours; occ = -100 where
+    has == False.  stage 'geometry' leaves rgb = 0."""
+    L.need_cuda(packed, pts, c_geo)
+    Q = pts.shape[0]
+    dev = pts.device
+    raw = torch.zeros(Q, 4, dtype=torch.float32, device=dev)
+    color = stage == "color"
+    scratch = torch.empty(Q, 32, dtype=torch.float32, device=dev) if color else None
+    has8 = has.to(torch.uint8).contiguous()
+    L.check(L.load().glorie_render_mlp(
+        L.ptr(packed), L.ptr(pts.contiguous().float()),
+        L.ptr(views.contiguous().float()) if color else None,
+        L.ptr(cloud_pos.contiguous()) if color else None, L.ptr(col_feats.contiguous()) if color else None,
+        L.ptr(c_geo.contiguous()), L.ptr(I.contiguous()) if color else None,
+        L.ptr(weights.contiguous()) if color else None, L.ptr(has8), Q, L.ptr(scratch), L.ptr(raw),
+        int(color), L.stream_ptr()), "glorie_render_mlp")
+    return raw

@@ -221,6 +221,21 @@ int glorie_idw_gather(const float* D, const int64_t* I, const int* nn, const flo
                       int min_nn, int expo_weighting, float* c_out, float* w_out,
                       uint8_t* has_out, void* stream);
 
+/* Fused decoders: POINT.forward(p, npc, stage, ...) minus the neighbour search
+ *   reference: src/modules/conv_onet/models/decoder.py:175-225 (MLP_geometry.forward),
+ *   :340-389 + :228-243 (per-neighbour F_theta + IDW sum), :391-433 (MLP_color.forward),
+ *   :460-501 (POINT.forward), src/utils/Renderer.py:206-207 (occupancy -100 without neighbours)
+ * packed: glorie_decoder_pack_floats() floats, layout in csrc/mlp.hip (built by
+ * glorie_slam_amd.point_ops.pack_decoders from the state dict).  pts/views [Q,3]; cloud_pos
+ * [Np,3]; col_feats [Np,32]; c_geo [Q,32] + weights [Q,8] + has [Q] from glorie_idw_gather;
+ * I [Q,8] from glorie_knn_query; c_col_scratch [Q,32]; raw [Q,4] = (r,g,b,occ), rgb written
+ * only when stage_color != 0 (caller zero-fills otherwise).  All fp32, MFMA 16x16x4 f32. */
+size_t glorie_decoder_pack_floats(void);
+int glorie_render_mlp(const float* packed, const float* pts, const float* views,
+                      const float* cloud_pos, const float* col_feats, const float* c_geo,
+                      const int64_t* I, const float* weights, const uint8_t* has, int Q,
+                      float* c_col_scratch, float* raw, int stage_color, void* stream);
+
 /* raw2outputs_nerf_color(raw, z_vals, rays_d, coef)
  *   reference: src/utils/common.py:261-299
  * raw [R,S,4] (rgb, occupancy), z_vals [R,S] -> depth [R], var [R], rgb [R,3],

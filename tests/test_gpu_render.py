@@ -184,3 +184,63 @@ def test_render_batch_ray_end_to_end(gpu):
     assert np.all(np.isfinite(d.cpu().numpy()))
     assert np.abs(d.cpu().numpy()[ok] - depth[ok]).max() < 0.06 * depth.max()
     assert (c.cpu().numpy() >= 0).all() and (c.cpu().numpy() <= 1).all()
+
+
+def test_fused_mlp_matches_torch_path_and_reference(gpu):
+    """the MFMA decoder kernels == the torch nn.Linear path == the reference fixture"""
+    from glorie_slam_amd.decoder import POINT
+    from glorie_slam_amd.neural_point import NeuralPointCloud
+    f = np.load(os.path.join(GOLD, "decoders.npz"))
+    t = lambda k: torch.from_numpy(f[k]).to(gpu)
+    torch.manual_seed(43)
+    dec = POINT(_cfg(gpu), c_dim=32, hidden_size=128, use_view_direction=True).eval().to(gpu)
+    npc = NeuralPointCloud(_cfg(gpu))
+    npc.add_points(t("cloud"), t("geo"), t("col"))
+    args = (t("p")[None], npc, "color", npc.geo_feats, npc.col_feats)
+    kw = dict(pts_num=10, cloud_pos=npc.cloud_pos(), pts_views_d=t("views"), dynamic_r_query=t("radius"))
+    with torch.no_grad():
+        dec.use_fused = True
+        raw_f, rm_f, pm_f, cnt_f = dec(*args, **kw)
+        dec.use_fused = False
+        raw_t, rm_t, pm_t, cnt_t = dec(*args, **kw)
+    pm = f["point_mask"]
+    assert torch.equal(pm_f, pm_t) and torch.equal(rm_f, rm_t) and torch.equal(cnt_f, cnt_t)
+    rf, rt = raw_f.cpu().numpy(), raw_t.cpu().numpy()
+    assert np.all(rf[~pm, 3] == -100.0)
+    np.testing.assert_allclose(rf[pm, 3], rt[pm, 3], rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(rf[pm, :3], rt[pm, :3], rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(rf[pm, 3], f["occ"][pm], rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(rf[pm, :3], f["rgb"][pm], rtol=1e-3, atol=1e-3)
+    with torch.no_grad():
+        dec.use_fused = True
+        raw_g, *_ = dec(args[0], npc, "geometry", npc.geo_feats, npc.col_feats, **kw)
+    assert torch.all(raw_g[:, :3] == 0) and torch.allclose(raw_g[:, 3], raw_f[:, 3])
+
+
+def test_fused_mlp_ragged_sizes(gpu):
+    """sample counts that are not multiples of the 64-sample tile"""
+    import glorie_slam_amd.synth as synth
+    from glorie_slam_amd.decoder import POINT
+    from glorie_slam_amd.neural_point import NeuralPointCloud
+    cfg = _cfg(gpu)
+    pts, geo, col = synth.box_cloud(n_hits=3000)
+    t = lambda x: torch.from_numpy(x).to(gpu)
+    npc = NeuralPointCloud(cfg)
+    npc.add_points(t(pts), t(geo), t(col))
+    torch.manual_seed(1)
+    dec = POINT(cfg, use_view_direction=True).eval().to(gpu)
+    rng = np.random.default_rng(0)
+    for Q in (10, 70, 650):
+        p = t((pts[rng.integers(0, len(pts), Q)] * rng.uniform(0.97, 1.03, (Q, 1))).astype(np.float32))
+        v = t(rng.standard_normal((Q, 3)).astype(np.float32))
+        r = t(rng.uniform(0.05, 0.3, (Q, 1)).astype(np.float32))
+        with torch.no_grad():
+            dec.use_fused = True
+            a, _, pm, _ = dec(p[None], npc, "color", npc.geo_feats, npc.col_feats, pts_num=10, pts_views_d=v, dynamic_r_query=r)
+            dec.use_fused = False
+            b, _, pm2, _ = dec(p[None], npc, "color", npc.geo_feats, npc.col_feats, pts_num=10, pts_views_d=v, dynamic_r_query=r)
+        assert torch.equal(pm, pm2)
+        b[~pm, 3] = -100.0          # Renderer.py:206-207 (the fused path applies it itself)
+        a, b, pm = a.cpu().numpy(), b.cpu().numpy(), pm.cpu().numpy()
+        np.testing.assert_allclose(a[:, 3], b[:, 3], rtol=2e-3, atol=1e-3)
+        np.testing.assert_allclose(a[pm, :3], b[pm, :3], rtol=2e-3, atol=1e-3)
