@@ -170,10 +170,16 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % max(ndev, 1)   # (testing only: several ranks may share one GPU with gloo)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("GLORIE_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     g, video, graph = build_graph(device, rank=rank, world=world)
     K = g["K"]

@@ -147,6 +147,123 @@ __global__ __launch_bounds__(256) void corr_lookup_r3_kernel(
   }
 }
 
+
+// ------------------------------------------------------------------------------------
+// v2: lane = (pixel group g of 8 consecutive pixels, window row r).  Per level a lane issues
+// 8 independent 16-byte row loads (one per pixel of its group) before using any of them, and
+// every output channel of the group is ONE 16-byte store; across the 8 groups of a wave that
+// is a full 128-byte line per channel (the v1 kernel issues 2-byte stores: 8x more store
+// instructions, 1.8x write amplification in WRITE_SIZE).  Row r+1 comes from lane+1 via a DPP
+// row shift.  Requires HW % 8 == 0.  Arithmetic identical to v1 (bit-exact fp16).
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned dpp_next(unsigned v) {
+  // lane i <- lane i+1 inside a row of 16 lanes (row_shl:1); the last row lane is unused
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xf, 0xf, true);
+}
+
+template <typename T> struct Pack8;
+template <> struct Pack8<_Float16> {
+  typedef __attribute__((ext_vector_type(4))) unsigned vec;  // 8 halfs
+  static __device__ __forceinline__ void next(const _Float16 (&s)[8], _Float16 (&n)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned lo = __builtin_bit_cast(unsigned short, s[2 * i]);
+      const unsigned hi = __builtin_bit_cast(unsigned short, s[2 * i + 1]);
+      const unsigned v = dpp_next(lo | (hi << 16));
+      n[2 * i] = __builtin_bit_cast(_Float16, (unsigned short)(v & 0xffffu));
+      n[2 * i + 1] = __builtin_bit_cast(_Float16, (unsigned short)(v >> 16));
+    }
+  }
+};
+template <> struct Pack8<float> {
+  static __device__ __forceinline__ void next(const float (&s)[8], float (&n)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) n[i] = __uint_as_float(dpp_next(__float_as_uint(s[i])));
+  }
+};
+
+template <typename T>
+struct __attribute__((aligned(16))) Out8 { T v[8]; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void corr_lookup_r3_v2_kernel(
+    CorrLevels lv, int num_levels, int scale_coords, const float* __restrict__ coords,
+    T* __restrict__ out, int HW, int out_channels) {
+  constexpr int R = 3, RD = 7, WIN = 8, PG = 8;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int row = lane & 7, grp = lane >> 3;
+  const int n = blockIdx.y;
+  const int pb = (blockIdx.x * 4 + wv) * 64 + grp * PG;   // first pixel of this lane's group
+  const bool live = pb < HW;                              // HW % 8 == 0: groups are all-or-nothing
+  const int pc = live ? pb : HW - PG;
+
+  float x0[PG], y0[PG];
+  {
+    const float4* cx = reinterpret_cast<const float4*>(coords + ((size_t)n * 2 + 0) * HW + pc);
+    const float4* cy = reinterpret_cast<const float4*>(coords + ((size_t)n * 2 + 1) * HW + pc);
+    const float4 a = cx[0], b = cx[1], c = cy[0], d = cy[1];
+    x0[0] = a.x; x0[1] = a.y; x0[2] = a.z; x0[3] = a.w; x0[4] = b.x; x0[5] = b.y; x0[6] = b.z; x0[7] = b.w;
+    y0[0] = c.x; y0[1] = c.y; y0[2] = c.z; y0[3] = c.w; y0[4] = d.x; y0[5] = d.y; y0[6] = d.z; y0[7] = d.w;
+  }
+  float inv = 1.0f;
+  for (int l = 0; l < num_levels; ++l) {
+    const int h2 = lv.h2[l], w2 = lv.w2[l];
+    const T* vol = reinterpret_cast<const T*>(lv.vol[l]);
+    T s[PG][WIN];
+    float dxs[PG], dys[PG];
+    // phase 1: issue the 8 row loads of this lane
+#pragma unroll
+    for (int q = 0; q < PG; ++q) {
+      const float xs = scale_coords ? x0[q] * inv : x0[q];
+      const float ys = scale_coords ? y0[q] * inv : y0[q];
+      const float fx = floorf(xs), fy = floorf(ys);
+      dxs[q] = xs - fx;
+      dys[q] = ys - fy;
+      const int ix0 = static_cast<int>(fx) - R;
+      const int y1 = static_cast<int>(fy) - R + row;
+#pragma unroll
+      for (int i = 0; i < WIN; ++i) s[q][i] = (T)0.0f;
+      if (y1 >= 0 && y1 < h2) {
+        const T* rowp = vol + ((size_t)n * HW + pc + q) * ((size_t)h2 * w2) + (size_t)y1 * w2;
+        if (ix0 >= 0 && ix0 + WIN <= w2) {
+          Row8<T> r;
+          __builtin_memcpy(&r, rowp + ix0, sizeof(r));
+#pragma unroll
+          for (int i = 0; i < WIN; ++i) s[q][i] = r.v[i];
+        } else {
+#pragma unroll
+          for (int i = 0; i < WIN; ++i) {
+            const int x1 = ix0 + i;
+            if (x1 >= 0 && x1 < w2) s[q][i] = rowp[x1];
+          }
+        }
+      }
+    }
+    inv *= 0.5f;
+    // phase 2: blend and store, one 16-byte store per output channel
+    Out8<T> o[RD];
+#pragma unroll
+    for (int q = 0; q < PG; ++q) {
+      T nx[WIN];
+      Pack8<T>::next(s[q], nx);
+      const float dx = dxs[q], dy = dys[q];
+      const T w00 = weight_cast<T>((1.0f - dx) * (1.0f - dy));
+      const T w01 = weight_cast<T>((1.0f - dx) * dy);
+      const T w10 = weight_cast<T>(dx * (1.0f - dy));
+      const T w11 = weight_cast<T>(dx * dy);
+#pragma unroll
+      for (int i = 0; i < RD; ++i)
+        o[i].v[q] = blend4(s[q][i], nx[i], s[q][i + 1], nx[i + 1], w00, w01, w10, w11);
+    }
+    if (live && row < RD) {
+      T* op = out + ((size_t)n * out_channels + (size_t)l * RD * RD + row) * HW + pb;
+#pragma unroll
+      for (int i = 0; i < RD; ++i)
+        *reinterpret_cast<Out8<T>*>(op + (size_t)i * RD * HW) = o[i];
+    }
+  }
+}
+
 // generic-radius fallback: one thread per pixel, same arithmetic order.
 template <typename T>
 __global__ __launch_bounds__(256) void corr_lookup_generic_kernel(
@@ -191,7 +308,12 @@ static int launch_lookup(const CorrLevels& lv, int L, int scale, const float* co
                          int N, int HW, int radius, hipStream_t st) {
   if (N == 0 || HW == 0) return GLORIE_OK;
   const int chans = L * (2 * radius + 1) * (2 * radius + 1);
-  if (radius == 3) {
+  if (radius == 3 && HW % 8 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
+      (reinterpret_cast<uintptr_t>(coords) & 15) == 0) {
+    dim3 grid((HW + 255) / 256, N);
+    hipLaunchKernelGGL(corr_lookup_r3_v2_kernel<T>, grid, dim3(256), 0, st, lv, L, scale, coords,
+                       reinterpret_cast<T*>(out), HW, chans);
+  } else if (radius == 3) {
     dim3 grid((HW + 31) / 32, N);
     hipLaunchKernelGGL(corr_lookup_r3_kernel<T>, grid, dim3(256), 0, st, lv, L, scale, coords,
                        reinterpret_cast<T*>(out), HW, chans);
