@@ -341,6 +341,296 @@ __global__ __launch_bounds__(256) void mlp_col_kernel(ColParams P, const float* 
   }
 }
 
+
+// ====================================================================================
+// v2 kernels: 128 samples / 8 waves per workgroup, weights streamed through LDS in 32-row
+// chunks (double buffered, shared by the 8 waves), embedding / feature A-fragments kept in
+// registers, fast softplus.  Same arithmetic (exact fp32 MFMA); only the transcendental
+// approximations of softplus differ (v_exp/v_log, |err| < 1e-6).
+// ====================================================================================
+constexpr int kTM2 = 128;
+constexpr int kLdw = 144;                 // chunk row stride: (k*144 + col) % 32 is conflict free
+constexpr int kChunkFloats = 32 * kLdw;   // one 32 x 128 weight chunk in LDS
+constexpr int kLdh = 130;
+
+__device__ __forceinline__ float softplus100_fast(float x) {
+  const float t = 100.0f * x;
+  return t > 20.0f ? x : 0.01f * __logf(1.0f + __expf(t));
+}
+
+struct ChunkRegs { float4 a, b; };
+
+// thread t of 512 moves 8 floats: row = t >> 4 (0..31), cols (t & 15) * 8 .. + 7
+__device__ __forceinline__ ChunkRegs chunk_load(const float* __restrict__ Wall, int chunk) {
+  const int t = threadIdx.x;
+  const float4* src = reinterpret_cast<const float4*>(Wall + ((size_t)chunk * 32 + (t >> 4)) * 128 + (t & 15) * 8);
+  ChunkRegs r;
+  r.a = src[0];
+  r.b = src[1];
+  return r;
+}
+__device__ __forceinline__ void chunk_store(float* Wb, const ChunkRegs& r) {
+  const int t = threadIdx.x;
+  float4* dst = reinterpret_cast<float4*>(Wb + (t >> 4) * kLdw + (t & 15) * 8);
+  dst[0] = r.a;
+  dst[1] = r.b;
+}
+
+// acc[t] += a_k * W[k][16t + lane&15] for NS k-steps, A from a register fragment
+template <int A0, int NS, int NREG>
+__device__ __forceinline__ void mma_regs(f32x4 (&acc)[8], const float (&a)[NREG], const float* Wb) {
+  const int lane = threadIdx.x & 63;
+  const float* wp = Wb + (lane >> 4) * kLdw + (lane & 15);
+#pragma unroll
+  for (int sidx = 0; sidx < NS; ++sidx) {
+    const float av = a[A0 + sidx];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wp[sidx * 4 * kLdw + 16 * t], acc[t], 0, 0, 0);
+  }
+}
+// A from this wave's rows of the activation buffer (8 k-steps starting at column h0)
+__device__ __forceinline__ void mma_lds(f32x4 (&acc)[8], const float* Hrow, int h0, const float* Wb) {
+  const int lane = threadIdx.x & 63;
+  const float* wp = Wb + (lane >> 4) * kLdw + (lane & 15);
+  const float* ap = Hrow + h0 + (lane >> 4);
+#pragma unroll
+  for (int sidx = 0; sidx < 8; ++sidx) {
+    const float av = ap[4 * sidx];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wp[sidx * 4 * kLdw + 16 * t], acc[t], 0, 0, 0);
+  }
+}
+
+__global__ __launch_bounds__(512) void mlp_col_v2_kernel(ColParams P, const float* __restrict__ Wall,
+                                                         const float* __restrict__ pts,
+                                                         const float* __restrict__ views,
+                                                         const float* __restrict__ c_col, int Q,
+                                                         float* __restrict__ raw) {
+  extern __shared__ float smem[];
+  float* Wbuf = smem;                         // [2][32][144]
+  float* H = smem + 2 * kChunkFloats;         // [128][130]
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  const int r = lane & 15, g = lane >> 4;
+  const int q0 = blockIdx.x * kTM2;
+  const int q = min(q0 + wv * 16 + r, Q - 1);
+  float* Hrow = H + (wv * 16 + r) * kLdh;     // A-operand row of this lane
+  float* Hw = H + (wv * 16) * kLdh;           // this wave's 16 rows (C/D stores)
+
+  // ---- A fragments held in registers: embedding e[20] (k = 4j + g) and feature c[8]
+  float e[20], c[8];
+  {
+    const float px = kTwoPi * pts[(size_t)q * 3 + 0], py = kTwoPi * pts[(size_t)q * 3 + 1],
+                pz = kTwoPi * pts[(size_t)q * 3 + 2];
+    float vx = views[(size_t)q * 3 + 0], vy = views[(size_t)q * 3 + 1], vz = views[(size_t)q * 3 + 2];
+    const float nrm = fmaxf(sqrtf(vx * vx + vy * vy + vz * vz), 1e-12f);
+    vx = kTwoPi * (vx / nrm); vy = kTwoPi * (vy / nrm); vz = kTwoPi * (vz / nrm);
+#pragma unroll
+    for (int j = 0; j < 20; ++j) {
+      const int f = 4 * j + g;             // feature index 0..79
+      const int blk = f / 20, ff = f - blk * 20;
+      const float* Bm = blk < 2 ? P.Bp : P.Bv;
+      const float x = blk < 2 ? px : vx, y = blk < 2 ? py : vy, z = blk < 2 ? pz : vz;
+      const float a = fmaf(z, Bm[40 + ff], fmaf(y, Bm[20 + ff], x * Bm[ff]));
+      e[j] = (blk & 1) ? cosf(a) : sinf(a);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) c[j] = c_col[(size_t)q * 32 + 4 * j + g];
+  }
+
+  f32x4 acc[8];
+  constexpr int NC = 27;
+  ChunkRegs nxt = chunk_load(Wall, 0);
+  chunk_store(Wbuf, nxt);
+  __syncthreads();
+
+  auto act = [&](int li) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const float bb = P.bias[li * 128 + 16 * t + (lane & 15)];
+      const float fb = P.fcb[li * 128 + 16 * t + (lane & 15)];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) acc[t][rr] = softplus100_fast(acc[t][rr] + bb) + fb;
+    }
+  };
+  auto store_h = [&]() {
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) Hw[((lane >> 4) * 4 + rr) * kLdh + 16 * t + (lane & 15)] = acc[t][rr];
+  };
+
+#define GL_CHUNK(cidx, BODY)                                        \
+  {                                                                 \
+    if ((cidx) + 1 < NC) nxt = chunk_load(Wall, (cidx) + 1);        \
+    const float* Wb = Wbuf + ((cidx) & 1) * kChunkFloats;           \
+    BODY;                                                           \
+    if ((cidx) + 1 < NC) chunk_store(Wbuf + (((cidx) + 1) & 1) * kChunkFloats, nxt); \
+    __syncthreads();                                                \
+  }
+
+  // layer 0: W0 (80 rows -> chunks 0..2), Fc0 (chunk 3)
+  zero<8>(acc);
+  GL_CHUNK(0, (mma_regs<0, 8, 20>(acc, e, Wb)))
+  GL_CHUNK(1, (mma_regs<8, 8, 20>(acc, e, Wb)))
+  GL_CHUNK(2, (mma_regs<16, 4, 20>(acc, e, Wb)))
+  act(0);
+  GL_CHUNK(3, (mma_regs<0, 8, 8>(acc, c, Wb), store_h()))
+  // layer 1
+  zero<8>(acc);
+  GL_CHUNK(4, (mma_lds(acc, Hrow, 0, Wb)))
+  GL_CHUNK(5, (mma_lds(acc, Hrow, 32, Wb)))
+  GL_CHUNK(6, (mma_lds(acc, Hrow, 64, Wb)))
+  GL_CHUNK(7, (mma_lds(acc, Hrow, 96, Wb)))
+  act(1);
+  GL_CHUNK(8, (mma_regs<0, 8, 8>(acc, c, Wb), store_h()))
+  // layer 2
+  zero<8>(acc);
+  GL_CHUNK(9, (mma_lds(acc, Hrow, 0, Wb)))
+  GL_CHUNK(10, (mma_lds(acc, Hrow, 32, Wb)))
+  GL_CHUNK(11, (mma_lds(acc, Hrow, 64, Wb)))
+  GL_CHUNK(12, (mma_lds(acc, Hrow, 96, Wb)))
+  act(2);
+  GL_CHUNK(13, (mma_regs<0, 8, 8>(acc, c, Wb), store_h()))
+  // layer 3 (skip): W3e on the embedding, W3h on the hidden state
+  zero<8>(acc);
+  GL_CHUNK(14, (mma_regs<0, 8, 20>(acc, e, Wb)))
+  GL_CHUNK(15, (mma_regs<8, 8, 20>(acc, e, Wb)))
+  GL_CHUNK(16, (mma_regs<16, 4, 20>(acc, e, Wb)))
+  GL_CHUNK(17, (mma_lds(acc, Hrow, 0, Wb)))
+  GL_CHUNK(18, (mma_lds(acc, Hrow, 32, Wb)))
+  GL_CHUNK(19, (mma_lds(acc, Hrow, 64, Wb)))
+  GL_CHUNK(20, (mma_lds(acc, Hrow, 96, Wb)))
+  act(3);
+  GL_CHUNK(21, (mma_regs<0, 8, 8>(acc, c, Wb), store_h()))
+  // layer 4
+  zero<8>(acc);
+  GL_CHUNK(22, (mma_lds(acc, Hrow, 0, Wb)))
+  GL_CHUNK(23, (mma_lds(acc, Hrow, 32, Wb)))
+  GL_CHUNK(24, (mma_lds(acc, Hrow, 64, Wb)))
+  GL_CHUNK(25, (mma_lds(acc, Hrow, 96, Wb)))
+  act(4);
+  GL_CHUNK(26, (mma_regs<0, 8, 8>(acc, c, Wb), store_h()))
+#undef GL_CHUNK
+  // output layer 128 -> 3 (B straight from global: 16 columns, 3 real)
+  f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+  {
+    const float* ap = Hrow + g;
+    const float* wp = P.Wout + g * 16 + r;
+#pragma unroll 8
+    for (int sidx = 0; sidx < 32; ++sidx)
+      o = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * sidx], wp[sidx * 64], o, 0, 0, 0);
+  }
+  if (r < 3) {
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int qq = q0 + wv * 16 + g * 4 + rr;
+      if (qq < Q) raw[(size_t)qq * 4 + r] = 1.0f / (1.0f + __expf(-(o[rr] + P.bout[r])));
+    }
+  }
+}
+
+// per-neighbour F_theta, v2: W1 (52 x 128) resident in LDS for the whole workgroup
+__global__ __launch_bounds__(512) void mlp_nb_v2_kernel(NbParams P, const float* __restrict__ pts,
+                                                        const float* __restrict__ cloud,
+                                                        const float* __restrict__ col_feats,
+                                                        const int64_t* __restrict__ I,
+                                                        const float* __restrict__ wts,
+                                                        const uint8_t* __restrict__ has, int Q,
+                                                        float* __restrict__ c_col) {
+  constexpr int LDX = 66;
+  extern __shared__ float smem[];
+  float* W1s = smem;                          // [52][144]
+  float* X = W1s + 52 * kLdw;                 // [128][66]
+  float* Y = X + kTM2 * LDX;                  // [128][130]
+  float* wbuf = Y + kTM2 * kLdh;              // [128][8]
+  int* ibuf = reinterpret_cast<int*>(wbuf + kTM2 * 8);  // [128][8]
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  const int r = lane & 15, g = lane >> 4;
+  const int q0 = blockIdx.x * kTM2;
+  for (int idx = tid; idx < 52 * 128; idx += 512) W1s[(idx >> 7) * kLdw + (idx & 127)] = P.W1[idx];
+  for (int idx = tid; idx < kTM2 * 8; idx += 512) {
+    const int row = idx >> 3;
+    const int q = min(q0 + row, Q - 1);
+    const int ii = (int)I[(size_t)q * 8 + (idx & 7)];
+    wbuf[idx] = (q0 + row < Q && ii >= 0) ? wts[(size_t)q * 8 + (idx & 7)] : 0.0f;
+    ibuf[idx] = ii < 0 ? 0 : ii;
+  }
+  __syncthreads();
+  f32x4 ysum[8];
+  zero<8>(ysum);
+  const float* Xrow = X + (wv * 16 + r) * LDX + g;
+  float b1[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) b1[t] = P.b1[16 * t + (lane & 15)];
+  for (int k = 0; k < 8; ++k) {
+    {  // stage x = [sin(rel B) 10 | cos(rel B) 10 | col_feat 32]; 4 threads per sample row
+      const int row = tid >> 2, part = tid & 3;
+      const int q = min(q0 + row, Q - 1);
+      const int pt = ibuf[row * 8 + k];
+      const float rx = kTwoPi * (cloud[(size_t)pt * 3 + 0] - pts[(size_t)q * 3 + 0]);
+      const float ry = kTwoPi * (cloud[(size_t)pt * 3 + 1] - pts[(size_t)q * 3 + 1]);
+      const float rz = kTwoPi * (cloud[(size_t)pt * 3 + 2] - pts[(size_t)q * 3 + 2]);
+      for (int f = part; f < 10; f += 4) {
+        const float a = fmaf(rz, P.B[20 + f], fmaf(ry, P.B[10 + f], rx * P.B[f]));
+        float sn, cs;
+        sincosf(a, &sn, &cs);
+        X[row * LDX + f] = sn;
+        X[row * LDX + 10 + f] = cs;
+      }
+      const float4* src = reinterpret_cast<const float4*>(col_feats + (size_t)pt * 32 + part * 8);
+      const float4 v0 = src[0], v1 = src[1];
+      float* dst = X + row * LDX + 20 + part * 8;
+      dst[0] = v0.x; dst[1] = v0.y; dst[2] = v0.z; dst[3] = v0.w;
+      dst[4] = v1.x; dst[5] = v1.y; dst[6] = v1.z; dst[7] = v1.w;
+    }
+    __syncthreads();
+    f32x4 acc[8];
+    zero<8>(acc);
+    {
+      const float* wp = W1s + g * kLdw + (lane & 15);
+#pragma unroll
+      for (int sidx = 0; sidx < 13; ++sidx) {
+        const float av = Xrow[4 * sidx];
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wp[sidx * 4 * kLdw + 16 * t], acc[t], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const float w = wbuf[(wv * 16 + g * 4 + rr) * 8 + k];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) ysum[t][rr] += w * softplus100_fast(acc[t][rr] + b1[t]);
+    }
+    __syncthreads();
+  }
+  float* Yw = Y + (wv * 16) * kLdh;
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) Yw[(g * 4 + rr) * kLdh + 16 * t + (lane & 15)] = ysum[t][rr];
+  __syncthreads();
+  f32x4 o[2];
+  zero<2>(o);
+  gemm16<2>(o, Yw, kLdh, 128, P.W2, 32, 0);
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int row = wv * 16 + g * 4 + rr;
+      const int q = q0 + row;
+      if (q < Q) {
+        float sw = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sw += wbuf[row * 8 + k];
+        const int col = 16 * t + (lane & 15);
+        c_col[(size_t)q * 32 + col] = has[q] ? o[t][rr] + P.b2[col] * sw : 0.0f;
+      }
+    }
+}
+
 }  // namespace glorie
 
 using namespace glorie;
@@ -359,7 +649,7 @@ extern "C" size_t glorie_decoder_pack_floats(void) {
   size_t nb = 3 * 10 + 2 + 52 * 128 + 128 + 128 * 32 + 32;
   size_t col = 3 * 20 * 2 + 80 * 128 + 128 * 128 * 2 + 80 * 128 + 128 * 128 * 2 + 128 * 16 + 5 * 32 * 128 +
                5 * 128 * 2 + 4;
-  return geo + nb + col;
+  return geo + nb + col + (size_t)27 * 32 * 128;
 }
 
 extern "C" int glorie_render_mlp(const float* packed, const float* pts, const float* views,
@@ -387,12 +677,25 @@ extern "C" int glorie_render_mlp(const float* packed, const float* pts, const fl
   k.W2 = c.take(128 * 128); k.W3e = c.take(80 * 128); k.W3h = c.take(128 * 128); k.W4 = c.take(128 * 128);
   k.Wout = c.take(128 * 16); k.Fc = c.take(5 * 32 * 128); k.bias = c.take(5 * 128); k.fcb = c.take(5 * 128);
   k.bout = c.take(4);
+  const float* col_chunks = c.take((size_t)27 * 32 * 128);
   const int blocks = (Q + kTM - 1) / kTM;
   hipLaunchKernelGGL(mlp_geo_kernel, dim3(blocks), dim3(256), 0, st, g, pts, c_geo, has, Q, raw);
   if (stage_color) {
-    hipLaunchKernelGGL(mlp_nb_kernel, dim3(blocks), dim3(256), 0, st, n, pts, cloud_pos, col_feats, I,
-                       weights, has, Q, c_col_scratch);
-    hipLaunchKernelGGL(mlp_col_kernel, dim3(blocks), dim3(256), 0, st, k, pts, views, c_col_scratch, Q, raw);
+    const int blocks2 = (Q + kTM2 - 1) / kTM2;
+    const size_t nb_lds = sizeof(float) * (52 * kLdw + kTM2 * 66 + kTM2 * kLdh + kTM2 * 8) + sizeof(int) * kTM2 * 8;
+    const size_t col_lds = sizeof(float) * (2 * kChunkFloats + kTM2 * kLdh);
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_nb_v2_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)nb_lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_col_v2_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)col_lds);
+      attr = true;
+    }
+    hipLaunchKernelGGL(mlp_nb_v2_kernel, dim3(blocks2), dim3(512), nb_lds, st, n, pts, cloud_pos, col_feats,
+                       I, weights, has, Q, c_col_scratch);
+    hipLaunchKernelGGL(mlp_col_v2_kernel, dim3(blocks2), dim3(512), col_lds, st, k, col_chunks, pts, views,
+                       c_col_scratch, Q, raw);
   }
   return check_launch();
 }
