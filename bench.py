@@ -120,7 +120,59 @@ def render_pass(npc, dec, ren, rays, device):
     return n
 
 
-def cpu_baseline_step(g, n_edges=2):
+def _pmc_traffic():
+    """per-launch HBM bytes of the gather kernels from the committed PMC summary (separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, corrected as MI355X_MICROARCH.md prescribes;
+    see profiles/README.md).  None when the summary is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_gathers.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        return d["corr_lookup"]["hbm_bytes"], d["knn_query"]["hbm_bytes"] + 2 * d["idw_gather"]["hbm_bytes"]
+    except Exception:
+        return None, None
+
+
+def cpu_baseline_rays(n_rays=192):
+    """oracle brute-force KNN + torch-CPU decoders + compositing on `n_rays` rays of the frame"""
+    import glorie_slam_amd.synth as synth
+    from glorie_slam_amd.decoder import POINT
+    from oracle import knn as oknn
+    pts, geo, col = synth.box_cloud()
+    ro, rd, depth, radius, _ = synth.box_rays()
+    sel = np.linspace(0, ro.shape[0] - 1, n_rays).astype(np.int64)
+    S = 10
+    z = depth[sel, None] * np.linspace(0.95, 1.05, S, dtype=np.float32)[None]
+    p = (ro[sel, None] + rd[sel, None] * z[..., None]).reshape(-1, 3).astype(np.float32)
+    rq = np.repeat(radius[sel], S)[:, None]
+    cfg = render_cfg("cpu")
+    torch.manual_seed(43)
+    dec = POINT(cfg, use_view_direction=True).eval()
+    cloud_t = torch.from_numpy(pts)
+
+    class NPC:
+        def get_radius_query(self):
+            return 0.08
+
+        def cloud_pos(self):
+            return cloud_t
+
+        def find_neighbors_faiss(self, pos, step='query', dynamic_radius=None, **kw):
+            D, I = oknn.knn_bruteforce(pts, pos.numpy(), 8, chunk=64)
+            D, I = torch.from_numpy(D), torch.from_numpy(I)
+            return D, I, (D < dynamic_radius.reshape(-1, 1) ** 2).sum(-1).int()
+
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        raw, *_ = dec(torch.from_numpy(p)[None], NPC(), "color", torch.from_numpy(geo), torch.from_numpy(col),
+                      pts_num=S, cloud_pos=cloud_t, pts_views_d=torch.from_numpy(np.repeat(rd[sel], S, 0)),
+                      dynamic_r_query=torch.from_numpy(rq))
+        oknn.composite(raw.reshape(n_rays, S, 4).numpy(), z)
+    dt = time.perf_counter() - t0
+    return n_rays / dt, dt
+
+
+def cpu_baseline_step(g, n_edges=12):
     """Oracle ("port") timing of one step on a bounded sample: `n_edges` edges of the
     correlation lookup + update operator, and one BA call on a 4-keyframe 30x40 sub-problem;
     scaled to the full G8 step (36 edges, HW=4800)."""
@@ -143,20 +195,23 @@ def cpu_baseline_step(g, n_edges=2):
         t1 = time.perf_counter()
         net(x(128), x(128), x(196), x(4), ii, ii)
         t_upd = (time.perf_counter() - t1) / n_edges
-    gs = synth.keyframe_graph(K=4, h=30, w=40, radius=2)
+    gs = synth.keyframe_graph(K=6, h=30, w=40, radius=3)
     c, _ = ogeom.reproject(gs["poses"], gs["disps"], gs["intrinsics"], gs["ii"], gs["jj"])
     tgt = (c.transpose(0, 3, 1, 2) + gs["noise"]).astype(np.float32)
     t1 = time.perf_counter()
     oba.ba(gs["poses"], gs["disps"], gs["intrinsics"][0], tgt, gs["weight"], gs["eta"], gs["ii"], gs["jj"],
-           1, 4, 2, 1e-4, 0.1)
+           1, 6, 2, 1e-4, 0.1)
     t_ba_small = time.perf_counter() - t1
     scale = (36 * 4800) / (len(gs["ii"]) * 30 * 40)
     N = len(g["ii"])
     step_s = N * (t_corr + t_upd) + t_ba_small * scale
+    rays_s, rays_dt = cpu_baseline_rays()
     return dict(value=1.0 / step_s, unit="BA-update iters/s", cores=torch.get_num_threads(), kind="port",
+                rays_per_sec=rays_s,
                 sample=f"oracle corr lookup + torch-CPU update operator on {n_edges} of {N} edges, "
-                       f"oracle BA on a 4-keyframe 30x40 graph scaled by pixel-edges (x{scale:.1f}); "
-                       f"{time.perf_counter() - t0:.1f}s of CPU work")
+                       f"oracle BA (2 GN iterations) on a 6-keyframe 30x40 graph scaled by pixel-edges "
+                       f"(x{scale:.1f}); rays: 192 rays of the frame, brute-force KNN over the 524k-point cloud + "
+                       f"torch-CPU decoders ({rays_dt:.1f}s); {time.perf_counter() - t0:.1f}s of CPU work")
 
 
 def main():
@@ -279,6 +334,22 @@ def main():
     knn_ms = e0.elapsed_time(e1) / 5
     knn_bytes = 2156.0 * pq.shape[0]
     knn_gbs = knn_bytes / (knn_ms * 1e-3) / 1e9
+    # fused decoders alone: executed FLOPs (post-sum F_theta form, 358,848 FLOP per sample)
+    D_, I_, nn_ = npc.index.search(pq, 8, radius_per_query=rq)
+    cg_, has_, w_ = point_ops.idw_gather(D_, I_, nn_, npc.geo_feats, radius_per_query=rq, return_weights=True)
+    vq = rays["d"][:nq].repeat_interleave(S, dim=0).contiguous()
+    packed = dec._packed()
+    for _ in range(2):
+        point_ops.render_mlp(packed, pq, vq, npc.cloud_pos(), npc.col_feats, cg_, I_, w_, has_)
+    e0.record()
+    for _ in range(5):
+        point_ops.render_mlp(packed, pq, vq, npc.cloud_pos(), npc.col_feats, cg_, I_, w_, has_)
+    e1.record()
+    torch.cuda.synchronize()
+    mlp_ms = e0.elapsed_time(e1) / 5
+    mlp_flops = 2.0 * 179424.0 * pq.shape[0]
+    mlp_tf = mlp_flops / (mlp_ms * 1e-3) / 1e12
+    corr_traffic, knn_traffic = _pmc_traffic()
 
     out = {
         "metric": "DSPO BA-update iters/sec + rendered rays/sec, 640x480 Replica keyframe graph",
@@ -294,17 +365,21 @@ def main():
                    "parallelism": ("single GPU" if world == 1 else
                                    f"edges sharded by source keyframe over {world} GPUs + RCCL all-reduce of the "
                                    f"reduced normal equations; rays sharded {world} ways")},
-        "roofline": {"bound": "hbm", "kernel": "corr_lookup_r3_kernel<f16>",
+        "roofline": {"bound": "hbm", "kernel": "corr_lookup_r3_v2_kernel<f16>",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": corr_traffic if (world == 1 and N == 36) else None,
                      "alg_bytes_per_launch": alg_bytes, "ms_per_launch": corr_ms},
         "rays_per_sec": rays_per_s,
         "render": {"rays_local": int(n_r // render_reps), "samples_per_ray": int(S), "cloud_points": int(npc.pts_num()),
                    "ms_per_frame_shard": 1e3 * t_r / render_reps},
         "roofline_knn": {"bound": "hbm", "kernel": "knn_query_kernel<8> + 2x idw_gather_kernel",
                          "achieved": knn_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": knn_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "frac": knn_gbs / HBM_PEAK_GBS, "traffic": knn_traffic,
                          "alg_bytes_per_launch": knn_bytes, "ms_per_launch": knn_ms},
+        "roofline_mlp": {"bound": "mfma", "kernel": "mlp_geo + mlp_nb_v2 + mlp_col_v2 (fp32 MFMA 16x16x4)",
+                         "achieved": mlp_tf, "peak": 157.3, "unit": "TFLOP/s", "frac": mlp_tf / 157.3,
+                         "traffic": None, "flops_per_launch": mlp_flops, "ms_per_launch": mlp_ms},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_step(g)

@@ -527,7 +527,7 @@ __global__ __launch_bounds__(256) void ba_solve_lds_kernel(BaWork wk, int n, flo
   const int tid = threadIdx.x;
   if (tid == 0) fail = (wk.status[0] & BA_ST_M_MISMATCH) ? 1 : 0;
   for (int idx = tid; idx < n * (n + 1) / 2; idx += 256) {
-    int r = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
+    int r = (int)((sqrtf(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
     while ((r + 1) * (r + 2) / 2 <= idx) ++r;
     while (r * (r + 1) / 2 > idx) --r;
     const int c = idx - r * (r + 1) / 2;
@@ -553,7 +553,8 @@ __global__ __launch_bounds__(256) void ba_solve_lds_kernel(BaWork wk, int n, flo
     const int m = n - j - 1;
     const int cnt = m * (m + 1) / 2;
     for (int idx = tid; idx < cnt; idx += 256) {
-      int rr = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
+      // triangular index decode in fp32 (exact after the two correction loops for idx < 2^23)
+      int rr = (int)((sqrtf(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
       while ((rr + 1) * (rr + 2) / 2 <= idx) ++rr;
       while (rr * (rr + 1) / 2 > idx) --rr;
       const int cc = idx - rr * (rr + 1) / 2;
