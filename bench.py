@@ -33,7 +33,7 @@ def make_cfg(H=480, W=640, buffer=16, device="cuda:0"):
     }
 
 
-def build_graph(device, K=8, h=60, w=80, rank=0, world=1):
+def build_graph(device, K=8, h=60, w=80, rank=0, world=1, corr_impl="volume"):
     import glorie_slam_amd.synth as synth
     from glorie_slam_amd.depth_video import DepthVideo
     from glorie_slam_amd.factor_graph import FactorGraph
@@ -59,7 +59,7 @@ def build_graph(device, K=8, h=60, w=80, rank=0, world=1):
     video.mono_disps[:K] = t(mono.astype(np.float32))
     torch.manual_seed(43)
     net = UpdateModule().to(device).eval()
-    graph = FactorGraph(video, net, device=str(device), corr_impl="volume", max_factors=-1)
+    graph = FactorGraph(video, net, device=str(device), corr_impl=corr_impl, max_factors=-1)
     sel = np.ones(len(g["ii"]), bool)
     if world > 1:   # edges sharded by source keyframe (glorie_slam_amd.dist)
         from glorie_slam_amd import dist as gdist

@@ -27,6 +27,7 @@ SIGNATURES = {
     "glorie_ctx_destroy": (_c_int, [_vp]),
     "glorie_corr_index_fwd": (_c_int, [_vp, _vp, _vp] + [_c_int] * 7 + [_vp]),
     "glorie_corr_lookup_pyramid": (_c_int, [_vp, _c_int, _vp, _vp] + [_c_int] * 7 + [_vp]),
+    "glorie_corr_otf": (_c_int, [_vp, _vp, _c_int, _vp, _vp, _vp, _vp] + [_c_int] * 4 + [_vp]),
     "glorie_altcorr_fwd": (_c_int, [_vp] * 4 + [_c_int] * 8 + [_vp]),
     "glorie_reproject": (_c_int, [_vp] * 7 + [_c_int] * 3 + [_vp]),
     "glorie_frame_distance": (_c_int, [_vp] * 6 + [_c_int] * 3 + [_c_f, _vp]),

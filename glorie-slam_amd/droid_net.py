@@ -232,3 +232,36 @@ class AltCorrBlock:
         if squeeze:
             corr = corr.squeeze(-1)
         return corr.contiguous()
+
+
+class OtfCorrBlock:
+    """Volume-free correlation on the matrix cores (csrc/corr_otf.hip): same call contract as
+    AltCorrBlock (`OtfCorrBlock(fmaps)(coords, ii, jj)` -> [B, N, 196, H, W]) and the values a
+    CorrBlock volume lookup returns up to fp16 rounding, without the 61 MB/edge volume.
+    fmaps: [1, F, C, H, W] (video.fmaps viewed like factor_graph.py:266-268)."""
+
+    def __init__(self, fmaps, num_levels=4, radius=3):
+        assert radius == 3
+        self.num_levels = num_levels
+        self.radius = radius
+        B, N, C, H, W = fmaps.shape
+        f = fmaps.view(B * N, C, H, W).half() / 4.0
+        self.shape = (H, W, C)
+        self.levels = []
+        for i in range(num_levels):
+            self.levels.append(f.permute(0, 2, 3, 1).reshape(B * N, -1, C).contiguous())
+            if i + 1 < num_levels:
+                f = F.avg_pool2d(f, kernel_size=2, stride=2)
+
+    def __call__(self, coords, ii, jj):
+        import ctypes
+        from . import _lib as L
+        batch, num, ht, wd, _ = coords.shape
+        c = coords.permute(0, 1, 4, 2, 3).contiguous().view(batch * num, 2, ht, wd).float()
+        H, W, C = self.shape
+        out = torch.empty(batch * num, self.num_levels * 49, ht, wd, dtype=torch.float16, device=c.device)
+        arr = (ctypes.c_void_p * self.num_levels)(*[v.data_ptr() for v in self.levels])
+        L.check(L.load().glorie_corr_otf(L.ptr(self.levels[0]), ctypes.cast(arr, ctypes.c_void_p),
+                                         self.num_levels, L.ptr(c), L.ptr(ii.contiguous()), L.ptr(jj.contiguous()),
+                                         L.ptr(out), batch * num, H, W, C, L.stream_ptr()), "glorie_corr_otf")
+        return out.view(batch, num, -1, ht, wd)

@@ -13,7 +13,7 @@ arguments.  What changed underneath:
 import numpy as np
 import torch
 
-from .droid_net import CorrBlock, AltCorrBlock, HalfUpdate
+from .droid_net import CorrBlock, AltCorrBlock, HalfUpdate, OtfCorrBlock
 
 
 def coords_grid(ht, wd, device):
@@ -44,6 +44,18 @@ class FactorGraph:
         self._uniq_cache = None
         # fp16 / channels_last inference copy of the update operator (droid_net.HalfUpdate)
         self.fast_update = HalfUpdate(update_op) if str(device).startswith("cuda") else None
+
+    def _otf_block(self):
+        """volume-free correlation operator over the stored feature maps (corr_impl == 'otf'),
+        rebuilt when the feature buffer was written (new keyframe)"""
+        fm = self.video.fmaps
+        key = (fm._version, self.video.counter.value)
+        if getattr(self, "_otf_key", None) != key:
+            num, rig, ch, ht, wd = fm.shape
+            self._otf = OtfCorrBlock(fm.view(1, num * rig, ch, ht, wd))
+            self._otf_key = key
+            self._otf_rig = rig
+        return self._otf
 
     # ---- host mirrors ----------------------------------------------------------------
     @staticmethod
@@ -109,6 +121,9 @@ class FactorGraph:
             self.corr = corr if self.corr is None else self.corr.cat(corr)
             inp = self.video.inps[ii].to(self.device).unsqueeze(0)
             self.inp = inp if self.inp is None else torch.cat([self.inp, inp], 1)
+        elif self.corr_impl == "otf":
+            inp = self.video.inps[ii].to(self.device).unsqueeze(0)
+            self.inp = inp if self.inp is None else torch.cat([self.inp, inp], 1)
         target, _ = self.video.reproject(ii, jj)
         weight = torch.zeros_like(target)
         self._uniq_cache = None
@@ -169,7 +184,12 @@ class FactorGraph:
         """factor_graph.py:212-256"""
         coords1, mask = self.video.reproject(self.ii, self.jj)
         motn = self._motion(coords1)
-        corr = self.corr(coords1)
+        if self.corr_impl == "otf":
+            blk = self._otf_block()
+            rig = self._otf_rig
+            corr = blk(coords1, rig * self.ii, rig * self.jj + (self.ii == self.jj).long())
+        else:
+            corr = self.corr(coords1)
         uniq = self._unique_ii()
         if self.fast_update is not None:
             self.net, delta, weight, damping, upmask = \

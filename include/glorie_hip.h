@@ -76,6 +76,19 @@ int glorie_corr_lookup_pyramid(const void* const* volumes, int num_levels,
                                int N, int h1, int w1, int h2, int w2, int radius,
                                int dtype, void* stream);
 
+/* Volume-free form of CorrBlock.__call__ / AltCorrBlock.__call__
+ *   reference: src/modules/droid_net/corr.py:43-53 (volume lookup), :79-145 (alt-corr),
+ *   src/lib/altcorr_kernel.cu:27-149
+ * fmap1 [F,h*w,C] fp16 channel-last, pre-scaled by 1/4 (corr.py:70-71); fmap2_levels[l]
+ * [F,(h>>l)*(w>>l),C] fp16 = avg-pooled pyramid of the same maps; coords [N,2,h,w] f32
+ * (unscaled); ii/jj [N] int64 select the source / target frame of every edge;
+ * out [N, L*49, h, w] fp16 (radius 3).  C must be 128.  Dot products run on
+ * v_mfma_f32_16x16x32_f16 (fp32 accumulate) and are rounded to fp16 before the fp16 bilinear
+ * blend, i.e. the values a materialised fp16 volume would hold. */
+int glorie_corr_otf(const void* fmap1, const void* const* fmap2_levels, int num_levels,
+                    const float* coords, const int64_t* ii, const int64_t* jj, void* out,
+                    int N, int h, int w, int C, void* stream);
+
 /* droid_backends.altcorr_forward(fmap1, fmap2, coords, radius)
  *   reference: src/lib/droid.cpp:195-205, src/lib/altcorr_kernel.cu:27-149,290-319
  * fmap1 [B,H,W,C], fmap2 [B,H2,W2,C], coords [B,S,H,W,2] f32, out [B,S,(2r+1)^2,H,W].
