@@ -1,0 +1,166 @@
+"""Host-side mirrors on the GPU: FactorGraph (topology, update, update_lowmem) and DepthVideo."""
+import numpy as np
+import pytest
+import torch
+
+import glorie_slam_amd.synth as synth
+from oracle import geom as ogeom, topology as otopo
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(dev, H, W, buffer, ba="DSPO"):
+    return {"cam": {"H_out": H, "W_out": W},
+            "tracking": {"buffer": buffer, "backend": {"BA_type": ba}, "mono_thres": 0.1,
+                         "multiview_filter": {"thresh": 0.01, "visible_num": 2}, "store_images": False},
+            "device": str(dev), "setting": "t", "scene": "s", "data": {"output": "/tmp"}}
+
+
+def make_video(dev, K, h, w, buffer=None, graph="keyframe", ba="DSPO"):
+    from glorie_slam_amd.depth_video import DepthVideo
+    g = synth.keyframe_graph(K=K, h=h, w=w, radius=3) if graph == "keyframe" else synth.loop_graph(K=K, h=h, w=w)
+    fmaps, nets, inps = synth.feature_maps(K, h, w)
+    video = DepthVideo(_cfg(dev, 8 * h, 8 * w, buffer or K, ba))
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    video.poses[:K] = t(g["poses"][:K])
+    video.disps[:K] = t(g["disps"][:K])
+    video.intrinsics[:] = t(g["intrinsics"][0])
+    video.fmaps[:K] = t(fmaps)
+    video.nets[:K] = t(nets)
+    video.inps[:K] = t(inps)
+    video.counter.value = K
+    rng = np.random.default_rng(0)
+    mono = g["disps"][:K] * rng.uniform(0.7, 1.4, (K, 1, 1)) + rng.uniform(-0.03, 0.03, (K, 1, 1))
+    video.mono_disps[:K] = t(mono.astype(np.float32))
+    return g, video
+
+
+def make_graph(dev, video, corr_impl="volume", max_factors=-1):
+    from glorie_slam_amd.factor_graph import FactorGraph
+    from glorie_slam_amd.droid_net import UpdateModule
+    torch.manual_seed(43)
+    net = UpdateModule().to(dev).eval()
+    return FactorGraph(video, net, device=str(dev), corr_impl=corr_impl, max_factors=max_factors)
+
+
+def edges_of(graph):
+    return list(zip(graph.ii.cpu().tolist(), graph.jj.cpu().tolist()))
+
+
+def test_distance_matches_oracle_and_is_symmetric(gpu):
+    g, video = make_video(gpu, 6, 24, 32)
+    d = video.distance(beta=0.3).cpu().numpy()
+    K = 6
+    ii, jj = np.meshgrid(np.arange(K), np.arange(K), indexing="ij")
+    d1 = ogeom.frame_distance(g["poses"], g["disps"], g["intrinsics"][0], ii.reshape(-1), jj.reshape(-1), 0.3)
+    d2 = ogeom.frame_distance(g["poses"], g["disps"], g["intrinsics"][0], jj.reshape(-1), ii.reshape(-1), 0.3)
+    np.testing.assert_allclose(d.reshape(-1), 0.5 * (d1 + d2), rtol=2e-5, atol=1e-5)
+    np.testing.assert_allclose(d, d.T, rtol=1e-6)
+
+
+def test_topology_matches_literal_restatement(gpu):
+    """bit-exact graph topology: the numpy topology code vs the loop-by-loop oracle, fed with the
+    distances the HIP kernel produced"""
+    g, video = make_video(gpu, 24, 16, 20, graph="loop")
+    graph = make_graph(gpu, video, max_factors=60)
+    graph.add_neighborhood_factors(0, 8, r=3)
+    assert edges_of(graph) == otopo.neighborhood(0, 8, 3)
+    # frontend proximity edges
+    t = video.counter.value
+    t0, t1 = t - 10, max(t - 20, 0)
+    ii, jj = np.meshgrid(np.arange(t0, t), np.arange(t1, t), indexing="ij")
+    d = video.distance(ii.reshape(-1), jj.reshape(-1), beta=0.75).cpu().numpy()
+    before = edges_of(graph)
+    want = otopo.proximity(d, t, before, t0=t0, t1=t1, rad=1, nms=1, thresh=16.0, max_factors=60)
+    graph.add_proximity_factors(t0, t1, rad=1, nms=1, beta=0.75, thresh=16.0, remove=False)
+    have = set(before)
+    want_new = []
+    for e in want:                      # add_factors drops duplicates, keeps order
+        if e not in have:
+            want_new.append(e)
+    assert edges_of(graph)[len(before):] == want_new
+    assert len(want_new) > 10
+    # backend proximity edges on a fresh graph
+    graph2 = make_graph(gpu, video, corr_impl="alt", max_factors=6 * t)
+    ii, jj = np.meshgrid(np.arange(0, t), np.arange(0, t), indexing="ij")
+    d = video.distance(ii.reshape(-1), jj.reshape(-1), beta=0.75).cpu().numpy()
+    want = otopo.backend_proximity(d, 0, t, nms=5, radius=1, thresh=25.0, max_factors=6 * t)
+    n = graph2.add_backend_proximity_factors(0, t, nms=5, radius=1, thresh=25.0, max_factors=6 * t, beta=0.75)
+    seen, want_u = set(), []
+    for e in want:
+        if e not in seen:
+            seen.add(e)
+            want_u.append(e)
+    assert edges_of(graph2) == want_u and n == len(want_u) and n > 2 * t
+
+
+@pytest.mark.parametrize("corr_impl", ["volume", "otf"])
+def test_update_runs_and_keeps_state_consistent(gpu, corr_impl):
+    g, video = make_video(gpu, 6, 24, 32)
+    graph = make_graph(gpu, video, corr_impl=corr_impl)
+    graph.add_neighborhood_factors(0, 6, r=2)
+    N = graph.ii.shape[0]
+    p0 = video.poses.clone()
+    for it in range(4):
+        graph.update(t0=1, t1=6, itrs=2, opt_type="pose_depth" if it % 2 == 0 else "depth_scale")
+    torch.cuda.synchronize()
+    assert graph.net.shape == (1, N, 128, 24, 32) and graph.target.shape == (1, N, 24, 32, 2)
+    assert torch.isfinite(video.poses).all() and torch.isfinite(video.disps).all()
+    assert torch.equal(video.poses[0], p0[0])                       # pose 0 stays fixed
+    assert (video.disps[:6] >= 1e-5).all()
+    assert torch.isfinite(video.disps_up[:6]).all() and video.disps_up[:6].abs().sum() > 0
+    assert (graph.age == 4).all()
+    # quaternions stay unit length through the retractions
+    assert torch.allclose(video.poses[:6, 3:].norm(dim=-1), torch.ones(6, device=gpu), atol=1e-4)
+
+
+def test_volume_and_otf_updates_agree(gpu):
+    """one update with the volume lookup vs the volume-free lookup: same flow targets within the
+    fp16 tolerance of SURVEY 8(d)"""
+    outs = []
+    for impl in ("volume", "otf"):
+        g, video = make_video(gpu, 5, 24, 32, ba="DBA")
+        graph = make_graph(gpu, video, corr_impl=impl)
+        graph.add_neighborhood_factors(0, 5, r=2)
+        graph.update(t0=1, t1=5, itrs=2)
+        outs.append((graph.target.clone(), video.poses.clone()))
+    assert torch.allclose(outs[0][0], outs[1][0], rtol=2e-2, atol=2e-2)
+    assert torch.allclose(outs[0][1], outs[1][1], atol=1e-3)
+
+
+def test_update_lowmem_backend_path(gpu):
+    g, video = make_video(gpu, 10, 16, 24, graph="loop")
+    graph = make_graph(gpu, video, corr_impl="alt", max_factors=60)
+    n = graph.add_backend_proximity_factors(0, 10, nms=2, radius=1, thresh=50.0, max_factors=60, beta=0.75)
+    assert n > 0
+    graph.update_lowmem(t0=1, t1=10, itrs=2, steps=2)
+    torch.cuda.synchronize()
+    assert torch.isfinite(video.poses).all() and torch.isfinite(video.disps).all()
+    assert graph.net.dtype == torch.float16 and torch.isfinite(graph.target).all()
+
+
+def test_rm_factors_and_rm_keyframe(gpu):
+    g, video = make_video(gpu, 6, 16, 24, buffer=8)
+    graph = make_graph(gpu, video)
+    graph.add_neighborhood_factors(0, 6, r=2)
+    n0 = graph.ii.shape[0]
+    mask = graph.ii == 5
+    graph.rm_factors(mask, store=True)
+    assert graph.ii.shape[0] == n0 - int(mask.sum()) and graph.ii_inac.shape[0] == int(mask.sum())
+    assert graph.corr.corr_pyramid[0].shape[0] == graph.ii.shape[0]
+    graph.rm_keyframe(3)
+    assert int(graph.ii.max()) <= 4 and not ((graph.ii == 3) & (graph.jj == 3)).any()
+    graph.update(t0=1, t1=5, itrs=1)
+    assert torch.isfinite(video.poses).all()
+
+
+def test_normalize_and_valid_mask(gpu):
+    g, video = make_video(gpu, 7, 16, 24)
+    p = video.poses.clone()
+    s = video.disps[:7].mean().item()
+    video.normalize()
+    assert abs(video.disps[:7].mean().item() - 1.0) < 1e-5
+    assert torch.allclose(video.poses[:7, :3], p[:7, :3] * s, rtol=1e-5)
+    assert video.dirty[:7].all()
+    video.update_valid_depth_mask(up=False)
+    assert video.valid_depth_mask_small[:7].any()
