@@ -29,6 +29,12 @@ SIGNATURES = {
     "glorie_corr_lookup_pyramid": (_c_int, [_vp, _c_int, _vp, _vp] + [_c_int] * 7 + [_vp]),
     "glorie_corr_otf": (_c_int, [_vp, _vp, _c_int, _vp, _vp, _vp, _vp] + [_c_int] * 4 + [_vp]),
     "glorie_altcorr_fwd": (_c_int, [_vp] * 4 + [_c_int] * 8 + [_vp]),
+    "glorie_bias_act": (_c_int, [_vp, _c_int, _vp, _vp, _c_int, ctypes.c_long, _c_int, _c_int, _vp]),
+    "glorie_gru_glo_terms": (_c_int, [_vp, _c_int, _vp, _vp, _c_int, _vp, _vp, _c_int, _vp, _c_int, _vp, _c_int, _c_int, _vp]),
+    "glorie_gru_gate_zr": (_c_int, [_vp, _c_int, _vp, _c_int, _vp, _c_int, _vp, _c_int, _vp, _c_int, _c_int, _c_int, _vp]),
+    "glorie_gru_gate_q": (_c_int, [_vp, _c_int, _vp, _c_int, _vp, _c_int, _vp, _c_int, _vp, _c_int, _vp, _c_int, _c_int, _c_int, _vp]),
+    "glorie_segment_mean": (_c_int, [_vp, _c_int, _vp, _c_int, _vp, _c_int, _vp, _c_int, _c_int, _c_int, _vp]),
+    "glorie_conv3x3_small": (_c_int, [_vp, _c_int, _vp, _c_int, _vp, _vp, _c_int, _c_int, _c_int, ctypes.c_float, _vp, _vp, _c_int, _c_int, _c_int, _vp]),
     "glorie_reproject": (_c_int, [_vp] * 7 + [_c_int] * 3 + [_vp]),
     "glorie_frame_distance": (_c_int, [_vp] * 6 + [_c_int] * 3 + [_c_f, _vp]),
     "glorie_iproj": (_c_int, [_vp] * 4 + [_c_int] * 3 + [_vp]),

@@ -13,7 +13,7 @@ arguments.  What changed underneath:
 import numpy as np
 import torch
 
-from .droid_net import CorrBlock, AltCorrBlock, HalfUpdate, OtfCorrBlock
+from .droid_net import CorrBlock, AltCorrBlock, FusedUpdate, OtfCorrBlock
 
 
 def coords_grid(ht, wd, device):
@@ -42,8 +42,9 @@ class FactorGraph:
         self.ii_bad, self.jj_bad = long0(), long0()
         self.target_inac, self.weight_inac = zero_tw(), zero_tw()
         self._uniq_cache = None
-        # fp16 / channels_last inference copy of the update operator (droid_net.HalfUpdate)
-        self.fast_update = HalfUpdate(update_op) if str(device).startswith("cuda") else None
+        # fp16 channels-last form of the update operator with fused element-wise stages
+        # (droid_net.FusedUpdate, csrc/gru.hip)
+        self.fast_update = FusedUpdate(update_op) if str(device).startswith("cuda") else None
 
     def _otf_block(self):
         """volume-free correlation operator over the stored feature maps (corr_impl == 'otf'),

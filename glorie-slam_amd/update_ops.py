@@ -1,0 +1,146 @@
+"""Fused element-wise stages of the update operator (csrc/gru.hip) on channels-last fp16 maps.
+
+Every tensor argument is a 4-D fp16 map [N, C, h, w] whose memory is channels-last
+([pixel][channel]) -- either a whole `torch.channels_last` tensor or a CHANNEL SLICE of a wider
+one (`buf[:, 128:256]`), which is how the `torch.cat([net, inp, corr, flow])` of the reference
+(gru.py:22-23, droid_net.py:121-122) is replaced by writing producers into slices.
+reference: src/modules/droid_net/gru.py:20-34, droid_net.py:106-139.
+"""
+import torch
+
+from . import _lib as L
+
+ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SOFTPLUS = 0, 1, 2, 3
+
+
+def _rows(t, name):
+    """(row stride in halfs) of a channels-last map or channel slice thereof"""
+    if t.dtype != torch.float16 or t.dim() != 4:
+        raise RuntimeError(f"{name}: expected a 4-D float16 map, got {t.dtype} {tuple(t.shape)}")
+    n, c, h, w = t.shape
+    sn, sc, sh, sw = t.stride()
+    if c > 1 and sc != 1:
+        raise RuntimeError(f"{name}: not channels-last (channel stride {sc})")
+    if (w > 1 and sh != w * sw) or (h * w > 1 and n > 1 and sn != h * w * sw) or sw < c:
+        raise RuntimeError(f"{name}: rows are not uniformly strided {tuple(t.stride())}")
+    if sw % 8 or t.data_ptr() % 16:
+        raise RuntimeError(f"{name}: rows must be 16-byte aligned")
+    return sw
+
+
+def bias_act(x, bias, act, out=None):
+    """out = act(x + bias[c]); `out` may alias x (in place) or be a channel slice"""
+    L.need_cuda(x)
+    out = x if out is None else out
+    xs, ys = _rows(x, "x"), _rows(out, "out")
+    n, c, h, w = x.shape
+    if tuple(out.shape) != tuple(x.shape):
+        raise RuntimeError("bias_act: shape mismatch")
+    if bias is not None and (bias.dtype != torch.float32 or bias.numel() != c or not bias.is_contiguous()):
+        raise RuntimeError("bias_act: bias must be contiguous float32 [C]")
+    L.check(L.load().glorie_bias_act(L.ptr(x), xs, L.ptr(bias) if bias is not None else None, L.ptr(out),
+                                     ys, n * h * w, c, act, L.stream_ptr()), "glorie_bias_act")
+    return out
+
+
+def _terms(g, width, name):
+    if g.dtype != torch.float32 or g.dim() != 2 or g.shape[1] != width or g.stride(1) != 1:
+        raise RuntimeError(f"{name}: expected float32 [N,{width}] rows (column slices allowed)")
+    return g.stride(0)
+
+
+def gru_glo_terms(wn, bw, net, G, Gb, parts=16):
+    """glo[n] = mean_pixels sigmoid(wn + bw) * net (gru.py:25-26); returns g = glo @ G + Gb,
+    float32 [N, M]: the convz_glo | convr_glo | convq_glo terms (G [128, M], biases in Gb)"""
+    L.need_cuda(wn, net, G, Gb)
+    n, c, h, w = net.shape
+    if c != 128 or tuple(wn.shape) != tuple(net.shape) or G.shape[0] != 128 or not G.is_contiguous() \
+            or G.dtype != torch.float32 or Gb.dtype != torch.float32 or Gb.numel() != G.shape[1]:
+        raise RuntimeError("gru_glo_terms: bad shapes")
+    M = G.shape[1]
+    partial = torch.empty((n, parts, 128), dtype=torch.float32, device=net.device)
+    g = torch.empty((n, M), dtype=torch.float32, device=net.device)
+    L.check(L.load().glorie_gru_glo_terms(L.ptr(wn), _rows(wn, "wn"), L.ptr(bw), L.ptr(net), _rows(net, "net"),
+                                          L.ptr(G), L.ptr(Gb), M, L.ptr(partial), parts, L.ptr(g), n, h * w,
+                                          L.stream_ptr()), "glorie_gru_glo_terms")
+    return g
+
+
+def gru_gate_zr(zr, g, net, z, rnet):
+    """z = sigmoid(zr[:, :128] + g[n, :128]); rnet = sigmoid(zr[:, 128:] + g[n, 128:]) * net
+    (gru.py:28-30).  zr: raw [N,256,h,w] output of the merged convz|convr; g float32 [N,256]"""
+    L.need_cuda(zr, net, z, rnet, g)
+    n, c, h, w = net.shape
+    if c != 128 or zr.shape[1] != 256 or g.shape[0] != n:
+        raise RuntimeError("gru_gate_zr: bad shapes")
+    L.check(L.load().glorie_gru_gate_zr(L.ptr(zr), _rows(zr, "zr"), L.ptr(g), _terms(g, 256, "g"), L.ptr(net),
+                                        _rows(net, "net"), L.ptr(z), _rows(z, "z"), L.ptr(rnet),
+                                        _rows(rnet, "rnet"), n, h * w, L.stream_ptr()), "glorie_gru_gate_zr")
+
+
+def gru_gate_q(qc, gq, z, net, out, out2=None):
+    """out = (1 - z) * net + z * tanh(qc + gq[n])   (gru.py:31-33); gq float32 [N,128];
+    out2: optional second destination (e.g. the net slice of the GRU input buffer)"""
+    L.need_cuda(qc, z, net, out, gq)
+    n, c, h, w = net.shape
+    if c != 128 or gq.shape[0] != n:
+        raise RuntimeError("gru_gate_q: bad shapes")
+    L.check(L.load().glorie_gru_gate_q(L.ptr(qc), _rows(qc, "qc"), L.ptr(gq), _terms(gq, 128, "gq"), L.ptr(z),
+                                       _rows(z, "z"), L.ptr(net), _rows(net, "net"), L.ptr(out), _rows(out, "out"),
+                                       L.ptr(out2), _rows(out2, "out2") if out2 is not None else 0, n, h * w,
+                                       L.stream_ptr()), "glorie_gru_gate_q")
+    return out
+
+
+def segment_mean(x, ix, groups, bias=None, relu=False):
+    """out[g] = mean over edges e with ix[e] == g of act(x[e] + bias): scatter_mean of GraphAgg
+    (droid_net.py:53-59).  x [N,128,h,w] channels-last fp16 (slice allowed), ix int64 [N]
+    -> [groups,128,h,w] channels-last fp16"""
+    L.need_cuda(x, ix)
+    n, c, h, w = x.shape
+    if c != 128 or ix.dtype != torch.int64 or ix.numel() != n or not ix.is_contiguous():
+        raise RuntimeError("segment_mean: x must be [N,128,h,w], ix int64 [N]")
+    out = torch.empty((groups, 128, h, w), dtype=torch.float16, device=x.device,
+                      memory_format=torch.channels_last)
+    L.check(L.load().glorie_segment_mean(L.ptr(x), _rows(x, "x"), L.ptr(bias), int(relu), L.ptr(ix), n,
+                                         L.ptr(out), 128, groups, h * w, L.stream_ptr()), "glorie_segment_mean")
+    return out
+
+
+def pack_conv3x3_small(weights):
+    """weights: list (one per group) of conv weights [K,128,3,3] -> fp16 MFMA B fragments
+    [groups][NT][4][64][8] (layout documented in include/glorie_hip.h)"""
+    K = weights[0].shape[0]
+    ncols = 9 * K
+    nt = 1 if ncols <= 16 else 2
+    packs = []
+    for wgt in weights:
+        if tuple(wgt.shape) != (K, 128, 3, 3):
+            raise RuntimeError("pack_conv3x3_small: expected [K,128,3,3] weights")
+        cols = torch.zeros(nt * 16, 128, dtype=torch.float32, device=wgt.device)
+        # column d*K + j  <-  w[j, :, d]
+        cols[:ncols] = wgt.detach().float().reshape(K, 128, 9).permute(2, 0, 1).reshape(ncols, 128)
+        # [t][col][kk][kg][i] -> [t][kk][kg][col][i]   (lane = kg*16 + col)
+        packs.append(cols.view(nt, 16, 4, 4, 8).permute(0, 2, 3, 1, 4).reshape(nt, 4, 64, 8))
+    return torch.stack(packs).half().contiguous()
+
+
+def conv3x3_small(x, w_packed, out_bias, K, acts, scale=1.0, in_bias=None, in_relu=False):
+    """3x3 convolution 128 -> K (<= 3) channels per group on consecutive 128-channel slices of the
+    channels-last fp16 map x [N, 128*groups(+), h, w] -> float32 [groups, N, h, w, K]
+    (heads of the update operator, droid_net.py:85-93,42-44)"""
+    L.need_cuda(x, w_packed)
+    groups = w_packed.shape[0]
+    n, c, h, w = x.shape
+    if c < 128 * groups or len(acts) != groups:
+        raise RuntimeError("conv3x3_small: bad shapes")
+    P = n * h * w
+    taps = torch.empty((P, groups * 9 * K), dtype=torch.float32, device=x.device)
+    out = torch.empty((groups, n, h, w, K), dtype=torch.float32, device=x.device)
+    packed = 0
+    for gidx, a in enumerate(acts):
+        packed |= int(a) << (4 * gidx)
+    L.check(L.load().glorie_conv3x3_small(L.ptr(x), _rows(x, "x"), L.ptr(in_bias), int(in_relu), L.ptr(w_packed),
+                                          L.ptr(out_bias), groups, K, packed, float(scale), L.ptr(taps),
+                                          L.ptr(out), n, h, w, L.stream_ptr()), "glorie_conv3x3_small")
+    return out

@@ -97,6 +97,50 @@ int glorie_altcorr_fwd(const float* fmap1, const float* fmap2, const float* coor
                        float* out, int B, int S, int H, int W, int H2, int W2, int C,
                        int radius, void* stream);
 
+/* Fused stages of UpdateModule / ConvGRU / GraphAgg between the (MIOpen) convolutions
+ *   reference: src/modules/droid_net/gru.py:20-34, src/modules/droid_net/droid_net.py:34-66,106-139
+ * All activations are channels-last fp16: row p (= edge*HW + pixel) holds C contiguous halfs;
+ * `*_stride` is the distance between rows in halfs, so operands may be channel slices of wider
+ * buffers (e.g. the 448-channel GRU input), which is how torch.cat disappears.
+ * act codes: 0 none, 1 ReLU, 2 sigmoid, 3 softplus.
+ *   glorie_bias_act      y = act(x + bias); C % 8 == 0
+ *   glorie_gru_glo_terms glo[n][c] = mean_p sigmoid(wn + bw) * net (gru.py:25-26), then
+ *                        g[n][o] = Gb[o] + sum_c glo[n][c] G[c][o], o < M: the convz_glo | convr_glo |
+ *                        convq_glo terms with the conv biases folded into Gb.  `partial` is a
+ *                        workspace of N*parts*128 floats (parts = pixel slices reduced in parallel;
+ *                        the final sum runs in a fixed order: deterministic).
+ *   glorie_gru_gate_zr   z = sigmoid(zc + g[n][0:128]); rnet = sigmoid(rc + g[n][128:256]) * net;
+ *                        zr = raw output [P,256] of the merged convz|convr     (gru.py:28-30)
+ *   glorie_gru_gate_q    out = (1 - z) * net + z * tanh(qc + gq[n])            (gru.py:31-33);
+ *                        out2 (nullable) receives a second copy (net slice of the next GRU input)
+ *   glorie_segment_mean  out[g] = mean_{e: ix[e]==g} act(x[e] + bias), C = 128: scatter_mean of
+ *                        GraphAgg (droid_net.py:53-59) with the bias+ReLU of conv1 folded in
+ *   glorie_conv3x3_small 3x3 convolution, zero padding, 128 -> K<=3 channels for `groups`<=4 heads
+ *                        reading consecutive 128-channel slices of x (delta / weight / eta heads,
+ *                        droid_net.py:85-93,42-44): out[grp][p][j] = scale * act_grp(out_bias +
+ *                        conv(act_in(x + in_bias))), fp32.  act_packed = act codes, 4 bits per
+ *                        group.  `taps` = workspace of P*groups*9K floats.  w_packed = fp16 MFMA B
+ *                        fragments [groups][NT][4][64][8], NT = 1 if 9K <= 16 else 2: element
+ *                        [grp][t][kk][lane][i] = w[grp][j][32kk + 8(lane>>4) + i][d] for column
+ *                        16t + (lane&15) = 3*3 tap d (row-major ky,kx) * K + j, zero beyond 9K. */
+int glorie_bias_act(const void* x, int x_stride, const float* bias, void* y, int y_stride,
+                    long P, int C, int act, void* stream);
+int glorie_gru_glo_terms(const void* wn, int w_stride, const float* bw, const void* net, int n_stride,
+                         const float* G, const float* Gb, int M, float* partial, int parts, float* g,
+                         int N, int HW, void* stream);
+int glorie_gru_gate_zr(const void* zr, int zr_stride, const float* g, int g_stride, const void* net,
+                       int n_stride, void* z, int z_stride, void* rnet, int r_stride, int N, int HW,
+                       void* stream);
+int glorie_gru_gate_q(const void* qc, int q_stride, const float* gq, int gq_stride, const void* z,
+                      int z_stride, const void* net, int n_stride, void* out, int o_stride, void* out2,
+                      int o2_stride, int N, int HW, void* stream);
+int glorie_segment_mean(const void* x, int x_stride, const float* bias, int relu, const int64_t* ix,
+                        int N, void* out, int o_stride, int G, int HW, void* stream);
+int glorie_conv3x3_small(const void* x, int x_stride, const float* in_bias, int in_relu,
+                         const void* w_packed, const float* out_bias, int groups, int K,
+                         int act_packed, float scale, float* taps, float* out, int N, int H, int W,
+                         void* stream);
+
 /* ------------------------------------------------------------------------------------ */
 /* A/B. projective geometry                                                              */
 /* ------------------------------------------------------------------------------------ */

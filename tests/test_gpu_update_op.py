@@ -1,0 +1,155 @@
+"""Fused update operator (csrc/gru.hip + droid_net.FusedUpdate) against the plain fp32 PyTorch
+module with the same weights (the tier's floating-point reference for this operator).
+
+Tolerance: the reference runs this operator under fp16 autocast (factor_graph.py:211), so the
+comparison against fp32 carries the fp16 noise of 12 stacked convolutions: 2e-2 absolute on
+O(1) activations, and the fused path must be at least as close to fp32 as the autocast path."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _cl_half(n, c, h, w, dev, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return torch.randn(n, c, h, w, generator=g).to(dev).half().contiguous(memory_format=torch.channels_last)
+
+
+def test_bias_act_slices(gpu):
+    from glorie_slam_amd import update_ops as U
+    x = _cl_half(3, 64, 5, 7, gpu, 0)
+    b = torch.linspace(-1, 1, 64, device=gpu)
+    wide = torch.zeros(3, 448, 5, 7, device=gpu, dtype=torch.float16).contiguous(memory_format=torch.channels_last)
+    U.bias_act(x, b, U.ACT_RELU, out=wide[:, 384:448])
+    ref = F.relu(x.float() + b.view(1, -1, 1, 1)).half()
+    assert torch.equal(wide[:, 384:448], ref)
+    assert float(wide[:, :384].abs().max()) == 0.0
+    y = U.bias_act(x.clone(memory_format=torch.preserve_format), b, U.ACT_SIGMOID)
+    torch.testing.assert_close(y.float(), torch.sigmoid(x.float() + b.view(1, -1, 1, 1)), atol=1e-3, rtol=1e-3)
+    z = U.bias_act(x.clone(memory_format=torch.preserve_format), None, U.ACT_NONE)
+    assert torch.equal(z, x)
+    with pytest.raises(RuntimeError):
+        U.bias_act(x.contiguous(), b, U.ACT_RELU)          # NCHW rows are not channels-last
+
+
+def test_gru_gates_match_torch(gpu):
+    from glorie_slam_amd import update_ops as U
+    n, h, w = 4, 6, 9
+    net = _cl_half(n, 128, h, w, gpu, 1)
+    wn = _cl_half(n, 128, h, w, gpu, 2)
+    zr = _cl_half(n, 256, h, w, gpu, 3)
+    qc = _cl_half(n, 128, h, w, gpu, 4)
+    bw = torch.randn(128, device=gpu)
+    G = torch.randn(128, 384, device=gpu) / 11.0
+    Gb = torch.randn(384, device=gpu)
+    g = U.gru_glo_terms(wn, bw, net, G, Gb, parts=5)
+    glo = (torch.sigmoid(wn.float() + bw.view(1, -1, 1, 1)) * net.float()).mean((2, 3))
+    torch.testing.assert_close(g, (glo.double() @ G.double() + Gb.double()).float(), atol=2e-5, rtol=1e-4)
+    assert torch.equal(g, U.gru_glo_terms(wn, bw, net, G, Gb, parts=5))     # deterministic
+    hx = torch.zeros(n, 448, h, w, device=gpu, dtype=torch.float16).contiguous(memory_format=torch.channels_last)
+    z = torch.empty_like(net)
+    U.gru_gate_zr(zr, g[:, :256], net, z, hx[:, :128])
+    zref = torch.sigmoid(zr[:, :128].float() + g[:, :128].view(n, 128, 1, 1))
+    rref = torch.sigmoid(zr[:, 128:].float() + g[:, 128:256].view(n, 128, 1, 1)) * net.float()
+    torch.testing.assert_close(z.float(), zref, atol=1e-3, rtol=1e-3)
+    torch.testing.assert_close(hx[:, :128].float(), rref, atol=2e-3, rtol=2e-3)
+    out = torch.empty_like(net)
+    U.gru_gate_q(qc, g[:, 256:], z, net, out, out2=hx[:, :128])
+    q = torch.tanh(qc.float() + g[:, 256:].reshape(n, 128, 1, 1))
+    ref = (1 - z.float()) * net.float() + z.float() * q
+    torch.testing.assert_close(out.float(), ref, atol=3e-3, rtol=2e-3)
+    assert torch.equal(hx[:, :128], out)
+
+
+def test_segment_mean(gpu):
+    from glorie_slam_amd import update_ops as U
+    n, h, w = 7, 5, 6
+    wide = _cl_half(n, 384, h, w, gpu, 5)
+    x = wide[:, 256:384]
+    ix = torch.tensor([0, 2, 2, 0, 3, 2, 0], device=gpu)           # group 1 is empty -> zeros
+    b = torch.randn(128, device=gpu)
+    out = U.segment_mean(x, ix, 4, bias=b, relu=True)
+    act = F.relu(x.float() + b.view(1, -1, 1, 1))
+    for gidx in range(4):
+        m = ix == gidx
+        ref = act[m].mean(0) if bool(m.any()) else torch.zeros_like(act[0])
+        torch.testing.assert_close(out[gidx].float(), ref, atol=2e-3, rtol=2e-3)
+    plain = U.segment_mean(x, ix, 4)
+    torch.testing.assert_close(plain[2].float(), x.float()[ix == 2].mean(0), atol=2e-3, rtol=2e-3)
+
+
+@pytest.mark.parametrize("K,groups", [(2, 2), (1, 1), (3, 1)])
+def test_conv3x3_small_matches_conv2d(gpu, K, groups):
+    from glorie_slam_amd import update_ops as U
+    n, h, w = 3, 7, 10                                               # 210 pixels: ragged last tile
+    x = _cl_half(n, 384, h, w, gpu, 6)
+    g = torch.Generator(device="cpu").manual_seed(8)
+    ws = [(torch.randn(K, 128, 3, 3, generator=g) / 20).to(gpu) for _ in range(groups)]
+    ob = torch.randn(groups * K, generator=g).to(gpu)
+    ib = torch.randn(128 * groups, generator=g).to(gpu)
+    acts = [U.ACT_NONE, U.ACT_SIGMOID, U.ACT_SOFTPLUS, U.ACT_RELU][:groups]
+    out = U.conv3x3_small(x, U.pack_conv3x3_small(ws), ob, K, acts, scale=0.5, in_bias=ib, in_relu=True)
+    assert tuple(out.shape) == (groups, n, h, w, K)
+    for gi in range(groups):
+        xin = F.relu(x[:, 128 * gi:128 * (gi + 1)].float() + ib[128 * gi:128 * (gi + 1)].view(1, -1, 1, 1))
+        xin = xin.half().float()                                     # the kernel rounds its operand to fp16
+        ref = F.conv2d(xin, ws[gi].half().float(), ob[K * gi:K * (gi + 1)], padding=1)
+        ref = [ref, torch.sigmoid(ref), F.softplus(ref), F.relu(ref)][gi] * 0.5
+        torch.testing.assert_close(out[gi], ref.permute(0, 2, 3, 1), atol=2e-3, rtol=2e-3)
+    # no input transform
+    out2 = U.conv3x3_small(x, U.pack_conv3x3_small(ws), None, K, [U.ACT_NONE] * groups)
+    ref = F.conv2d(x[:, :128].float(), ws[0].half().float(), None, padding=1)
+    torch.testing.assert_close(out2[0], ref.permute(0, 2, 3, 1), atol=2e-3, rtol=2e-3)
+
+
+def _inputs(dev, n, h, w, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=g).to(dev)
+    net = torch.tanh(r(1, n, 128, h, w))
+    inp = torch.relu(r(1, n, 128, h, w))
+    corr = 2.0 * r(1, n, 196, h, w)
+    flow = torch.clamp(4.0 * r(1, n, 4, h, w), -64, 64)
+    return net, inp, corr, flow
+
+
+@pytest.mark.parametrize("n,h,w", [(6, 12, 16), (10, 30, 40)])
+def test_fused_update_matches_fp32_module(gpu, n, h, w):
+    from glorie_slam_amd.droid_net import UpdateModule, HalfUpdate, FusedUpdate
+    torch.manual_seed(7)
+    mod = UpdateModule().to(gpu).eval()
+    net, inp, corr, flow = _inputs(gpu, n, h, w)
+    ii = torch.tensor([i // 3 for i in range(n)], device=gpu)
+    with torch.no_grad():
+        ref = mod(net, inp, corr, flow, ii, None)
+    fused = FusedUpdate(mod)(net, inp, corr, flow, ii, None)
+    half = HalfUpdate(mod)(net, inp, corr, flow, ii, None)
+    names = ["net", "delta", "weight", "eta", "upmask"]
+    for name, a, b, c in zip(names, ref, fused, half):
+        assert tuple(a.shape) == tuple(b.shape), name
+        err_f = float((a.float() - b.float()).abs().max())
+        err_h = float((a.float() - c.float()).abs().max())
+        scale = max(1.0, float(a.abs().max()))
+        assert err_f <= 2e-2 * scale, (name, err_f)
+        assert err_f <= 2.0 * err_h + 2e-3 * scale, (name, err_f, err_h)
+
+
+def test_fused_update_without_graph_aggregation_and_repack(gpu):
+    from glorie_slam_amd.droid_net import UpdateModule, FusedUpdate
+    torch.manual_seed(9)
+    mod = UpdateModule().to(gpu).eval()
+    net, inp, corr, flow = _inputs(gpu, 4, 8, 8, seed=3)
+    fu = FusedUpdate(mod)
+    out = fu(net, inp, corr, flow)
+    assert len(out) == 3
+    with torch.no_grad():
+        ref = mod(net, inp, corr, flow)
+        torch.testing.assert_close(out[1].float(), ref[1], atol=2e-2, rtol=2e-2)
+        # a parameter update must be picked up (weights are re-packed on version change)
+        mod.delta[2].bias.add_(1.0)
+        ref2 = mod(net, inp, corr, flow)
+    out2 = fu(net, inp, corr, flow)
+    torch.testing.assert_close(out2[1].float(), ref2[1], atol=2e-2, rtol=2e-2)
+    # the recurrent state can be fed back as returned (channels-last strides)
+    out3 = fu(out2[0], inp, corr, flow)
+    assert torch.isfinite(out3[0].float()).all()
