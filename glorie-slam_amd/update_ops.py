@@ -144,3 +144,50 @@ def conv3x3_small(x, w_packed, out_bias, K, acts, scale=1.0, in_bias=None, in_re
                                           L.ptr(out_bias), groups, K, packed, float(scale), L.ptr(taps),
                                           L.ptr(out), n, h, w, L.stream_ptr()), "glorie_conv3x3_small")
     return out
+
+
+EPI_BIAS_ACT, EPI_GRU_ZR, EPI_GRU_Q = 0, 1, 2
+
+
+def pack_conv_igemm(weight):
+    """conv weight [Nout, C, k, k] (k = 1 or 3) -> the fp16 operand of glorie_conv_igemm:
+    [taps][npad][C] (npad = Nout rounded up to 128, zero rows) followed by 64 zero halfs"""
+    nout, C, kh, kw = weight.shape
+    if kh != kw or kh not in (1, 3) or C % 64:
+        raise RuntimeError("pack_conv_igemm: need 1x1 or 3x3 weights with C % 64 == 0")
+    taps, npad = kh * kw, (nout + 127) // 128 * 128
+    w = torch.zeros(taps, npad, C, dtype=torch.float16, device=weight.device)
+    w[:, :nout] = weight.detach().permute(2, 3, 0, 1).reshape(taps, nout, C).half()
+    return torch.cat([w.reshape(-1), torch.zeros(64, dtype=torch.float16, device=weight.device)])
+
+
+def conv_igemm(xa, xb, w_packed, taps, nout, out, epilogue=EPI_BIAS_ACT, terms=None, act=ACT_NONE,
+               net=None, z=None, out2=None):
+    """Implicit-GEMM convolution with fused epilogue (csrc/conv.hip, include/glorie_hip.h).
+    xa / xb: channels-last fp16 maps [N,Ca,h,w] / [N,Cb,h,w] (either may be None); writes `out`
+    (and `out2` for the GRU gates) and returns `out`."""
+    ref = xa if xa is not None else xb
+    L.need_cuda(ref, w_packed, out)
+    n, _, h, w = ref.shape
+    ca = xa.shape[1] if xa is not None else 0
+    cb = xb.shape[1] if xb is not None else 0
+    npad = (nout + 127) // 128 * 128
+    if w_packed.dtype != torch.float16 or w_packed.numel() != taps * npad * (ca + cb) + 64:
+        raise RuntimeError("conv_igemm: packed weights do not match (taps, nout, channels)")
+    if epilogue == EPI_BIAS_ACT:
+        if terms is not None and (terms.dtype != torch.float32 or terms.numel() != nout or not terms.is_contiguous()):
+            raise RuntimeError("conv_igemm: bias must be contiguous float32 [nout]")
+        ts = 0
+    else:
+        ts = _terms(terms, nout, "terms")
+        if terms.shape[0] != n:
+            raise RuntimeError("conv_igemm: one row of gate terms per map")
+    opt = lambda t, name: (L.ptr(t), _rows(t, name) if t is not None else 0)
+    (pa, sa), (pb, sb) = opt(xa, "xa"), opt(xb, "xb")
+    (pn, sn), (pz, sz), (po2, so2) = opt(net, "net"), opt(z, "z"), opt(out2, "out2")
+    if out.shape[1] != (128 if epilogue != EPI_BIAS_ACT else nout) or out.shape[0] != n:
+        raise RuntimeError("conv_igemm: bad output shape")
+    L.check(L.load().glorie_conv_igemm(pa, sa, ca, pb, sb, cb, L.ptr(w_packed), taps, nout, epilogue,
+                                       L.ptr(terms), ts, act, pn, sn, pz, sz, L.ptr(out), _rows(out, "out"),
+                                       po2, so2, n, h, w, L.stream_ptr()), "glorie_conv_igemm")
+    return out

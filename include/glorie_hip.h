@@ -141,6 +141,28 @@ int glorie_conv3x3_small(const void* x, int x_stride, const float* in_bias, int 
                          int act_packed, float scale, float* taps, float* out, int N, int H, int W,
                          void* stream);
 
+/* Implicit-GEMM convolution (3x3 zero-padded, or 1x1) on the matrix cores with fused epilogues:
+ * the wide convolutions of UpdateModule / ConvGRU (droid_net.py:73-104, gru.py:10-19).
+ *   out[p][n] = epilogue( sum_taps sum_c x[p + off(tap)][c] * w[tap][n][c] ),  fp16 in, fp32 accumulate
+ * Input = channels-last fp16 rows in up to two channel segments (xa: ca channels, xb: cb channels,
+ * each with its own row stride; ca, cb multiples of 64; either may be 0) -- the GRU input
+ * [net | inp, corr, flow] without a concatenation.  N maps of H x W pixels.
+ * w_packed: fp16 [taps][npad][ca+cb] (npad = nout rounded up to 128, padding rows zero, tap order
+ * row-major ky,kx, channel order segment A then B) followed by 64 zero halfs.  nout % 4 == 0.
+ * epilogue 0: out[p][n] = act(acc + terms[n])                 terms = bias [nout] or NULL
+ * epilogue 1: GRU gates, nout = 256 (convz | convr merged, gru.py:28-30):
+ *             out[p][c]  = z = sigmoid(acc[c] + terms[e][c]),             c < 128
+ *             out2[p][c] = sigmoid(acc[128+c] + terms[e][128+c]) * net[p][c]
+ * epilogue 2: GRU blend, nout = 128 (gru.py:31-33):
+ *             out[p][c] = (1 - z[p][c]) * net[p][c] + z[p][c] * tanh(acc[c] + terms[e][c])
+ * e = p / (H*W) is the map (edge) index; terms rows are terms_stride floats apart (gates) and come
+ * from glorie_gru_glo_terms.  out / out2 / net / z are fp16 rows with their own strides (halfs). */
+int glorie_conv_igemm(const void* xa, int xa_stride, int ca, const void* xb, int xb_stride, int cb,
+                      const void* w_packed, int taps, int nout, int epilogue, const float* terms,
+                      int terms_stride, int act, const void* net, int net_stride, const void* z,
+                      int z_stride, void* out, int out_stride, void* out2, int out2_stride, int N,
+                      int H, int W, void* stream);
+
 /* ------------------------------------------------------------------------------------ */
 /* A/B. projective geometry                                                              */
 /* ------------------------------------------------------------------------------------ */

@@ -153,3 +153,56 @@ def test_fused_update_without_graph_aggregation_and_repack(gpu):
     # the recurrent state can be fed back as returned (channels-last strides)
     out3 = fu(out2[0], inp, corr, flow)
     assert torch.isfinite(out3[0].float()).all()
+
+
+# ---- implicit-GEMM convolution (csrc/conv.hip) -------------------------------------------------
+def _conv_ref(xs, weight, bias=None):
+    x = torch.cat([t.float() for t in xs if t is not None], 1)
+    return F.conv2d(x, weight.half().float(), bias, padding=weight.shape[-1] // 2)
+
+
+@pytest.mark.parametrize("n,h,w,ca,cb,nout,k", [(3, 7, 10, 128, 320, 128, 3),     # ragged pixel tile, 2 segments
+                                                 (2, 12, 16, 0, 128, 64, 3),       # padded output tile
+                                                 (2, 9, 8, 128, 0, 384, 3),        # 3 output tiles
+                                                 (5, 6, 6, 64, 64, 576, 1)])       # 1x1
+def test_conv_igemm_matches_conv2d(gpu, n, h, w, ca, cb, nout, k):
+    from glorie_slam_amd import update_ops as U
+    xa = _cl_half(n, ca, h, w, gpu, 11) if ca else None
+    wide = _cl_half(n, cb + 64, h, w, gpu, 12) if cb else None
+    xb = wide[:, 64:64 + cb] if cb else None                           # a channel slice: row stride != channels
+    g = torch.Generator(device="cpu").manual_seed(13)
+    weight = (torch.randn(nout, ca + cb, k, k, generator=g) / (3.0 * (ca + cb) ** 0.5)).to(gpu)
+    bias = torch.randn(nout, generator=g).to(gpu)
+    out = torch.empty((n, nout, h, w), dtype=torch.float16, device=gpu, memory_format=torch.channels_last)
+    U.conv_igemm(xa, xb, U.pack_conv_igemm(weight), k * k, nout, out, terms=bias, act=U.ACT_RELU)
+    ref = F.relu(_conv_ref([xa, xb], weight, bias))
+    torch.testing.assert_close(out.float(), ref, atol=4e-3, rtol=4e-3)
+    out2 = torch.empty_like(out)
+    U.conv_igemm(xa, xb, U.pack_conv_igemm(weight), k * k, nout, out2)
+    torch.testing.assert_close(out2.float(), _conv_ref([xa, xb], weight), atol=4e-3, rtol=4e-3)
+
+
+def test_conv_igemm_gru_epilogues(gpu):
+    from glorie_slam_amd import update_ops as U
+    n, h, w = 3, 10, 13
+    net = _cl_half(n, 128, h, w, gpu, 21)
+    hx = _cl_half(n, 320, h, w, gpu, 22)
+    g = torch.Generator(device="cpu").manual_seed(23)
+    wzr = (torch.randn(256, 448, 3, 3, generator=g) / 60).to(gpu)
+    wq = (torch.randn(128, 448, 3, 3, generator=g) / 60).to(gpu)
+    terms = torch.randn(n, 384, generator=g).to(gpu)
+    z = torch.empty_like(net)
+    rnet = torch.empty_like(net)
+    U.conv_igemm(net, hx, U.pack_conv_igemm(wzr), 9, 256, z, epilogue=U.EPI_GRU_ZR, terms=terms[:, :256],
+                 net=net, out2=rnet)
+    zr = _conv_ref([net, hx], wzr) + terms[:, :256].view(n, 256, 1, 1)
+    zref = torch.sigmoid(zr[:, :128])
+    rref = torch.sigmoid(zr[:, 128:]) * net.float()
+    torch.testing.assert_close(z.float(), zref, atol=3e-3, rtol=3e-3)
+    torch.testing.assert_close(rnet.float(), rref, atol=3e-3, rtol=3e-3)
+    new = torch.empty_like(net)
+    U.conv_igemm(rnet, hx, U.pack_conv_igemm(wq), 9, 128, new, epilogue=U.EPI_GRU_Q, terms=terms[:, 256:],
+                 net=net, z=z)
+    q = torch.tanh(_conv_ref([rnet, hx], wq) + terms[:, 256:].reshape(n, 128, 1, 1))
+    ref = (1 - z.float()) * net.float() + z.float() * q
+    torch.testing.assert_close(new.float(), ref, atol=4e-3, rtol=4e-3)

@@ -1,0 +1,47 @@
+"""Times glorie_conv_igemm against MIOpen (F.conv2d, fp16 channels-last) on the update operator's
+wide convolutions at the G8 shape (36 edges, 60x80).  Usage (GPU box): python tools/bench_conv.py"""
+import os
+import sys
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from glorie_slam_amd import update_ops as U  # noqa: E402
+
+
+def timed(fn, iters=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e3
+
+
+def main():
+    dev = torch.device("cuda:0")
+    n, h, w = 36, 60, 80
+    P = n * h * w
+    torch.manual_seed(0)
+    cl = lambda c: torch.randn(n, c, h, w, device=dev).half().contiguous(memory_format=torch.channels_last)
+    for (cin, nout, k) in [(448, 256, 3), (448, 128, 3), (128, 384, 3), (128, 128, 3), (128, 64, 3), (128, 128, 1)]:
+        x = cl(cin)
+        wt = (torch.randn(nout, cin, k, k, device=dev) / (cin * k * k) ** 0.5)
+        wcl = wt.half().contiguous(memory_format=torch.channels_last)
+        wp = U.pack_conv_igemm(wt)
+        out = torch.empty((n, nout, h, w), dtype=torch.float16, device=dev, memory_format=torch.channels_last)
+        t_ref = timed(lambda: F.conv2d(x, wcl, padding=k // 2))
+        t_own = timed(lambda: U.conv_igemm(x, None, wp, k * k, nout, out))
+        err = float((out.float() - F.conv2d(x, wcl, padding=k // 2).float()).abs().max())
+        fl = 2.0 * P * cin * k * k * nout
+        print(f"{cin:4d}->{nout:4d} {k}x{k}: miopen {t_ref:7.1f} us ({fl / t_ref / 1e6:6.0f} TF/s)   "
+              f"igemm {t_own:7.1f} us ({fl / t_own / 1e6:6.0f} TF/s)   max|diff| {err:.4f}", flush=True)
+
+
+if __name__ == "__main__":
+    main()

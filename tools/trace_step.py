@@ -1,0 +1,19 @@
+"""Prints the kernels of the last BA-update step of a rocprofv3 kernel trace (csv), i.e. everything
+between two consecutive launches of a marker kernel (the fullest such window).  Usage: python tools/trace_step.py <kernel_trace.csv> [marker]"""
+import csv
+import sys
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+marker = sys.argv[2] if len(sys.argv) > 2 else "corr_lookup"
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+idx = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"]]
+# the window between consecutive markers with the most kernels in it, latest wins
+a, b = max(zip(idx[:-1], idx[1:]), key=lambda ab: (ab[1] - ab[0], ab[0]))
+tot = 0.0
+t_first = int(rows[a]["Start_Timestamp"])
+for r in rows[a:b]:
+    d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    tot += d
+    print(f'{(int(r["Start_Timestamp"]) - t_first) / 1e3:9.1f} {d:8.1f}  {r["Kernel_Name"][:100]}')
+span = (int(rows[b]["Start_Timestamp"]) - t_first) / 1e3
+print(f"kernels {b - a}  busy {tot:.1f} us  span {span:.1f} us")
