@@ -43,6 +43,7 @@ SIGNATURES = {
     "glorie_iproj": (_c_int, [_vp] * 4 + [_c_int] * 3 + [_vp]),
     "glorie_depth_filter": (_c_int, [_vp] * 6 + [_c_int] * 4 + [_vp]),
     "glorie_cvx_upsample": (_c_int, [_vp] * 4 + [_c_int] * 5 + [_vp]),
+    "glorie_cvx_upsample_nhwc": (_c_int, [_vp, _vp, _vp, _c_int, _vp, _c_int, _c_int, _c_int, _c_int, _vp]),
     "glorie_ba": (_c_int, [_vp] * 10 + [_c_int] * 8 + [_c_f, _c_f, _c_int, _c_int, _vp, _vp, _vp]),
     "glorie_ba_build_system": (_c_int, [_vp] * 10 + [_c_int] * 8 + [_vp, _vp]),
     "glorie_ba_solve_update": (_c_int, [_vp] * 5 + [_c_int] * 7 + [_c_f, _c_f, _c_int, _c_int] + [_vp] * 4),

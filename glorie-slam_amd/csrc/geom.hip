@@ -295,6 +295,53 @@ __global__ __launch_bounds__(256) void cvx_upsample_kernel(
   }
 }
 
+// Same operator on a CHANNELS-LAST fp16 mask ([pixel][576], what the 1x1 upmask convolution of
+// GraphAgg writes): lane = (sub-row a, pixel q of a group of 8).  For tap k the 8 sub-column
+// weights of (a) are 16 contiguous bytes, a wave reads 8 pixels x 128 contiguous bytes per tap and
+// writes 8 sub-rows x 256 contiguous bytes.  grid (ceil(HW/8)*64/256, M)
+typedef __attribute__((ext_vector_type(8))) _Float16 mask8;
+
+__global__ __launch_bounds__(256) void cvx_upsample_nhwc_kernel(
+    const float* __restrict__ disps, const int64_t* __restrict__ ix, const _Float16* __restrict__ mask,
+    int ms, float* __restrict__ disps_up, int h, int w, int softmax_f32) {
+  const int HW = h * w;
+  const int m = blockIdx.y;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int a = (t >> 3) & 7;
+  const int p = (t >> 6) * 8 + (t & 7);
+  if (p >= HW) return;
+  const int frame = static_cast<int>(ix[m]);
+  const float* dmap = disps + (size_t)frame * HW;
+  const int y = p / w, x = p - y * w;
+  float nb[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
+    nb[k] = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? dmap[yy * w + xx] : 0.0f;
+  }
+  const _Float16* row = mask + ((size_t)m * HW + p) * ms + a * 8;
+  mask8 v[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) v[k] = *reinterpret_cast<const mask8*>(row + k * 64);
+  float outv[8];
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    float mx = (float)v[0][b];
+#pragma unroll
+    for (int k = 1; k < 9; ++k) mx = fmaxf(mx, (float)v[k][b]);
+    float e[9], sum = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { e[k] = expf((float)v[k][b] - mx); sum += e[k]; }
+    float acc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc += round_like_mask<_Float16>(e[k] / sum, softmax_f32 != 0) * nb[k];
+    outv[b] = acc;
+  }
+  float* o = disps_up + (size_t)frame * 64 * HW + (size_t)(8 * y + a) * (8 * w) + 8 * x;
+  reinterpret_cast<float4*>(o)[0] = make_float4(outv[0], outv[1], outv[2], outv[3]);
+  reinterpret_cast<float4*>(o)[1] = make_float4(outv[4], outv[5], outv[6], outv[7]);
+}
+
 }  // namespace glorie
 
 using namespace glorie;
@@ -364,5 +411,18 @@ extern "C" int glorie_cvx_upsample(const float* disps, const int64_t* ix, const 
                        disps, ix, reinterpret_cast<const float*>(mask), disps_up, h, w, 1);
   else
     return GLORIE_EUNSUPPORTED;
+  return check_launch();
+}
+
+extern "C" int glorie_cvx_upsample_nhwc(const float* disps, const int64_t* ix, const void* mask,
+                                        int mask_stride, float* disps_up, int M, int h, int w,
+                                        int softmax_f32, void* stream) {
+  if (M < 0 || h < 0 || w < 0 || mask_stride < 576 || (mask_stride & 7)) return GLORIE_EINVAL;
+  if (M == 0 || h * w == 0) return GLORIE_OK;
+  if (!disps || !ix || !mask || !disps_up) return GLORIE_EINVAL;
+  const int groups = (h * w + 7) / 8;
+  hipLaunchKernelGGL(cvx_upsample_nhwc_kernel, dim3((groups * 64 + 255) / 256, M), dim3(256), 0,
+                     (hipStream_t)stream, disps, ix, reinterpret_cast<const _Float16*>(mask), mask_stride,
+                     disps_up, h, w, softmax_f32);
   return check_launch();
 }

@@ -137,7 +137,8 @@ class DepthVideo:
     def upsample(self, ix, mask, softmax_f32=False):
         """disps_up[ix] = cvx_upsample(disps[ix], mask)  (depth_video.py:140-144)"""
         m = mask.reshape(-1, 576, mask.shape[-2], mask.shape[-1])
-        if not m.is_contiguous():
+        if not m.is_contiguous() and not (m.dtype == torch.float16 and
+                                          m.is_contiguous(memory_format=torch.channels_last)):
             m = m.contiguous()
         droid_backends.cvx_upsample(self.disps, ix.contiguous(), m, self.disps_up, softmax_f32=softmax_f32)
 

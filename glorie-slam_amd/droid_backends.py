@@ -157,12 +157,20 @@ def cvx_upsample(disps, ix, mask, disps_up, softmax_f32=False):
     """disps_up[ix] = cvx_upsample(disps[ix], mask) in place (droid_net.py:9-23,
     depth_video.py:140-144).  mask [M,576,h,w] f16|f32."""
     L.need_cuda(disps, ix, mask, disps_up)
-    L.need_contiguous(disps=disps, ix=ix, mask=mask, disps_up=disps_up)
     _i64(ix, "ix")
     M = ix.shape[0]
     h, w = disps.shape[1:]
     if mask.numel() != M * 576 * h * w:
         raise RuntimeError(f"mask has {mask.numel()} elements, expected {M}*576*{h}*{w}")
+    if mask.dim() == 4 and mask.dtype == torch.float16 and not mask.is_contiguous() \
+            and mask.is_contiguous(memory_format=torch.channels_last):
+        # channels-last logits straight from the upmask convolution: no layout pass
+        L.need_contiguous(disps=disps, ix=ix, disps_up=disps_up)
+        L.check(L.load().glorie_cvx_upsample_nhwc(L.ptr(disps), L.ptr(ix), L.ptr(mask), 576, L.ptr(disps_up),
+                                                  M, h, w, int(bool(softmax_f32)), L.stream_ptr()),
+                "glorie_cvx_upsample_nhwc")
+        return disps_up
+    L.need_contiguous(disps=disps, ix=ix, mask=mask, disps_up=disps_up)
     L.check(L.load().glorie_cvx_upsample(L.ptr(disps), L.ptr(ix), L.ptr(mask), L.ptr(disps_up), M, h,
                                          w, L.dtype_code(mask), int(bool(softmax_f32)),
                                          L.stream_ptr()), "glorie_cvx_upsample")

@@ -154,35 +154,35 @@ class HalfUpdate:
 
 
 class FusedUpdate:
-    """Inference form of an UpdateModule built for gfx950: fp16 channels-last maps, the wide
-    convolutions through MIOpen WITHOUT bias, and everything else in the kernels of csrc/gru.hip
-    (update_ops).  Differences to evaluating the module:
+    """Inference form of an UpdateModule built for gfx950 (scope row A4): fp16 channels-last maps,
+    every wide convolution on the implicit-GEMM MFMA kernel of csrc/conv.hip with its consumer
+    fused into the epilogue, the rest in the kernels of csrc/gru.hip (update_ops):
 
-      * convz and convr (gru.py:13-14) are one convolution with 256 output channels; delta[0],
+      * convz and convr (gru.py:13-14) are one convolution with 256 output channels whose
+        epilogue applies the gates (z, r * net); convq's epilogue is the GRU blend; delta[0],
         weight[0] and agg.conv1 (droid_net.py:85-93,38) -- three 3x3 convolutions of the same
-        input -- are one with 384;
+        input -- are one with 384 output channels and a bias+ReLU epilogue;
+      * torch.cat([net, inp, corr, flow]) never happens: the convolution reads two channel
+        segments ([net] or [r*net], and one persistent [N,320,h,w] buffer that the encoders write
+        their slices of).  The inp slice is re-filled only when the caller passes a different
+        tensor than at the previous call;
       * the 1x1 corr_encoder[0] reads the NCHW output of the correlation lookup as a transposed
-        GEMM operand and lands channels-last (no layout pass over the 196-channel map);
-      * torch.cat([net, inp, corr, flow]) never happens: producers write their channel slice of
-        one persistent [N,448,h,w] buffer, and r*net overwrites the net slice for convq.  The net
-        and inp slices are only re-filled when the caller passes tensors other than the ones seen
-        at the previous call (the recurrent state returned by the previous call is already there);
-      * bias + ReLU / sigmoid / tanh, the global-context terms and the GRU blend are 1 launch each
-        (fp32 math in registers, one rounding to fp16), instead of ~40 PyTorch launches;
+        GEMM operand (hipBLASLt) and lands channels-last: no layout pass over the 196-channel map;
+      * the global-context vector and its three 1x1 convolutions are two small launches
+        (glorie_gru_glo_terms);
       * the 128 -> 2 / 128 -> 1 heads (delta[2], weight[2], agg.eta) are the tap-GEMM + stencil
-        kernel glorie_conv3x3_small with the preceding bias+ReLU folded into its operand load;
-        GraphAgg's scatter_mean is glorie_segment_mean (fixed summation order).
+        kernel glorie_conv3x3_small; GraphAgg's scatter_mean is glorie_segment_mean (fixed order);
+        the upmask logits stay channels-last for glorie_cvx_upsample_nhwc.
 
-    Same call signature and return values as UpdateModule.forward (droid_net.py:106-139); delta,
-    weight and eta come back in float32.  The weights are re-packed whenever a parameter of the
-    source module changes."""
+    Only flow_encoder[0] (7x7 on 4 channels) still goes through MIOpen.  Same call signature and
+    return values as UpdateModule.forward (droid_net.py:106-139); delta, weight and eta come back
+    in float32.  Weights are re-packed whenever a parameter of the source module changes."""
 
     def __init__(self, module):
         self.src = module
         self._ver = None
         self._hx = None
-        self._net_key = None      # (tensor kept alive, version) whose values sit in hx[:, 0:128]
-        self._inp_key = None
+        self._inp_key = None      # (tensor kept alive, version) whose values sit in the inp slice of hx
 
     # -- weight packing ----------------------------------------------------------------
     def _sync(self):
@@ -191,30 +191,30 @@ class FusedUpdate:
         if self._ver == ver:
             return
         m = self.src
-        cl = lambda w: w.detach().half().contiguous(memory_format=torch.channels_last)
         f32 = lambda b: b.detach().float().contiguous()
         g = m.gru
         W = {}
         W["ce1_t"] = m.corr_encoder[0].weight.detach().view(128, -1).t().half().contiguous()
         W["ce1_b"] = f32(m.corr_encoder[0].bias)
-        W["ce2"], W["ce2_b"] = cl(m.corr_encoder[2].weight), f32(m.corr_encoder[2].bias)
-        W["fe1"], W["fe1_b"] = cl(m.flow_encoder[0].weight), f32(m.flow_encoder[0].bias)
-        W["fe2"], W["fe2_b"] = cl(m.flow_encoder[2].weight), f32(m.flow_encoder[2].bias)
-        W["zr"] = cl(torch.cat([g.convz.weight, g.convr.weight], 0))
-        W["q"] = cl(g.convq.weight)
-        W["w"], W["w_b"] = cl(g.w.weight), f32(g.w.bias)
+        W["ce2"], W["ce2_b"] = U.pack_conv_igemm(m.corr_encoder[2].weight), f32(m.corr_encoder[2].bias)
+        W["fe1"] = m.flow_encoder[0].weight.detach().half().contiguous(memory_format=torch.channels_last)
+        W["fe1_b"] = f32(m.flow_encoder[0].bias)
+        W["fe2"], W["fe2_b"] = U.pack_conv_igemm(m.flow_encoder[2].weight), f32(m.flow_encoder[2].bias)
+        W["zr"] = U.pack_conv_igemm(torch.cat([g.convz.weight, g.convr.weight], 0))
+        W["q"] = U.pack_conv_igemm(g.convq.weight)
+        W["w"], W["w_b"] = U.pack_conv_igemm(g.w.weight), f32(g.w.bias)
         # glo terms: g[n] = glo[n] @ G + (bias of the 1x1 glo conv + bias of the 3x3 gate conv)
         W["G"] = f32(torch.cat([g.convz_glo.weight.view(128, 128), g.convr_glo.weight.view(128, 128),
                                 g.convq_glo.weight.view(128, 128)], 0).t())
         W["G_b"] = f32(torch.cat([g.convz_glo.bias + g.convz.bias, g.convr_glo.bias + g.convr.bias,
                                   g.convq_glo.bias + g.convq.bias]))
-        W["h1"] = cl(torch.cat([m.delta[0].weight, m.weight[0].weight, m.agg.conv1.weight], 0))
+        W["h1"] = U.pack_conv_igemm(torch.cat([m.delta[0].weight, m.weight[0].weight, m.agg.conv1.weight], 0))
         W["h1_b"] = f32(torch.cat([m.delta[0].bias, m.weight[0].bias, m.agg.conv1.bias]))
         W["h2"] = U.pack_conv3x3_small([m.delta[2].weight, m.weight[2].weight])
         W["h2_b"] = f32(torch.cat([m.delta[2].bias, m.weight[2].bias]))
-        W["a2"], W["a2_b"] = cl(m.agg.conv2.weight), f32(m.agg.conv2.bias)
+        W["a2"], W["a2_b"] = U.pack_conv_igemm(m.agg.conv2.weight), f32(m.agg.conv2.bias)
         W["eta"], W["eta_b"] = U.pack_conv3x3_small([m.agg.eta[0].weight]), f32(m.agg.eta[0].bias)
-        W["up"], W["up_b"] = cl(m.agg.upmask[0].weight), m.agg.upmask[0].bias.detach().half()
+        W["up"], W["up_b"] = U.pack_conv_igemm(m.agg.upmask[0].weight), f32(m.agg.upmask[0].bias)
         self.W = W
         self._ver = ver
 
@@ -222,10 +222,6 @@ class FusedUpdate:
     def _cl(t):
         b, n, c, h, w = t.shape
         return t.reshape(b * n, c, h, w).half().contiguous(memory_format=torch.channels_last)
-
-    @staticmethod
-    def _same(key, t):
-        return key is not None and key[0] is t and key[1] == t._version
 
     @torch.no_grad()
     def __call__(self, net, inp, corr, flow=None, ii=None, jj=None, groups=None):
@@ -235,40 +231,37 @@ class FusedUpdate:
         batch, num, _, ht, wd = net.shape
         n, hw = batch * num, ht * wd
         dev = net.device
-        if self._hx is None or tuple(self._hx.shape) != (n, 448, ht, wd) or self._hx.device != dev:
-            self._hx = torch.empty((n, 448, ht, wd), dtype=torch.float16, device=dev,
-                                   memory_format=torch.channels_last)
-            self._net_key = self._inp_key = None
+        cl_map = lambda c: torch.empty((n, c, ht, wd), dtype=torch.float16, device=dev,
+                                       memory_format=torch.channels_last)
+        if self._hx is None or tuple(self._hx.shape) != (n, 320, ht, wd) or self._hx.device != dev:
+            self._hx = cl_map(320)                     # [inp | corr features | flow features]
+            self._inp_key = None
         hx = self._hx
         net0 = self._cl(net)
-        if not self._same(self._net_key, net):
-            U.bias_act(net0, None, U.ACT_NONE, out=hx[:, 0:128])
-        if not self._same(self._inp_key, inp):
-            U.bias_act(self._cl(inp), None, U.ACT_NONE, out=hx[:, 128:256])
+        if self._inp_key is None or self._inp_key[0] is not inp or self._inp_key[1] != inp._version:
+            U.bias_act(self._cl(inp), None, U.ACT_NONE, out=hx[:, 0:128])
             self._inp_key = (inp, inp._version)
-        # corr_encoder / flow_encoder (droid_net.py:73-83): conv -> fused bias+ReLU -> conv -> slice of hx
+        # corr_encoder (droid_net.py:73-77): 1x1 as a transposed GEMM on the NCHW lookup output
         c1 = torch.matmul(corr.reshape(n, -1, hw).half().transpose(1, 2), W["ce1_t"])
         c1 = c1.view(n, ht, wd, 128).permute(0, 3, 1, 2)
         U.bias_act(c1, W["ce1_b"], U.ACT_RELU)
-        U.bias_act(F.conv2d(c1, W["ce2"], padding=1), W["ce2_b"], U.ACT_RELU, out=hx[:, 256:384])
+        U.conv_igemm(c1, None, W["ce2"], 9, 128, hx[:, 128:256], terms=W["ce2_b"], act=U.ACT_RELU)
+        # flow_encoder (droid_net.py:79-83)
         if flow is None:
             flow = torch.zeros(batch, num, 4, ht, wd, device=dev)
         f1 = F.conv2d(self._cl(flow), W["fe1"], padding=3)
         U.bias_act(f1, W["fe1_b"], U.ACT_RELU)
-        U.bias_act(F.conv2d(f1, W["fe2"], padding=1), W["fe2_b"], U.ACT_RELU, out=hx[:, 384:448])
+        U.conv_igemm(f1, None, W["fe2"], 9, 64, hx[:, 256:320], terms=W["fe2_b"], act=U.ACT_RELU)
         # ConvGRU (gru.py:20-34)
-        g = U.gru_glo_terms(F.conv2d(net0, W["w"]), W["w_b"], net0, W["G"], W["G_b"])
-        z = torch.empty_like(net0)
-        U.gru_gate_zr(F.conv2d(hx, W["zr"], padding=1), g[:, 0:256], net0, z, hx[:, 0:128])
-        new = torch.empty_like(net0)
-        U.gru_gate_q(F.conv2d(hx, W["q"], padding=1), g[:, 256:384], z, net0, new, out2=hx[:, 0:128])
+        wn = U.conv_igemm(net0, None, W["w"], 1, 128, cl_map(128))
+        g = U.gru_glo_terms(wn, W["w_b"], net0, W["G"], W["G_b"])
+        z, rnet, new = cl_map(128), cl_map(128), cl_map(128)
+        U.conv_igemm(net0, hx, W["zr"], 9, 256, z, epilogue=U.EPI_GRU_ZR, terms=g[:, 0:256], net=net0, out2=rnet)
+        U.conv_igemm(rnet, hx, W["q"], 9, 128, new, epilogue=U.EPI_GRU_Q, terms=g[:, 256:384], net=net0, z=z)
         net_out = new.view(batch, num, 128, ht, wd)
-        self._net_key = (net_out, net_out._version)
-        # heads (droid_net.py:85-93) + first conv of GraphAgg (droid_net.py:38,53), bias+ReLU folded
-        # into the consumers
-        h1 = F.conv2d(new, W["h1"], padding=1)
-        dw = U.conv3x3_small(h1, W["h2"], W["h2_b"], 2, (U.ACT_NONE, U.ACT_SIGMOID),
-                             in_bias=W["h1_b"], in_relu=True)
+        # heads (droid_net.py:85-93) + first conv of GraphAgg (droid_net.py:38,53)
+        h1 = U.conv_igemm(new, None, W["h1"], 9, 384, cl_map(384), terms=W["h1_b"], act=U.ACT_RELU)
+        dw = U.conv3x3_small(h1, W["h2"], W["h2_b"], 2, (U.ACT_NONE, U.ACT_SIGMOID))
         delta = dw[0].view(batch, num, ht, wd, 2)
         weight = dw[1].view(batch, num, ht, wd, 2)
         if ii is None:
@@ -279,12 +272,15 @@ class FusedUpdate:
             ngroups = uniq.shape[0]
         else:
             ix, ngroups = groups
-        agg = U.segment_mean(h1[:, 256:384], ix.contiguous(), ngroups, bias=W["h1_b"][256:384], relu=True)
-        a2 = F.conv2d(agg, W["a2"], padding=1)
-        U.bias_act(a2, W["a2_b"], U.ACT_RELU)
+        agg = U.segment_mean(h1[:, 256:384], ix.contiguous(), ngroups)
+        a2 = torch.empty((ngroups, 128, ht, wd), dtype=torch.float16, device=dev,
+                         memory_format=torch.channels_last)
+        U.conv_igemm(agg, None, W["a2"], 9, 128, a2, terms=W["a2_b"], act=U.ACT_RELU)
         eta = U.conv3x3_small(a2, W["eta"], W["eta_b"], 1, (U.ACT_SOFTPLUS,), scale=0.01)
-        upmask = F.conv2d(a2, W["up"], W["up_b"]).view(batch, -1, 8 * 8 * 9, ht, wd)
-        return net_out, delta, weight, eta.view(batch, ngroups, ht, wd), upmask
+        up = torch.empty((ngroups, 576, ht, wd), dtype=torch.float16, device=dev,
+                         memory_format=torch.channels_last)
+        U.conv_igemm(a2, None, W["up"], 1, 576, up, terms=W["up_b"])
+        return net_out, delta, weight, eta.view(batch, ngroups, ht, wd), up.view(batch, ngroups, 576, ht, wd)
 
 
 # --------------------------------------------------------------------------------------

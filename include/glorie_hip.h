@@ -204,6 +204,10 @@ int glorie_depth_filter(const float* poses, const float* disps, const float* int
 int glorie_cvx_upsample(const float* disps, const int64_t* ix, const void* mask,
                         float* disps_up, int M, int h, int w, int mask_dtype,
                         int softmax_f32, void* stream);
+/* same operator, mask given channels-last in fp16: row (m*h*w + pixel) holds the 576 logits,
+ * rows `mask_stride` halfs apart -- the layout the 1x1 upmask convolution produces */
+int glorie_cvx_upsample_nhwc(const float* disps, const int64_t* ix, const void* mask, int mask_stride,
+                             float* disps_up, int M, int h, int w, int softmax_f32, void* stream);
 
 /* ------------------------------------------------------------------------------------ */
 /* B. dense bundle adjustment                                                            */

@@ -91,3 +91,9 @@ def test_cvx_upsample(gpu, half):
     got = up.cpu().numpy()
     np.testing.assert_allclose(got[ix], ref, rtol=1e-3 if half else 1e-5, atol=2e-4 if half else 1e-6)
     assert np.all(got[[1, 2]] == 0)
+    if half:
+        # channels-last logits (layout of the upmask convolution) take the nhwc kernel: same values
+        up2 = torch.zeros(B, 8 * h, 8 * w, device=gpu)
+        mcl = _t(mask, gpu).contiguous(memory_format=torch.channels_last)
+        db.cvx_upsample(_t(disps, gpu), _t(ix, gpu), mcl, up2, softmax_f32=False)
+        assert torch.equal(up2, up)
