@@ -26,6 +26,7 @@
 //   pixel tiles: the 9 taps, the halo rows and the output-channel tiles of a pixel range hit L2.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "common.hiph"
 
 namespace glorie {
@@ -50,9 +51,7 @@ struct ConvArgs {
   const _Float16* z; int z_stride;
 };
 
-constexpr int kTile = 128;        // pixels and output channels per workgroup
-constexpr int kBK = 64;           // channels per K step
-constexpr int kTileBytes = kTile * kBK * 2;
+constexpr int kTileN = 128;       // output channels per workgroup
 
 __device__ __forceinline__ float csigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float ctanh(float x) {
@@ -65,35 +64,59 @@ __device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int EPI>
+// NB = 16-pixel blocks per wave (pixel tile = 32*NB), BK = channels per K step (32 | 64)
+template <int EPI, int NB, int BK>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
-  __shared__ __attribute__((aligned(16))) char smem[4 * kTileBytes];   // 2 buffers x (pixel tile, weight tile)
+#if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (buffer-resource types are device-only)
+  constexpr int PT = 32 * NB;                 // pixels per workgroup
+  constexpr int RB = BK * 2;                  // bytes per staged row
+  constexpr int SL = RB / 16;                 // 16-byte slots per row
+  constexpr int SH = RB == 128 ? 1 : 2;       // swizzle key of row r = (r >> SH) & (SL - 1): conflict-free b128 reads
+  constexpr int RPI = 64 / SL;                // rows per wave-wide DMA instruction
+  constexpr int XI = PT / RPI / 4;            // DMA instructions per wave per step: pixel tile
+  constexpr int WI = kTileN / RPI / 4;        //                                      weight tile
+  constexpr int XBYTES = PT * RB, WBYTES = kTileN * RB;
+  constexpr int KK = BK / 32;
+  __shared__ __attribute__((aligned(16))) char smem[2 * (XBYTES + WBYTES)];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int col = lane & 15, kg = lane >> 4;
   const int wm = wv >> 1, wn = wv & 1;
 
   // XCD-aware (bijective) remap of the workgroup id, then (pixel tile, output-channel tile)
-  const int nwg = gridDim.x, ntn = a.npad / kTile;
+  const int nwg = gridDim.x, ntn = a.npad / kTileN;
   const int xcd = blockIdx.x & 7, q = nwg >> 3, r = nwg & 7;
   const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
   const int pt = lid / ntn, nt = lid - pt * ntn;
-  const long p0 = (long)pt * kTile;
-  const int n0 = nt * kTile;
+  const long p0 = (long)pt * PT;
+  const int n0 = nt * kTileN;
 
-  const int nchunks = a.cha + a.chb;
-  const int C = nchunks * kBK;
-  const int T = a.taps * nchunks;
-  const _Float16* zeros = a.w + (size_t)a.taps * a.npad * C;
+  const int cpc = 64 / BK;                    // K steps per 64-channel chunk
+  const int nsteps_tap = (a.cha + a.chb) * cpc;
+  const int C = (a.cha + a.chb) * 64;
+  const int T = a.taps * nsteps_tap;
 
-  // staging roles: instruction i of wave wv fills rows (i*4 + wv)*8 .. +7, lane -> (row, 16-byte slot)
-  const int srow = lane >> 3, slot = lane & 7;
-  long prow[4];
-  int vmask[4];
+  // Staging through buffer descriptors: address = base + SGPR offset (tap shift, channel chunk:
+  // wave-uniform, changes per step) + VGPR offset (row, swizzled slot: per lane, loop-invariant).
+  // A lane whose row falls outside the map for this tap gets bit 31 set in its VGPR offset: the
+  // hardware range check fails and the DMA writes ZEROS into LDS -- zero padding costs three VALU
+  // instructions per load and no branch.  The descriptor base sits `back` rows before the tensor
+  // so that the SGPR offset of the (-1,-1) tap is not negative.
+  const int back = a.taps == 9 ? a.W + 1 : 0;
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(a.xa - (long)back * a.xa_stride), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(a.xb - (long)back * a.xb_stride), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, 0x7fffffff, 0x00020000);
+
+  // staging roles: DMA instruction i of wave wv fills rows (i*4 + wv)*RPI .. +RPI-1; lane -> (row, slot)
+  const int srow = lane / SL, slot = lane % SL;
+  unsigned voffA[XI], voffB[XI], woff[WI];
+  int vmask[XI];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = (i * 4 + wv) * 8 + srow;
+  for (int i = 0; i < XI; ++i) {
+    const int row = (i * 4 + wv) * RPI + srow;
+    const int sw = (slot ^ ((row >> SH) & (SL - 1))) << 3;          // swizzled 16-byte slot, in halfs
     const long p = p0 + row;
-    prow[i] = p;
     int m = 0;
     if (p < a.P) {
       const int xw = (int)(p % a.W), yh = (int)((p / a.W) % a.H);
@@ -108,66 +131,77 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
       }
     }
     vmask[i] = m;
+    const long pc = p < a.P ? p : 0;
+    voffA[i] = (unsigned)((pc * a.xa_stride + sw) * 2);
+    voffB[i] = (unsigned)((pc * a.xb_stride + sw) * 2);
   }
-  const int sw_src = (slot ^ srow) << 3;     // (row & 7) == srow: swizzled 16-byte slot, in halfs
+#pragma unroll
+  for (int i = 0; i < WI; ++i) {
+    const int row = (i * 4 + wv) * RPI + srow;
+    woff[i] = (unsigned)(((size_t)row * C + ((slot ^ ((row >> SH) & (SL - 1))) << 3)) * 2);
+  }
 
   auto stage = [&](int t, int buf) {
-    const int d = t / nchunks, ch = t - d * nchunks;
-    const int shift = a.taps == 9 ? (d / 3 - 1) * a.W + (d % 3 - 1) : 0;
+    const int d = t / nsteps_tap, st = t - d * nsteps_tap;
+    const int ch = st / cpc, sub = st - ch * cpc;        // 64-channel chunk, BK-wide part of it
+    const int shift = (a.taps == 9 ? (d / 3 - 1) * a.W + (d % 3 - 1) : 0) + back;
     const bool segA = ch < a.cha;
-    const _Float16* xbase = segA ? a.xa : a.xb;
     const int xs = segA ? a.xa_stride : a.xb_stride;
-    const int coff = (segA ? ch : ch - a.cha) * kBK + sw_src;
-    char* lx = smem + buf * 2 * kTileBytes;
-    char* lw = lx + kTileBytes;
-    const _Float16* wsrc = a.w + ((size_t)d * a.npad + n0) * C + ch * kBK + sw_src;
+    const unsigned xsoff = (unsigned)((shift * xs + (segA ? ch : ch - a.cha) * 64 + sub * BK) * 2);
+    const unsigned wsoff = (unsigned)((((size_t)d * a.npad + n0) * C + ch * 64 + sub * BK) * 2);
+    char* lx = smem + buf * (XBYTES + WBYTES);
+    char* lw = lx + XBYTES;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int rb = (i * 4 + wv) * 8;
-      const _Float16* src = ((vmask[i] >> d) & 1) ? xbase + (prow[i] + shift) * xs + coff : zeros + slot * 8;
-      glds16(src, lx + rb * 128);
-      glds16(wsrc + (size_t)(rb + srow) * C, lw + rb * 128);
+    for (int i = 0; i < XI; ++i) {
+      const unsigned inv = ~((unsigned)vmask[i] >> d);
+      const unsigned vo = (inv << 31) | (segA ? voffA[i] : voffB[i]);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(segA ? rA : rB,
+          (__attribute__((address_space(3))) void*)(lx + (i * 4 + wv) * RPI * RB), 16, vo, xsoff, 0, 0);
     }
+#pragma unroll
+    for (int i = 0; i < WI; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rW,
+          (__attribute__((address_space(3))) void*)(lw + (i * 4 + wv) * RPI * RB), 16, woff[i], wsoff, 0, 0);
   };
 
-  f32x4 acc[4][4];
+  f32x4 acc[4][NB];
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ni = 0; ni < NB; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // fragment read offsets: row = 64*w? + 16*blk + col, logical slot kk*4 + kg, swizzled with (row & 7) = col & 7
-  int foff[2];
+  // fragment reads: row = 16*blk + col, logical slot kk*4 + kg, swizzle key (row >> SH) & (SL-1) = (col >> SH) & (SL-1)
+  int foff[KK];
 #pragma unroll
-  for (int kk = 0; kk < 2; ++kk) foff[kk] = col * 128 + (((kk * 4 + kg) ^ (col & 7)) << 4);
-  const int wbase = kTileBytes + wm * 64 * 128, xbase_l = wn * 64 * 128;
+  for (int kk = 0; kk < KK; ++kk) foff[kk] = col * RB + (((kk * 4 + kg) ^ ((col >> SH) & (SL - 1))) << 4);
+  const int wbase = XBYTES + wm * 64 * RB, xbase_l = wn * (16 * NB) * RB;
 
   stage(0, 0);
   for (int t = 0; t < T; ++t) {
     __syncthreads();                           // tile t landed (vmcnt(0) + barrier); buffer (t+1)&1 is free
     if (t + 1 < T) stage(t + 1, (t + 1) & 1);
-    const char* base = smem + (t & 1) * 2 * kTileBytes;
+    const char* base = smem + (t & 1) * (XBYTES + WBYTES);
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      f16x8 wf[4], xf[4];
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-        wf[mi] = *reinterpret_cast<const f16x8*>(base + wbase + mi * 16 * 128 + foff[kk]);
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
-        xf[ni] = *reinterpret_cast<const f16x8*>(base + xbase_l + ni * 16 * 128 + foff[kk]);
+    for (int kk = 0; kk < KK; ++kk) {
+      f16x8 wf[4], xf[NB];
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
+        wf[mi] = *reinterpret_cast<const f16x8*>(base + wbase + mi * 16 * RB + foff[kk]);
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
+      for (int ni = 0; ni < NB; ++ni)
+        xf[ni] = *reinterpret_cast<const f16x8*>(base + xbase_l + ni * 16 * RB + foff[kk]);
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NB; ++ni)
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[mi], xf[ni], acc[mi][ni], 0, 0, 0);
     }
   }
 
-  // ---- epilogue: lane owns channels n0 + wm*64 + mi*16 + kg*4 .. +3 of pixel p0 + wn*64 + ni*16 + col ----
+  // ---- epilogue: lane owns channels n0 + wm*64 + mi*16 + kg*4 .. +3 of pixel p0 + wn*16*NB + ni*16 + col ----
 #pragma unroll
-  for (int ni = 0; ni < 4; ++ni) {
-    const long p = p0 + wn * 64 + ni * 16 + col;
+  for (int ni = 0; ni < NB; ++ni) {
+    const long p = p0 + wn * (16 * NB) + ni * 16 + col;
     if (p >= a.P) continue;
     const int e = (int)(p / a.HW);
 #pragma unroll
@@ -217,6 +251,22 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
       }
     }
   }
+#endif
+}
+
+template <int NB, int BK>
+static int launch_conv(const ConvArgs& a, int epilogue, hipStream_t st) {
+  constexpr int PT = 32 * NB;
+  const long ptiles = (a.P + PT - 1) / PT;
+  const long nwg = ptiles * (a.npad / kTileN);
+  if (nwg > 0x7fffffffL) return GLORIE_EINVAL;
+  const dim3 grid((unsigned)nwg), block(256);
+  switch (epilogue) {
+    case EPI_BIAS_ACT: hipLaunchKernelGGL((conv_igemm_kernel<EPI_BIAS_ACT, NB, BK>), grid, block, 0, st, a); break;
+    case EPI_GRU_ZR: hipLaunchKernelGGL((conv_igemm_kernel<EPI_GRU_ZR, NB, BK>), grid, block, 0, st, a); break;
+    default: hipLaunchKernelGGL((conv_igemm_kernel<EPI_GRU_Q, NB, BK>), grid, block, 0, st, a); break;
+  }
+  return check_launch();
 }
 
 }  // namespace glorie
@@ -229,7 +279,7 @@ extern "C" int glorie_conv_igemm(const void* xa, int xa_stride, int ca, const vo
                                  int net_stride, const void* z, int z_stride, void* out, int out_stride,
                                  void* out2, int out2_stride, int N, int H, int W, void* stream) {
   if (N < 0 || H <= 0 || W <= 0 || (taps != 1 && taps != 9) || nout <= 0 || (nout & 3)) return GLORIE_EINVAL;
-  if (ca < 0 || cb < 0 || (ca % kBK) || (cb % kBK) || ca + cb == 0) return GLORIE_EINVAL;
+  if (ca < 0 || cb < 0 || (ca % 64) || (cb % 64) || ca + cb == 0) return GLORIE_EINVAL;
   if ((ca && (!xa || (xa_stride & 7))) || (cb && (!xb || (xb_stride & 7)))) return GLORIE_EINVAL;
   if (!w_packed || !out || (out_stride & 3)) return GLORIE_EINVAL;
   if (epilogue == EPI_GRU_ZR && (nout != 256 || !terms || !net || !out2 || (terms_stride & 3))) return GLORIE_EINVAL;
@@ -237,25 +287,26 @@ extern "C" int glorie_conv_igemm(const void* xa, int xa_stride, int ca, const vo
   if (epilogue < 0 || epilogue > 2) return GLORIE_EINVAL;
   if (N == 0) return GLORIE_OK;
   ConvArgs a;
-  a.xa = reinterpret_cast<const _Float16*>(xa); a.xa_stride = xa_stride; a.cha = ca / kBK;
-  a.xb = reinterpret_cast<const _Float16*>(xb); a.xb_stride = xb_stride; a.chb = cb / kBK;
+  a.xa = reinterpret_cast<const _Float16*>(xa); a.xa_stride = xa_stride; a.cha = ca / 64;
+  a.xb = reinterpret_cast<const _Float16*>(xb); a.xb_stride = xb_stride; a.chb = cb / 64;
   a.w = reinterpret_cast<const _Float16*>(w_packed);
-  a.taps = taps; a.nout = nout; a.npad = (nout + kTile - 1) / kTile * kTile;
+  a.taps = taps; a.nout = nout; a.npad = (nout + kTileN - 1) / kTileN * kTileN;
   a.P = (long)N * H * W; a.H = H; a.W = W; a.HW = H * W;
   a.out = reinterpret_cast<_Float16*>(out); a.out_stride = out_stride;
   a.out2 = reinterpret_cast<_Float16*>(out2); a.out2_stride = out2_stride;
   a.terms = terms; a.terms_stride = terms_stride; a.act = act;
   a.net = reinterpret_cast<const _Float16*>(net); a.net_stride = net_stride;
   a.z = reinterpret_cast<const _Float16*>(z); a.z_stride = z_stride;
-  const long ptiles = (a.P + kTile - 1) / kTile;
-  const long nwg = ptiles * (a.npad / kTile);
-  if (nwg > 0x7fffffffL) return GLORIE_EINVAL;
-  const dim3 grid((unsigned)nwg), block(256);
+  // buffer-descriptor addressing: 31-bit byte offsets per input segment and for the weights
+  const long lim = 0x7fffffffL;
+  if (((a.P + W + 2) * (long)xa_stride + 64) * 2 > lim || ((a.P + W + 2) * (long)xb_stride + 64) * 2 > lim ||
+      ((long)taps * a.npad * (ca + cb) + 64) * 2 > lim)
+    return GLORIE_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  switch (epilogue) {
-    case EPI_BIAS_ACT: hipLaunchKernelGGL(conv_igemm_kernel<EPI_BIAS_ACT>, grid, block, 0, st, a); break;
-    case EPI_GRU_ZR: hipLaunchKernelGGL(conv_igemm_kernel<EPI_GRU_ZR>, grid, block, 0, st, a); break;
-    default: hipLaunchKernelGGL(conv_igemm_kernel<EPI_GRU_Q>, grid, block, 0, st, a); break;
+  static const int variant = [] { const char* v = getenv("GLORIE_CONV_VARIANT"); return v ? atoi(v) : 0; }();
+  switch (variant) {
+    case 1: return launch_conv<4, 32>(a, epilogue, st);
+    case 2: return launch_conv<8, 32>(a, epilogue, st);
+    default: return launch_conv<4, 64>(a, epilogue, st);
   }
-  return check_launch();
 }
