@@ -9,24 +9,24 @@
 //   input [net | inp, corr, flow] is never concatenated, and r*net can live in its own buffer
 //   while other workgroups still read net as halo rows (a fused r*net epilogue that overwrote a
 //   net slice in place would race with them).
-// * Workgroup tile = 128 output channels x 128 pixels, 4 waves as 2 x 2, each 64 x 64 =
-//   4 x 4 accumulator blocks of v_mfma_f32_16x16x32_f16.  The MFMA "A" operand is the WEIGHT
-//   tile, "B" the pixel tile, so a lane ends up with 4 consecutive output channels of one pixel
-//   (8-byte epilogue loads/stores) instead of 4 pixels of one channel.
-// * K loop = taps x 64-channel chunks.  Both tiles ([128 rows][64 halfs] = 16 KB each) are staged
-//   with global_load_lds_dwordx4 (HBM/L2 -> LDS without touching VGPRs), double buffered, one
-//   barrier per step.  The LDS image is lane-linear as the DMA requires; the 16-byte slot of a row
-//   is XOR-swizzled with (row & 7) on the SOURCE address and on the fragment read, which turns the
-//   8-way bank conflict of 128-byte rows into 2-way.
-// * Zero padding: a tap that falls outside the map (or a pixel row beyond P) sources its 128
-//   bytes from a zero block appended to the packed weights -- no branches in the K loop.
+// * Workgroup tile = 128 output channels x 128 (or 256) pixels, 4 waves as 2 x 2, each 64 channels
+//   x 64 (128) pixels = 4 x 4 (4 x 8) accumulator blocks of v_mfma_f32_16x16x32_f16.  The MFMA "A"
+//   operand is the WEIGHT tile, "B" the pixel tile, so a lane ends up with 4 consecutive output
+//   channels of one pixel (8-byte epilogue loads/stores) instead of 4 pixels of one channel.
+// * K loop = 64-channel chunks x taps (taps innermost: the 9 shifted reads of a chunk hit L2).
+//   Both tiles are staged with buffer_load_dwordx4 ... lds (HBM/L2 -> LDS without touching VGPRs),
+//   double buffered, one barrier per step; all fragment reads of a step are issued before the
+//   next DMA and the MFMAs.  The LDS image is lane-linear as the DMA requires; the 16-byte slot of
+//   a row is XOR-swizzled on the SOURCE address and on the fragment read (conflict-free b128 reads).
+// * Zero padding: a lane whose row is outside the map for the current tap sets bit 31 of its
+//   buffer offset; the hardware range check then writes zeros into LDS (tools/probes/
+//   buffer_lds_probe.hip pins that behaviour) -- no branch and no zero page in the K loop.
 // * Epilogues: bias + activation; the GRU z/r gates (sigmoid, r * net); the GRU blend
 //   (1 - z) * net + z * tanh(.).  The per-edge global-context terms come from glorie_gru_glo_terms.
 // * Consecutive workgroup ids are remapped so that one XCD (private L2) owns a contiguous range of
 //   pixel tiles: the 9 taps, the halo rows and the output-channel tiles of a pixel range hit L2.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
 #include "common.hiph"
 
 namespace glorie {
@@ -41,7 +41,7 @@ enum { CACT_NONE = 0, CACT_RELU = 1, CACT_SIGMOID = 2 };
 struct ConvArgs {
   const _Float16* xa; int xa_stride; int cha;   // segment A: cha 64-channel chunks
   const _Float16* xb; int xb_stride; int chb;   // segment B
-  const _Float16* w;                            // [taps][npad][C] halfs, then 64 zero halfs
+  const _Float16* w;                            // [taps][npad][C] halfs (+ 64 halfs of padding)
   int taps, npad, nout;
   long P; int H, W, HW;
   _Float16* out; int out_stride;
@@ -71,7 +71,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   constexpr int PT = 32 * NB;                 // pixels per workgroup
   constexpr int RB = BK * 2;                  // bytes per staged row
   constexpr int SL = RB / 16;                 // 16-byte slots per row
-  constexpr int SH = RB == 128 ? 1 : 2;       // swizzle key of row r = (r >> SH) & (SL - 1): conflict-free b128 reads
   constexpr int RPI = 64 / SL;                // rows per wave-wide DMA instruction
   constexpr int XI = PT / RPI / 4;            // DMA instructions per wave per step: pixel tile
   constexpr int WI = kTileN / RPI / 4;        //                                      weight tile
@@ -81,6 +80,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int col = lane & 15, kg = lane >> 4;
   const int wm = wv >> 1, wn = wv & 1;
+
+  // 16-byte slot swizzle key of an LDS row: ds_read_b128 of 16 consecutive rows is conflict-free for
+  // the hardware's lane groups ({0-3,12-15,20-27}, ...) with these keys (brute-force checked)
+  auto key = [](int row) { return RB == 128 ? (row & 7) : ((row >> 1) & 3); };
 
   // XCD-aware (bijective) remap of the workgroup id, then (pixel tile, output-channel tile)
   const int nwg = gridDim.x, ntn = a.npad / kTileN;
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
   for (int i = 0; i < XI; ++i) {
     const int row = (i * 4 + wv) * RPI + srow;
-    const int sw = (slot ^ ((row >> SH) & (SL - 1))) << 3;          // swizzled 16-byte slot, in halfs
+    const int sw = (slot ^ key(row)) << 3;          // swizzled 16-byte slot, in halfs
     const long p = p0 + row;
     int m = 0;
     if (p < a.P) {
@@ -138,12 +141,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
   for (int i = 0; i < WI; ++i) {
     const int row = (i * 4 + wv) * RPI + srow;
-    woff[i] = (unsigned)(((size_t)row * C + ((slot ^ ((row >> SH) & (SL - 1))) << 3)) * 2);
+    woff[i] = (unsigned)(((size_t)row * C + ((slot ^ key(row)) << 3)) * 2);
   }
 
   auto stage = [&](int t, int buf) {
-    const int d = t / nsteps_tap, st = t - d * nsteps_tap;
-    const int ch = st / cpc, sub = st - ch * cpc;        // 64-channel chunk, BK-wide part of it
+    // K order: 64-channel chunk outermost, the taps inside it -- the 9 shifted reads of a chunk of
+    // the workgroup's pixel rows follow each other, so all but the first hit L2 (tap-major order
+    // has a reuse distance of the whole [pixels x C] panel of every resident workgroup: > L2)
+    const int per_chunk = a.taps * cpc;
+    const int ch = t / per_chunk, rem = t - ch * per_chunk;
+    const int d = rem / cpc, sub = rem - d * cpc;        // tap, BK-wide part of the 64-channel chunk
     const int shift = (a.taps == 9 ? (d / 3 - 1) * a.W + (d % 3 - 1) : 0) + back;
     const bool segA = ch < a.cha;
     const int xs = segA ? a.xa_stride : a.xb_stride;
@@ -170,32 +177,36 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
     for (int ni = 0; ni < NB; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // fragment reads: row = 16*blk + col, logical slot kk*4 + kg, swizzle key (row >> SH) & (SL-1) = (col >> SH) & (SL-1)
+  // fragment reads: row = 16*blk + col, logical slot kk*4 + kg, swizzle key(row) = key(col)
   int foff[KK];
 #pragma unroll
-  for (int kk = 0; kk < KK; ++kk) foff[kk] = col * RB + (((kk * 4 + kg) ^ ((col >> SH) & (SL - 1))) << 4);
+  for (int kk = 0; kk < KK; ++kk) foff[kk] = col * RB + (((kk * 4 + kg) ^ key(col)) << 4);
   const int wbase = XBYTES + wm * 64 * RB, xbase_l = wn * (16 * NB) * RB;
 
   stage(0, 0);
   for (int t = 0; t < T; ++t) {
     __syncthreads();                           // tile t landed (vmcnt(0) + barrier); buffer (t+1)&1 is free
-    if (t + 1 < T) stage(t + 1, (t + 1) & 1);
     const char* base = smem + (t & 1) * (XBYTES + WBYTES);
+    // all fragment reads of the step go out first (one exposed LDS latency per step, not per kk), the
+    // DMA of the next tile is issued in their shadow, then the MFMAs run back to back
+    f16x8 wf[KK][4], xf[KK][NB];
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk) {
-      f16x8 wf[4], xf[NB];
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
-        wf[mi] = *reinterpret_cast<const f16x8*>(base + wbase + mi * 16 * RB + foff[kk]);
+        wf[kk][mi] = *reinterpret_cast<const f16x8*>(base + wbase + mi * 16 * RB + foff[kk]);
 #pragma unroll
       for (int ni = 0; ni < NB; ++ni)
-        xf[ni] = *reinterpret_cast<const f16x8*>(base + xbase_l + ni * 16 * RB + foff[kk]);
+        xf[kk][ni] = *reinterpret_cast<const f16x8*>(base + xbase_l + ni * 16 * RB + foff[kk]);
+    }
+    if (t + 1 < T) stage(t + 1, (t + 1) & 1);
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NB; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[mi], xf[ni], acc[mi][ni], 0, 0, 0);
-    }
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kk][mi], xf[kk][ni], acc[mi][ni], 0, 0, 0);
   }
 
   // ---- epilogue: lane owns channels n0 + wm*64 + mi*16 + kg*4 .. +3 of pixel p0 + wn*16*NB + ni*16 + col ----
@@ -303,10 +314,11 @@ extern "C" int glorie_conv_igemm(const void* xa, int xa_stride, int ca, const vo
       ((long)taps * a.npad * (ca + cb) + 64) * 2 > lim)
     return GLORIE_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  static const int variant = [] { const char* v = getenv("GLORIE_CONV_VARIANT"); return v ? atoi(v) : 0; }();
-  switch (variant) {
-    case 1: return launch_conv<4, 32>(a, epilogue, st);
-    case 2: return launch_conv<8, 32>(a, epilogue, st);
-    default: return launch_conv<4, 64>(a, epilogue, st);
-  }
+  // Tile choice: 256-pixel tiles (NB = 8, BK = 32) stage fewer weight bytes per FLOP and win when
+  // the weight panel is wide (>= 3 output tiles), unless halving the workgroup count costs an
+  // extra partially filled round of the 2 x 256 workgroup slots (measured: tools/bench_conv.py).
+  const long slots = 512, ntn = a.npad / kTileN;
+  const long nwg4 = (a.P + 127) / 128 * ntn, nwg8 = (a.P + 255) / 256 * ntn;
+  const bool wide = ntn >= 3 && 2 * ((nwg8 + slots - 1) / slots) <= (nwg4 + slots - 1) / slots;
+  return wide ? launch_conv<8, 32>(a, epilogue, st) : launch_conv<4, 64>(a, epilogue, st);
 }
