@@ -100,6 +100,7 @@ __global__ __launch_bounds__(256) void glo_partial_kernel(const _Float16* __rest
   }
 }
 
+// grid (N, M/128): every block re-sums the parts of its edge (2 KB each) and produces 128 outputs
 __global__ __launch_bounds__(128) void glo_terms_kernel(const float* __restrict__ partial, int parts,
                                                         const float* __restrict__ G,
                                                         const float* __restrict__ Gb, int M,
@@ -110,11 +111,17 @@ __global__ __launch_bounds__(128) void glo_terms_kernel(const float* __restrict_
   for (int q = 0; q < parts; ++q) s += partial[((size_t)n * parts + q) * 128 + threadIdx.x];
   glo[threadIdx.x] = s / (float)HW;
   __syncthreads();
-  for (int o = threadIdx.x; o < M; o += 128) {
-    float acc = Gb[o];
-    for (int c = 0; c < 128; ++c) acc = fmaf(glo[c], G[(size_t)c * M + o], acc);
-    g[(size_t)n * M + o] = acc;
+  const int o = blockIdx.y * 128 + threadIdx.x;
+  if (o >= M) return;
+  float acc0 = Gb[o], acc1 = 0.0f, acc2 = 0.0f, acc3 = 0.0f;
+#pragma unroll 8
+  for (int c = 0; c < 128; c += 4) {
+    acc0 = fmaf(glo[c], G[(size_t)c * M + o], acc0);
+    acc1 = fmaf(glo[c + 1], G[(size_t)(c + 1) * M + o], acc1);
+    acc2 = fmaf(glo[c + 2], G[(size_t)(c + 2) * M + o], acc2);
+    acc3 = fmaf(glo[c + 3], G[(size_t)(c + 3) * M + o], acc3);
   }
+  g[(size_t)n * M + o] = (acc0 + acc1) + (acc2 + acc3);
 }
 
 // z = sigmoid(zc + gz[n]); rnet = sigmoid(rc + gr[n]) * net       (gru.py:28-30)
@@ -332,7 +339,7 @@ extern "C" int glorie_gru_glo_terms(const void* wn, int w_stride, const float* b
   hipLaunchKernelGGL(glo_partial_kernel, dim3(N, parts), dim3(256), 0, st,
                      reinterpret_cast<const _Float16*>(wn), w_stride, bw,
                      reinterpret_cast<const _Float16*>(net), n_stride, partial, HW);
-  hipLaunchKernelGGL(glo_terms_kernel, dim3(N), dim3(128), 0, st, partial, parts, G, Gb, M, g, HW);
+  hipLaunchKernelGGL(glo_terms_kernel, dim3(N, (M + 127) / 128), dim3(128), 0, st, partial, parts, G, Gb, M, g, HW);
   return check_launch();
 }
 

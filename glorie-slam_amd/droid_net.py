@@ -174,7 +174,7 @@ class FusedUpdate:
         kernel glorie_conv3x3_small; GraphAgg's scatter_mean is glorie_segment_mean (fixed order);
         the upmask logits stay channels-last for glorie_cvx_upsample_nhwc.
 
-    Only flow_encoder[0] (7x7 on 4 channels) still goes through MIOpen.  Same call signature and
+    No convolution goes through MIOpen (flow_encoder[0] is glorie_flow_conv7).  Same call signature and
     return values as UpdateModule.forward (droid_net.py:106-139); delta, weight and eta come back
     in float32.  Weights are re-packed whenever a parameter of the source module changes."""
 
@@ -197,8 +197,7 @@ class FusedUpdate:
         W["ce1_t"] = m.corr_encoder[0].weight.detach().view(128, -1).t().half().contiguous()
         W["ce1_b"] = f32(m.corr_encoder[0].bias)
         W["ce2"], W["ce2_b"] = U.pack_conv_igemm(m.corr_encoder[2].weight), f32(m.corr_encoder[2].bias)
-        W["fe1"] = m.flow_encoder[0].weight.detach().half().contiguous(memory_format=torch.channels_last)
-        W["fe1_b"] = f32(m.flow_encoder[0].bias)
+        W["fe1"], W["fe1_b"] = U.pack_flow_conv7(m.flow_encoder[0].weight), f32(m.flow_encoder[0].bias)
         W["fe2"], W["fe2_b"] = U.pack_conv_igemm(m.flow_encoder[2].weight), f32(m.flow_encoder[2].bias)
         W["zr"] = U.pack_conv_igemm(torch.cat([g.convz.weight, g.convr.weight], 0))
         W["q"] = U.pack_conv_igemm(g.convq.weight)
@@ -249,8 +248,8 @@ class FusedUpdate:
         # flow_encoder (droid_net.py:79-83)
         if flow is None:
             flow = torch.zeros(batch, num, 4, ht, wd, device=dev)
-        f1 = F.conv2d(self._cl(flow), W["fe1"], padding=3)
-        U.bias_act(f1, W["fe1_b"], U.ACT_RELU)
+        fl = flow.reshape(n, 4, ht, wd).permute(0, 2, 3, 1).float().contiguous()   # no copy for a [.., h, w, 4] motion map
+        f1 = U.flow_conv7(fl, W["fe1"], W["fe1_b"], cl_map(128))
         U.conv_igemm(f1, None, W["fe2"], 9, 64, hx[:, 256:320], terms=W["fe2_b"], act=U.ACT_RELU)
         # ConvGRU (gru.py:20-34)
         wn = U.conv_igemm(net0, None, W["w"], 1, 128, cl_map(128))

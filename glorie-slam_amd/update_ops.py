@@ -191,3 +191,24 @@ def conv_igemm(xa, xb, w_packed, taps, nout, out, epilogue=EPI_BIAS_ACT, terms=N
                                        L.ptr(terms), ts, act, pn, sn, pz, sz, L.ptr(out), _rows(out, "out"),
                                        po2, so2, n, h, w, L.stream_ptr()), "glorie_conv_igemm")
     return out
+
+
+def pack_flow_conv7(weight):
+    """flow_encoder[0] weight [128,4,7,7] -> fp16 [128][224], column ky*32 + kx*4 + c (kx = 7 zero)"""
+    if tuple(weight.shape) != (128, 4, 7, 7):
+        raise RuntimeError("pack_flow_conv7: expected [128,4,7,7]")
+    w = torch.zeros(128, 7, 8, 4, dtype=torch.float16, device=weight.device)
+    w[:, :, :7] = weight.detach().permute(0, 2, 3, 1).half()
+    return w.reshape(128, 224).contiguous()
+
+
+def flow_conv7(flow, w_packed, bias, out):
+    """out = relu(conv7x7(flow) + bias); flow float32 [N,h,w,4] contiguous (channels-last motion
+    map), out channels-last fp16 [N,128,h,w] (slice allowed)   (droid_net.py:79-81)"""
+    L.need_cuda(flow, w_packed, bias, out)
+    n, h, w, c = flow.shape
+    if c != 4 or flow.dtype != torch.float32 or not flow.is_contiguous() or out.shape[1] != 128:
+        raise RuntimeError("flow_conv7: flow must be contiguous float32 [N,h,w,4]")
+    L.check(L.load().glorie_flow_conv7(L.ptr(flow), L.ptr(w_packed), L.ptr(bias), L.ptr(out), _rows(out, "out"),
+                                       n, h, w, L.stream_ptr()), "glorie_flow_conv7")
+    return out

@@ -163,6 +163,13 @@ int glorie_conv_igemm(const void* xa, int xa_stride, int ca, const void* xb, int
                       int z_stride, void* out, int out_stride, void* out2, int out2_stride, int N,
                       int H, int W, void* stream);
 
+/* flow_encoder[0] (droid_net.py:79-81): 7x7 convolution, zero padding 3, 4 -> 128 channels, + bias
+ * + ReLU.  flow: float32 channels-last motion map [N*H*W][4]; out: fp16 rows of 128 channels,
+ * out_stride halfs apart.  w_packed: fp16 [128][224], column ky*32 + kx*4 + c = weight[n][c][ky][kx],
+ * the 8th tap of every stencil row (kx = 7) zero. */
+int glorie_flow_conv7(const float* flow, const void* w_packed, const float* bias, void* out,
+                      int out_stride, int N, int H, int W, void* stream);
+
 /* ------------------------------------------------------------------------------------ */
 /* A/B. projective geometry                                                              */
 /* ------------------------------------------------------------------------------------ */

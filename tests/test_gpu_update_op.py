@@ -206,3 +206,18 @@ def test_conv_igemm_gru_epilogues(gpu):
     q = torch.tanh(_conv_ref([rnet, hx], wq) + terms[:, 256:].reshape(n, 128, 1, 1))
     ref = (1 - z.float()) * net.float() + z.float() * q
     torch.testing.assert_close(new.float(), ref, atol=4e-3, rtol=4e-3)
+
+
+def test_flow_conv7_matches_conv2d(gpu):
+    from glorie_slam_amd import update_ops as U
+    n, h, w = 3, 9, 11                                              # 297 pixels: ragged last tile, maps < 7 wide halo
+    g = torch.Generator(device="cpu").manual_seed(31)
+    flow = (8.0 * torch.randn(n, h, w, 4, generator=g)).to(gpu)
+    weight = (torch.randn(128, 4, 7, 7, generator=g) / 14).to(gpu)
+    bias = torch.randn(128, generator=g).to(gpu)
+    wide = torch.zeros((n, 192, h, w), dtype=torch.float16, device=gpu).contiguous(memory_format=torch.channels_last)
+    U.flow_conv7(flow, U.pack_flow_conv7(weight), bias, wide[:, 64:192])
+    x = flow.permute(0, 3, 1, 2).half().float()
+    ref = F.relu(F.conv2d(x, weight.half().float(), bias, padding=3))
+    torch.testing.assert_close(wide[:, 64:192].float(), ref, atol=2e-2, rtol=4e-3)
+    assert float(wide[:, :64].abs().max()) == 0.0
