@@ -521,10 +521,15 @@ __global__ __launch_bounds__(64) void ba_assemble_kernel(BaWork wk, const int64_
 __device__ __forceinline__ int tri(int r, int c) { return r * (r + 1) / 2 + c; }  // r >= c
 
 __global__ __launch_bounds__(256) void ba_solve_lds_kernel(BaWork wk, int n, float lm, float ep) {
-  extern __shared__ double Ls[];  // packed lower triangle + rhs + flag
-  double* x = Ls + n * (n + 1) / 2;
+  // The right-hand side rides along as row n of the packed lower triangle: the factorisation of
+  // the augmented matrix leaves y = L^-1 b in that row (same operations, in the same order, as a
+  // column-oriented forward substitution), so the solve costs 2 barriers per column instead of
+  // 4 + 2 + 2.  The back substitution runs in one wave without barriers when n <= 64.
+  extern __shared__ double Ls[];  // packed lower triangle of the (n+1) x (n+1) augmented matrix
+  double* x = Ls + (n + 1) * (n + 2) / 2;
   __shared__ int fail;
   const int tid = threadIdx.x;
+  const int n1 = n + 1;
   if (tid == 0) fail = (wk.status[0] & BA_ST_M_MISMATCH) ? 1 : 0;
   for (int idx = tid; idx < n * (n + 1) / 2; idx += 256) {
     int r = (int)((sqrtf(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
@@ -535,35 +540,37 @@ __global__ __launch_bounds__(256) void ba_solve_lds_kernel(BaWork wk, int n, flo
     if (r == c) v += (double)ep + (double)lm * v;
     Ls[idx] = v;
   }
-  for (int i = tid; i < n; i += 256) x[i] = wk.vd[i];
+  for (int i = tid; i < n; i += 256) Ls[tri(n, i)] = wk.vd[i];
   __syncthreads();
-  // right-looking Cholesky
+  // right-looking Cholesky; the diagonal keeps d_j (not sqrt) until the end of its column step
   for (int j = 0; j < n; ++j) {
     const double d = Ls[tri(j, j)];
-    if (!(d > 0.0)) {  // also catches NaN
-      if (tid == 0) fail = 1;
-    }
-    __syncthreads();
-    if (fail) break;
+    if (!(d > 0.0) && tid == 0) fail = 1;  // also catches NaN; checked after the loop (result discarded)
     const double dj = sqrt(d);
+    for (int r = j + 1 + tid; r < n1; r += 256) Ls[tri(r, j)] = Ls[tri(r, j)] / dj;
     __syncthreads();
-    for (int r = j + tid; r < n; r += 256) Ls[tri(r, j)] = (r == j) ? dj : Ls[tri(r, j)] / dj;
-    __syncthreads();
-    // trailing update: rows r > j, cols j < c <= r
-    const int m = n - j - 1;
+    // trailing update: rows j < r <= n (row n = rhs), cols j < c <= min(r, n - 1)
+    const int m = n - j - 1;               // remaining matrix rows/cols
     const int cnt = m * (m + 1) / 2;
-    for (int idx = tid; idx < cnt; idx += 256) {
-      // triangular index decode in fp32 (exact after the two correction loops for idx < 2^23)
-      int rr = (int)((sqrtf(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
-      while ((rr + 1) * (rr + 2) / 2 <= idx) ++rr;
-      while (rr * (rr + 1) / 2 > idx) --rr;
-      const int cc = idx - rr * (rr + 1) / 2;
-      const int r = j + 1 + rr, c = j + 1 + cc;
+    for (int idx = tid; idx < cnt + m; idx += 256) {
+      int r, c;
+      if (idx < cnt) {
+        // triangular index decode in fp32 (exact after the two correction loops for idx < 2^23)
+        int rr = (int)((sqrtf(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
+        while ((rr + 1) * (rr + 2) / 2 <= idx) ++rr;
+        while (rr * (rr + 1) / 2 > idx) --rr;
+        const int cc = idx - rr * (rr + 1) / 2;
+        r = j + 1 + rr;
+        c = j + 1 + cc;
+      } else {
+        r = n;
+        c = j + 1 + (idx - cnt);
+      }
       Ls[tri(r, c)] -= Ls[tri(r, j)] * Ls[tri(c, j)];
     }
+    if (tid == 0) Ls[tri(j, j)] = dj;
     __syncthreads();
   }
-  __syncthreads();
   if (fail) {
     for (int i = tid; i < n; i += 256) wk.dx[i] = 0.0f;
     if (tid == 0) {
@@ -572,15 +579,22 @@ __global__ __launch_bounds__(256) void ba_solve_lds_kernel(BaWork wk, int n, flo
     }
     return;
   }
-  // forward substitution L y = b (column oriented)
-  for (int j = 0; j < n; ++j) {
-    if (tid == 0) x[j] = x[j] / Ls[tri(j, j)];
-    __syncthreads();
-    const double xj = x[j];
-    for (int r = j + 1 + tid; r < n; r += 256) x[r] -= Ls[tri(r, j)] * xj;
-    __syncthreads();
+  // backward substitution L^T x = y, y = row n of the factor
+  if (n <= 64) {
+    if (tid < 64) {                                     // one wave, lane r owns x[r]
+      double xr = tid < n ? Ls[tri(n, tid)] : 0.0;
+      for (int j = n - 1; j >= 0; --j) {
+        const double ljj = Ls[tri(j, j)];
+        const double xj = __shfl(xr, j, 64) / ljj;
+        if (tid == j) xr = xj;
+        if (tid < j) xr -= Ls[tri(j, tid)] * xj;
+      }
+      if (tid < n) wk.dx[tid] = (float)xr;
+    }
+    return;
   }
-  // backward substitution L^T x = y
+  for (int i = tid; i < n; i += 256) x[i] = Ls[tri(n, i)];
+  __syncthreads();
   for (int j = n - 1; j >= 0; --j) {
     if (tid == 0) x[j] = x[j] / Ls[tri(j, j)];
     __syncthreads();
@@ -896,7 +910,7 @@ static int ba_solve_update(const BaPlan& pl, float* poses, float* disps, const i
   const BaWork& wk = pl.wk;
   const int n6 = pl.n6;
   if (n6 <= kSolveMaxN) {
-    const size_t lds = sizeof(double) * ((size_t)n6 * (n6 + 1) / 2 + n6);
+    const size_t lds = sizeof(double) * ((size_t)(n6 + 1) * (n6 + 2) / 2 + n6);
     hipLaunchKernelGGL(ba_solve_lds_kernel, dim3(1), dim3(256), lds, st, wk, n6, lm, ep);
   } else {
     if ((size_t)n6 * sizeof(double) > 128 * 1024) return GLORIE_EUNSUPPORTED;

@@ -88,7 +88,9 @@ extern "C" int glorie_flow_conv7(const float* flow, const void* w_packed, const 
   if (N == 0) return GLORIE_OK;
   if (!flow || !w_packed || !bias || !out) return GLORIE_EINVAL;
   const long P = (long)N * H * W, ntiles = (P + 15) / 16;
-  const unsigned grid = (unsigned)((ntiles + 3) / 4 < 1024 ? (ntiles + 3) / 4 : 1024);
+  // 2 workgroups per CU (59 KB of LDS each): the weight panel is loaded once per workgroup, so few,
+  // long-running workgroups amortise it
+  const unsigned grid = (unsigned)((ntiles + 3) / 4 < 512 ? (ntiles + 3) / 4 : 512);
   hipLaunchKernelGGL(flow_conv7_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, flow,
                      reinterpret_cast<const _Float16*>(w_packed), bias, reinterpret_cast<_Float16*>(out),
                      out_stride, P, H, W);

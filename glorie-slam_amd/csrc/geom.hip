@@ -295,6 +295,23 @@ __global__ __launch_bounds__(256) void cvx_upsample_kernel(
   }
 }
 
+// motion features of the update operator (factor_graph.py:219-221): per edge and pixel
+//   [coords1 - coords0, target - coords1] clamped to +-64, as one channels-last float4
+__global__ __launch_bounds__(256) void motion_kernel(const float2* __restrict__ coords1,
+                                                     const float2* __restrict__ coords0,
+                                                     const float2* __restrict__ target,
+                                                     float4* __restrict__ out, long total, int HW, float lim) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const float2 c1 = coords1[i], c0 = coords0[i % HW], t = target[i];
+  float4 o;
+  o.x = fminf(fmaxf(c1.x - c0.x, -lim), lim);
+  o.y = fminf(fmaxf(c1.y - c0.y, -lim), lim);
+  o.z = fminf(fmaxf(t.x - c1.x, -lim), lim);
+  o.w = fminf(fmaxf(t.y - c1.y, -lim), lim);
+  out[i] = o;
+}
+
 // Same operator on a CHANNELS-LAST fp16 mask ([pixel][576], what the 1x1 upmask convolution of
 // GraphAgg writes): lane = (sub-row a, pixel q of a group of 8).  For tap k the 8 sub-column
 // weights of (a) are 16 contiguous bytes, a wave reads 8 pixels x 128 contiguous bytes per tap and
@@ -424,5 +441,18 @@ extern "C" int glorie_cvx_upsample_nhwc(const float* disps, const int64_t* ix, c
   hipLaunchKernelGGL(cvx_upsample_nhwc_kernel, dim3((groups * 64 + 255) / 256, M), dim3(256), 0,
                      (hipStream_t)stream, disps, ix, reinterpret_cast<const _Float16*>(mask), mask_stride,
                      disps_up, h, w, softmax_f32);
+  return check_launch();
+}
+
+extern "C" int glorie_motion(const float* coords1, const float* coords0, const float* target, float* out,
+                             int N, int h, int w, float limit, void* stream) {
+  if (N < 0 || h < 0 || w < 0) return GLORIE_EINVAL;
+  const long total = (long)N * h * w;
+  if (total == 0) return GLORIE_OK;
+  if (!coords1 || !coords0 || !target || !out) return GLORIE_EINVAL;
+  hipLaunchKernelGGL(motion_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const float2*>(coords1), reinterpret_cast<const float2*>(coords0),
+                     reinterpret_cast<const float2*>(target), reinterpret_cast<float4*>(out), total, h * w,
+                     limit);
   return check_launch();
 }

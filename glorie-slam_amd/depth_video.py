@@ -174,6 +174,12 @@ class DepthVideo:
         return d.reshape(N, N) if return_matrix else d
 
     # ---- bundle adjustment -----------------------------------------------------------
+    def deferred_any_on(self):
+        """pinned int32[1]: `any edge enabled` of the last depth_scale stage recorded into a hipGraph"""
+        if getattr(self, "_any_on_host", None) is None:
+            self._any_on_host = torch.ones(1, dtype=torch.int32).pin_memory()
+        return self._any_on_host
+
     def dspo(self, target, weight, eta, ii, jj, t0=1, t1=None, itrs=2, lm=1e-4, ep=0.1,
              motion_only=False, opt_type="pose_depth"):
         with self.get_lock():

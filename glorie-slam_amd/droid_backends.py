@@ -153,6 +153,21 @@ def reproject(poses, disps, intrinsics, ii, jj, return_valid=True):
     return coords, valid
 
 
+def motion(coords1, coords0, target, limit=64.0):
+    """[coords1 - coords0, target - coords1].clamp(+-limit) (factor_graph.py:219-221) as ONE
+    launch.  coords1, target [..., N, h, w, 2] f32, coords0 [h, w, 2] -> [N, h, w, 4] f32"""
+    L.need_cuda(coords1, coords0, target)
+    L.need_contiguous(coords1=coords1, coords0=coords0, target=target)
+    h, w = coords0.shape[-3], coords0.shape[-2]
+    n = coords1.numel() // (h * w * 2)
+    if target.numel() != coords1.numel() or coords0.numel() != h * w * 2:
+        raise RuntimeError("motion: shape mismatch")
+    out = torch.empty((n, h, w, 4), dtype=torch.float32, device=coords1.device)
+    L.check(L.load().glorie_motion(L.ptr(coords1), L.ptr(coords0), L.ptr(target), L.ptr(out), n, h, w,
+                                   float(limit), L.stream_ptr()), "glorie_motion")
+    return out
+
+
 def cvx_upsample(disps, ix, mask, disps_up, softmax_f32=False):
     """disps_up[ix] = cvx_upsample(disps[ix], mask) in place (droid_net.py:9-23,
     depth_video.py:140-144).  mask [M,576,h,w] f16|f32."""

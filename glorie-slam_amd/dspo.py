@@ -54,7 +54,14 @@ def depth_scale_stage(video, target, weight, eta, ii, jj, itrs, lm, ep):
             # the fallback decision must be identical on every rank (it selects a collective path)
             import torch.distributed as dist
             dist.all_reduce(any_on, op=dist.ReduceOp.MAX, group=shard["group"])
-        if not bool(any_on.item()):   # the one scalar sync: decides the stage-1 fallback
+        if any_on.is_cuda and torch.cuda.is_current_stream_capturing():
+            # hipGraph capture: no host decision is possible here.  With every edge off the stage-2
+            # launch below leaves all frames untouched, so it is recorded unconditionally; the flag
+            # goes to pinned memory and the owner of the graph (FactorGraph.update) runs the stage-1
+            # fallback after the replay if it reads 0.
+            video.deferred_any_on().copy_(any_on, non_blocking=True)
+            video.deferred_fallback = True
+        elif not bool(any_on.item()):   # the one scalar sync: decides the stage-1 fallback
             return False
     if n <= 0:
         return False

@@ -13,6 +13,7 @@ arguments.  What changed underneath:
 import numpy as np
 import torch
 
+from . import droid_backends
 from .droid_net import CorrBlock, AltCorrBlock, FusedUpdate, OtfCorrBlock
 
 
@@ -23,7 +24,10 @@ def coords_grid(ht, wd, device):
 
 
 class FactorGraph:
-    def __init__(self, video, update_op, device="cuda:0", corr_impl="volume", max_factors=-1):
+    def __init__(self, video, update_op, device="cuda:0", corr_impl="volume", max_factors=-1,
+                 use_graphs=False):
+        """use_graphs: replay `update()` as a hipGraph while the edge set is unchanged (a BA-update
+        iteration is ~100 short launches; issuing them from Python costs as much as running them)"""
         self.video = video
         self.update_op = update_op
         self.device = device
@@ -42,6 +46,9 @@ class FactorGraph:
         self.ii_bad, self.jj_bad = long0(), long0()
         self.target_inac, self.weight_inac = zero_tw(), zero_tw()
         self._uniq_cache = None
+        self.use_graphs = bool(use_graphs) and str(device).startswith("cuda")
+        self._topo = 0                      # bumped whenever the edge set changes
+        self._graphs = {}                   # (topology, arguments) -> captured update
         # fp16 channels-last form of the update operator with fused element-wise stages
         # (droid_net.FusedUpdate, csrc/gru.hip)
         self.fast_update = FusedUpdate(update_op) if str(device).startswith("cuda") else None
@@ -128,6 +135,8 @@ class FactorGraph:
         target, _ = self.video.reproject(ii, jj)
         weight = torch.zeros_like(target)
         self._uniq_cache = None
+        self._topo += 1
+        self._graphs.clear()
         self.ii = torch.cat([self.ii, ii], 0)
         self.jj = torch.cat([self.jj, jj], 0)
         self.age = torch.cat([self.age, torch.zeros_like(ii)], 0)
@@ -138,6 +147,8 @@ class FactorGraph:
     def rm_factors(self, mask, store=False):
         mask = mask.to(self.ii.device)
         self._uniq_cache = None
+        self._topo += 1
+        self._graphs.clear()
         if store:
             self.ii_inac = torch.cat([self.ii_inac, self.ii[mask]], 0)
             self.jj_inac = torch.cat([self.jj_inac, self.jj[mask]], 0)
@@ -176,13 +187,69 @@ class FactorGraph:
 
     # ---- one BA-update iteration -----------------------------------------------------
     def _motion(self, coords1):
+        """[1, N, 4, h, w] view of the channels-last motion map (factor_graph.py:219-221)"""
+        if coords1.is_cuda:
+            m = droid_backends.motion(coords1.contiguous(), self.coords0.contiguous(), self.target.contiguous())
+            return m.permute(0, 3, 1, 2).unsqueeze(0)
         motn = torch.cat([coords1 - self.coords0, self.target - coords1], dim=-1)
         return motn.permute(0, 1, 4, 2, 3).clamp(-64.0, 64.0)
 
     @torch.no_grad()
     def update(self, t0=None, t1=None, itrs=2, use_inactive=False, EP=1e-7, motion_only=False,
                opt_type="pose_depth"):
-        """factor_graph.py:212-256"""
+        """factor_graph.py:212-256.  With use_graphs the launch sequence of one call is captured
+        the second time it is seen for the current edge set and replayed afterwards."""
+        sharded = getattr(self.video, "shard", None) is not None and self.video.shard["world"] > 1
+        if not self.use_graphs or use_inactive or sharded or self.corr_impl == "otf" or self.ii.numel() == 0:
+            return self._update_eager(t0, t1, itrs, use_inactive, EP, motion_only, opt_type)
+        key = (self._topo, t0, t1, itrs, float(EP), bool(motion_only), opt_type)
+        ent = self._graphs.get(key)
+        if ent is None:                     # first sighting: run eagerly (packs weights, sizes scratch buffers)
+            self._graphs[key] = "seen"
+            return self._update_eager(t0, t1, itrs, use_inactive, EP, motion_only, opt_type)
+        if ent == "seen":
+            ent = self._capture(key, (t0, t1, itrs, False, EP, motion_only, opt_type))
+        graph, s_net, s_target, s_weight, deferred = ent
+        for dst, src in ((s_net, self.net), (s_target, self.target), (s_weight, self.weight)):
+            if src is not dst:
+                dst.copy_(src)
+        graph.replay()
+        self.net, self.target, self.weight = s_net, s_target, s_weight
+        if deferred is not None:
+            # the recorded depth_scale stage could not take its stage-1 fallback decision on the host
+            # (dspo.depth_scale_stage): read the flag it left in pinned memory and redo it here
+            torch.cuda.current_stream().synchronize()
+            if int(self.video.deferred_any_on()[0]) == 0:
+                damping, uq, upmask, t0_, t1_ = deferred
+                self.video.dspo(self.target, self.weight, damping, self.ii, self.jj, t0_, t1_, itrs, 1e-4, 0.1,
+                                motion_only, "pose_depth")
+                self.video.upsample(self._unique_ii(), upmask)
+
+    def _capture(self, key, args):
+        """capture one update() on static copies of the recurrent state (net, target, weight);
+        everything else it touches (video buffers, damping, age) is updated in place already"""
+        s_net = self.net.clone(memory_format=torch.preserve_format)
+        s_target, s_weight = self.target.clone(), self.weight.clone()
+        keep = (self.net, self.target, self.weight)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        self.net, self.target, self.weight = s_net, s_target, s_weight
+        self.video.deferred_fallback = False
+        with torch.cuda.graph(graph):
+            self._update_eager(*args)
+            s_net.copy_(self.net)
+            s_target.copy_(self.target)
+            s_weight.copy_(self.weight)
+        # the capture did not execute anything: restore the state the caller had
+        self.net, self.target, self.weight = keep
+        deferred = self._ba_args if self.video.deferred_fallback else None
+        ent = (graph, s_net, s_target, s_weight, deferred)
+        self._graphs[key] = ent
+        return ent
+
+    @torch.no_grad()
+    def _update_eager(self, t0=None, t1=None, itrs=2, use_inactive=False, EP=1e-7, motion_only=False,
+                      opt_type="pose_depth"):
         coords1, mask = self.video.reproject(self.ii, self.jj)
         motn = self._motion(coords1)
         if self.corr_impl == "otf":
@@ -219,6 +286,7 @@ class FactorGraph:
             assert t1 is not None, "sharded BA needs an explicit (global) t1"
             uq = torch.unique(torch.cat([torch.arange(t0, t1, device=ii.device), ii]))
         damping = .2 * self.damping[uq].contiguous() + EP
+        self._ba_args = (damping, uq, upmask, t0, t1)    # what a deferred stage-1 fallback of a replay needs
         self.video.ba(target, weight, damping, ii, jj, t0, t1, iters=itrs, lm=1e-4, ep=0.1,
                       motion_only=motion_only, opt_type=opt_type)
         self.video.upsample(uniq, upmask)

@@ -211,6 +211,12 @@ int glorie_depth_filter(const float* poses, const float* disps, const float* int
 int glorie_cvx_upsample(const float* disps, const int64_t* ix, const void* mask,
                         float* disps_up, int M, int h, int w, int mask_dtype,
                         int softmax_f32, void* stream);
+/* motion features of the update operator (factor_graph.py:219-221):
+ * out[n][p] = clamp([coords1 - coords0, target - coords1], -limit, limit) as float4 per pixel
+ * (coords1, target [N,h,w,2]; coords0 [h,w,2]; out [N,h,w,4] = a channels-last 4-channel map) */
+int glorie_motion(const float* coords1, const float* coords0, const float* target, float* out, int N,
+                  int h, int w, float limit, void* stream);
+
 /* same operator, mask given channels-last in fp16: row (m*h*w + pixel) holds the 576 logits,
  * rows `mask_stride` halfs apart -- the layout the 1x1 upmask convolution produces */
 int glorie_cvx_upsample_nhwc(const float* disps, const int64_t* ix, const void* mask, int mask_stride,

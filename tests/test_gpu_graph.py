@@ -164,3 +164,31 @@ def test_normalize_and_valid_mask(gpu):
     assert video.dirty[:7].all()
     video.update_valid_depth_mask(up=False)
     assert video.valid_depth_mask_small[:7].any()
+
+
+def test_graph_replay_matches_eager(gpu):
+    """use_graphs=True (hipGraph replay of update()) walks the same states as eager launches"""
+    outs = []
+    for use_graphs in (False, True):
+        g, video = make_video(gpu, 6, 24, 32)
+        video.cfg["tracking"]["multiview_filter"]["thresh"] = 0.25     # let stage 2 run (random-init operator)
+        from glorie_slam_amd.factor_graph import FactorGraph
+        from glorie_slam_amd.droid_net import UpdateModule
+        torch.manual_seed(43)
+        net = UpdateModule().to(gpu).eval()
+        graph = FactorGraph(video, net, device=str(gpu), use_graphs=use_graphs)
+        graph.add_factors(torch.as_tensor(g["ii"], device=gpu), torch.as_tensor(g["jj"], device=gpu))
+        for i in range(8):
+            graph.update(t0=1, t1=6, itrs=2, opt_type="pose_depth" if i % 2 == 0 else "depth_scale")
+        if use_graphs:
+            assert sum(1 for v in graph._graphs.values() if v != "seen") == 2     # both stages replayed
+        outs.append([t.float().clone() for t in (video.poses, video.disps, video.disps_up, video.depth_scale,
+                                                  graph.net, graph.target, graph.weight, graph.damping)])
+    names = ["poses", "disps", "disps_up", "depth_scale", "net", "target", "weight", "damping"]
+    for name, a, b in zip(names, *outs):
+        assert torch.isfinite(a).all(), name
+        torch.testing.assert_close(a, b, atol=2e-3, rtol=2e-3, msg=lambda m, n=name: f"{n}: {m}")
+    # a topology change drops the captured graphs
+    graph.rm_factors(graph.ii == 0, store=False)
+    assert len(graph._graphs) == 0
+    graph.update(t0=1, t1=6, itrs=2)
