@@ -22,6 +22,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+MFMA_F16_PEAK_TF = 2500.0  # same guide: ~2.5 PFLOP/s dense f16/bf16 (not the 2:1-sparsity figure)
 
 
 def make_cfg(H=480, W=640, buffer=16, device="cuda:0"):
@@ -126,16 +127,38 @@ def render_pass(npc, dec, ren, rays, device):
 
 
 def _pmc_traffic():
-    """per-launch HBM bytes of the gather kernels from the committed PMC summary (separate
+    """per-launch HBM bytes of the profiled kernels from the committed PMC summary (separate
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, corrected as MI355X_MICROARCH.md prescribes;
-    see profiles/README.md).  None when the summary is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_gathers.json")
+    see profiles/README.md).  None when the summary is absent.  -> (conv, corr, knn)"""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_kernels.json")
     try:
         with open(path) as f:
             d = json.load(f)
-        return d["corr_lookup"]["hbm_bytes"], d["knn_query"]["hbm_bytes"] + 2 * d["idw_gather"]["hbm_bytes"]
     except Exception:
-        return None, None
+        return None, None, None
+    get = lambda k: d[k]["hbm_bytes"] if k in d and d[k].get("hbm_bytes") is not None else None
+    knn = None
+    if get("knn_query") is not None and get("idw_gather") is not None:
+        knn = get("knn_query") + 2 * get("idw_gather")
+    return get("conv_igemm_gru_zr"), get("corr_lookup"), knn
+
+
+def gru_gate_conv_workload(device, N, ht, wd):
+    """the dominant kernel of a BA-update step in isolation: the merged convz|convr 3x3 convolution
+    of the ConvGRU (448 -> 256 channels, gate epilogue) on the step's shapes; returns a launcher and
+    its algorithmic FLOPs (2 * pixels * 9 * 448 * 256; SURVEY.md 8(d): the update operator is MFMA work)"""
+    from glorie_slam_amd import update_ops as U
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    cl = lambda c: torch.randn(N, c, ht, wd, generator=gen).to(device).half().contiguous(memory_format=torch.channels_last)
+    net, hx = cl(128), cl(320)
+    wzr = U.pack_conv_igemm((torch.randn(256, 448, 3, 3, generator=gen) / 63.0).to(device))
+    terms = torch.randn(N, 384, generator=gen).to(device)
+    z, rnet = torch.empty_like(net), torch.empty_like(net)
+
+    def launch():
+        U.conv_igemm(net, hx, wzr, 9, 256, z, epilogue=U.EPI_GRU_ZR, terms=terms[:, :256], net=net, out2=rnet)
+
+    return launch, 2.0 * N * ht * wd * 9 * 448 * 256
 
 
 def cpu_baseline_rays(n_rays=192):
@@ -283,8 +306,21 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    # ---- roofline of the dominant gather kernel (corr lookup), HIP events on the launch stream
+    # ---- roofline of the dominant kernel of a step (GRU gate convolution, 23 % of it): HIP events on
+    # the launch stream around back-to-back launches
     reset()
+    conv_launch, conv_flops = gru_gate_conv_workload(device, graph.ii.shape[0], graph.ht, graph.wd)
+    for _ in range(3):
+        conv_launch()
+    cv0, cv1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    cv0.record()
+    for _ in range(20):
+        conv_launch()
+    cv1.record()
+    torch.cuda.synchronize()
+    conv_ms = cv0.elapsed_time(cv1) / 20
+    conv_tf = conv_flops / (conv_ms * 1e-3) / 1e12
+    # ---- roofline of the correlation gather (the HBM-bound kernel north_star names)
     coords1, _ = video.reproject(graph.ii, graph.jj)
     reps = 20
     for _ in range(3):
@@ -359,7 +395,8 @@ def main():
     mlp_ms = e0.elapsed_time(e1) / 5
     mlp_flops = 2.0 * 179424.0 * pq.shape[0]
     mlp_tf = mlp_flops / (mlp_ms * 1e-3) / 1e12
-    corr_traffic, knn_traffic = _pmc_traffic()
+    conv_traffic, corr_traffic, knn_traffic = _pmc_traffic()
+    full = world == 1 and N == 36
 
     out = {
         "metric": "DSPO BA-update iters/sec + rendered rays/sec, 640x480 Replica keyframe graph",
@@ -375,17 +412,20 @@ def main():
                    "parallelism": ("single GPU" if world == 1 else
                                    f"edges sharded by source keyframe over {world} GPUs + RCCL all-reduce of the "
                                    f"reduced normal equations; rays sharded {world} ways")},
-        "roofline": {"bound": "hbm", "kernel": "corr_lookup_r3_v2_kernel<f16>",
-                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": corr_traffic if (world == 1 and N == 36) else None,
-                     "alg_bytes_per_launch": alg_bytes, "ms_per_launch": corr_ms},
+        "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel<EPI_GRU_ZR,4,64> (ConvGRU convz|convr, 448->256, 3x3)",
+                     "achieved": conv_tf, "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s",
+                     "frac": conv_tf / MFMA_F16_PEAK_TF, "traffic": conv_traffic if full else None,
+                     "flops_per_launch": conv_flops, "ms_per_launch": conv_ms},
+        "roofline_corr": {"bound": "hbm", "kernel": "corr_lookup_r3_v2_kernel<f16>",
+                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": achieved / HBM_PEAK_GBS, "traffic": corr_traffic if full else None,
+                          "alg_bytes_per_launch": alg_bytes, "ms_per_launch": corr_ms},
         "rays_per_sec": rays_per_s,
         "render": {"rays_local": int(n_r // render_reps), "samples_per_ray": int(S), "cloud_points": int(npc.pts_num()),
                    "ms_per_frame_shard": 1e3 * t_r / render_reps},
         "roofline_knn": {"bound": "hbm", "kernel": "knn_query_kernel<8> + 2x idw_gather_kernel",
                          "achieved": knn_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": knn_gbs / HBM_PEAK_GBS, "traffic": knn_traffic,
+                         "frac": knn_gbs / HBM_PEAK_GBS, "traffic": knn_traffic if world == 1 else None,
                          "alg_bytes_per_launch": knn_bytes, "ms_per_launch": knn_ms},
         "roofline_mlp": {"bound": "mfma", "kernel": "mlp_geo + mlp_nb_v2 + mlp_col_v2 (fp32 MFMA 16x16x4)",
                          "achieved": mlp_tf, "peak": 157.3, "unit": "TFLOP/s", "frac": mlp_tf / 157.3,

@@ -1,4 +1,5 @@
-"""Workload for the HBM-traffic (PMC) passes of the two gather kernels + a calibration copy.
+"""Workload for the HBM-traffic (PMC) passes: GRU gate convolution, the two gather kernels, and a
+calibration copy.
 
     cd /tmp && export TMPDIR=/tmp
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d <out>/fetch -o g -- python profiles/pmc_gathers.py
@@ -18,6 +19,9 @@ g, video, graph = bench.build_graph(dev)
 coords1, _ = video.reproject(graph.ii, graph.jj)
 for _ in range(3):
     graph.corr(coords1)
+conv_launch, _ = bench.gru_gate_conv_workload(dev, graph.ii.shape[0], graph.ht, graph.wd)
+for _ in range(3):
+    conv_launch()
 npc, dec, ren, rays = bench.build_renderer(dev)
 S = ren.N_surface
 nq = 65536

@@ -5,7 +5,7 @@ Corrections (MI355X_MICROARCH.md, section HBM): counters are in KiB; on gfx950 F
 128-byte requests at 64 bytes, i.e. reports 1/2 of the bytes of wide reads -- calibrated here on
 the 1 GiB device copy contained in the same run (expected 1 GiB read, 1 GiB written).
 
-    python profiles/summarize_pmc.py gpurun_out/pmc_fetch gpurun_out/pmc_write > profiles/r01_pmc_gathers.json
+    python profiles/summarize_pmc.py gpurun_out/pmc_fetch gpurun_out/pmc_write > profiles/r01_pmc_kernels.json
 """
 import csv
 import json
@@ -31,10 +31,13 @@ def main(fetch_dir, write_dir):
     write_corr = GiB_KiB / cal_w     # ~1.0
     out = {"calibration": {"copy_bytes": 1 << 30, "FETCH_SIZE_KiB": cal_f, "WRITE_SIZE_KiB": cal_w,
                            "fetch_correction": fetch_corr, "write_correction": write_corr}}
-    for key, pred in (("corr_lookup", lambda n: "corr_lookup" in n), ("knn_query", lambda n: "knn_query" in n),
+    for key, pred in (("conv_igemm_gru_zr", lambda n: "conv_igemm_kernel<1" in n or "conv_igemm_kernelILi1" in n),
+                      ("corr_lookup", lambda n: "corr_lookup" in n), ("knn_query", lambda n: "knn_query" in n),
                       ("idw_gather", lambda n: "idw_gather" in n)):
         fv, nf = mean_of(f, pred)
         wv, nw = mean_of(w, pred)
+        if fv is None or wv is None:
+            continue
         out[key] = {"launches": nf, "FETCH_SIZE_KiB": fv, "WRITE_SIZE_KiB": wv,
                     "hbm_read_bytes": fv * 1024 * fetch_corr, "hbm_write_bytes": wv * 1024 * write_corr,
                     "hbm_bytes": fv * 1024 * fetch_corr + wv * 1024 * write_corr}
