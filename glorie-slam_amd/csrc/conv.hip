@@ -14,10 +14,14 @@
 //   operand is the WEIGHT tile, "B" the pixel tile, so a lane ends up with 4 consecutive output
 //   channels of one pixel (8-byte epilogue loads/stores) instead of 4 pixels of one channel.
 // * K loop = 64-channel chunks x taps (taps innermost: the 9 shifted reads of a chunk hit L2).
-//   Both tiles are staged with buffer_load_dwordx4 ... lds (HBM/L2 -> LDS without touching VGPRs),
-//   double buffered, one barrier per step; all fragment reads of a step are issued before the
-//   next DMA and the MFMAs.  The LDS image is lane-linear as the DMA requires; the 16-byte slot of
-//   a row is XOR-swizzled on the SOURCE address and on the fragment read (conflict-free b128 reads).
+//   Both tiles are staged with buffer_load_dwordx4 ... lds (HBM/L2 -> LDS without touching VGPRs)
+//   into ONE LDS stage (32 KB), 3 workgroups per CU.  Per step: barrier (tile landed) -> all 16
+//   fragment reads -> barrier (every wave holds its fragments: the stage is free) -> DMA of the
+//   next tile into the same stage -> 32 MFMAs from registers while it streams in.  Occupancy plus
+//   this register-level double buffering measured faster than two or three LDS stages with fewer
+//   resident workgroups (kept as template variants ST = 2 | 3, NW = 8).  The LDS image is
+//   lane-linear as the DMA requires; the 16-byte slot of a row is XOR-swizzled on the SOURCE
+//   address and on the fragment read (conflict-free b128 reads).
 // * Zero padding: a lane whose row is outside the map for the current tap sets bit 31 of its
 //   buffer offset; the hardware range check then writes zeros into LDS (tools/probes/
 //   buffer_lds_probe.hip pins that behaviour) -- no branch and no zero page in the K loop.
@@ -64,22 +68,24 @@ __device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-// NB = 16-pixel blocks per wave (pixel tile = 32*NB), BK = channels per K step (32 | 64)
-template <int EPI, int NB, int BK>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
+// NB = 16-pixel blocks per wave, BK = channels per K step (32 | 64), NW = waves (2 channel halves x
+// NW/2 pixel groups: pixel tile = NW/2 * 16*NB), ST = LDS stages (2: one __syncthreads per step;
+// 3: loads run two steps ahead, counted vmcnt + raw barrier so that they stay in flight across it)
+template <int EPI, int NB, int BK, int NW, int ST>
+__global__ __launch_bounds__(64 * NW, ST == 3 ? 1 : (ST == 1 ? 3 : 2)) void conv_igemm_kernel(ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (buffer-resource types are device-only)
-  constexpr int PT = 32 * NB;                 // pixels per workgroup
+  constexpr int PT = (NW / 2) * 16 * NB;      // pixels per workgroup
   constexpr int RB = BK * 2;                  // bytes per staged row
   constexpr int SL = RB / 16;                 // 16-byte slots per row
   constexpr int RPI = 64 / SL;                // rows per wave-wide DMA instruction
-  constexpr int XI = PT / RPI / 4;            // DMA instructions per wave per step: pixel tile
-  constexpr int WI = kTileN / RPI / 4;        //                                      weight tile
+  constexpr int XI = PT / RPI / NW;           // DMA instructions per wave per step: pixel tile
+  constexpr int WI = kTileN / RPI / NW;       //                                      weight tile
   constexpr int XBYTES = PT * RB, WBYTES = kTileN * RB;
   constexpr int KK = BK / 32;
-  __shared__ __attribute__((aligned(16))) char smem[2 * (XBYTES + WBYTES)];
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // ST x (pixel tile, weight tile), one array
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int col = lane & 15, kg = lane >> 4;
-  const int wm = wv >> 1, wn = wv & 1;
+  const int wm = wv & 1, wn = wv >> 1;
 
   // 16-byte slot swizzle key of an LDS row: ds_read_b128 of 16 consecutive rows is conflict-free for
   // the hardware's lane groups ({0-3,12-15,20-27}, ...) with these keys (brute-force checked)
@@ -117,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   int vmask[XI];
 #pragma unroll
   for (int i = 0; i < XI; ++i) {
-    const int row = (i * 4 + wv) * RPI + srow;
+    const int row = (i * NW + wv) * RPI + srow;
     const int sw = (slot ^ key(row)) << 3;          // swizzled 16-byte slot, in halfs
     const long p = p0 + row;
     int m = 0;
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   }
 #pragma unroll
   for (int i = 0; i < WI; ++i) {
-    const int row = (i * 4 + wv) * RPI + srow;
+    const int row = (i * NW + wv) * RPI + srow;
     woff[i] = (unsigned)(((size_t)row * C + ((slot ^ key(row)) << 3)) * 2);
   }
 
@@ -163,12 +169,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
       const unsigned inv = ~((unsigned)vmask[i] >> d);
       const unsigned vo = (inv << 31) | (segA ? voffA[i] : voffB[i]);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(segA ? rA : rB,
-          (__attribute__((address_space(3))) void*)(lx + (i * 4 + wv) * RPI * RB), 16, vo, xsoff, 0, 0);
+          (__attribute__((address_space(3))) void*)(lx + (i * NW + wv) * RPI * RB), 16, vo, xsoff, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < WI; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rW,
-          (__attribute__((address_space(3))) void*)(lw + (i * 4 + wv) * RPI * RB), 16, woff[i], wsoff, 0, 0);
+          (__attribute__((address_space(3))) void*)(lw + (i * NW + wv) * RPI * RB), 16, woff[i], wsoff, 0, 0);
   };
 
   f32x4 acc[4][NB];
@@ -184,9 +190,21 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   const int wbase = XBYTES + wm * 64 * RB, xbase_l = wn * (16 * NB) * RB;
 
   stage(0, 0);
+  if (ST == 3 && T > 1) stage(1, 1);
+  int cur = 0;                                 // LDS stage holding tile t
   for (int t = 0; t < T; ++t) {
-    __syncthreads();                           // tile t landed (vmcnt(0) + barrier); buffer (t+1)&1 is free
-    const char* base = smem + (t & 1) * (XBYTES + WBYTES);
+    if (ST == 1) {
+      __syncthreads();                         // tile t landed
+    } else if (ST == 2) {
+      __syncthreads();                         // tile t landed (vmcnt(0) + barrier); the other buffer is free
+    } else {
+      // my loads of tile t have landed when at most the XI + WI loads of tile t+1 are still in flight;
+      // after the barrier everybody's have, and everybody is done reading the stage tile t+2 goes to
+      if (t + 1 < T) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XI + WI) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    const char* base = smem + cur * (XBYTES + WBYTES);
     // all fragment reads of the step go out first (one exposed LDS latency per step, not per kk), the
     // DMA of the next tile is issued in their shadow, then the MFMAs run back to back
     f16x8 wf[KK][4], xf[KK][NB];
@@ -199,7 +217,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
       for (int ni = 0; ni < NB; ++ni)
         xf[kk][ni] = *reinterpret_cast<const f16x8*>(base + xbase_l + ni * 16 * RB + foff[kk]);
     }
-    if (t + 1 < T) stage(t + 1, (t + 1) & 1);
+    if (ST == 1) {
+      // single LDS stage, 4 workgroups per CU.  Every fragment of the step is in registers now, so
+      // once all waves got theirs the buffer is free: tile t+1 streams into it under the MFMAs.
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (t + 1 < T) stage(t + 1, 0);
+    } else if (ST == 2) {
+      if (t + 1 < T) stage(t + 1, cur ^ 1);
+    } else {
+      if (t + 2 < T) stage(t + 2, cur >= 1 ? cur - 1 : 2);     // (cur + 2) % 3
+    }
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
@@ -207,6 +235,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
         for (int ni = 0; ni < NB; ++ni)
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kk][mi], xf[kk][ni], acc[mi][ni], 0, 0, 0);
+    if (ST > 1) cur = (cur + 1 == ST) ? 0 : cur + 1;
   }
 
   // ---- epilogue: lane owns channels n0 + wm*64 + mi*16 + kg*4 .. +3 of pixel p0 + wn*16*NB + ni*16 + col ----
@@ -265,17 +294,30 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 #endif
 }
 
-template <int NB, int BK>
+template <int EPI, int NB, int BK, int NW, int ST>
+static void launch_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
+  constexpr int RB = BK * 2, PT = (NW / 2) * 16 * NB;
+  constexpr size_t lds = (size_t)ST * (PT * RB + kTileN * RB);
+  static bool attr = false;            // > 64 KB of dynamic LDS needs the opt-in once per kernel
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<EPI, NB, BK, NW, ST>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  hipLaunchKernelGGL((conv_igemm_kernel<EPI, NB, BK, NW, ST>), grid, dim3(64 * NW), lds, st, a);
+}
+
+template <int NB, int BK, int NW, int ST>
 static int launch_conv(const ConvArgs& a, int epilogue, hipStream_t st) {
-  constexpr int PT = 32 * NB;
+  constexpr int PT = (NW / 2) * 16 * NB;
   const long ptiles = (a.P + PT - 1) / PT;
   const long nwg = ptiles * (a.npad / kTileN);
   if (nwg > 0x7fffffffL) return GLORIE_EINVAL;
-  const dim3 grid((unsigned)nwg), block(256);
+  const dim3 grid((unsigned)nwg);
   switch (epilogue) {
-    case EPI_BIAS_ACT: hipLaunchKernelGGL((conv_igemm_kernel<EPI_BIAS_ACT, NB, BK>), grid, block, 0, st, a); break;
-    case EPI_GRU_ZR: hipLaunchKernelGGL((conv_igemm_kernel<EPI_GRU_ZR, NB, BK>), grid, block, 0, st, a); break;
-    default: hipLaunchKernelGGL((conv_igemm_kernel<EPI_GRU_Q, NB, BK>), grid, block, 0, st, a); break;
+    case EPI_BIAS_ACT: launch_one<EPI_BIAS_ACT, NB, BK, NW, ST>(a, grid, st); break;
+    case EPI_GRU_ZR: launch_one<EPI_GRU_ZR, NB, BK, NW, ST>(a, grid, st); break;
+    default: launch_one<EPI_GRU_Q, NB, BK, NW, ST>(a, grid, st); break;
   }
   return check_launch();
 }
@@ -314,11 +356,8 @@ extern "C" int glorie_conv_igemm(const void* xa, int xa_stride, int ca, const vo
       ((long)taps * a.npad * (ca + cb) + 64) * 2 > lim)
     return GLORIE_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  // Tile choice: 256-pixel tiles (NB = 8, BK = 32) stage fewer weight bytes per FLOP and win when
-  // the weight panel is wide (>= 3 output tiles), unless halving the workgroup count costs an
-  // extra partially filled round of the 2 x 256 workgroup slots (measured: tools/bench_conv.py).
-  const long slots = 512, ntn = a.npad / kTileN;
-  const long nwg4 = (a.P + 127) / 128 * ntn, nwg8 = (a.P + 255) / 256 * ntn;
-  const bool wide = ntn >= 3 && 2 * ((nwg8 + slots - 1) / slots) <= (nwg4 + slots - 1) / slots;
-  return wide ? launch_conv<8, 32>(a, epilogue, st) : launch_conv<4, 64>(a, epilogue, st);
+  // Measured on the update operator's layers at 36x60x80 (tools/bench_conv.py): the single-stage
+  // 128x128 tile at 3 workgroups per CU beats the double-buffered variants (2 per CU: 930, 8 waves
+  // with a 3-stage ring and counted vmcnt: 830, 256-pixel tiles: 850 TFLOP/s on the 448->256 layer).
+  return launch_conv<4, 64, 4, 1>(a, epilogue, st);
 }
