@@ -1,0 +1,200 @@
+// Preparation of the DSPO depth_scale stage (scope row B) as 4 launches instead of ~70 PyTorch ones:
+//   DepthVideo.update_valid_depth_mask(up=False)   /root/reference/src/depth_video.py:326-361
+//   align_scale_and_shift(mono, est, valid)        /root/reference/src/utils/common.py:401-437
+//   bad-frame / edge filtering by mono_thres       /root/reference/src/depth_video.py:228-247
+//
+//   1. prep_stats:  per frame mean depth (-> two-view threshold) and mean disparity
+//   2. depth_filter (csrc/geom.hip): consistent-neighbour count per pixel
+//   3. prep_align:  one workgroup per frame -- nanmedian of the depths that passed the filter by an
+//      exact 4-pass radix select in LDS (torch.nanmedian = lower median), the validity mask
+//      depth < 3*median, the 5 weighted sums of the least-squares fit, scale/shift, mean absolute
+//      residual and the frame's `bad` flag
+//   4. prep_edges:  edge_on[e] = !(bad[ii] | bad[jj]) and the "any edge on" flag
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+#include "common.hiph"
+
+extern "C" int glorie_depth_filter(const float* poses, const float* disps, const float* intrinsics,
+                                   const int64_t* ix, const float* thresh, float* count, int B, int num,
+                                   int h, int w, void* stream);
+
+namespace glorie {
+
+__device__ __forceinline__ double block_sum(double v, double* red) {
+  // 1024 threads = 16 waves; fixed order -> deterministic
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wv] = v;
+  __syncthreads();
+  double s = 0.0;
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += red[i];
+  return s;
+}
+
+__global__ __launch_bounds__(1024) void prep_stats_kernel(const float* __restrict__ disps, int HW,
+                                                          float mv_thresh, float* __restrict__ thresh,
+                                                          float* __restrict__ avg_disp,
+                                                          int64_t* __restrict__ ix) {
+  __shared__ double red[16];
+  const int f = blockIdx.x;
+  const float* d = disps + (size_t)f * HW;
+  double sd = 0.0, sz = 0.0;
+  for (int k = threadIdx.x; k < HW; k += blockDim.x) {
+    const float v = d[k];
+    sd += (double)v;
+    sz += (double)(1.0f / v);
+  }
+  const double td = block_sum(sd, red);
+  const double tz = block_sum(sz, red);
+  if (threadIdx.x == 0) {
+    thresh[f] = mv_thresh * (float)(tz / (double)HW);
+    avg_disp[f] = (float)(td / (double)HW);
+    ix[f] = f;
+  }
+}
+
+// dynamic LDS: HW keys (uint32)
+__global__ __launch_bounds__(1024) void prep_align_kernel(
+    const float* __restrict__ disps, const float* __restrict__ mono, const float* __restrict__ count,
+    const float* __restrict__ avg_disp, int HW, float visible, float mono_thres,
+    uint8_t* __restrict__ valid_mask, float* __restrict__ scales, float* __restrict__ shifts,
+    uint8_t* __restrict__ bad) {
+  extern __shared__ uint32_t keys[];
+  __shared__ double red[16];
+  __shared__ unsigned hist[256];
+  __shared__ unsigned sel_prefix, sel_k;
+  const int f = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const float* d = disps + (size_t)f * HW;
+  const float* m = mono + (size_t)f * HW;
+  const float* c = count + (size_t)f * HW;
+
+  // ---- keys of the depths that passed the two-view filter (positive floats order like uints) ----
+  double nv = 0.0;
+  for (int k = tid; k < HW; k += nt) {
+    const bool ok = c[k] >= visible;
+    const float z = 1.0f / d[k];
+    keys[k] = (ok && !isnan(z)) ? __float_as_uint(z) : 0xffffffffu;
+    nv += (ok && !isnan(z)) ? 1.0 : 0.0;
+  }
+  const int nvalid = (int)block_sum(nv, red);
+  float med = nanf("");
+  if (nvalid > 0) {
+    if (tid == 0) { sel_prefix = 0u; sel_k = (unsigned)((nvalid - 1) / 2); }   // lower median
+    unsigned mask = 0u;
+    for (int pass = 3; pass >= 0; --pass) {
+      if (tid < 256) hist[tid] = 0u;
+      __syncthreads();
+      const unsigned prefix = sel_prefix;
+      for (int k = tid; k < HW; k += nt) {
+        const unsigned key = keys[k];
+        if (key != 0xffffffffu && (key & mask) == prefix) atomicAdd(&hist[(key >> (8 * pass)) & 255u], 1u);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        unsigned kk = sel_k, b = 0;
+        for (; b < 256; ++b) {
+          if (kk < hist[b]) break;
+          kk -= hist[b];
+        }
+        sel_k = kk;
+        sel_prefix = prefix | (b << (8 * pass));
+      }
+      mask |= 0xffu << (8 * pass);
+      __syncthreads();
+    }
+    med = __uint_as_float(sel_prefix);
+  }
+  // ---- mask + least squares  target(est disparity) ~ scale * prediction(mono) + shift ----
+  const float lim = 3.0f * med;
+  double a00 = 0, a01 = 0, a11 = 0, b0 = 0, b1 = 0;
+  for (int k = tid; k < HW; k += nt) {
+    const unsigned key = keys[k];
+    const bool on = key != 0xffffffffu && __uint_as_float(key) < lim;
+    valid_mask[(size_t)f * HW + k] = on ? 1 : 0;
+    if (on) {
+      const float p = m[k], t = d[k];
+      a00 += (double)(p * p);
+      a01 += (double)p;
+      a11 += 1.0;
+      b0 += (double)(p * t);
+      b1 += (double)t;
+    }
+  }
+  const float A00 = (float)block_sum(a00, red), A01 = (float)block_sum(a01, red);
+  const float A11 = (float)block_sum(a11, red), B0 = (float)block_sum(b0, red), B1 = (float)block_sum(b1, red);
+  const float det = A00 * A11 - A01 * A01;
+  const float scale = (A11 * B0 - A01 * B1) / det;
+  const float shift = (-A01 * B0 + A00 * B1) / det;
+  double es = 0.0;
+  for (int k = tid; k < HW; k += nt) {
+    const unsigned key = keys[k];
+    if (key != 0xffffffffu && __uint_as_float(key) < lim) es += (double)fabsf(scale * m[k] + shift - d[k]);
+  }
+  const float err = (float)block_sum(es, red) / A11;
+  if (tid == 0) {
+    scales[f] = scale;
+    shifts[f] = shift;
+    bool b = false;
+    if (mono_thres > 0.0f)
+      b = (err / avg_disp[f] > mono_thres) || isnan(err) || (scale < 0.0f) || (A11 < 0.5f * (float)HW);
+    bad[f] = b ? 1 : 0;
+  }
+}
+
+__global__ __launch_bounds__(256) void prep_edges_kernel(const uint8_t* __restrict__ bad,
+                                                         const int64_t* __restrict__ ii,
+                                                         const int64_t* __restrict__ jj, int N, int n,
+                                                         uint8_t* __restrict__ edge_on, int* __restrict__ any_on) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= N) return;
+  const int i = (int)ii[e], j = (int)jj[e];
+  const bool bi = (i >= 0 && i < n) ? bad[i] != 0 : false;      // frames beyond the counter are never "bad"
+  const bool bj = (j >= 0 && j < n) ? bad[j] != 0 : false;
+  const bool on = !(bi || bj);
+  edge_on[e] = on ? 1 : 0;
+  if (on) atomicOr(any_on, 1);
+}
+
+}  // namespace glorie
+
+using namespace glorie;
+
+extern "C" int glorie_dspo_prepare(const float* poses, const float* disps, const float* intrinsics,
+                                   const float* mono_disps, int B, int n, int h, int w, float mv_thresh,
+                                   int visible_num, float mono_thres, const int64_t* ii, const int64_t* jj,
+                                   int N, uint8_t* valid_mask, float* scales, float* shifts,
+                                   uint8_t* edge_on, int* any_on, void* scratch, void* stream) {
+  if (B < 0 || n < 0 || n > B || h <= 0 || w <= 0 || N < 0) return GLORIE_EINVAL;
+  const int HW = h * w;
+  if ((size_t)HW * 4 > 150 * 1024) return GLORIE_EUNSUPPORTED;
+  if (!any_on) return GLORIE_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  GLORIE_TRY(check_hip(hipMemsetAsync(any_on, 0, sizeof(int), st)));
+  if (n == 0) return GLORIE_OK;
+  if (!poses || !disps || !intrinsics || !mono_disps || !valid_mask || !scales || !shifts || !scratch ||
+      (N > 0 && (!ii || !jj || !edge_on)))
+    return GLORIE_EINVAL;
+  // scratch: count [n*HW] f32 | thresh [n] | avg [n] | ix [n] i64 | bad [n] u8
+  char* sp = reinterpret_cast<char*>(scratch);
+  float* count = reinterpret_cast<float*>(sp);
+  float* thresh = count + (size_t)n * HW;
+  float* avg = thresh + n;
+  int64_t* ix = reinterpret_cast<int64_t*>(sp + ((((size_t)n * HW + 2 * n) * 4 + 7) / 8) * 8);
+  uint8_t* bad = reinterpret_cast<uint8_t*>(ix + n);
+  hipLaunchKernelGGL(prep_stats_kernel, dim3(n), dim3(1024), 0, st, disps, HW, mv_thresh, thresh, avg, ix);
+  GLORIE_TRY(glorie_depth_filter(poses, disps, intrinsics, ix, thresh, count, B, n, h, w, stream));
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(prep_align_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL(prep_align_kernel, dim3(n), dim3(1024), (size_t)HW * 4, st, disps, mono_disps, count, avg,
+                     HW, (float)visible_num, mono_thres, valid_mask, scales, shifts, bad);
+  if (N > 0)
+    hipLaunchKernelGGL(prep_edges_kernel, dim3((N + 255) / 256), dim3(256), 0, st, bad, ii, jj, N, n, edge_on,
+                       any_on);
+  return check_launch();
+}

@@ -168,6 +168,32 @@ def motion(coords1, coords0, target, limit=64.0):
     return out
 
 
+def dspo_prepare(poses, disps, intrinsics, mono_disps, n, mv_thresh, visible_num, mono_thres, ii, jj,
+                 valid_mask, depth_scale, depth_shift):
+    """update_valid_depth_mask(up=False) + align_scale_and_shift + the mono_thres edge filter of the
+    depth_scale stage (depth_video.py:228-247,326-361) in 4 launches and without a host sync.
+    Writes valid_mask[:n] (bool), depth_scale[:n], depth_shift[:n]; returns (edge_on uint8 [N],
+    any_on int32 [1])."""
+    L.need_cuda(poses, disps, intrinsics, mono_disps, ii, jj, valid_mask, depth_scale, depth_shift)
+    L.need_contiguous(poses=poses, disps=disps, intrinsics=intrinsics, mono_disps=mono_disps, ii=ii, jj=jj,
+                      valid_mask=valid_mask, depth_scale=depth_scale, depth_shift=depth_shift)
+    _i64(ii, "ii"), _i64(jj, "jj")
+    if valid_mask.dtype != torch.bool or valid_mask.shape != disps.shape:
+        raise RuntimeError("valid_mask must be a bool tensor of the shape of disps")
+    B, h, w = disps.shape
+    N = ii.shape[0]
+    dev = disps.device
+    edge_on = torch.empty(N, dtype=torch.uint8, device=dev)
+    any_on = torch.empty(1, dtype=torch.int32, device=dev)
+    scratch = torch.empty(n * h * w * 4 + n * 32 + 64, dtype=torch.uint8, device=dev)
+    L.check(L.load().glorie_dspo_prepare(L.ptr(poses), L.ptr(disps), L.ptr(intrinsics), L.ptr(mono_disps), B,
+                                         int(n), h, w, float(mv_thresh), int(visible_num),
+                                         float(mono_thres or 0.0), L.ptr(ii), L.ptr(jj), N, L.ptr(valid_mask),
+                                         L.ptr(depth_scale), L.ptr(depth_shift), L.ptr(edge_on), L.ptr(any_on),
+                                         L.ptr(scratch), L.stream_ptr()), "glorie_dspo_prepare")
+    return edge_on, any_on
+
+
 def cvx_upsample(disps, ix, mask, disps_up, softmax_f32=False):
     """disps_up[ix] = cvx_upsample(disps[ix], mask) in place (droid_net.py:9-23,
     depth_video.py:140-144).  mask [M,576,h,w] f16|f32."""

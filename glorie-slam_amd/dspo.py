@@ -22,7 +22,7 @@ def scale_shift_step(video, target, weight, eta, ii, jj, edge_on, itrs, lm, ep, 
     weight = weight.reshape(-1, h, w, 2).contiguous().float()
     eta = eta.reshape(-1, h, w).contiguous().float()
     N, M, B = ii.shape[0], eta.shape[0], video.disps.shape[0]
-    vm = video.valid_depth_mask_small.to(torch.uint8).contiguous()
+    vm = video.valid_depth_mask_small.contiguous().view(torch.uint8)      # bool storage is one byte per element
     eo = edge_on.to(torch.uint8).contiguous() if edge_on is not None else None
     L.check(L.load().glorie_dspo_scale_shift(
         video.ctx().handle, L.ptr(video.poses), L.ptr(video.disps), L.ptr(video.intrinsics),
@@ -32,23 +32,39 @@ def scale_shift_step(video, target, weight, eta, ii, jj, edge_on, itrs, lm, ep, 
         L.stream_ptr()), "glorie_dspo_scale_shift")
 
 
-def depth_scale_stage(video, target, weight, eta, ii, jj, itrs, lm, ep):
-    """returns `success` like DepthVideo.dspo(opt_type='depth_scale')"""
+def _prepare_torch(video, n, ii, jj):
+    """the reference's formulation, op by op (CPU tensors / cross-check for the fused kernels)"""
     video.update_valid_depth_mask(up=False)
-    n = video.counter.value
     mono_d, est_d, valid_d = video.mono_disps[:n], video.disps[:n], video.valid_depth_mask_small[:n]
     scale_t, shift_t, error_t = align_scale_and_shift(mono_d, est_d, valid_d)
     video.depth_scale[:n] = scale_t
     video.depth_shift[:n] = shift_t
-    edge_on = None
-    if video.mono_thres:
-        avg = est_d.mean(dim=[1, 2])
-        bad = (error_t / avg > video.mono_thres) | error_t.isnan() | (scale_t < 0) | \
-              (valid_d.sum(dim=[1, 2]) < valid_d.shape[1] * valid_d.shape[2] * 0.5)
-        bad_full = torch.zeros(video.disps.shape[0], dtype=torch.bool, device=bad.device)
-        bad_full[:n] = bad
-        edge_on = ~(bad_full[ii] | bad_full[jj])
-        any_on = edge_on.any().to(torch.int32).reshape(1)
+    if not video.mono_thres:
+        return None, None
+    avg = est_d.mean(dim=[1, 2])
+    bad = (error_t / avg > video.mono_thres) | error_t.isnan() | (scale_t < 0) | \
+          (valid_d.sum(dim=[1, 2]) < valid_d.shape[1] * valid_d.shape[2] * 0.5)
+    bad_full = torch.zeros(video.disps.shape[0], dtype=torch.bool, device=bad.device)
+    bad_full[:n] = bad
+    edge_on = ~(bad_full[ii] | bad_full[jj])
+    return edge_on, edge_on.any().to(torch.int32).reshape(1)
+
+
+def depth_scale_stage(video, target, weight, eta, ii, jj, itrs, lm, ep, fused=True):
+    """returns `success` like DepthVideo.dspo(opt_type='depth_scale')"""
+    n = video.counter.value
+    if fused and video.disps.is_cuda and n > 0:
+        from . import droid_backends
+        mv = video.cfg['tracking']['multiview_filter']
+        edge_on, any_on = droid_backends.dspo_prepare(
+            video.poses, video.disps, video.intrinsics[0].contiguous(), video.mono_disps, n, mv['thresh'],
+            mv['visible_num'], video.mono_thres, ii.contiguous(), jj.contiguous(), video.valid_depth_mask_small,
+            video.depth_scale, video.depth_shift)
+        if not video.mono_thres:
+            edge_on = None
+    else:
+        edge_on, any_on = _prepare_torch(video, n, ii, jj)
+    if edge_on is not None:
         shard = getattr(video, "shard", None)
         if shard is not None and shard["world"] > 1:
             # the fallback decision must be identical on every rank (it selects a collective path)

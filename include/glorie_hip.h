@@ -281,6 +281,20 @@ int glorie_dspo_scale_shift(glorie_ctx* ctx, const float* poses, float* disps,
                             int w, int iterations, float lm, float ep, float alpha, float* dz_out,
                             void* stream);
 
+/* Preparation of the depth_scale stage in 4 launches (depth_video.py:228-247,326-361,
+ * common.py:401-437): two-view validity mask of frames [0,n) at BA resolution (threshold
+ * mv_thresh * mean depth, >= visible_num consistent neighbours, depth < 3 * nanmedian), per-frame
+ * least-squares scale/shift of mono_disps onto disps under that mask, and the mono_thres filter:
+ * bad(f) = err/mean(disp) > mono_thres | isnan(err) | scale < 0 | valid pixels < HW/2;
+ * edge_on[e] = !(bad[ii[e]] | bad[jj[e]]); *any_on = any(edge_on).  mono_thres <= 0 disables the
+ * filter (all edges on).  Outputs: valid_mask [n,h,w] bytes, scales/shifts [n], edge_on [N] bytes,
+ * any_on device int.  scratch: >= n*h*w*4 + n*32 + 64 bytes.  No host synchronisation. */
+int glorie_dspo_prepare(const float* poses, const float* disps, const float* intrinsics,
+                        const float* mono_disps, int B, int n, int h, int w, float mv_thresh,
+                        int visible_num, float mono_thres, const int64_t* ii, const int64_t* jj, int N,
+                        uint8_t* valid_mask, float* scales, float* shifts, uint8_t* edge_on,
+                        int* any_on, void* scratch, void* stream);
+
 /* ------------------------------------------------------------------------------------ */
 /* C. neural point cloud renderer                                                        */
 /* ------------------------------------------------------------------------------------ */

@@ -92,3 +92,45 @@ def test_stage2_failure_zeroes_all_scale_updates(gpu):
                                            g["intrinsics"], g["ii"], g["jj"], g["mono"], g["scales"],
                                            g["shifts"], g["vmask"], lm=-3.0, ep=-1.0)
     np.testing.assert_allclose(gd, d, rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("mv_thresh,mono_thres", [(0.25, 0.1), (0.05, 0.1), (0.25, 0.0)])
+def test_fused_prepare_matches_reference_formulation(gpu, mv_thresh, mono_thres):
+    """glorie_dspo_prepare (validity mask + nanmedian + least squares + edge filter, 4 launches)
+    against the reference's op-by-op torch formulation on the same video state"""
+    from test_gpu_graph import make_video
+    from glorie_slam_amd import dspo as gdspo
+    res = []
+    for fused in (False, True):
+        g, video = make_video(gpu, 7, 24, 32)
+        video.cfg["tracking"]["multiview_filter"]["thresh"] = mv_thresh
+        video.mono_thres = mono_thres
+        # make two frames "bad": a frame whose mono prior is anti-correlated, and one with holes
+        video.mono_disps[2] = -video.mono_disps[2] + 1.0
+        video.mono_disps[4] += torch.linspace(0, 3, 24 * 32, device=gpu).view(24, 32).sin() * 0.3
+        ii = torch.as_tensor(g["ii"], device=gpu)
+        jj = torch.as_tensor(g["jj"], device=gpu)
+        n = video.counter.value
+        if fused:
+            from glorie_slam_amd import droid_backends as db
+            mv = video.cfg["tracking"]["multiview_filter"]
+            eo, any_on = db.dspo_prepare(video.poses, video.disps, video.intrinsics[0].contiguous(),
+                                         video.mono_disps, n, mv["thresh"], mv["visible_num"], video.mono_thres,
+                                         ii, jj, video.valid_depth_mask_small, video.depth_scale, video.depth_shift)
+            eo = eo.bool()
+        else:
+            eo, any_on = gdspo._prepare_torch(video, n, ii, jj)
+            if eo is None:
+                eo, any_on = torch.ones_like(ii, dtype=torch.bool), torch.ones(1, dtype=torch.int32, device=gpu)
+        res.append((video.valid_depth_mask_small[:n].clone(), video.depth_scale[:n].clone(),
+                    video.depth_shift[:n].clone(), eo.clone(), int(any_on.item())))
+    (m0, s0, t0, e0, a0), (m1, s1, t1, e1, a1) = res
+    assert float((m0 != m1).float().mean()) < 2e-3          # borderline pixels of the fp32 threshold only
+    assert 0.05 < float(m0.float().mean()) < 1.0
+    ok = torch.isfinite(s0)
+    assert torch.equal(ok, torch.isfinite(s1))
+    torch.testing.assert_close(s1[ok], s0[ok], rtol=2e-3, atol=2e-4)
+    torch.testing.assert_close(t1[ok], t0[ok], rtol=2e-3, atol=2e-4)
+    assert torch.equal(e0, e1) and a0 == a1
+    if mono_thres and mv_thresh == 0.25:
+        assert not bool(e0.all()) and bool(e0.any())          # the filter removed some edges, not all
