@@ -178,8 +178,13 @@ class FusedUpdate:
     return values as UpdateModule.forward (droid_net.py:106-139); delta, weight and eta come back
     in float32.  Weights are re-packed whenever a parameter of the source module changes."""
 
-    def __init__(self, module):
+    def __init__(self, module, inplace=False):
+        """inplace: write the new recurrent state over the `net` argument when that already is an
+        fp16 channels-last map (the blend epilogue reads and writes the same element in one lane,
+        and no later kernel reads halo rows of the old state) -- callers that replay the update as
+        a hipGraph keep one persistent state buffer this way"""
         self.src = module
+        self.inplace = inplace
         self._ver = None
         self._hx = None
         self._inp_key = None      # (tensor kept alive, version) whose values sit in the inp slice of hx
@@ -254,7 +259,9 @@ class FusedUpdate:
         # ConvGRU (gru.py:20-34)
         wn = U.conv_igemm(net0, None, W["w"], 1, 128, cl_map(128))
         g = U.gru_glo_terms(wn, W["w_b"], net0, W["G"], W["G_b"])
-        z, rnet, new = cl_map(128), cl_map(128), cl_map(128)
+        z, rnet = cl_map(128), cl_map(128)
+        aliased = net0.data_ptr() == net.data_ptr() and net.dtype == torch.float16
+        new = net0 if (self.inplace and aliased) else cl_map(128)
         U.conv_igemm(net0, hx, W["zr"], 9, 256, z, epilogue=U.EPI_GRU_ZR, terms=g[:, 0:256], net=net0, out2=rnet)
         U.conv_igemm(rnet, hx, W["q"], 9, 128, new, epilogue=U.EPI_GRU_Q, terms=g[:, 256:384], net=net0, z=z)
         net_out = new.view(batch, num, 128, ht, wd)

@@ -51,7 +51,7 @@ class FactorGraph:
         self._graphs = {}                   # (topology, arguments) -> captured update
         # fp16 channels-last form of the update operator with fused element-wise stages
         # (droid_net.FusedUpdate, csrc/gru.hip)
-        self.fast_update = FusedUpdate(update_op) if str(device).startswith("cuda") else None
+        self.fast_update = FusedUpdate(update_op, inplace=self.use_graphs) if str(device).startswith("cuda") else None
 
     def _otf_block(self):
         """volume-free correlation operator over the stored feature maps (corr_impl == 'otf'),
@@ -237,7 +237,8 @@ class FactorGraph:
         self.video.deferred_fallback = False
         with torch.cuda.graph(graph):
             self._update_eager(*args)
-            s_net.copy_(self.net)
+            if self.net.data_ptr() != s_net.data_ptr():     # FusedUpdate(inplace) already wrote s_net
+                s_net.copy_(self.net)
             s_target.copy_(self.target)
             s_weight.copy_(self.weight)
         # the capture did not execute anything: restore the state the caller had
