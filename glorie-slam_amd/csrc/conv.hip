@@ -73,6 +73,7 @@ __device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
 // 3: loads run two steps ahead, counted vmcnt + raw barrier so that they stay in flight across it)
 template <int EPI, int NB, int BK, int NW, int ST>
 __global__ __launch_bounds__(64 * NW, ST == 3 ? 1 : (ST == 1 ? 3 : 2)) void conv_igemm_kernel(ConvArgs a) {
+  constexpr int NST = ST == 4 ? 2 : ST;     // LDS stages (ST = 4: two stages + register-resident fragments)
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (buffer-resource types are device-only)
   constexpr int PT = (NW / 2) * 16 * NB;      // pixels per workgroup
   constexpr int RB = BK * 2;                  // bytes per staged row
@@ -190,11 +191,15 @@ __global__ __launch_bounds__(64 * NW, ST == 3 ? 1 : (ST == 1 ? 3 : 2)) void conv
   const int wbase = XBYTES + wm * 64 * RB, xbase_l = wn * (16 * NB) * RB;
 
   stage(0, 0);
-  if (ST == 3 && T > 1) stage(1, 1);
+  if ((ST == 3 || ST == 4) && T > 1) stage(1, 1);
   int cur = 0;                                 // LDS stage holding tile t
   for (int t = 0; t < T; ++t) {
     if (ST == 1) {
       __syncthreads();                         // tile t landed
+    } else if (ST == 4) {
+      if (t + 1 < T) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XI + WI) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
     } else if (ST == 2) {
       __syncthreads();                         // tile t landed (vmcnt(0) + barrier); the other buffer is free
     } else {
@@ -223,6 +228,11 @@ __global__ __launch_bounds__(64 * NW, ST == 3 ? 1 : (ST == 1 ? 3 : 2)) void conv
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       if (t + 1 < T) stage(t + 1, 0);
+    } else if (ST == 4) {
+      // as ST = 1 but with two stages: the freed stage receives tile t+2, so a DMA has two steps to land
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (t + 2 < T) stage(t + 2, cur);
     } else if (ST == 2) {
       if (t + 1 < T) stage(t + 1, cur ^ 1);
     } else {
@@ -235,7 +245,7 @@ __global__ __launch_bounds__(64 * NW, ST == 3 ? 1 : (ST == 1 ? 3 : 2)) void conv
 #pragma unroll
         for (int ni = 0; ni < NB; ++ni)
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kk][mi], xf[kk][ni], acc[mi][ni], 0, 0, 0);
-    if (ST > 1) cur = (cur + 1 == ST) ? 0 : cur + 1;
+    if (NST > 1) cur = (cur + 1 == NST) ? 0 : cur + 1;
   }
 
   // ---- epilogue: lane owns channels n0 + wm*64 + mi*16 + kg*4 .. +3 of pixel p0 + wn*16*NB + ni*16 + col ----
@@ -297,7 +307,7 @@ __global__ __launch_bounds__(64 * NW, ST == 3 ? 1 : (ST == 1 ? 3 : 2)) void conv
 template <int EPI, int NB, int BK, int NW, int ST>
 static void launch_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
   constexpr int RB = BK * 2, PT = (NW / 2) * 16 * NB;
-  constexpr size_t lds = (size_t)ST * (PT * RB + kTileN * RB);
+  constexpr size_t lds = (size_t)(ST == 4 ? 2 : ST) * (PT * RB + kTileN * RB);
   static bool attr = false;            // > 64 KB of dynamic LDS needs the opt-in once per kernel
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<EPI, NB, BK, NW, ST>),
@@ -357,7 +367,9 @@ extern "C" int glorie_conv_igemm(const void* xa, int xa_stride, int ca, const vo
     return GLORIE_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   // Measured on the update operator's layers at 36x60x80 (tools/bench_conv.py): the single-stage
-  // 128x128 tile at 3 workgroups per CU beats the double-buffered variants (2 per CU: 930, 8 waves
-  // with a 3-stage ring and counted vmcnt: 830, 256-pixel tiles: 850 TFLOP/s on the 448->256 layer).
+  // 128x128 tile at 3 workgroups per CU (1050 TFLOP/s on the 448->256 layer) beats every variant with
+  // more LDS stages and fewer resident workgroups: 2 stages 930, 2 stages + register-resident fragments
+  // (loads two steps ahead, ST = 4) 915, 8 waves with a 3-stage ring and counted vmcnt 830, 256-pixel
+  // tiles 850.
   return launch_conv<4, 64, 4, 1>(a, epilogue, st);
 }
