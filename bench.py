@@ -416,7 +416,7 @@ def main():
                      "achieved": conv_tf, "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s",
                      "frac": conv_tf / MFMA_F16_PEAK_TF, "traffic": conv_traffic if full else None,
                      "flops_per_launch": conv_flops, "ms_per_launch": conv_ms},
-        "roofline_corr": {"bound": "hbm", "kernel": "corr_lookup_r3_v2_kernel<f16>",
+        "roofline_corr": {"bound": "hbm", "kernel": "corr_lookup_r3_tiled_kernel (fp16, 4x8-tiled pyramid)",
                           "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": achieved / HBM_PEAK_GBS, "traffic": corr_traffic if full else None,
                           "alg_bytes_per_launch": alg_bytes, "ms_per_launch": corr_ms},

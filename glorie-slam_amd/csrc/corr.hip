@@ -264,6 +264,106 @@ __global__ __launch_bounds__(256) void corr_lookup_r3_v2_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------
+// v3: the v2 lane mapping on a TILED pyramid.  Each plane is stored as 4-row x 8-column blocks of
+// 64 bytes ([ceil(h2/4)][ceil(w2/8)][4][8] halfs, zero padded): the 8x8 window of a pixel then touches
+// 5.2 of the 64-byte HBM sectors on average instead of 8 rows x 1.2 sectors (the per-pixel planes
+// share nothing between neighbouring pixels, so the over-fetch of a row-major plane is structural:
+// 4.3x the useful bytes, profiles/r01_pmc_kernels.json).  A window row lives in two horizontally
+// adjacent blocks; the lane issues one unaligned 16-byte load into each (at +sh and +sh-8 halfs of
+// the block row, sh = window start mod 8; the bytes outside the block row are masked off, the
+// padding columns hold zeros) and merges them with a bit-field insert -- no per-tap fallback path.
+// Arithmetic identical to v1/v2 (bit-exact fp16).  The volume needs 16 bytes of readable slack on
+// either side (a plane is >= 256 bytes: the Python side allocates one spare plane before and after).
+// ------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+__global__ __launch_bounds__(256) void corr_lookup_r3_tiled_kernel(
+    CorrLevels lv, int num_levels, const float* __restrict__ coords, _Float16* __restrict__ out,
+    int HW, int out_channels) {
+  typedef _Float16 T;
+  constexpr int R = 3, RD = 7, WIN = 8, PG = 8;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int row = lane & 7, grp = lane >> 3;
+  const int n = blockIdx.y;
+  const int pb = (blockIdx.x * 4 + wv) * 64 + grp * PG;   // first pixel of this lane's group
+  const bool live = pb < HW;                              // HW % 8 == 0: groups are all-or-nothing
+  const int pc = live ? pb : HW - PG;
+
+  float x0[PG], y0[PG];
+  {
+    const float4* cx = reinterpret_cast<const float4*>(coords + ((size_t)n * 2 + 0) * HW + pc);
+    const float4* cy = reinterpret_cast<const float4*>(coords + ((size_t)n * 2 + 1) * HW + pc);
+    const float4 a = cx[0], b = cx[1], c = cy[0], d = cy[1];
+    x0[0] = a.x; x0[1] = a.y; x0[2] = a.z; x0[3] = a.w; x0[4] = b.x; x0[5] = b.y; x0[6] = b.z; x0[7] = b.w;
+    y0[0] = c.x; y0[1] = c.y; y0[2] = c.z; y0[3] = c.w; y0[4] = d.x; y0[5] = d.y; y0[6] = d.z; y0[7] = d.w;
+  }
+  float inv = 1.0f;
+  for (int l = 0; l < num_levels; ++l) {
+    const int h2 = lv.h2[l], w2 = lv.w2[l];
+    const int nbx = (w2 + 7) >> 3, nby = (h2 + 3) >> 2;
+    const size_t plane = (size_t)nbx * nby * 32;           // halfs per tiled plane
+    const T* vol = reinterpret_cast<const T*>(lv.vol[l]);
+    u32x4 la[PG], lb[PG];
+    int shs[PG], oka[PG], okb[PG];
+    float dxs[PG], dys[PG];
+    // phase 1: issue the 16 loads of this lane (2 per pixel of the group)
+#pragma unroll
+    for (int q = 0; q < PG; ++q) {
+      const float xs = x0[q] * inv, ys = y0[q] * inv;
+      const float fx = floorf(xs), fy = floorf(ys);
+      dxs[q] = xs - fx;
+      dys[q] = ys - fy;
+      const int ix0 = static_cast<int>(fx) - R;
+      const int y1 = static_cast<int>(fy) - R + row;
+      const bool yok = y1 >= 0 && y1 < h2;
+      const int bx0 = ix0 >> 3, sh = ix0 & 7;               // floor division / modulo for negative starts too
+      const bool va = yok && bx0 >= 0 && bx0 < nbx;
+      const bool vb = yok && sh > 0 && bx0 + 1 >= 0 && bx0 + 1 < nbx;
+      const int yc = yok ? y1 : 0;
+      const T* base = vol + ((size_t)n * HW + pc + q) * plane + ((size_t)(yc >> 2) * nbx) * 32 + (yc & 3) * 8;
+      const T* pa = base + (va ? bx0 * 32 + sh : 0);
+      const T* pbk = base + (vb ? (bx0 + 1) * 32 + sh - 8 : 0);
+      __builtin_memcpy(&la[q], pa, 16);
+      __builtin_memcpy(&lb[q], pbk, 16);
+      shs[q] = sh; oka[q] = va; okb[q] = vb;
+    }
+    inv *= 0.5f;
+    // phase 2: merge the two block rows, blend and store, one 16-byte store per output channel
+    Out8<T> o[RD];
+#pragma unroll
+    for (int q = 0; q < PG; ++q) {
+      const int cnt = 8 - shs[q];                         // taps served by block A: halfs [0, cnt)
+      u32x4 sv;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int t = cnt - 2 * k;
+        const unsigned m = t >= 2 ? 0xffffffffu : (t == 1 ? 0x0000ffffu : 0u);
+        const unsigned a = oka[q] ? la[q][k] : 0u, b = okb[q] ? lb[q][k] : 0u;
+        sv[k] = (a & m) | (b & ~m);
+      }
+      T sq[WIN];
+      __builtin_memcpy(sq, &sv, 16);
+      T nx[WIN];
+      Pack8<T>::next(sq, nx);
+      const float dx = dxs[q], dy = dys[q];
+      const T w00 = weight_cast<T>((1.0f - dx) * (1.0f - dy));
+      const T w01 = weight_cast<T>((1.0f - dx) * dy);
+      const T w10 = weight_cast<T>(dx * (1.0f - dy));
+      const T w11 = weight_cast<T>(dx * dy);
+#pragma unroll
+      for (int i = 0; i < RD; ++i)
+        o[i].v[q] = blend4(sq[i], nx[i], sq[i + 1], nx[i + 1], w00, w01, w10, w11);
+    }
+    if (live && row < RD) {
+      T* op = out + ((size_t)n * out_channels + (size_t)l * RD * RD + row) * HW + pb;
+#pragma unroll
+      for (int i = 0; i < RD; ++i)
+        *reinterpret_cast<Out8<T>*>(op + (size_t)i * RD * HW) = o[i];
+    }
+  }
+}
+
 // generic-radius fallback: one thread per pixel, same arithmetic order.
 template <typename T>
 __global__ __launch_bounds__(256) void corr_lookup_generic_kernel(
@@ -363,4 +463,26 @@ extern "C" int glorie_corr_lookup_pyramid(const void* const* volumes, int num_le
   if (dtype == GLORIE_F32)
     return launch_lookup<float>(lv, num_levels, 1, coords, out, N, h1 * w1, radius, st);
   return GLORIE_EUNSUPPORTED;
+}
+
+extern "C" int glorie_corr_lookup_pyramid_tiled(const void* const* volumes, int num_levels,
+                                                const float* coords, void* out, int N, int h1, int w1,
+                                                int h2, int w2, void* stream) {
+  if (num_levels < 1 || num_levels > kMaxLevels || N < 0 || h1 < 0 || w1 < 0) return GLORIE_EINVAL;
+  const int HW = h1 * w1;
+  if (N == 0 || HW == 0) return GLORIE_OK;
+  if (!volumes || !coords || !out) return GLORIE_EINVAL;
+  if (HW % 8 || (reinterpret_cast<uintptr_t>(out) & 15) || (reinterpret_cast<uintptr_t>(coords) & 15))
+    return GLORIE_EUNSUPPORTED;
+  CorrLevels lv{};
+  for (int l = 0; l < num_levels; ++l) {
+    if (!volumes[l]) return GLORIE_EINVAL;
+    lv.vol[l] = volumes[l];
+    lv.h2[l] = h2 >> l;
+    lv.w2[l] = w2 >> l;
+  }
+  dim3 grid((HW + 255) / 256, N);
+  hipLaunchKernelGGL(corr_lookup_r3_tiled_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     lv, num_levels, coords, reinterpret_cast<_Float16*>(out), HW, num_levels * 49);
+  return check_launch();
 }

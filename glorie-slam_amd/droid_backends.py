@@ -63,6 +63,40 @@ def corr_lookup_pyramid(pyramid, coords, radius):
     return out
 
 
+def tile_corr_level(vol):
+    """[P, h2, w2] fp16 plane stack -> tiled [P, ceil(h2/4)*ceil(w2/8)*32] (64-byte blocks of 4 rows x
+    8 columns, zero padded), allocated with one spare plane on either side (read slack of the
+    unaligned block-row loads of the tiled lookup kernel)"""
+    P, h2, w2 = vol.shape
+    nby, nbx = (h2 + 3) // 4, (w2 + 7) // 8
+    store = torch.zeros((P + 2, nby, nbx, 4, 8), dtype=vol.dtype, device=vol.device)
+    padded = torch.nn.functional.pad(vol, (0, nbx * 8 - w2, 0, nby * 4 - h2))
+    store[1:P + 1] = padded.view(P, nby, 4, nbx, 8).permute(0, 1, 3, 2, 4)
+    return store.view(P + 2, -1)[1:P + 1]
+
+
+def corr_lookup_pyramid_tiled(pyramid, coords, h2, w2):
+    """CorrBlock.__call__ body on tiled levels (see tile_corr_level): pyramid = list of
+    [N*h1*w1, plane_l] fp16, coords [N,2,h1,w1] f32 UNscaled -> [N, L*49, h1, w1]; bit-identical to
+    corr_lookup_pyramid on the row-major volumes."""
+    L.need_cuda(coords, *pyramid)
+    N, _, h1, w1 = coords.shape
+    nl = len(pyramid)
+    for l, v in enumerate(pyramid):
+        nby, nbx = ((h2 >> l) + 3) // 4, ((w2 >> l) + 7) // 8
+        if v.dtype != torch.float16 or v.dim() != 2 or v.shape[0] != N * h1 * w1 or v.shape[1] != nby * nbx * 32 \
+                or v.stride(1) != 1 or v.stride(0) != v.shape[1]:
+            raise RuntimeError(f"tiled pyramid level {l} has shape {tuple(v.shape)}")
+    if not coords.is_contiguous() or coords.dtype != torch.float32:
+        raise RuntimeError("coords must be contiguous float32")
+    out = torch.empty((N, nl * 49, h1, w1), dtype=torch.float16, device=coords.device)
+    arr = (ctypes.c_void_p * nl)(*[v.data_ptr() for v in pyramid])
+    L.check(L.load().glorie_corr_lookup_pyramid_tiled(ctypes.cast(arr, ctypes.c_void_p), nl, L.ptr(coords),
+                                                      L.ptr(out), N, h1, w1, h2, w2, L.stream_ptr()),
+            "glorie_corr_lookup_pyramid_tiled")
+    return out
+
+
 def corr_index_backward(volume, coords, corr_grad, radius):
     raise NotImplementedError("corr_index_backward: training-only; the SLAM hot path runs under "
                               "no_grad (factor_graph.py:213)")

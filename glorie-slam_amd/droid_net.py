@@ -296,17 +296,29 @@ class CorrBlock:
     """All-pairs correlation pyramid + windowed lookup (corr.py:25-76).
 
     The pyramid is built with torch (fp16 GEMM under autocast, like the reference) and kept
-    per edge; the lookup of all 4 levels + the channel concatenation is one HIP launch."""
+    per edge; the lookup of all 4 levels + the channel concatenation is one HIP launch.
 
-    def __init__(self, fmap1, fmap2, num_levels=4, radius=3):
+    tiled (default on CUDA for radius 3): every plane is re-stored once, at construction, as 64-byte
+    blocks of 4 rows x 8 columns (droid_backends.tile_corr_level) and looked up by the tiled kernel:
+    same values bit for bit, 35 % less HBM traffic per lookup.  `corr_pyramid` then holds
+    [N*h1*w1, plane_l] tensors instead of the reference's [N, h1, w1, h2>>l, w2>>l]."""
+
+    def __init__(self, fmap1, fmap2, num_levels=4, radius=3, tiled=None):
         self.num_levels = num_levels
         self.radius = radius
         corr = CorrBlock.corr(fmap1, fmap2)
         batch, num, h1, w1, h2, w2 = corr.shape
+        self.dims = (h1, w1, h2, w2)
+        if tiled is None:
+            tiled = corr.is_cuda and radius == 3 and (h1 * w1) % 8 == 0 and corr.dtype == torch.float16
+        self.tiled = bool(tiled)
         corr = corr.reshape(batch * num * h1 * w1, 1, h2, w2)
         self.corr_pyramid = []
         for i in range(num_levels):
-            self.corr_pyramid.append(corr.view(batch * num, h1, w1, h2 // 2 ** i, w2 // 2 ** i))
+            if self.tiled:
+                self.corr_pyramid.append(droid_backends.tile_corr_level(corr[:, 0]))
+            else:
+                self.corr_pyramid.append(corr.view(batch * num, h1, w1, h2 // 2 ** i, w2 // 2 ** i))
             if i + 1 < num_levels:
                 corr = F.avg_pool2d(corr, kernel_size=2, stride=2)
 
@@ -320,16 +332,40 @@ class CorrBlock:
     def __call__(self, coords):
         batch, num, ht, wd, _ = coords.shape
         c = coords.permute(0, 1, 4, 2, 3).contiguous().view(batch * num, 2, ht, wd).float()
-        pyr = [v if v.is_contiguous() else v.contiguous() for v in self.corr_pyramid]
-        out = droid_backends.corr_lookup_pyramid(pyr, c, self.radius)
+        if self.tiled:
+            out = droid_backends.corr_lookup_pyramid_tiled(self.corr_pyramid, c, self.dims[2], self.dims[3])
+        else:
+            pyr = [v if v.is_contiguous() else v.contiguous() for v in self.corr_pyramid]
+            out = droid_backends.corr_lookup_pyramid(pyr, c, self.radius)
         return out.view(batch, num, -1, ht, wd)
 
+    @staticmethod
+    def _with_slack(rows):
+        """copy a list of [P_i, plane] tensors into one allocation with a spare plane on either side"""
+        total = sum(r.shape[0] for r in rows)
+        store = torch.zeros((total + 2, rows[0].shape[1]), dtype=rows[0].dtype, device=rows[0].device)
+        at = 1
+        for r in rows:
+            store[at:at + r.shape[0]] = r
+            at += r.shape[0]
+        return store[1:total + 1]
+
     def cat(self, other):
-        self.corr_pyramid = [torch.cat([a, b], 0) for a, b in zip(self.corr_pyramid, other.corr_pyramid)]
+        if self.tiled != other.tiled:
+            raise RuntimeError("cannot concatenate tiled and row-major correlation pyramids")
+        if self.tiled:
+            self.corr_pyramid = [self._with_slack([a, b]) for a, b in zip(self.corr_pyramid, other.corr_pyramid)]
+        else:
+            self.corr_pyramid = [torch.cat([a, b], 0) for a, b in zip(self.corr_pyramid, other.corr_pyramid)]
         return self
 
     def __getitem__(self, index):
-        self.corr_pyramid = [v[index] for v in self.corr_pyramid]
+        if self.tiled:
+            hw = self.dims[0] * self.dims[1]
+            self.corr_pyramid = [self._with_slack([v.view(-1, hw, v.shape[1])[index].reshape(-1, v.shape[1])])
+                                 for v in self.corr_pyramid]
+        else:
+            self.corr_pyramid = [v[index] for v in self.corr_pyramid]
         return self
 
 

@@ -70,6 +70,44 @@ def test_corr_lookup_pyramid_bit_exact(gpu):
     assert np.array_equal(got.view(np.uint16), ref.view(np.uint16))
 
 
+@pytest.mark.parametrize("N,h,w,margin", [(2, 30, 40, 5.0), (3, 24, 32, 12.0), (1, 60, 80, 3.0), (2, 12, 14, 20.0)])
+def test_corr_lookup_tiled_bit_exact(gpu, N, h, w, margin):
+    """tiled pyramid (64-byte 4x8 blocks) == row-major pyramid == oracle, incl. windows that leave the
+    map on every side and level planes whose size is not a multiple of the block (7x10, 3x3, ...)"""
+    from glorie_slam_amd import droid_backends as db
+    rng = np.random.default_rng(11)
+    levels = [rng.standard_normal((N, h, w, h >> l, w >> l)).astype(np.float16) for l in range(4)]
+    coords = _coords(rng, N, h, w, h, w, margin=margin)
+    coords[0, :, 0, :4] = np.array([[-3.0, -2.5, 0.0, w - 0.25], [-3.0, 0.49, h + 2.0, h - 1.0]], np.float32)
+    vols = [torch.from_numpy(v).to(gpu) for v in levels]
+    ct = torch.from_numpy(coords).to(gpu)
+    plain = db.corr_lookup_pyramid(vols, ct, 3)
+    tiled = [db.tile_corr_level(v.view(N * h * w, h >> l, w >> l)) for l, v in enumerate(vols)]
+    got = db.corr_lookup_pyramid_tiled(tiled, ct, h, w)
+    assert torch.equal(got.view(torch.int16), plain.view(torch.int16))
+    if N * h * w <= 2400:
+        ref = ocorr.corr_lookup_pyramid(levels, coords, 3)
+        assert np.array_equal(got.cpu().numpy().view(np.uint16), ref.view(np.uint16))
+
+
+def test_corrblock_tiled_cat_and_index(gpu):
+    """CorrBlock in tiled mode: construction, cat, boolean indexing keep the lookup identical to the
+    row-major block"""
+    from glorie_slam_amd.droid_net import CorrBlock
+    g = torch.Generator(device="cpu").manual_seed(5)
+    f1 = torch.randn(1, 5, 128, 16, 24, generator=g).to(gpu).half()
+    f2 = torch.randn(1, 5, 128, 16, 24, generator=g).to(gpu).half()
+    coords = torch.rand(1, 5, 16, 24, 2, generator=g).to(gpu) * torch.tensor([30.0, 20.0], device=gpu) - 3.0
+    a = CorrBlock(f1, f2, tiled=False)
+    b = CorrBlock(f1, f2)
+    assert b.tiled and not a.tiled
+    assert torch.equal(a(coords), b(coords))
+    b2 = CorrBlock(f1[:, :3], f2[:, :3]).cat(CorrBlock(f1[:, 3:], f2[:, 3:]))
+    assert torch.equal(a(coords), b2(coords))
+    keep = torch.tensor([True, False, True, True, False], device=gpu)
+    assert torch.equal(a[keep](coords[:, keep]), b[keep](coords[:, keep]))
+
+
 def test_corr_empty_and_noncontiguous(gpu):
     from glorie_slam_amd import droid_backends as db
     vol = torch.zeros(0, 4, 4, 4, 4, dtype=torch.float16, device=gpu)
