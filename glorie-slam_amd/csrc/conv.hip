@@ -71,8 +71,9 @@ __device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
 // NB = 16-pixel blocks per wave, BK = channels per K step (32 | 64), NW = waves (2 channel halves x
 // NW/2 pixel groups: pixel tile = NW/2 * 16*NB), ST = LDS stages (2: one __syncthreads per step;
 // 3: loads run two steps ahead, counted vmcnt + raw barrier so that they stay in flight across it)
-template <int EPI, int NB, int BK, int NW, int ST>
+template <int EPI, int NB, int BK, int NW, int ST, int MB = 4>
 __global__ __launch_bounds__(64 * NW, ST == 3 ? 1 : (ST == 1 ? 3 : 2)) void conv_igemm_kernel(ConvArgs a) {
+  constexpr int TN = 32 * MB;               // output channels per workgroup (MB 16-channel blocks per wave)
   constexpr int NST = ST == 4 ? 2 : ST;     // LDS stages (ST = 4: two stages + register-resident fragments)
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (buffer-resource types are device-only)
   constexpr int PT = (NW / 2) * 16 * NB;      // pixels per workgroup
@@ -80,8 +81,8 @@ __global__ __launch_bounds__(64 * NW, ST == 3 ? 1 : (ST == 1 ? 3 : 2)) void conv
   constexpr int SL = RB / 16;                 // 16-byte slots per row
   constexpr int RPI = 64 / SL;                // rows per wave-wide DMA instruction
   constexpr int XI = PT / RPI / NW;           // DMA instructions per wave per step: pixel tile
-  constexpr int WI = kTileN / RPI / NW;       //                                      weight tile
-  constexpr int XBYTES = PT * RB, WBYTES = kTileN * RB;
+  constexpr int WI = TN / RPI / NW;           //                                      weight tile
+  constexpr int XBYTES = PT * RB, WBYTES = TN * RB;
   constexpr int KK = BK / 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // ST x (pixel tile, weight tile), one array
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -93,12 +94,12 @@ __global__ __launch_bounds__(64 * NW, ST == 3 ? 1 : (ST == 1 ? 3 : 2)) void conv
   auto key = [](int row) { return RB == 128 ? (row & 7) : ((row >> 1) & 3); };
 
   // XCD-aware (bijective) remap of the workgroup id, then (pixel tile, output-channel tile)
-  const int nwg = gridDim.x, ntn = a.npad / kTileN;
+  const int nwg = gridDim.x, ntn = (a.nout + TN - 1) / TN;
   const int xcd = blockIdx.x & 7, q = nwg >> 3, r = nwg & 7;
   const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
   const int pt = lid / ntn, nt = lid - pt * ntn;
   const long p0 = (long)pt * PT;
-  const int n0 = nt * kTileN;
+  const int n0 = nt * TN;
 
   const int cpc = 64 / BK;                    // K steps per 64-channel chunk
   const int nsteps_tap = (a.cha + a.chb) * cpc;
@@ -178,9 +179,9 @@ __global__ __launch_bounds__(64 * NW, ST == 3 ? 1 : (ST == 1 ? 3 : 2)) void conv
           (__attribute__((address_space(3))) void*)(lw + (i * NW + wv) * RPI * RB), 16, woff[i], wsoff, 0, 0);
   };
 
-  f32x4 acc[4][NB];
+  f32x4 acc[MB][NB];
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
+  for (int mi = 0; mi < MB; ++mi)
 #pragma unroll
     for (int ni = 0; ni < NB; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(64 * NW, ST == 3 ? 1 : (ST == 1 ? 3 : 2)) void conv
   int foff[KK];
 #pragma unroll
   for (int kk = 0; kk < KK; ++kk) foff[kk] = col * RB + (((kk * 4 + kg) ^ key(col)) << 4);
-  const int wbase = XBYTES + wm * 64 * RB, xbase_l = wn * (16 * NB) * RB;
+  const int wbase = XBYTES + wm * (16 * MB) * RB, xbase_l = wn * (16 * NB) * RB;
 
   stage(0, 0);
   if ((ST == 3 || ST == 4) && T > 1) stage(1, 1);
@@ -212,11 +213,11 @@ __global__ __launch_bounds__(64 * NW, ST == 3 ? 1 : (ST == 1 ? 3 : 2)) void conv
     const char* base = smem + cur * (XBYTES + WBYTES);
     // all fragment reads of the step go out first (one exposed LDS latency per step, not per kk), the
     // DMA of the next tile is issued in their shadow, then the MFMAs run back to back
-    f16x8 wf[KK][4], xf[KK][NB];
+    f16x8 wf[KK][MB], xf[KK][NB];
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk) {
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
+      for (int mi = 0; mi < MB; ++mi)
         wf[kk][mi] = *reinterpret_cast<const f16x8*>(base + wbase + mi * 16 * RB + foff[kk]);
 #pragma unroll
       for (int ni = 0; ni < NB; ++ni)
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(64 * NW, ST == 3 ? 1 : (ST == 1 ? 3 : 2)) void conv
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
+      for (int mi = 0; mi < MB; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NB; ++ni)
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kk][mi], xf[kk][ni], acc[mi][ni], 0, 0, 0);
@@ -255,8 +256,8 @@ __global__ __launch_bounds__(64 * NW, ST == 3 ? 1 : (ST == 1 ? 3 : 2)) void conv
     if (p >= a.P) continue;
     const int e = (int)(p / a.HW);
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-      const int n = n0 + wm * 64 + mi * 16 + kg * 4;
+    for (int mi = 0; mi < MB; ++mi) {
+      const int n = n0 + wm * (16 * MB) + mi * 16 + kg * 4;
       if (n >= a.nout) continue;
       const f32x4 v = acc[mi][ni];
       f16x4 o;
@@ -304,30 +305,30 @@ __global__ __launch_bounds__(64 * NW, ST == 3 ? 1 : (ST == 1 ? 3 : 2)) void conv
 #endif
 }
 
-template <int EPI, int NB, int BK, int NW, int ST>
+template <int EPI, int NB, int BK, int NW, int ST, int MB>
 static void launch_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
   constexpr int RB = BK * 2, PT = (NW / 2) * 16 * NB;
-  constexpr size_t lds = (size_t)(ST == 4 ? 2 : ST) * (PT * RB + kTileN * RB);
+  constexpr size_t lds = (size_t)(ST == 4 ? 2 : ST) * (PT * RB + 32 * MB * RB);
   static bool attr = false;            // > 64 KB of dynamic LDS needs the opt-in once per kernel
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<EPI, NB, BK, NW, ST>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<EPI, NB, BK, NW, ST, MB>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<EPI, NB, BK, NW, ST>), grid, dim3(64 * NW), lds, st, a);
+  hipLaunchKernelGGL((conv_igemm_kernel<EPI, NB, BK, NW, ST, MB>), grid, dim3(64 * NW), lds, st, a);
 }
 
-template <int NB, int BK, int NW, int ST>
+template <int NB, int BK, int NW, int ST, int MB = 4>
 static int launch_conv(const ConvArgs& a, int epilogue, hipStream_t st) {
   constexpr int PT = (NW / 2) * 16 * NB;
   const long ptiles = (a.P + PT - 1) / PT;
-  const long nwg = ptiles * (a.npad / kTileN);
+  const long nwg = ptiles * ((a.nout + 32 * MB - 1) / (32 * MB));
   if (nwg > 0x7fffffffL) return GLORIE_EINVAL;
   const dim3 grid((unsigned)nwg);
   switch (epilogue) {
-    case EPI_BIAS_ACT: launch_one<EPI_BIAS_ACT, NB, BK, NW, ST>(a, grid, st); break;
-    case EPI_GRU_ZR: launch_one<EPI_GRU_ZR, NB, BK, NW, ST>(a, grid, st); break;
-    default: launch_one<EPI_GRU_Q, NB, BK, NW, ST>(a, grid, st); break;
+    case EPI_BIAS_ACT: launch_one<EPI_BIAS_ACT, NB, BK, NW, ST, MB>(a, grid, st); break;
+    case EPI_GRU_ZR: launch_one<EPI_GRU_ZR, NB, BK, NW, ST, MB>(a, grid, st); break;
+    default: launch_one<EPI_GRU_Q, NB, BK, NW, ST, MB>(a, grid, st); break;
   }
   return check_launch();
 }
@@ -371,5 +372,7 @@ extern "C" int glorie_conv_igemm(const void* xa, int xa_stride, int ca, const vo
   // more LDS stages and fewer resident workgroups: 2 stages 930, 2 stages + register-resident fragments
   // (loads two steps ahead, ST = 4) 915, 8 waves with a 3-stage ring and counted vmcnt 830, 256-pixel
   // tiles 850.
+  // layers with <= 64 output channels (flow_encoder[2]) use a 64-channel tile instead of padding to 128
+  if (nout <= 64 && epilogue == EPI_BIAS_ACT) return launch_conv<4, 64, 4, 1, 2>(a, epilogue, st);
   return launch_conv<4, 64, 4, 1>(a, epilogue, st);
 }
