@@ -185,6 +185,11 @@ class FusedUpdate:
         a hipGraph keep one persistent state buffer this way"""
         self.src = module
         self.inplace = inplace
+        # flow encoder / global context on side streams: the branches do overlap (3 hardware queues in the
+        # trace) but every kernel involved is throughput-bound and slows down accordingly -- measured
+        # 2 % slower per step in an interleaved A/B, so it stays off
+        self.parallel = False
+        self._streams = None
         self._ver = None
         self._hx = None
         self._inp_key = None      # (tensor kept alive, version) whose values sit in the inp slice of hx
@@ -227,8 +232,15 @@ class FusedUpdate:
         b, n, c, h, w = t.shape
         return t.reshape(b * n, c, h, w).half().contiguous(memory_format=torch.channels_last)
 
+    def _side_streams(self, dev):
+        if self._streams is None or self._streams[0].device != dev:
+            self._streams = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+        return self._streams
+
     @torch.no_grad()
     def __call__(self, net, inp, corr, flow=None, ii=None, jj=None, groups=None):
+        """corr: the looked-up correlation features [1,N,196,h,w], or a callable returning them (it is
+        invoked on the caller's stream after the independent branches were forked)"""
         from . import update_ops as U
         self._sync()
         W = self.W
@@ -242,23 +254,39 @@ class FusedUpdate:
             self._inp_key = None
         hx = self._hx
         net0 = self._cl(net)
-        if self._inp_key is None or self._inp_key[0] is not inp or self._inp_key[1] != inp._version:
-            U.bias_act(self._cl(inp), None, U.ACT_NONE, out=hx[:, 0:128])
-            self._inp_key = (inp, inp._version)
+        # Three independent producers feed the GRU: the corr encoder (main stream, after the lookup), the
+        # flow encoder and the global-context terms.  With self.parallel the latter two run on side
+        # streams (parallel branches under hipGraph capture); see __init__ for why that is off.
+        main = torch.cuda.current_stream(dev)
+        side = self._side_streams(dev) if self.parallel else (main, main)
+        for st in side:
+            if st is not main:
+                st.wait_stream(main)
+        with torch.cuda.stream(side[0]):
+            # flow_encoder (droid_net.py:79-83)
+            if flow is None:
+                flow = torch.zeros(batch, num, 4, ht, wd, device=dev)
+            fl = flow.reshape(n, 4, ht, wd).permute(0, 2, 3, 1).float().contiguous()   # no copy for a [.., h, w, 4] motion map
+            f1 = U.flow_conv7(fl, W["fe1"], W["fe1_b"], cl_map(128))
+            U.conv_igemm(f1, None, W["fe2"], 9, 64, hx[:, 256:320], terms=W["fe2_b"], act=U.ACT_RELU)
+        with torch.cuda.stream(side[1]):
+            if self._inp_key is None or self._inp_key[0] is not inp or self._inp_key[1] != inp._version:
+                U.bias_act(self._cl(inp), None, U.ACT_NONE, out=hx[:, 0:128])
+                self._inp_key = (inp, inp._version)
+            # global context of the ConvGRU (gru.py:25-31)
+            wn = U.conv_igemm(net0, None, W["w"], 1, 128, cl_map(128))
+            g = U.gru_glo_terms(wn, W["w_b"], net0, W["G"], W["G_b"])
         # corr_encoder (droid_net.py:73-77): 1x1 as a transposed GEMM on the NCHW lookup output
+        if callable(corr):
+            corr = corr()                              # the lookup itself, issued behind the forks
         c1 = torch.matmul(corr.reshape(n, -1, hw).half().transpose(1, 2), W["ce1_t"])
         c1 = c1.view(n, ht, wd, 128).permute(0, 3, 1, 2)
         U.bias_act(c1, W["ce1_b"], U.ACT_RELU)
         U.conv_igemm(c1, None, W["ce2"], 9, 128, hx[:, 128:256], terms=W["ce2_b"], act=U.ACT_RELU)
-        # flow_encoder (droid_net.py:79-83)
-        if flow is None:
-            flow = torch.zeros(batch, num, 4, ht, wd, device=dev)
-        fl = flow.reshape(n, 4, ht, wd).permute(0, 2, 3, 1).float().contiguous()   # no copy for a [.., h, w, 4] motion map
-        f1 = U.flow_conv7(fl, W["fe1"], W["fe1_b"], cl_map(128))
-        U.conv_igemm(f1, None, W["fe2"], 9, 64, hx[:, 256:320], terms=W["fe2_b"], act=U.ACT_RELU)
+        for st in side:
+            if st is not main:
+                main.wait_stream(st)
         # ConvGRU (gru.py:20-34)
-        wn = U.conv_igemm(net0, None, W["w"], 1, 128, cl_map(128))
-        g = U.gru_glo_terms(wn, W["w_b"], net0, W["G"], W["G_b"])
         z, rnet = cl_map(128), cl_map(128)
         aliased = net0.data_ptr() == net.data_ptr() and net.dtype == torch.float16
         new = net0 if (self.inplace and aliased) else cl_map(128)

@@ -256,14 +256,17 @@ class FactorGraph:
         if self.corr_impl == "otf":
             blk = self._otf_block()
             rig = self._otf_rig
-            corr = blk(coords1, rig * self.ii, rig * self.jj + (self.ii == self.jj).long())
+            lookup = lambda: blk(coords1, rig * self.ii, rig * self.jj + (self.ii == self.jj).long())
         else:
-            corr = self.corr(coords1)
+            lookup = lambda: self.corr(coords1)
         uniq = self._unique_ii()
         if self.fast_update is not None:
+            # the lookup is handed over as a callable: FusedUpdate issues it behind the fork of its
+            # independent branches (flow encoder, global context), which then overlap with it
             self.net, delta, weight, damping, upmask = \
-                self.fast_update(self.net, self.inp, corr, motn, self.ii, self.jj, self._groups())
+                self.fast_update(self.net, self.inp, lookup, motn, self.ii, self.jj, self._groups())
         else:
+            corr = lookup()
             with torch.autocast("cuda", enabled=True):
                 self.net, delta, weight, damping, upmask = \
                     self.update_op(self.net, self.inp, corr, motn, self.ii, self.jj)
