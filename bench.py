@@ -6,7 +6,10 @@ keyframe graph G8 of BASELINE.md.
 A "step" is one `FactorGraph.update()` equivalent on graph G8 (8 keyframes, 36 edges, 60x80):
 reproject -> 4-level correlation lookup -> ConvGRU update operator -> dense BA (2 GN
 iterations) -> convex upsampling.  Inputs are resident in HBM before the timed region.
-Prints ONE JSON line (see the driver contract in the task statement).
+With N > 1 GPUs (torch.distributed, one rank per GPU) the graph grows to 6N+2 keyframes = 36N
+edges sharded by source keyframe (weak scaling, `value` in G8-sized updates per second); the
+rendered frame is split N ways.  Prints ONE JSON line (see the driver contract in the task
+statement).
 """
 import argparse
 import json
@@ -264,8 +267,15 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    # Workload.  1 GPU: graph G8 of BASELINE.md (8 keyframes, 36 edges) -- the configuration the metric is
+    # quoted on.  N GPUs: the same sliding-window topology over 6N+2 keyframes = 36N edges, sharded by source
+    # keyframe (36 edges per GPU on average: per-GPU work fixed -> "weak" scaling); one step then is one
+    # BA-update of the whole graph = N G8-sized updates, and `value` counts G8-sized updates per second.
+    # A 1.5 ms step of a 36-edge graph is below the launch + collective floor of any multi-GPU split, the
+    # sharding exists for the long graphs of BASELINE configs 4/5.
+    K_graph = 6 * world + 2
     # single-GPU: the ~100 launches of a step are replayed as a hipGraph (per edge set and stage)
-    g, video, graph = build_graph(device, rank=rank, world=world, use_graphs=(world == 1))
+    g, video, graph = build_graph(device, K=K_graph, rank=rank, world=world, use_graphs=(world == 1))
     K = g["K"]
     poses0, disps0 = video.poses.clone(), video.disps.clone()
     step_no = [0]
@@ -400,18 +410,22 @@ def main():
 
     out = {
         "metric": "DSPO BA-update iters/sec + rendered rays/sec, 640x480 Replica keyframe graph",
-        "value": args.steps / elapsed,
+        "value": world * args.steps / elapsed,
         "unit": "BA-update iters/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f16 corr/ConvGRU, f32 Jacobians, f64 solve", "data": "synthetic",
-        "config": {"workload": "G8: 8 keyframes, 36 edges, 60x80 (640x480/8), BA itrs=2, DSPO stages "
-                               "alternating; render: 524k-point cloud, one 640x480 view, 10 samples/ray",
+        "config": {"workload": (f"G8: 8 keyframes, 36 edges, 60x80 (640x480/8), BA itrs=2, DSPO stages alternating"
+                                if world == 1 else
+                                f"G8 topology over {K_graph} keyframes = {len(g['ii'])} edges (36 per GPU), 60x80, BA itrs=2, "
+                                f"DSPO stages alternating; value = G8-sized (36-edge) updates per second")
+                               + "; render: 524k-point cloud, one 640x480 view, 10 samples/ray",
                    "edges_local": int(N), "edges_total": int(len(g["ii"])), "hw": int(HW),
+                   "keyframes": int(K_graph),
                    "parallelism": ("single GPU" if world == 1 else
                                    f"edges sharded by source keyframe over {world} GPUs + RCCL all-reduce of the "
-                                   f"reduced normal equations; rays sharded {world} ways")},
+                                   f"reduced normal equations; rays of the one frame sharded {world} ways")},
         "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel<EPI_GRU_ZR,4,64> (ConvGRU convz|convr, 448->256, 3x3)",
                      "achieved": conv_tf, "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s",
                      "frac": conv_tf / MFMA_F16_PEAK_TF, "traffic": conv_traffic if full else None,

@@ -165,20 +165,21 @@ def test_ba_full_size_fixed_point_and_descent(gpu):
     assert c1 < 0.2 * c0
 
 
-def test_ba_sharded_equals_unsharded(gpu):
-    """build_system on two source-frame shards (two contexts on one GPU), summed like the RCCL
-    all-reduce would, then solve_update on each shard == glorie_ba on the whole graph."""
+@pytest.mark.parametrize("K,h,w,world", [(7, 16, 20, 2), (38, 8, 12, 4)])
+def test_ba_sharded_equals_unsharded(gpu, K, h, w, world):
+    """build_system on `world` source-frame shards (one context each, on one GPU), summed like the
+    RCCL all-reduce would, then solve_update on each shard == glorie_ba on the whole graph.
+    K = 38: 6P = 222 unknowns -> the blocked HBM Cholesky, as in the multi-GPU bench."""
     from glorie_slam_amd import _lib as L, dist as gdist
-    K = 7
-    g = make_problem(K, 16, 20, radius=3)
+    g = make_problem(K, h, w, radius=3)
     t0, t1, lm, ep = 1, K, 1e-4, 0.1
     rp, rd, rdx, rdz, st = run_gpu(g, gpu, t0, t1, 1)
-    owner = gdist.shard_frames(g["ii"], 2)
+    owner = gdist.shard_frames(g["ii"], world)
     B, h, w = g["disps"].shape
     n6 = 6 * (t1 - t0)
     lib = L.load()
     shards = []
-    for r in range(2):
+    for r in range(world):
         m = gdist.local_edges(g["ii"], owner, r)
         ii_l, jj_l = g["ii"][m], g["jj"][m]
         kx = sorted(set(list(range(t0, t1)) + ii_l.tolist()))
@@ -192,7 +193,7 @@ def test_ba_sharded_equals_unsharded(gpu):
                                            B, sh["N"], sh["M"], h, w, t0, t1, 0, L.ptr(sh["hv"]),
                                            L.stream_ptr()), "build")
         shards.append(sh)
-    total = shards[0]["hv"] + shards[1]["hv"]
+    total = sum(sh["hv"] for sh in shards)
     disps = g["disps"].copy()
     for sh in shards:
         sh["hv"].copy_(total)
@@ -200,7 +201,7 @@ def test_ba_sharded_equals_unsharded(gpu):
                                            L.ptr(sh["ii"]), L.ptr(sh["jj"]), B, sh["N"], sh["M"], h, w, t0, t1,
                                            lm, ep, 0, 0, L.ptr(sh["hv"]), None, None, L.stream_ptr()), "solve")
         torch.cuda.synchronize()
-        np.testing.assert_allclose(sh["poses"].cpu().numpy(), rp, atol=2e-6)
+        np.testing.assert_allclose(sh["poses"].cpu().numpy(), rp, atol=2e-6 if K < 20 else 2e-5)
         d = sh["disps"].cpu().numpy()
         disps[:len(sh["owned"])][sh["owned"]] = d[:len(sh["owned"])][sh["owned"]]
-    np.testing.assert_allclose(disps, rd, atol=2e-6)
+    np.testing.assert_allclose(disps, rd, atol=2e-6 if K < 20 else 2e-5)
