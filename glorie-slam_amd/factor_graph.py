@@ -200,30 +200,35 @@ class FactorGraph:
         """factor_graph.py:212-256.  With use_graphs the launch sequence of one call is captured
         the second time it is seen for the current edge set and replayed afterwards."""
         sharded = getattr(self.video, "shard", None) is not None and self.video.shard["world"] > 1
-        if not self.use_graphs or use_inactive or sharded or self.corr_impl == "otf" or self.ii.numel() == 0:
+        if not self.use_graphs or use_inactive or self.corr_impl == "otf" or self.ii.numel() == 0:
             return self._update_eager(t0, t1, itrs, use_inactive, EP, motion_only, opt_type)
-        key = (self._topo, t0, t1, itrs, float(EP), bool(motion_only), opt_type)
+        # sharded graphs: everything up to the BA is replayed, the BA (all-reduce of the normal equations,
+        # the all-reduced fallback decision) and the row exchange are issued eagerly behind it
+        key = (self._topo, t0, t1, itrs, float(EP), bool(motion_only), opt_type, sharded)
         ent = self._graphs.get(key)
         if ent is None:                     # first sighting: run eagerly (packs weights, sizes scratch buffers)
             self._graphs[key] = "seen"
             return self._update_eager(t0, t1, itrs, use_inactive, EP, motion_only, opt_type)
         if ent == "seen":
-            ent = self._capture(key, (t0, t1, itrs, False, EP, motion_only, opt_type))
-        graph, s_net, s_target, s_weight, deferred = ent
+            ent = self._capture(key, (t0, t1, itrs, False, EP, motion_only, opt_type, not sharded))
+        graph, s_net, s_target, s_weight, ba_args, deferred = ent
         for dst, src in ((s_net, self.net), (s_target, self.target), (s_weight, self.weight)):
             if src is not dst:
                 dst.copy_(src)
         graph.replay()
         self.net, self.target, self.weight = s_net, s_target, s_weight
-        if deferred is not None:
+        self._ba_args = ba_args
+        if sharded:
+            return self._update_finish(itrs, motion_only, opt_type)
+        if deferred:
             # the recorded depth_scale stage could not take its stage-1 fallback decision on the host
             # (dspo.depth_scale_stage): read the flag it left in pinned memory and redo it here
             torch.cuda.current_stream().synchronize()
             if int(self.video.deferred_any_on()[0]) == 0:
-                damping, uq, upmask, t0_, t1_ = deferred
-                self.video.dspo(self.target, self.weight, damping, self.ii, self.jj, t0_, t1_, itrs, 1e-4, 0.1,
-                                motion_only, "pose_depth")
-                self.video.upsample(self._unique_ii(), upmask)
+                target, weight, damping, ii, jj, uniq, upmask, t0_, t1_ = ba_args
+                self.video.dspo(target, weight, damping, ii, jj, t0_, t1_, itrs, 1e-4, 0.1, motion_only,
+                                "pose_depth")
+                self.video.upsample(uniq, upmask)
 
     def _capture(self, key, args):
         """capture one update() on static copies of the recurrent state (net, target, weight);
@@ -239,18 +244,20 @@ class FactorGraph:
             self._update_eager(*args)
             if self.net.data_ptr() != s_net.data_ptr():     # FusedUpdate(inplace) already wrote s_net
                 s_net.copy_(self.net)
+            # the BA arguments alias the recurrent state: keep them pointing at the static copies
+            ba_args = tuple(s_target if a is self.target else (s_weight if a is self.weight else a)
+                            for a in self._ba_args)
             s_target.copy_(self.target)
             s_weight.copy_(self.weight)
         # the capture did not execute anything: restore the state the caller had
         self.net, self.target, self.weight = keep
-        deferred = self._ba_args if self.video.deferred_fallback else None
-        ent = (graph, s_net, s_target, s_weight, deferred)
+        ent = (graph, s_net, s_target, s_weight, ba_args, bool(self.video.deferred_fallback))
         self._graphs[key] = ent
         return ent
 
     @torch.no_grad()
     def _update_eager(self, t0=None, t1=None, itrs=2, use_inactive=False, EP=1e-7, motion_only=False,
-                      opt_type="pose_depth"):
+                      opt_type="pose_depth", run_ba=True):
         coords1, mask = self.video.reproject(self.ii, self.jj)
         motn = self._motion(coords1)
         if self.corr_impl == "otf":
@@ -286,15 +293,25 @@ class FactorGraph:
         else:
             ii, jj, target, weight, uq = self.ii, self.jj, self.target, self.weight, uniq
         if sharded and opt_type == "pose_depth":
-            # a shard sees only its own source frames: the BA slots are unique(cat(arange(t0,t1), ii))
+            # a shard sees only its own source frames: the BA slots are unique(cat(arange(t0,t1), ii)),
+            # cached per edge set (torch.unique synchronises with the host)
             assert t1 is not None, "sharded BA needs an explicit (global) t1"
-            uq = torch.unique(torch.cat([torch.arange(t0, t1, device=ii.device), ii]))
+            ck = ("uq", self._topo, t0, t1)
+            if ck not in self._graphs:
+                self._graphs[ck] = torch.unique(torch.cat([torch.arange(t0, t1, device=ii.device), ii]))
+            uq = self._graphs[ck]
         damping = .2 * self.damping[uq].contiguous() + EP
-        self._ba_args = (damping, uq, upmask, t0, t1)    # what a deferred stage-1 fallback of a replay needs
+        self._ba_args = (target, weight, damping, ii, jj, uniq, upmask, t0, t1)
+        if run_ba:
+            self._update_finish(itrs, motion_only, opt_type)
+
+    def _update_finish(self, itrs, motion_only, opt_type):
+        """BA + upsampling (+ exchange of the owned rows when sharded) on the outputs of the update operator"""
+        target, weight, damping, ii, jj, uniq, upmask, t0, t1 = self._ba_args
         self.video.ba(target, weight, damping, ii, jj, t0, t1, iters=itrs, lm=1e-4, ep=0.1,
                       motion_only=motion_only, opt_type=opt_type)
         self.video.upsample(uniq, upmask)
-        if sharded:
+        if getattr(self.video, "shard", None) is not None and self.video.shard["world"] > 1:
             self.video.sync_owned("disps", "disps_up", "depth_scale", "depth_shift")
         self.age += 1
 
