@@ -240,7 +240,9 @@ class FactorGraph:
         graph = torch.cuda.CUDAGraph()
         self.net, self.target, self.weight = s_net, s_target, s_weight
         self.video.deferred_fallback = False
-        with torch.cuda.graph(graph):
+        # thread_local: calls of other threads (e.g. the RCCL watchdog of torch.distributed) must not
+        # invalidate the capture
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             self._update_eager(*args)
             if self.net.data_ptr() != s_net.data_ptr():     # FusedUpdate(inplace) already wrote s_net
                 s_net.copy_(self.net)
