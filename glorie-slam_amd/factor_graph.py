@@ -210,7 +210,14 @@ class FactorGraph:
             self._graphs[key] = "seen"
             return self._update_eager(t0, t1, itrs, use_inactive, EP, motion_only, opt_type)
         if ent == "seen":
-            ent = self._capture(key, (t0, t1, itrs, False, EP, motion_only, opt_type, not sharded))
+            try:
+                ent = self._capture(key, (t0, t1, itrs, False, EP, motion_only, opt_type, not sharded))
+            except Exception as exc:        # a failed capture must not take the step down: stay eager
+                import warnings
+                warnings.warn(f"hipGraph capture of FactorGraph.update failed ({exc!r}); running eagerly")
+                ent = self._graphs[key] = "eager"
+        if ent == "eager":
+            return self._update_eager(t0, t1, itrs, use_inactive, EP, motion_only, opt_type)
         graph, s_net, s_target, s_weight, ba_args, deferred = ent
         for dst, src in ((s_net, self.net), (s_target, self.target), (s_weight, self.weight)):
             if src is not dst:
@@ -240,19 +247,21 @@ class FactorGraph:
         graph = torch.cuda.CUDAGraph()
         self.net, self.target, self.weight = s_net, s_target, s_weight
         self.video.deferred_fallback = False
-        # thread_local: calls of other threads (e.g. the RCCL watchdog of torch.distributed) must not
-        # invalidate the capture
-        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-            self._update_eager(*args)
-            if self.net.data_ptr() != s_net.data_ptr():     # FusedUpdate(inplace) already wrote s_net
-                s_net.copy_(self.net)
-            # the BA arguments alias the recurrent state: keep them pointing at the static copies
-            ba_args = tuple(s_target if a is self.target else (s_weight if a is self.weight else a)
-                            for a in self._ba_args)
-            s_target.copy_(self.target)
-            s_weight.copy_(self.weight)
-        # the capture did not execute anything: restore the state the caller had
-        self.net, self.target, self.weight = keep
+        try:
+            # thread_local: calls of other threads (e.g. the RCCL watchdog of torch.distributed) must not
+            # invalidate the capture
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                self._update_eager(*args)
+                if self.net.data_ptr() != s_net.data_ptr():     # FusedUpdate(inplace) already wrote s_net
+                    s_net.copy_(self.net)
+                # the BA arguments alias the recurrent state: keep them pointing at the static copies
+                ba_args = tuple(s_target if a is self.target else (s_weight if a is self.weight else a)
+                                for a in self._ba_args)
+                s_target.copy_(self.target)
+                s_weight.copy_(self.weight)
+        finally:
+            # the capture did not execute anything: restore the state the caller had
+            self.net, self.target, self.weight = keep
         ent = (graph, s_net, s_target, s_weight, ba_args, bool(self.video.deferred_fallback))
         self._graphs[key] = ent
         return ent
