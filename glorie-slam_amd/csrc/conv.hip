@@ -72,7 +72,7 @@ __device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
 // NW/2 pixel groups: pixel tile = NW/2 * 16*NB), ST = LDS stages (2: one __syncthreads per step;
 // 3: loads run two steps ahead, counted vmcnt + raw barrier so that they stay in flight across it)
 template <int EPI, int NB, int BK, int NW, int ST, int MB = 4>
-__global__ __launch_bounds__(64 * NW, ST == 3 ? 1 : (ST == 1 ? 3 : 2)) void conv_igemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__(64 * NW, ST == 3 ? 1 : (ST == 1 ? (BK == 32 ? 4 : 3) : 2)) void conv_igemm_kernel(ConvArgs a) {
   constexpr int TN = 32 * MB;               // output channels per workgroup (MB 16-channel blocks per wave)
   constexpr int NST = ST == 4 ? 2 : ST;     // LDS stages (ST = 4: two stages + register-resident fragments)
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (buffer-resource types are device-only)
@@ -371,7 +371,7 @@ extern "C" int glorie_conv_igemm(const void* xa, int xa_stride, int ca, const vo
   // 128x128 tile at 3 workgroups per CU (1050 TFLOP/s on the 448->256 layer) beats every variant with
   // more LDS stages and fewer resident workgroups: 2 stages 930, 2 stages + register-resident fragments
   // (loads two steps ahead, ST = 4) 915, 8 waves with a 3-stage ring and counted vmcnt 830, 256-pixel
-  // tiles 850.
+  // tiles 850, 32-channel steps at 4 workgroups per CU 824.
   // layers with <= 64 output channels (flow_encoder[2]) use a 64-channel tile instead of padding to 128
   if (nout <= 64 && epilogue == EPI_BIAS_ACT) return launch_conv<4, 64, 4, 1, 2>(a, epilogue, st);
   return launch_conv<4, 64, 4, 1>(a, epilogue, st);
