@@ -197,7 +197,7 @@ class DepthVideo:
                 else:
                     droid_backends.ba(self.poses, self.disps, self.intrinsics[0].contiguous(), None,
                                       target, weight, eta, ii, jj, t0, t1, itrs, lm, ep, motion_only,
-                                      False, ctx=self.ctx())
+                                      False, ctx=self.ctx(), want_updates=False)
                 self.disps.clamp_(min=1e-5)
                 return True
             elif opt_type == "depth_scale":

@@ -256,7 +256,7 @@ def cvx_upsample(disps, ix, mask, disps_up, softmax_f32=False):
 # bundle adjustment
 # --------------------------------------------------------------------------------------
 def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, t1,
-       iterations, lm, ep, motion_only, depth_only=False, ctx=None):
+       iterations, lm, ep, motion_only, depth_only=False, ctx=None, want_updates=True):
     """reference: droid.cpp:89-119, droid_kernels.cu:1314-1437.  Returns [dx, dz] of the last
     iteration (the reference's return value, unused by its caller).  poses/disps updated in
     place."""
@@ -273,8 +273,10 @@ def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, 
     if motion_only and eta is None:
         M = 0
     ctx = ctx or L.default_context()
-    dx = torch.zeros((max(P, 0), 6), dtype=torch.float32, device=poses.device)
-    dz = torch.zeros((M, h * w), dtype=torch.float32, device=poses.device)
+    # [dx, dz] is the reference's return value; its one caller drops it (depth_video.py:217) -- callers
+    # that do so here pass want_updates=False and save two fill launches per BA
+    dx = torch.zeros((max(P, 0), 6), dtype=torch.float32, device=poses.device) if want_updates else None
+    dz = torch.zeros((M, h * w), dtype=torch.float32, device=poses.device) if want_updates else None
     if disps_sens is not None and (disps_sens.shape != disps.shape):
         raise RuntimeError("disps_sens must have the shape of disps")
     if motion_only and M == 0:
@@ -284,6 +286,7 @@ def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, 
                                L.ptr(disps_sens), L.ptr(targets), L.ptr(weights), L.ptr(eta),
                                L.ptr(ii), L.ptr(jj), B, N, M, h, w, int(t0), int(t1),
                                int(iterations), float(lm), float(ep), int(bool(motion_only)),
-                               int(bool(depth_only)), L.ptr(dx), L.ptr(dz) if dz.numel() else None,
+                               int(bool(depth_only)), L.ptr(dx),
+                               L.ptr(dz) if (dz is not None and dz.numel()) else None,
                                L.stream_ptr()), "glorie_ba")
-    return [dx, dz]
+    return [dx, dz] if want_updates else []

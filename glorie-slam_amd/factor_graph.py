@@ -311,7 +311,11 @@ class FactorGraph:
             if ck not in self._graphs:
                 self._graphs[ck] = torch.unique(torch.cat([torch.arange(t0, t1, device=ii.device), ii]))
             uq = self._graphs[ck]
-        damping = .2 * self.damping[uq].contiguous() + EP
+        if uq is uniq:
+            # same frames as just written: 0.2 * eta + EP straight from the operator's output (no gather)
+            damping = damping.reshape(-1, self.ht, self.wd).to(self.damping.dtype).mul(0.2).add_(EP)
+        else:
+            damping = .2 * self.damping[uq].contiguous() + EP
         self._ba_args = (target, weight, damping, ii, jj, uniq, upmask, t0, t1)
         if run_ba:
             self._update_finish(itrs, motion_only, opt_type)
