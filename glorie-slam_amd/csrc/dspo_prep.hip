@@ -157,6 +157,86 @@ __global__ __launch_bounds__(256) void prep_edges_kernel(const uint8_t* __restri
   if (on) atomicOr(any_on, 1);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Two-view validity mask for an arbitrary frame list and map size (scope row N4:
+// DepthVideo.update_valid_depth_mask(up=True) at full resolution, depth_video.py:326-361): the
+// nanmedian of 307,200 depths per frame does not fit LDS, so the radix select runs over global keys:
+// per pass one histogram kernel (LDS bins -> global atomics) and one 1-thread-per-frame bin pick.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void vmask_stats_kernel(const float* __restrict__ disps,
+                                                           const int64_t* __restrict__ ix, int HW,
+                                                           float mv_thresh, float* __restrict__ thresh) {
+  __shared__ double red[16];
+  const float* d = disps + (size_t)ix[blockIdx.x] * HW;
+  double sz = 0.0;
+  for (int k = threadIdx.x; k < HW; k += blockDim.x) sz += (double)(1.0f / d[k]);
+  const double tz = block_sum(sz, red);
+  if (threadIdx.x == 0) thresh[blockIdx.x] = mv_thresh * (float)(tz / (double)HW);
+}
+
+// count (float, in) -> key (uint32, in place): depth bits where the filter passed, else 0xffffffff
+__global__ __launch_bounds__(256) void vmask_keys_kernel(const float* __restrict__ disps,
+                                                         const int64_t* __restrict__ ix, int HW,
+                                                         float visible, uint32_t* __restrict__ keys,
+                                                         unsigned* __restrict__ sel /*[num][4]: nvalid,k,prefix,-*/) {
+  const int f = blockIdx.y;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  unsigned ok = 0;
+  if (p < HW) {
+    const float cnt = __uint_as_float(keys[(size_t)f * HW + p]);
+    const float z = 1.0f / disps[(size_t)ix[f] * HW + p];
+    ok = (cnt >= visible && !isnan(z)) ? 1u : 0u;
+    keys[(size_t)f * HW + p] = ok ? __float_as_uint(z) : 0xffffffffu;
+  }
+  const unsigned long long b = __ballot(ok);
+  if ((threadIdx.x & 63) == 0 && b) atomicAdd(&sel[f * 4 + 0], (unsigned)__popcll(b));
+}
+
+__global__ __launch_bounds__(256) void vmask_hist_kernel(const uint32_t* __restrict__ keys, int HW, int pass,
+                                                         const unsigned* __restrict__ sel,
+                                                         unsigned* __restrict__ hist /*[num][256]*/) {
+  __shared__ unsigned h[256];
+  const int f = blockIdx.y;
+  h[threadIdx.x] = 0u;
+  __syncthreads();
+  const unsigned mask = pass == 3 ? 0u : (0xffffffffu << (8 * (pass + 1)));
+  const unsigned prefix = sel[f * 4 + 2];
+  for (int p = blockIdx.x * 256 + threadIdx.x; p < HW; p += gridDim.x * 256) {
+    const unsigned key = keys[(size_t)f * HW + p];
+    if (key != 0xffffffffu && (key & mask) == prefix) atomicAdd(&h[(key >> (8 * pass)) & 255u], 1u);
+  }
+  __syncthreads();
+  if (h[threadIdx.x]) atomicAdd(&hist[f * 256 + threadIdx.x], h[threadIdx.x]);
+}
+
+// one thread per frame: pick the bin holding the k-th key, narrow the prefix, clear the histogram
+__global__ void vmask_pick_kernel(unsigned* __restrict__ sel, unsigned* __restrict__ hist, int num, int pass) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= num) return;
+  if (pass == 3) sel[f * 4 + 1] = sel[f * 4 + 0] ? (sel[f * 4 + 0] - 1) / 2 : 0;   // lower median
+  unsigned kk = sel[f * 4 + 1], b = 0;
+  for (; b < 256; ++b) {
+    const unsigned c = hist[f * 256 + b];
+    hist[f * 256 + b] = 0u;
+    if (kk < c) break;
+    kk -= c;
+  }
+  for (unsigned r = b + 1; r < 256; ++r) hist[f * 256 + r] = 0u;
+  sel[f * 4 + 1] = kk;
+  sel[f * 4 + 2] |= (b & 255u) << (8 * pass);
+}
+
+__global__ __launch_bounds__(256) void vmask_write_kernel(const uint32_t* __restrict__ keys, int HW,
+                                                          const unsigned* __restrict__ sel,
+                                                          uint8_t* __restrict__ mask) {
+  const int f = blockIdx.y;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= HW) return;
+  const float med = sel[f * 4 + 0] ? __uint_as_float(sel[f * 4 + 2]) : nanf("");
+  const unsigned key = keys[(size_t)f * HW + p];
+  mask[(size_t)f * HW + p] = (key != 0xffffffffu && __uint_as_float(key) < 3.0f * med) ? 1 : 0;
+}
+
 }  // namespace glorie
 
 using namespace glorie;
@@ -196,5 +276,35 @@ extern "C" int glorie_dspo_prepare(const float* poses, const float* disps, const
   if (N > 0)
     hipLaunchKernelGGL(prep_edges_kernel, dim3((N + 255) / 256), dim3(256), 0, st, bad, ii, jj, N, n, edge_on,
                        any_on);
+  return check_launch();
+}
+
+extern "C" int glorie_valid_depth_mask(const float* poses, const float* disps, const float* intrinsics,
+                                       const int64_t* ix, int B, int num, int h, int w, float mv_thresh,
+                                       int visible_num, uint8_t* mask, void* scratch, void* stream) {
+  if (B < 0 || num < 0 || h <= 0 || w <= 0) return GLORIE_EINVAL;
+  if (num == 0) return GLORIE_OK;
+  if (!poses || !disps || !intrinsics || !ix || !mask || !scratch) return GLORIE_EINVAL;
+  const int HW = h * w;
+  hipStream_t st = (hipStream_t)stream;
+  // scratch: count/keys [num*HW] 4 B | thresh [num] | sel [num][4] | hist [num][256]
+  float* count = reinterpret_cast<float*>(scratch);
+  float* thresh = count + (size_t)num * HW;
+  unsigned* sel = reinterpret_cast<unsigned*>(thresh + num);
+  unsigned* hist = sel + (size_t)num * 4;
+  GLORIE_TRY(check_hip(hipMemsetAsync(sel, 0, sizeof(unsigned) * ((size_t)num * 4 + (size_t)num * 256), st)));
+  hipLaunchKernelGGL(vmask_stats_kernel, dim3(num), dim3(1024), 0, st, disps, ix, HW, mv_thresh, thresh);
+  GLORIE_TRY(glorie_depth_filter(poses, disps, intrinsics, ix, thresh, count, B, num, h, w, stream));
+  const dim3 pix((HW + 255) / 256, num);
+  hipLaunchKernelGGL(vmask_keys_kernel, pix, dim3(256), 0, st, disps, ix, HW, (float)visible_num,
+                     reinterpret_cast<uint32_t*>(count), sel);
+  const int hb = (HW + 256 * 8 - 1) / (256 * 8);
+  for (int pass = 3; pass >= 0; --pass) {
+    hipLaunchKernelGGL(vmask_hist_kernel, dim3(hb, num), dim3(256), 0, st, reinterpret_cast<const uint32_t*>(count),
+                       HW, pass, sel, hist);
+    hipLaunchKernelGGL(vmask_pick_kernel, dim3((num + 63) / 64), dim3(64), 0, st, sel, hist, num, pass);
+  }
+  hipLaunchKernelGGL(vmask_write_kernel, pix, dim3(256), 0, st, reinterpret_cast<const uint32_t*>(count), HW, sel,
+                     mask);
   return check_launch();
 }

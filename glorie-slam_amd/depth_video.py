@@ -218,8 +218,10 @@ class DepthVideo:
 
     # ---- masks -----------------------------------------------------------------------
     @torch.no_grad()
-    def update_valid_depth_mask(self, up=True):
-        """two-view consistency mask (depth_video.py:326-361)"""
+    def update_valid_depth_mask(self, up=True, fused=True):
+        """two-view consistency mask (depth_video.py:326-361).  On the GPU the statistics, the depth
+        filter, the exact nanmedian (radix select) and the threshold are 12 launches of
+        glorie_valid_depth_mask; fused=False keeps the reference's op-by-op formulation."""
         if up:
             with self.get_lock():
                 dirty_index, = torch.where(self.dirty.clone())
@@ -228,20 +230,60 @@ class DepthVideo:
         else:
             dirty_index = torch.arange(self.counter.value, device=self.device)
         src = self.disps_up if up else self.disps
-        disps = torch.index_select(src, 0, dirty_index)
         intr = (self.intrinsics[0].detach() * (self.down_scale if up else 1.0)).contiguous()
-        depths = 1.0 / disps
-        thresh = (self.cfg['tracking']['multiview_filter']['thresh'] * depths.mean(dim=[1, 2])).contiguous()
-        count = droid_backends.depth_filter(self.poses, src, intr, dirty_index.contiguous(), thresh)
-        visible = self.cfg['tracking']['multiview_filter']['visible_num']
-        depths[~(count >= visible)] = torch.nan
-        med = depths.view(depths.shape[0], -1).nanmedian(dim=1).values
-        masks = depths < 3 * med[:, None, None]
+        mv = self.cfg['tracking']['multiview_filter']
+        if fused and src.is_cuda:
+            masks = droid_backends.valid_depth_mask(self.poses, src, intr, dirty_index.contiguous(), mv['thresh'],
+                                                    mv['visible_num'])
+        else:
+            disps = torch.index_select(src, 0, dirty_index)
+            depths = 1.0 / disps
+            thresh = (mv['thresh'] * depths.mean(dim=[1, 2])).contiguous()
+            count = droid_backends.depth_filter(self.poses, src, intr, dirty_index.contiguous(), thresh)
+            depths[~(count >= mv['visible_num'])] = torch.nan
+            med = depths.view(depths.shape[0], -1).nanmedian(dim=1).values
+            masks = depths < 3 * med[:, None, None]
         if up:
             self.valid_depth_mask[dirty_index] = masks
             self.dirty[dirty_index] = False
         else:
             self.valid_depth_mask_small[dirty_index] = masks
+
+    # ---- outputs ------------------------------------------------------
+    def get_pose(self, index, device):
+        """camera-to-world 4x4 matrix of keyframe `index` (depth_video.py:313-316: SE3(pose).inv().matrix());
+        poses are stored world-to-camera as [tx ty tz qx qy qz qw]"""
+        p = self.poses[index].detach().to(device=device, dtype=torch.float32)
+        t, (qx, qy, qz, qw) = p[:3], p[3:]
+        R = torch.stack([torch.stack([1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw), 2 * (qx * qz + qy * qw)]),
+                         torch.stack([2 * (qx * qy + qz * qw), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw)]),
+                         torch.stack([2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy)])])
+        c2w = torch.eye(4, dtype=torch.float32, device=p.device)
+        c2w[:3, :3] = R.t()
+        c2w[:3, 3] = -(R.t() @ t)
+        return c2w
+
+    def get_depth_and_pose(self, index, device):
+        """(depth [H,W], valid mask [H,W], c2w [4,4]) of keyframe `index` (depth_video.py:318-324)"""
+        with self.get_lock():
+            est_depth = 1.0 / self.disps_up[index].clone().to(device)
+            depth_mask = self.valid_depth_mask[index].clone().to(device)
+            c2w = self.get_pose(index, device)
+        return est_depth, depth_mask, c2w
+
+    def save_video(self, path):
+        """video.npz of the reference (depth_video.py:367-384): poses [n,4,4] c2w, depths [n,H,W],
+        timestamps [n], valid_depth_masks [n,H,W] (bool) for the n = counter keyframes"""
+        poses, depths, stamps, masks = [], [], [], []
+        for i in range(self.counter.value):
+            depth, mask, pose = self.get_depth_and_pose(i, "cpu")
+            poses.append(pose)
+            depths.append(depth)
+            stamps.append(self.timestamp[i].cpu())
+            masks.append(mask)
+        import numpy as np
+        np.savez(path, poses=torch.stack(poses, 0).numpy(), depths=torch.stack(depths, 0).numpy(),
+                 timestamps=torch.stack(stamps, 0).numpy(), valid_depth_masks=torch.stack(masks, 0).numpy())
 
     def set_dirty(self, index_start, index_end):
         self.dirty[index_start:index_end] = True

@@ -202,6 +202,22 @@ def motion(coords1, coords0, target, limit=64.0):
     return out
 
 
+def valid_depth_mask(poses, disps, intrinsics, ix, mv_thresh, visible_num):
+    """two-view validity mask of frames `ix` on the map stack `disps` [B,h,w]
+    (DepthVideo.update_valid_depth_mask, depth_video.py:326-361) -> bool [len(ix), h, w]"""
+    L.need_cuda(poses, disps, intrinsics, ix)
+    L.need_contiguous(poses=poses, disps=disps, intrinsics=intrinsics, ix=ix)
+    _i64(ix, "ix")
+    B, h, w = disps.shape
+    num = ix.shape[0]
+    mask = torch.empty((num, h, w), dtype=torch.bool, device=disps.device)
+    scratch = torch.empty(num * h * w * 4 + num * 1044 + 64, dtype=torch.uint8, device=disps.device)
+    L.check(L.load().glorie_valid_depth_mask(L.ptr(poses), L.ptr(disps), L.ptr(intrinsics), L.ptr(ix), B, num, h, w,
+                                             float(mv_thresh), int(visible_num), L.ptr(mask), L.ptr(scratch),
+                                             L.stream_ptr()), "glorie_valid_depth_mask")
+    return mask
+
+
 def dspo_prepare(poses, disps, intrinsics, mono_disps, n, mv_thresh, visible_num, mono_thres, ii, jj,
                  valid_mask, depth_scale, depth_shift):
     """update_valid_depth_mask(up=False) + align_scale_and_shift + the mono_thres edge filter of the

@@ -303,6 +303,16 @@ int glorie_dspo_prepare(const float* poses, const float* disps, const float* int
                         uint8_t* valid_mask, float* scales, float* shifts, uint8_t* edge_on,
                         int* any_on, void* scratch, void* stream);
 
+/* Two-view validity mask of the frames ix[0..num) of a depth video at any resolution
+ * (DepthVideo.update_valid_depth_mask, depth_video.py:326-361):
+ * thresh = mv_thresh * mean(1/disp); a pixel survives if >= visible_num of its 6 neighbour frames
+ * agree within thresh and its depth is below 3 x the (lower) median of the surviving depths.
+ * disps [B,h,w] is the map the mask is computed on (disps_up with intrinsics scaled by 8, or disps),
+ * mask [num,h,w] bytes.  scratch: >= num*h*w*4 + num*(4 + 16 + 1024) bytes.  No host sync. */
+int glorie_valid_depth_mask(const float* poses, const float* disps, const float* intrinsics,
+                            const int64_t* ix, int B, int num, int h, int w, float mv_thresh,
+                            int visible_num, uint8_t* mask, void* scratch, void* stream);
+
 /* ------------------------------------------------------------------------------------ */
 /* C. neural point cloud renderer                                                        */
 /* ------------------------------------------------------------------------------------ */

@@ -193,3 +193,43 @@ def test_graph_replay_matches_eager(gpu):
     graph.rm_factors(graph.ii == 0, store=False)
     assert len(graph._graphs) == 0
     graph.update(t0=1, t1=6, itrs=2)
+
+
+def test_full_resolution_valid_mask_and_video_npz(gpu, tmp_path):
+    """update_valid_depth_mask(up=True) through glorie_valid_depth_mask == the
+    reference's op-by-op formulation (global-memory radix-select median), and the video.npz format"""
+    from oracle import se3 as ose3
+    g, video = make_video(gpu, 6, 12, 16)
+    video.cfg["tracking"]["multiview_filter"]["thresh"] = 0.05
+    n = video.counter.value
+    video.disps_up[:n] = torch.nn.functional.interpolate(video.disps[:n, None], scale_factor=8, mode="bilinear",
+                                                         align_corners=False)[:, 0]
+    video.timestamp[:n] = torch.arange(n, device=gpu).float() * 0.1
+    masks = []
+    for fused in (False, True):
+        video.valid_depth_mask.zero_()
+        video.dirty[:n] = True
+        video.dirty[2] = False                                   # an index list with a hole
+        video.update_valid_depth_mask(up=True, fused=fused)
+        assert not bool(video.dirty.any())
+        masks.append(video.valid_depth_mask[:n].clone())
+    assert float((masks[0] != masks[1]).float().mean()) < 2e-3
+    assert 0.05 < float(masks[1].float().mean()) < 1.0 and not bool(masks[1][2].any())
+    # BA resolution through the same entry point
+    small = []
+    for fused in (False, True):
+        video.valid_depth_mask_small.zero_()
+        video.update_valid_depth_mask(up=False, fused=fused)
+        small.append(video.valid_depth_mask_small[:n].clone())
+    assert float((small[0] != small[1]).float().mean()) < 2e-3
+    # camera-to-world pose = inverse of the stored world-to-camera [t, q]
+    c2w = video.get_pose(3, "cpu").numpy()
+    w2c = ose3.matrix(g["poses"][3])
+    np.testing.assert_allclose(c2w @ w2c, np.eye(4), atol=1e-5)
+    path = str(tmp_path / "video.npz")
+    video.save_video(path)
+    z = np.load(path)
+    assert sorted(z.files) == ["depths", "poses", "timestamps", "valid_depth_masks"]
+    assert z["poses"].shape == (n, 4, 4) and z["depths"].shape == (n, 96, 128) and z["timestamps"].shape == (n,)
+    assert z["valid_depth_masks"].dtype == np.bool_ and z["valid_depth_masks"].shape == (n, 96, 128)
+    np.testing.assert_allclose(z["depths"][1], 1.0 / video.disps_up[1].cpu().numpy(), rtol=1e-6)
