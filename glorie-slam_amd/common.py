@@ -23,6 +23,20 @@ def get_rays(H, W, fx, fy, cx, cy, c2w, device, crop_edge_h=0, crop_edge_w=0, re
     return rays_o, rays_d
 
 
+def update_cam(cfg):
+    """common.py:377-398: intrinsics after the resize / edge crop of the pre-processing"""
+    cam = cfg['cam']
+    H, W = cam['H'], cam['W']
+    fx, fy, cx, cy = cam['fx'], cam['fy'], cam['cx'], cam['cy']
+    h_edge, w_edge = cam.get('H_edge', 0), cam.get('W_edge', 0)
+    H_out, W_out = cam['H_out'], cam['W_out']
+    fx = fx * (W_out + w_edge * 2) / W
+    fy = fy * (H_out + h_edge * 2) / H
+    cx = cx * (W_out + w_edge * 2) / W - w_edge
+    cy = cy * (H_out + h_edge * 2) / H - h_edge
+    return H_out, W_out, fx, fy, cx, cy
+
+
 def get_rays_from_uv(i, j, c2w, fx, fy, cx, cy, device):
     """common.py:39-54"""
     if isinstance(c2w, np.ndarray):

@@ -3,14 +3,28 @@ side of /root/reference/src/neural_point.py.  The faiss IndexIVFFlat is replaced
 exact cell-list search of libglorie_hip (`point_ops.KnnIndex`); `find_neighbors_faiss` and
 `sample_near_pcl` keep their signatures and return conventions.
 
-Point insertion driven by depth maps, deformation and proxy-depth rendering
-(neural_point.py:145-262, 377-575) are the "next" row N2 of SURVEY.md section 8(f) and are not
-part of this module yet; `add_points` below is the plain store/append they build on.
+Point-cloud maintenance: `add_neural_points` (radius-test insertion
+along the rays of a keyframe, neural_point.py:165-262), `add_points(video_idxs)` (full-resolution
+unprojection of keyframes, :145-162), `update_points_pos` (deformation after a pose/depth update,
+:378-438) and `retrain_updated_points`.  Every index (re)build is one counting sort on the device
+(`glorie_knn_build`), where the reference re-trains an IVF k-means.  Proxy-depth rendering
+(`proj_depth_map`, `get_proxy_render_depth`, :446-575) is not part of this module yet.
 """
 import numpy as np
 import torch
 
 from . import point_ops
+
+
+def se3_inv(poses):
+    """inverse of [tx ty tz qx qy qz qw] rigid transforms (lietorch SE3(poses).inv().data)"""
+    t, q = poses[..., :3], poses[..., 3:]
+    qi = torch.cat([-q[..., :3], q[..., 3:]], -1)
+    # rotate -t by qi:  v + 2 w (u x v) + 2 u x (u x v),  u = qi.xyz, w = qi.w
+    u, w = qi[..., :3], qi[..., 3:]
+    v = -t
+    uv = torch.cross(u, v, dim=-1)
+    return torch.cat([v + 2 * (w * uv + torch.cross(u, uv, dim=-1)), qi], -1).contiguous()
 
 
 class NeuralPointCloud(object):
@@ -28,7 +42,16 @@ class NeuralPointCloud(object):
         self.N_add = pc.get('N_add', 3)
         self.near_end_surface = pc.get('near_end_surface', 0.95)
         self.far_end_surface = pc.get('far_end_surface', 1.05)
-        self._cloud_pos = None
+        self.fix_interval_when_add_along_ray = pc.get('fix_interval_when_add_along_ray', False)
+        self._cloud_pos = None       # (input_pos) * N_add
+        self._input_pos = None       # locations of the depth inputs the cloud was seeded from
+        self._input_rgb = None
+        self._input_video_idx = None
+        self._input_j = None         # pixel of the input, depth[j, i]
+        self._input_i = None
+        self._input_depth = None
+        self._full_pcl = None        # [buffer,H,W,3] unprojected keyframes (allocated by add_points(video_idxs))
+        self._full_mask = None
         self._pts_num = 0
         self.geo_feats = None
         self.col_feats = None
@@ -45,6 +68,39 @@ class NeuralPointCloud(object):
 
     def pts_num(self):
         return self._pts_num
+
+    def input_pos(self):
+        return self._input_pos
+
+    def input_rgb(self):
+        return self._input_rgb
+
+    def input_i(self):
+        return self._input_i
+
+    def input_j(self):
+        return self._input_j
+
+    def input_video_idx(self):
+        return self._input_video_idx
+
+    def full_pcl(self):
+        return self._full_pcl
+
+    def full_mask(self):
+        return self._full_mask
+
+    def get_N_add(self):
+        return self.N_add
+
+    def get_near_end_surface(self):
+        return self.near_end_surface
+
+    def get_far_end_surface(self):
+        return self.far_end_surface
+
+    def is_fix_interval_when_add_along_ray(self):
+        return self.fix_interval_when_add_along_ray
 
     def get_radius_query(self):
         return self.radius_query
@@ -84,8 +140,14 @@ class NeuralPointCloud(object):
 
     # ---- store ------------------------------------------------------------------------
     def add_points(self, pts, geo_feats=None, col_feats=None):
-        """append points [n,3] (+ features, default N(0,0.1) as neural_point.py:243-246) and
-        rebuild the search structure"""
+        """Two call forms.
+        add_points(video_idxs: int | int64 tensor) -- the reference's method (neural_point.py:145-162):
+            unproject the full-resolution depth of those keyframes of `self.video` into
+            `_full_pcl` / `_full_mask`; returns the number of valid pixels.
+        add_points(pts [n,3] float, geo_feats=None, col_feats=None) -- plain append (+ features,
+            default N(0,0.1) as neural_point.py:243-246) and rebuild of the search structure."""
+        if isinstance(pts, int) or (torch.is_tensor(pts) and not pts.is_floating_point()):
+            return self._add_video_points(pts)
         pts = pts.detach().to(self.device, torch.float32).reshape(-1, 3)
         n = pts.shape[0]
         mk = lambda f: f.detach().to(self.device, torch.float32) if f is not None else \
@@ -100,6 +162,90 @@ class NeuralPointCloud(object):
         self._pts_num = self._cloud_pos.shape[0]
         self.index.set_points(self._cloud_pos)
         return n
+
+    def _add_video_points(self, video_idxs):
+        from . import droid_backends
+        v = self.video
+        if isinstance(video_idxs, int):
+            video_idxs = torch.tensor([video_idxs], dtype=torch.long, device=self.device)
+        if self._full_pcl is None:
+            B, H, W = v.disps_up.shape
+            self._full_pcl = torch.zeros(B, H, W, 3, device=self.device, dtype=torch.float)
+            self._full_mask = torch.zeros(B, H, W, device=self.device, dtype=torch.bool)
+        intrinsic = (v.intrinsics[0].detach() * float(v.down_scale)).contiguous()
+        masks = torch.index_select(v.valid_depth_mask.detach(), 0, video_idxs)
+        disps = torch.index_select(v.disps_up.detach(), 0, video_idxs).contiguous()
+        poses = torch.index_select(v.poses.detach(), 0, video_idxs).contiguous()
+        self._full_pcl[video_idxs] = droid_backends.iproj(se3_inv(poses), disps, intrinsic)   # SE3(poses).inv().data
+        self._full_mask[video_idxs] = masks
+        return torch.sum(masks)
+
+    def _z_along_ray(self, depth):
+        """the N_add sample depths around a surface depth (neural_point.py:215-229)"""
+        d = depth.unsqueeze(-1).repeat(1, self.N_add)
+        if self.fix_interval_when_add_along_ray:
+            return d + torch.linspace(-0.04, 0.04, steps=self.N_add, device=self.device).unsqueeze(0)
+        t = torch.linspace(0.0, 1.0, steps=self.N_add, device=self.device)
+        return self.near_end_surface * d * (1. - t) + self.far_end_surface * d * t
+
+    @torch.no_grad()
+    def add_neural_points(self, batch_rays_o, batch_rays_d, batch_gt_depth, batch_gt_color,
+                          video_idx, i, j, train=False, is_pts_grad=False, dynamic_radius=None):
+        """neural_point.py:165-262: seed N_add neural points along every ray whose surface point has no
+        neighbour within radius_add (radius_min / the per-ray dynamic radius) in the current cloud.
+        Returns the number of accepted rays.  `train` is accepted for signature compatibility: the cell
+        list is rebuilt exactly on every insertion."""
+        if not batch_rays_o.shape[0]:
+            return 0
+        mask = batch_gt_depth > 0
+        mask = mask * (batch_gt_depth < batch_gt_depth.quantile(0.8) * 2.0)
+        batch_gt_color = batch_gt_color * 255
+        batch_rays_o, batch_rays_d, batch_gt_depth, batch_gt_color = \
+            batch_rays_o[mask], batch_rays_d[mask], batch_gt_depth[mask], batch_gt_color[mask]
+        i, j = i[mask], j[mask]
+        if dynamic_radius is not None:
+            dynamic_radius = dynamic_radius[mask]
+        pts_gt = (batch_rays_o[..., None, :] + batch_rays_d[..., None, :] * batch_gt_depth[..., None, None]).reshape(-1, 3)
+        mask = torch.ones(pts_gt.shape[0], device=self.device).bool()
+        if self.index.ntotal > 0 and pts_gt.shape[0]:      # (reference: `index.is_trained`, i.e. a non-empty cloud)
+            _, _, neighbor_num_gt = self.find_neighbors_faiss(pts_gt, step='add', is_pts_grad=is_pts_grad,
+                                                              dynamic_radius=dynamic_radius)
+            mask = (neighbor_num_gt == 0)
+        new = dict(_input_pos=pts_gt[mask], _input_rgb=batch_gt_color[mask], _input_depth=batch_gt_depth[mask],
+                   _input_video_idx=video_idx * torch.ones_like(i[mask], dtype=torch.long, device=self.device),
+                   _input_i=i[mask], _input_j=j[mask])
+        for name, val in new.items():
+            val = val.detach().clone()
+            cur = getattr(self, name)
+            setattr(self, name, val if cur is None else torch.cat([cur, val]))
+        pts = batch_rays_o[..., None, :] + batch_rays_d[..., None, :] * self._z_along_ray(batch_gt_depth)[..., :, None]
+        pts = pts[mask].reshape(-1, 3)                 # auxiliary points share the mask of the surface point
+        if pts.shape[0]:
+            NeuralPointCloud.add_points(self, pts)     # append + N(0,0.1) features + rebuild of the cell list
+        return torch.sum(mask)
+
+    @torch.no_grad()
+    def update_points_pos(self, v_idx, depth, c2w, cfg):
+        """neural_point.py:378-438: move the points that were unprojected from keyframe v_idx after its
+        depth map / pose changed (call retrain_updated_points afterwards, like the reference)"""
+        from .common import get_rays_from_uv, update_cam
+        depth = depth.to(self.device)
+        frame_mask = (self._input_video_idx == v_idx)
+        if frame_mask.sum() == 0:
+            return
+        pj, pi = self._input_j[frame_mask], self._input_i[frame_mask]
+        depth_prev = self._input_depth[frame_mask]
+        pd = depth[pj, pi]
+        bad = (pd == 0.0)
+        if bad.sum() > 0:
+            scale = torch.sum(depth_prev[~bad] * pd[~bad]) / torch.sum(depth_prev[~bad] * depth_prev[~bad])   # get_scale
+            pd[bad] = scale * depth_prev[bad]
+        _, _, fx, fy, cx, cy = update_cam(cfg)
+        rays_o, rays_d = get_rays_from_uv(pi, pj, c2w, fx, fy, cx, cy, self.device)
+        self._input_pos[frame_mask] = (rays_o[..., None, :] + rays_d[..., None, :] * pd[..., None, None]).reshape(-1, 3)
+        self._input_depth[frame_mask] = pd.clone()
+        pts = (rays_o[..., None, :] + rays_d[..., None, :] * self._z_along_ray(pd)[..., :, None]).reshape(-1, 3)
+        self._cloud_pos[frame_mask.unsqueeze(-1).repeat(1, self.N_add).reshape(-1)] = pts
 
     def retrain_updated_points(self):
         """after positions changed (deformation): rebuild (neural_point.py:441-444)"""

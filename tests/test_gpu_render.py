@@ -244,3 +244,87 @@ def test_fused_mlp_ragged_sizes(gpu):
         a, b, pm = a.cpu().numpy(), b.cpu().numpy(), pm.cpu().numpy()
         np.testing.assert_allclose(a[:, 3], b[:, 3], rtol=2e-3, atol=1e-3)
         np.testing.assert_allclose(a[pm, :3], b[pm, :3], rtol=2e-3, atol=1e-3)
+
+
+# ---- point-cloud maintenance ---------------------------------------------------
+def _npc_cfg(dev, H=48, W=64):
+    cfg = _cfg(dev)
+    cfg["cam"] = {"H": H, "W": W, "fx": 40.0, "fy": 40.0, "cx": W / 2 - 0.5, "cy": H / 2 - 0.5, "H_out": H, "W_out": W,
+                  "H_edge": 0, "W_edge": 0}
+    cfg["pointcloud"].update(N_add=3, near_end_surface=0.98, far_end_surface=1.02, radius_add=0.04, radius_min=0.02,
+                             fix_interval_when_add_along_ray=False)
+    return cfg
+
+
+def test_add_neural_points_radius_test_and_deformation(gpu):
+    """add_neural_points (neural_point.py:165-262) against a brute-force restatement of its radius test,
+    then update_points_pos (378-438) + retrain_updated_points"""
+    from glorie_slam_amd.neural_point import NeuralPointCloud
+    from glorie_slam_amd.common import get_rays_from_uv
+    cfg = _npc_cfg(gpu)
+    H, W = 48, 64
+    npc = NeuralPointCloud(cfg)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    c2w = torch.eye(4)
+    c2w[:3, 3] = torch.tensor([0.1, -0.2, 0.3])
+    jj, ii = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    ii, jj = ii.reshape(-1).to(gpu), jj.reshape(-1).to(gpu)
+    depth = (1.5 + 0.3 * torch.rand(H, W, generator=g)).to(gpu)
+    depth[::7, ::5] = 0.0                                          # holes
+    depth[3, 4] = 40.0                                             # beyond 2 x the 0.8 quantile: rejected
+    ro, rd = get_rays_from_uv(ii.float(), jj.float(), c2w, 40.0, 40.0, W / 2 - 0.5, H / 2 - 0.5, gpu)
+    col = torch.rand(H * W, 3, generator=g).to(gpu)
+    d = depth[jj, ii]
+    n1 = int(npc.add_neural_points(ro, rd, d, col, 0, ii, jj))
+    keep = (d > 0) & (d < d.quantile(0.8) * 2.0)
+    assert n1 == int(keep.sum()) and npc.pts_num() == 3 * n1         # empty cloud: every valid ray accepted
+    assert npc.input_pos().shape == (n1, 3) and int(npc.input_video_idx().max()) == 0
+    # second keyframe, shifted camera: only rays whose surface point has no neighbour within radius_add
+    c2w2 = c2w.clone()
+    c2w2[0, 3] += 0.02
+    ro2, rd2 = get_rays_from_uv(ii.float(), jj.float(), c2w2, 40.0, 40.0, W / 2 - 0.5, H / 2 - 0.5, gpu)
+    cloud_before = npc.cloud_pos().clone()
+    n2 = int(npc.add_neural_points(ro2, rd2, d, col, 1, ii, jj))
+    pts_gt = (ro2 + rd2 * d[:, None])[keep]
+    dist = torch.cdist(pts_gt.double(), cloud_before.double())
+    expect = (dist.min(1).values ** 2 > 0.04 ** 2)
+    near_tie = ((dist.min(1).values ** 2 - 0.04 ** 2).abs() < 1e-6)
+    assert abs(n2 - int(expect.sum())) <= int(near_tie.sum())
+    assert npc.pts_num() == 3 * (n1 + n2) and npc.index.ntotal == npc.pts_num()
+    assert npc.geo_feats.shape == (npc.pts_num(), cfg["model"]["c_dim"])
+    # deformation of keyframe 0: new depth map (with holes -> rescaled previous depth), same pose
+    depth2 = depth * 1.1
+    depth2[5, 6] = 0.0
+    before = npc.cloud_pos().clone()
+    npc.update_points_pos(0, depth2, c2w, cfg)
+    npc.retrain_updated_points()
+    moved = (npc.cloud_pos() - before).abs().sum(1) > 0
+    assert int(moved.sum()) >= 3 * n1 - 9 and not bool(moved[3 * n1:].any())     # only keyframe 0's points moved
+    fm = npc.input_video_idx() == 0
+    z = ((npc.input_pos()[fm] - c2w[:3, 3].to(gpu)) * -1)[:, 2]                 # camera looks down -z
+    torch.testing.assert_close(z, npc._input_depth[fm], atol=1e-5, rtol=1e-5)
+    D, I, nn = npc.find_neighbors_faiss(npc.input_pos()[:64], step="query")
+    assert bool((nn > 0).all())
+
+
+def test_add_points_from_video_unprojects_keyframes(gpu):
+    """add_points(video_idxs) (neural_point.py:145-162): iproj with the inverse stored pose"""
+    from test_gpu_graph import make_video
+    from glorie_slam_amd.neural_point import NeuralPointCloud
+    from oracle import se3 as ose3
+    g, video = make_video(gpu, 5, 6, 8)
+    n = video.counter.value
+    video.disps_up[:n] = torch.nn.functional.interpolate(video.disps[:n, None], scale_factor=8, mode="nearest")[:, 0]
+    video.valid_depth_mask[:n] = True
+    video.valid_depth_mask[1, :4] = False
+    npc = NeuralPointCloud(_npc_cfg(gpu), video)
+    cnt = int(npc.add_points(torch.tensor([1, 3], device=gpu)))
+    assert cnt == int(video.valid_depth_mask[[1, 3]].sum())
+    assert torch.equal(npc.full_mask()[1], video.valid_depth_mask[1])
+    # pixel (v,u) of keyframe 3: X_world = inv(w2c) * ((u-cx)/fx, (v-cy)/fy, 1) / disp
+    fx, fy, cx, cy = (video.intrinsics[0] * 8).cpu().numpy()
+    v, u = 20, 33
+    dsp = float(video.disps_up[3, v, u])
+    Xc = np.array([(u - cx) / fx / dsp, (v - cy) / fy / dsp, 1.0 / dsp, 1.0])
+    Xw = np.linalg.inv(ose3.matrix(g["poses"][3])) @ Xc
+    np.testing.assert_allclose(npc.full_pcl()[3, v, u].cpu().numpy(), Xw[:3], rtol=1e-4, atol=1e-4)
