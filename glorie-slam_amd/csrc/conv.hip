@@ -344,6 +344,8 @@ extern "C" int glorie_conv_igemm(const void* xa, int xa_stride, int ca, const vo
                                  void* out2, int out2_stride, int N, int H, int W, void* stream) {
   if (N < 0 || H <= 0 || W <= 0 || (taps != 1 && taps != 9) || nout <= 0 || (nout & 3)) return GLORIE_EINVAL;
   if (ca < 0 || cb < 0 || (ca % 64) || (cb % 64) || ca + cb == 0) return GLORIE_EINVAL;
+  if (epilogue < 0 || epilogue > 2) return GLORIE_EINVAL;
+  if (N == 0) return GLORIE_OK;               // nothing to do: pointers of empty maps may be null
   if ((ca && (!xa || (xa_stride & 7))) || (cb && (!xb || (xb_stride & 7)))) return GLORIE_EINVAL;
   if (!w_packed || !out || (out_stride & 3)) return GLORIE_EINVAL;
   if (epilogue == EPI_GRU_ZR && (nout != 256 || !terms || !net || !out2 || (terms_stride & 3))) return GLORIE_EINVAL;

@@ -221,3 +221,33 @@ def test_flow_conv7_matches_conv2d(gpu):
     ref = F.relu(F.conv2d(x, weight.half().float(), bias, padding=3))
     torch.testing.assert_close(wide[:, 64:192].float(), ref, atol=2e-2, rtol=4e-3)
     assert float(wide[:, :64].abs().max()) == 0.0
+
+
+def test_empty_inputs_are_no_ops(gpu):
+    """zero edges / zero frames: every new entry point returns without touching its outputs"""
+    from glorie_slam_amd import update_ops as U, droid_backends as db
+    e = lambda *s: torch.empty(*s, dtype=torch.float16, device=gpu).contiguous(memory_format=torch.channels_last)
+    x, out = e(0, 128, 6, 8), e(0, 128, 6, 8)
+    wt = torch.randn(128, 128, 3, 3, device=gpu)
+    U.conv_igemm(x, None, U.pack_conv_igemm(wt), 9, 128, out)
+    U.bias_act(x, None, U.ACT_RELU)
+    assert U.conv3x3_small(x, U.pack_conv3x3_small([wt[:2]]), None, 2, [U.ACT_NONE]).shape == (1, 0, 6, 8, 2)
+    assert U.segment_mean(x, torch.zeros(0, dtype=torch.int64, device=gpu), 3).abs().sum() == 0
+    flow = torch.empty(0, 6, 8, 4, device=gpu)
+    U.flow_conv7(flow, U.pack_flow_conv7(torch.randn(128, 4, 7, 7, device=gpu)), torch.zeros(128, device=gpu), out)
+    c = torch.empty(0, 2, 6, 8, device=gpu)
+    lv = [db.tile_corr_level(torch.empty(0, 6 >> l, 8 >> l, dtype=torch.float16, device=gpu)) for l in range(3)]
+    assert db.corr_lookup_pyramid_tiled(lv, c, 6, 8).shape == (0, 147, 6, 8)
+    poses = torch.zeros(4, 7, device=gpu)
+    poses[:, 6] = 1
+    disps = torch.ones(4, 6, 8, device=gpu)
+    intr = torch.tensor([4.0, 4.0, 4.0, 3.0], device=gpu)
+    m = db.valid_depth_mask(poses, disps, intr, torch.zeros(0, dtype=torch.int64, device=gpu), 0.01, 2)
+    assert m.shape == (0, 6, 8)
+    mask = torch.zeros(4, 6, 8, dtype=torch.bool, device=gpu)
+    eo, any_on = db.dspo_prepare(poses, disps, intr, disps.clone(), 0, 0.01, 2, 0.1,
+                                 torch.zeros(0, dtype=torch.int64, device=gpu), torch.zeros(0, dtype=torch.int64, device=gpu),
+                                 mask, torch.ones(4, device=gpu), torch.zeros(4, device=gpu))
+    assert eo.numel() == 0 and int(any_on) == 0
+    assert db.motion(torch.empty(0, 6, 8, 2, device=gpu), torch.zeros(6, 8, 2, device=gpu),
+                     torch.empty(0, 6, 8, 2, device=gpu)).shape == (0, 6, 8, 4)
