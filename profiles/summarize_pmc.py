@@ -24,9 +24,11 @@ def mean_of(rows, pred):
 def main(fetch_dir, write_dir):
     f, w = load(fetch_dir), load(write_dir)
     GiB_KiB = float(1 << 20)
-    cal_f, _ = mean_of(f, lambda n: "copyBuffer" in n and True)
-    cal_f = max(float(r["Counter_Value"]) for r in f if "copyBuffer" in r["Kernel_Name"])
-    cal_w = max(float(r["Counter_Value"]) for r in w if "copyBuffer" in r["Kernel_Name"])
+    # calibration = the LAST device copy of the run (the 1 GiB clone at the end of pmc_gathers.py); other
+    # copyBuffer launches (e.g. re-tiling the correlation pyramid) are larger
+    last = lambda rows: [r for r in sorted(rows, key=lambda r: int(r["Dispatch_Id"])) if "copyBuffer" in r["Kernel_Name"]][-1]
+    cal_f = float(last(f)["Counter_Value"])
+    cal_w = float(last(w)["Counter_Value"])
     fetch_corr = GiB_KiB / cal_f     # ~2.0 on gfx950
     write_corr = GiB_KiB / cal_w     # ~1.0
     out = {"calibration": {"copy_bytes": 1 << 30, "FETCH_SIZE_KiB": cal_f, "WRITE_SIZE_KiB": cal_w,
