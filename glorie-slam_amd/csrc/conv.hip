@@ -373,7 +373,8 @@ extern "C" int glorie_conv_igemm(const void* xa, int xa_stride, int ca, const vo
   // 128x128 tile at 3 workgroups per CU (1050 TFLOP/s on the 448->256 layer) beats every variant with
   // more LDS stages and fewer resident workgroups: 2 stages 930, 2 stages + register-resident fragments
   // (loads two steps ahead, ST = 4) 915, 8 waves with a 3-stage ring and counted vmcnt 830, 256-pixel
-  // tiles 850, 32-channel steps at 4 workgroups per CU 824.
+  // tiles 850, 32-channel steps at 4 workgroups per CU 824; the same wave tile on v_mfma_f32_32x32x16_f16
+  // (16 instead of 32 MFMAs per step) 945.
   // layers with <= 64 output channels (flow_encoder[2]) use a 64-channel tile instead of padding to 128
   if (nout <= 64 && epilogue == EPI_BIAS_ACT) return launch_conv<4, 64, 4, 1, 2>(a, epilogue, st);
   return launch_conv<4, 64, 4, 1>(a, epilogue, st);
