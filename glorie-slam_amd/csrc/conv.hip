@@ -19,7 +19,8 @@
 //   fragment reads -> barrier (every wave holds its fragments: the stage is free) -> DMA of the
 //   next tile into the same stage -> 32 MFMAs from registers while it streams in.  Occupancy plus
 //   this register-level double buffering measured faster than two or three LDS stages with fewer
-//   resident workgroups (kept as template variants ST = 2 | 3, NW = 8).  The LDS image is
+//   resident workgroups (ST = 2 is kept as a template variant; the other measurements are listed at
+//   the dispatch below).  The LDS image is
 //   lane-linear as the DMA requires; the 16-byte slot of a row is XOR-swizzled on the SOURCE
 //   address and on the fragment read (conflict-free b128 reads).
 // * Zero padding: a lane whose row is outside the map for the current tap sets bit 31 of its
@@ -69,12 +70,12 @@ __device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
 }
 
 // NB = 16-pixel blocks per wave, BK = channels per K step (32 | 64), NW = waves (2 channel halves x
-// NW/2 pixel groups: pixel tile = NW/2 * 16*NB), ST = LDS stages (2: one __syncthreads per step;
-// 3: loads run two steps ahead, counted vmcnt + raw barrier so that they stay in flight across it)
+// NW/2 pixel groups: pixel tile = NW/2 * 16*NB), ST = LDS stages (1: single stage + register-resident
+// fragments, the shipped form; 2: classic double buffering with one __syncthreads per step)
 template <int EPI, int NB, int BK, int NW, int ST, int MB = 4>
-__global__ __launch_bounds__(64 * NW, ST == 3 ? 1 : (ST == 1 ? (BK == 32 ? 4 : 3) : 2)) void conv_igemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__(64 * NW, ST == 1 ? 3 : 2) void conv_igemm_kernel(ConvArgs a) {
   constexpr int TN = 32 * MB;               // output channels per workgroup (MB 16-channel blocks per wave)
-  constexpr int NST = ST == 4 ? 2 : ST;     // LDS stages (ST = 4: two stages + register-resident fragments)
+  static_assert(ST == 1 || ST == 2, "LDS stages");
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (buffer-resource types are device-only)
   constexpr int PT = (NW / 2) * 16 * NB;      // pixels per workgroup
   constexpr int RB = BK * 2;                  // bytes per staged row
@@ -192,24 +193,9 @@ __global__ __launch_bounds__(64 * NW, ST == 3 ? 1 : (ST == 1 ? (BK == 32 ? 4 : 3
   const int wbase = XBYTES + wm * (16 * MB) * RB, xbase_l = wn * (16 * NB) * RB;
 
   stage(0, 0);
-  if ((ST == 3 || ST == 4) && T > 1) stage(1, 1);
   int cur = 0;                                 // LDS stage holding tile t
   for (int t = 0; t < T; ++t) {
-    if (ST == 1) {
-      __syncthreads();                         // tile t landed
-    } else if (ST == 4) {
-      if (t + 1 < T) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XI + WI) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-    } else if (ST == 2) {
-      __syncthreads();                         // tile t landed (vmcnt(0) + barrier); the other buffer is free
-    } else {
-      // my loads of tile t have landed when at most the XI + WI loads of tile t+1 are still in flight;
-      // after the barrier everybody's have, and everybody is done reading the stage tile t+2 goes to
-      if (t + 1 < T) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XI + WI) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-    }
+    __syncthreads();                           // tile t landed (vmcnt(0) + barrier); ST = 2: the other stage is free
     const char* base = smem + cur * (XBYTES + WBYTES);
     // all fragment reads of the step go out first (one exposed LDS latency per step, not per kk), the
     // DMA of the next tile is issued in their shadow, then the MFMAs run back to back
@@ -224,20 +210,13 @@ __global__ __launch_bounds__(64 * NW, ST == 3 ? 1 : (ST == 1 ? (BK == 32 ? 4 : 3
         xf[kk][ni] = *reinterpret_cast<const f16x8*>(base + xbase_l + ni * 16 * RB + foff[kk]);
     }
     if (ST == 1) {
-      // single LDS stage, 4 workgroups per CU.  Every fragment of the step is in registers now, so
+      // single LDS stage, 3 workgroups per CU.  Every fragment of the step is in registers now, so
       // once all waves got theirs the buffer is free: tile t+1 streams into it under the MFMAs.
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       if (t + 1 < T) stage(t + 1, 0);
-    } else if (ST == 4) {
-      // as ST = 1 but with two stages: the freed stage receives tile t+2, so a DMA has two steps to land
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      if (t + 2 < T) stage(t + 2, cur);
-    } else if (ST == 2) {
-      if (t + 1 < T) stage(t + 1, cur ^ 1);
     } else {
-      if (t + 2 < T) stage(t + 2, cur >= 1 ? cur - 1 : 2);     // (cur + 2) % 3
+      if (t + 1 < T) stage(t + 1, cur ^ 1);
     }
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk)
@@ -246,7 +225,7 @@ __global__ __launch_bounds__(64 * NW, ST == 3 ? 1 : (ST == 1 ? (BK == 32 ? 4 : 3
 #pragma unroll
         for (int ni = 0; ni < NB; ++ni)
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kk][mi], xf[kk][ni], acc[mi][ni], 0, 0, 0);
-    if (NST > 1) cur = (cur + 1 == NST) ? 0 : cur + 1;
+    if (ST == 2) cur ^= 1;
   }
 
   // ---- epilogue: lane owns channels n0 + wm*64 + mi*16 + kg*4 .. +3 of pixel p0 + wn*16*NB + ni*16 + col ----
@@ -308,7 +287,7 @@ __global__ __launch_bounds__(64 * NW, ST == 3 ? 1 : (ST == 1 ? (BK == 32 ? 4 : 3
 template <int EPI, int NB, int BK, int NW, int ST, int MB>
 static void launch_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
   constexpr int RB = BK * 2, PT = (NW / 2) * 16 * NB;
-  constexpr size_t lds = (size_t)(ST == 4 ? 2 : ST) * (PT * RB + 32 * MB * RB);
+  constexpr size_t lds = (size_t)ST * (PT * RB + 32 * MB * RB);
   static bool attr = false;            // > 64 KB of dynamic LDS needs the opt-in once per kernel
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<EPI, NB, BK, NW, ST, MB>),
