@@ -262,19 +262,33 @@ __device__ __forceinline__ void knn_search(const float4* __restrict__ sorted,
     const int x0 = max(cx - m, 0), x1 = min(cx + m, g.nx - 1);
     const int y0 = max(cy - m, 0), y1 = min(cy + m, g.ny - 1);
     const int z0 = max(cz - m, 0), z1 = min(cz + m, g.nz - 1);
+    // Cells of one (z, y) row are consecutive in `starts` and their points consecutive in `sorted`: a
+    // face row of the shell is ONE contiguous point range (2 dependent index loads per row instead
+    // of 2 per cell), and the range is walked 4 points at a time with independent 16-byte loads
+    // (a lane's search is a chain of dependent loads: this is what bounds the kernel).
+    auto scan = [&](int b, int e) {
+      int t = b;
+      for (; t + 3 < e; t += 4) {
+        const float4 p0 = sorted[t], p1 = sorted[t + 1], p2 = sorted[t + 2], p3 = sorted[t + 3];
+        top.push(dist2_exact(qx, qy, qz, p0), __float_as_int(p0.w));
+        top.push(dist2_exact(qx, qy, qz, p1), __float_as_int(p1.w));
+        top.push(dist2_exact(qx, qy, qz, p2), __float_as_int(p2.w));
+        top.push(dist2_exact(qx, qy, qz, p3), __float_as_int(p3.w));
+      }
+      for (; t < e; ++t) {
+        const float4 p = sorted[t];
+        top.push(dist2_exact(qx, qy, qz, p), __float_as_int(p.w));
+      }
+    };
     for (int z = z0; z <= z1; ++z)
       for (int y = y0; y <= y1; ++y) {
         const bool face = (abs(z - cz) == m) || (abs(y - cy) == m);
-        // on a face row every x belongs to the shell; otherwise only the two end cells
-        const int step = face ? 1 : max(x1 - x0, 1);
-        for (int x = x0; x <= x1; x += step) {
-          if (!face && abs(x - cx) != m) continue;
-          const int cell = (z * g.ny + y) * g.nx + x;
-          const int b = starts[cell], e = starts[cell + 1];
-          for (int t = b; t < e; ++t) {
-            const float4 p = sorted[t];
-            top.push(dist2_exact(qx, qy, qz, p), __float_as_int(p.w));
-          }
+        const int row = (z * g.ny + y) * g.nx;
+        if (face) {                                   // every x of the row belongs to the shell
+          scan(starts[row + x0], starts[row + x1 + 1]);
+        } else {                                      // only the two end cells (if they are on the shell)
+          if (abs(x0 - cx) == m) scan(starts[row + x0], starts[row + x0 + 1]);
+          if (x1 != x0 && abs(x1 - cx) == m) scan(starts[row + x1], starts[row + x1 + 1]);
         }
       }
     // distance from q to the faces of the scanned cube that still have cells behind them
