@@ -64,7 +64,7 @@ __global__ __launch_bounds__(1024) void prep_align_kernel(
   extern __shared__ uint32_t keys[];
   __shared__ double red[16];
   __shared__ unsigned hist[256];
-  __shared__ unsigned sel_prefix, sel_k;
+  __shared__ unsigned sel_prefix, sel_k, wsum[4];
   const int f = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
   const float* d = disps + (size_t)f * HW;
   const float* m = mono + (size_t)f * HW;
@@ -92,14 +92,26 @@ __global__ __launch_bounds__(1024) void prep_align_kernel(
         if (key != 0xffffffffu && (key & mask) == prefix) atomicAdd(&hist[(key >> (8 * pass)) & 255u], 1u);
       }
       __syncthreads();
-      if (tid == 0) {
-        unsigned kk = sel_k, b = 0;
-        for (; b < 256; ++b) {
-          if (kk < hist[b]) break;
-          kk -= hist[b];
+      {
+        // which bin holds the k-th key: inclusive scan of the 256 bins over the first 4 waves
+        const unsigned kk = sel_k;
+        const unsigned hv = tid < 256 ? hist[tid] : 0u;
+        unsigned incl = hv;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const unsigned v = __shfl_up(incl, off, 64);
+          if ((tid & 63) >= off) incl += v;
         }
-        sel_k = kk;
-        sel_prefix = prefix | (b << (8 * pass));
+        if (tid < 256 && (tid & 63) == 63) wsum[tid >> 6] = incl;
+        __syncthreads();
+        if (tid < 256) {
+          for (int q = 0; q < (tid >> 6); ++q) incl += wsum[q];
+          const unsigned excl = incl - hv;
+          if (kk >= excl && kk < incl) {          // exactly one bin (the k-th key exists: nvalid > k)
+            sel_k = kk - excl;
+            sel_prefix = prefix | ((unsigned)tid << (8 * pass));
+          }
+        }
       }
       mask |= 0xffu << (8 * pass);
       __syncthreads();
