@@ -49,6 +49,7 @@ class FactorGraph:
         self.use_graphs = bool(use_graphs) and str(device).startswith("cuda")
         self._topo = 0                      # bumped whenever the edge set changes
         self._graphs = {}                   # (topology, arguments) -> captured update
+        self._lowmem_update = None
         # fp16 channels-last form of the update operator with fused element-wise stages
         # (droid_net.FusedUpdate, csrc/gru.hip)
         self.fast_update = FusedUpdate(update_op, inplace=self.use_graphs) if str(device).startswith("cuda") else None
@@ -350,10 +351,18 @@ class FactorGraph:
                 iis, jjs = self.ii[v], self.jj[v]
                 corr1 = corr_op(coords1[:, v], rig * iis, rig * jjs + (iis == jjs).long())
                 uq = torch.unique(iis)
-                with torch.autocast("cuda", enabled=True):
-                    net, delta, weight, damping, upmask = \
-                        self.update_op(self.net[:, v], self.video.inps[None, iis], corr1, motn[:, v], iis, jjs)
-                self.video.upsample(uq, upmask, softmax_f32=True)
+                if self.fast_update is not None:
+                    # chunks differ in size: a second FusedUpdate (own buffers, never in place) serves them
+                    if self._lowmem_update is None:
+                        self._lowmem_update = FusedUpdate(self.update_op)
+                    net, delta, weight, damping, upmask = self._lowmem_update(
+                        self.net[:, v], self.video.inps[None, iis], corr1, motn[:, v].contiguous(), iis, jjs)
+                    self.video.upsample(uq, upmask, softmax_f32=True)   # inside autocast in the reference: fp32 softmax
+                else:
+                    with torch.autocast("cuda", enabled=True):
+                        net, delta, weight, damping, upmask = \
+                            self.update_op(self.net[:, v], self.video.inps[None, iis], corr1, motn[:, v], iis, jjs)
+                    self.video.upsample(uq, upmask, softmax_f32=True)
                 self.net[:, v] = net
                 self.target[:, v] = coords1[:, v] + delta.float()
                 self.weight[:, v] = weight.float()
