@@ -532,7 +532,7 @@ __global__ __launch_bounds__(512) void mlp_col_v2_kernel(ColParams P, const floa
 }
 
 // per-neighbour F_theta, v2: W1 (52 x 128) resident in LDS for the whole workgroup
-__global__ __launch_bounds__(512) void mlp_nb_v2_kernel(NbParams P, const float* __restrict__ pts,
+__global__ __launch_bounds__(512, 2) void mlp_nb_v2_kernel(NbParams P, const float* __restrict__ pts,
                                                         const float* __restrict__ cloud,
                                                         const float* __restrict__ col_feats,
                                                         const int64_t* __restrict__ I,
@@ -541,11 +541,14 @@ __global__ __launch_bounds__(512) void mlp_nb_v2_kernel(NbParams P, const float*
                                                         float* __restrict__ c_col) {
   constexpr int LDX = 66;
   extern __shared__ float smem[];
+  // 72 KB of LDS -> 2 workgroups (16 waves) per CU: the gather latency of one workgroup's staging phase
+  // is covered by the other's MFMAs.  The [128][130] buffer of the second layer reuses the whole region
+  // once the neighbour loop is over (the IDW weight sums it would overwrite are taken before).
   float* W1s = smem;                          // [52][144]
   float* X = W1s + 52 * kLdw;                 // [128][66]
-  float* Y = X + kTM2 * LDX;                  // [128][130]
-  float* wbuf = Y + kTM2 * kLdh;              // [128][8]
+  float* wbuf = X + kTM2 * LDX;               // [128][8]
   int* ibuf = reinterpret_cast<int*>(wbuf + kTM2 * 8);  // [128][8]
+  float* Y = smem;                            // [128][130], aliases W1s | X | wbuf | ibuf
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   const int r = lane & 15, g = lane >> 4;
   const int q0 = blockIdx.x * kTM2;
@@ -606,6 +609,14 @@ __global__ __launch_bounds__(512) void mlp_nb_v2_kernel(NbParams P, const float*
     }
     __syncthreads();
   }
+  float sw[4];                                // sum of the IDW weights of this lane's 4 rows
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    sw[rr] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sw[rr] += wbuf[(wv * 16 + g * 4 + rr) * 8 + k];
+  }
+  __syncthreads();                            // everybody is done with W1s / X / wbuf: Y may overwrite them
   float* Yw = Y + (wv * 16) * kLdh;
 #pragma unroll
   for (int t = 0; t < 8; ++t)
@@ -622,11 +633,8 @@ __global__ __launch_bounds__(512) void mlp_nb_v2_kernel(NbParams P, const float*
       const int row = wv * 16 + g * 4 + rr;
       const int q = q0 + row;
       if (q < Q) {
-        float sw = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) sw += wbuf[row * 8 + k];
         const int col = 16 * t + (lane & 15);
-        c_col[(size_t)q * 32 + col] = has[q] ? o[t][rr] + P.b2[col] * sw : 0.0f;
+        c_col[(size_t)q * 32 + col] = has[q] ? o[t][rr] + P.b2[col] * sw[rr] : 0.0f;
       }
     }
 }
@@ -682,7 +690,9 @@ extern "C" int glorie_render_mlp(const float* packed, const float* pts, const fl
   hipLaunchKernelGGL(mlp_geo_kernel, dim3(blocks), dim3(256), 0, st, g, pts, c_geo, has, Q, raw);
   if (stage_color) {
     const int blocks2 = (Q + kTM2 - 1) / kTM2;
-    const size_t nb_lds = sizeof(float) * (52 * kLdw + kTM2 * 66 + kTM2 * kLdh + kTM2 * 8) + sizeof(int) * kTM2 * 8;
+    const size_t nb_work = sizeof(float) * (52 * kLdw + kTM2 * 66 + kTM2 * 8) + sizeof(int) * kTM2 * 8;
+    const size_t nb_y = sizeof(float) * kTM2 * kLdh;
+    const size_t nb_lds = nb_work > nb_y ? nb_work : nb_y;
     const size_t col_lds = sizeof(float) * (2 * kChunkFloats + kTM2 * kLdh);
     static bool attr = false;
     if (!attr) {
