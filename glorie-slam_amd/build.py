@@ -23,6 +23,7 @@ INCLUDE = os.path.join(os.path.dirname(PKG_DIR), "include")
 HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
          "-Wall", "-Wno-unused-function", "-I", INCLUDE]
+FLAGS += os.environ.get("GLORIE_EXTRA_HIPFLAGS", "").split()   # kernel experiments (-DEXP_...)
 
 
 def _sources():

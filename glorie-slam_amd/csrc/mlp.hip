@@ -183,165 +183,6 @@ __global__ __launch_bounds__(256) void mlp_geo_kernel(GeoParams P, const float* 
   }
 }
 
-// ------------------------------------------------------------------------------------
-// per-neighbour colour features (F_theta) + IDW sum
-// ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void mlp_nb_kernel(NbParams P, const float* __restrict__ pts,
-                                                     const float* __restrict__ cloud,
-                                                     const float* __restrict__ col_feats,
-                                                     const int64_t* __restrict__ I,
-                                                     const float* __restrict__ wts,
-                                                     const uint8_t* __restrict__ has, int Q,
-                                                     float* __restrict__ c_col) {
-  constexpr int LDX = 66, LDY = 130;  // 52 -> pad, 128 -> pad
-  __shared__ float xbuf[kTM * LDX];
-  __shared__ float ybuf[kTM * LDY];
-  __shared__ float wbuf[kTM * 8];
-  __shared__ int ibuf[kTM * 8];
-  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-  const int q0 = blockIdx.x * kTM;
-  for (int idx = tid; idx < kTM * 8; idx += 256) {
-    const int r = idx >> 3;
-    const int q = min(q0 + r, Q - 1);
-    const int ii = (int)I[(size_t)q * 8 + (idx & 7)];
-    const float w = (q0 + r < Q && ii >= 0) ? wts[(size_t)q * 8 + (idx & 7)] : 0.0f;
-    wbuf[idx] = w;
-    ibuf[idx] = ii < 0 ? 0 : ii;
-  }
-  __syncthreads();
-  f32x4 ysum[8];
-  zero<8>(ysum);
-  const float* X = xbuf + wv * 16 * LDX;
-  for (int k = 0; k < 8; ++k) {
-    // stage x = [sin(rel B) (10), cos(rel B) (10), col_feat (32)]; 4 threads per sample row
-    {
-      const int r = tid >> 2, part = tid & 3;
-      const int q = min(q0 + r, Q - 1);
-      const int pt = ibuf[r * 8 + k];
-      const float rx = kTwoPi * (cloud[(size_t)pt * 3 + 0] - pts[(size_t)q * 3 + 0]);
-      const float ry = kTwoPi * (cloud[(size_t)pt * 3 + 1] - pts[(size_t)q * 3 + 1]);
-      const float rz = kTwoPi * (cloud[(size_t)pt * 3 + 2] - pts[(size_t)q * 3 + 2]);
-      for (int f = part; f < 10; f += 4) {
-        const float a = fmaf(rz, P.B[20 + f], fmaf(ry, P.B[10 + f], rx * P.B[f]));
-        float s, c;
-        sincosf(a, &s, &c);
-        xbuf[r * LDX + f] = s;
-        xbuf[r * LDX + 10 + f] = c;
-      }
-      const float4* src = reinterpret_cast<const float4*>(col_feats + (size_t)pt * 32 + part * 8);
-      const float4 v0 = src[0], v1 = src[1];
-      float* dst = xbuf + r * LDX + 20 + part * 8;
-      dst[0] = v0.x; dst[1] = v0.y; dst[2] = v0.z; dst[3] = v0.w;
-      dst[4] = v1.x; dst[5] = v1.y; dst[6] = v1.z; dst[7] = v1.w;
-    }
-    __syncthreads();
-    f32x4 acc[8];
-    zero<8>(acc);
-    gemm16<8>(acc, X, LDX, 52, P.W1, 128, 0);
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = wv * 16 + (lane >> 4) * 4 + r;
-        const float w = wbuf[row * 8 + k];
-        ysum[t][r] += w * softplus100(acc[t][r] + P.b1[16 * t + (lane & 15)]);
-      }
-    __syncthreads();
-  }
-  float* Y = ybuf + wv * 16 * LDY;
-  store_tile<8>(ysum, Y, LDY);
-  __syncthreads();
-  f32x4 o[2];
-  zero<2>(o);
-  gemm16<2>(o, Y, LDY, 128, P.W2, 32, 0);
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = wv * 16 + (lane >> 4) * 4 + r;
-      const int q = q0 + row;
-      if (q < Q) {
-        float sw = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) sw += wbuf[row * 8 + k];
-        const int col = 16 * t + (lane & 15);
-        c_col[(size_t)q * 32 + col] = has[q] ? o[t][r] + P.b2[col] * sw : 0.0f;
-      }
-    }
-}
-
-// ------------------------------------------------------------------------------------
-// colour decoder
-// ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void mlp_col_kernel(ColParams P, const float* __restrict__ pts,
-                                                      const float* __restrict__ views,
-                                                      const float* __restrict__ c_col, int Q,
-                                                      float* __restrict__ raw) {
-  constexpr int LDE = 82, LDH = 130, LDC = 34;
-  __shared__ float emb[kTM * LDE];
-  __shared__ float hbuf[kTM * LDH];
-  __shared__ float cbuf[kTM * LDC];
-  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-  const int q0 = blockIdx.x * kTM;
-  // embedding: [sin(pB) 20 | cos(pB) 20 | sin(vB) 20 | cos(vB) 20], v = normalised view direction
-  for (int idx = tid; idx < kTM * 40; idx += 256) {
-    const int r = idx / 40, f = idx - r * 40;
-    const int q = min(q0 + r, Q - 1);
-    float x, y, z;
-    const float* Bm;
-    int base;
-    if (f < 20) {
-      x = pts[(size_t)q * 3 + 0]; y = pts[(size_t)q * 3 + 1]; z = pts[(size_t)q * 3 + 2];
-      Bm = P.Bp; base = 0;
-    } else {
-      x = views[(size_t)q * 3 + 0]; y = views[(size_t)q * 3 + 1]; z = views[(size_t)q * 3 + 2];
-      const float nrm = fmaxf(sqrtf(x * x + y * y + z * z), 1e-12f);  // F.normalize(p=2, eps=1e-12)
-      x /= nrm; y /= nrm; z /= nrm;
-      Bm = P.Bv; base = 40;
-    }
-    const int ff = f % 20;
-    const float a = fmaf(kTwoPi * z, Bm[40 + ff], fmaf(kTwoPi * y, Bm[20 + ff], (kTwoPi * x) * Bm[ff]));
-    float s, c;
-    sincosf(a, &s, &c);
-    emb[r * LDE + base + ff] = s;
-    emb[r * LDE + base + 20 + ff] = c;
-  }
-  for (int idx = tid; idx < kTM * 32; idx += 256) {
-    const int r = idx >> 5, f = idx & 31;
-    const int q = min(q0 + r, Q - 1);
-    cbuf[r * LDC + f] = c_col[(size_t)q * 32 + f];
-  }
-  __syncthreads();
-  const float* E = emb + wv * 16 * LDE;
-  float* H = hbuf + wv * 16 * LDH;
-  const float* C = cbuf + wv * 16 * LDC;
-  f32x4 acc[8];
-  auto layer_tail = [&](int li) {
-    for_each_out<8>(acc, [&](float v, int, int col) { return softplus100(v + P.bias[li * 128 + col]) + P.fcb[li * 128 + col]; });
-    gemm16<8>(acc, C, LDC, 32, P.Fc + li * 32 * 128, 128, 0);
-    __syncthreads();
-    store_tile<8>(acc, H, LDH);
-    __syncthreads();
-  };
-  zero<8>(acc); gemm16<8>(acc, E, LDE, 80, P.W0, 128, 0); layer_tail(0);
-  zero<8>(acc); gemm16<8>(acc, H, LDH, 128, P.W1, 128, 0); layer_tail(1);
-  zero<8>(acc); gemm16<8>(acc, H, LDH, 128, P.W2, 128, 0); layer_tail(2);
-  zero<8>(acc); gemm16<8>(acc, E, LDE, 80, P.W3e, 128, 0); gemm16<8>(acc, H, LDH, 128, P.W3h, 128, 0); layer_tail(3);
-  zero<8>(acc); gemm16<8>(acc, H, LDH, 128, P.W4, 128, 0); layer_tail(4);
-  f32x4 o[1];
-  zero<1>(o);
-  gemm16<1>(o, H, LDH, 128, P.Wout, 16, 0);
-  const int col = lane & 15;
-  if (col < 3) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int q = q0 + wv * 16 + (lane >> 4) * 4 + r;
-      if (q < Q) raw[(size_t)q * 4 + col] = 1.0f / (1.0f + expf(-(o[0][r] + P.bout[col])));
-    }
-  }
-}
-
-
 // ====================================================================================
 // v2 kernels: 128 samples / 8 waves per workgroup, weights streamed through LDS in 32-row
 // chunks (double buffered, shared by the 8 waves), embedding / feature A-fragments kept in
@@ -349,14 +190,19 @@ __global__ __launch_bounds__(256) void mlp_col_kernel(ColParams P, const float* 
 // approximations of softplus differ (v_exp/v_log, |err| < 1e-6).
 // ====================================================================================
 constexpr int kTM2 = 128;
-constexpr int kLdw = 144;                 // chunk row stride: (k*144 + col) % 32 is conflict free
-constexpr int kChunkFloats = 32 * kLdw;   // one 32 x 128 weight chunk in LDS
-constexpr int kLdh = 130;
 
+// torch.nn.Softplus(beta=100, threshold=20) on the bare base-2 hardware transcendentals (v_exp_f32 /
+// v_log_f32, 1 ulp each):  ln(1 + e^(100 x)) / 100 = (ln 2 / 100) log2(1 + 2^(100 log2(e) x)).
+// On this chip VALU work does not hide behind fp32 MFMAs of the same SIMD (tools/probes/
+// mfma_valu_overlap.hip: the two add up), and expf / logf cost 3.7x these two instructions.
 __device__ __forceinline__ float softplus100_fast(float x) {
-  const float t = 100.0f * x;
-  return t > 20.0f ? x : 0.01f * __logf(1.0f + __expf(t));
+  const float e = __builtin_amdgcn_exp2f(144.26950408889634f * x);
+  const float y = 0.006931471805599453f * __builtin_amdgcn_logf(1.0f + e);
+  return x > 0.2f ? x : y;
 }
+// sin / cos of 2 pi rev on v_sin_f32 / v_cos_f32 (argument in revolutions, reduced with v_fract_f32)
+__device__ __forceinline__ float sin_rev(float rev) { return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(rev)); }
+__device__ __forceinline__ float cos_rev(float rev) { return __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(rev)); }
 
 struct ChunkRegs { float4 a, b; };
 
@@ -369,190 +215,221 @@ __device__ __forceinline__ ChunkRegs chunk_load(const float* __restrict__ Wall, 
   r.b = src[1];
   return r;
 }
-__device__ __forceinline__ void chunk_store(float* Wb, const ChunkRegs& r) {
+// ---- colour decoder, transposed formulation ------------------------------------------------
+// Every layer is evaluated as  H'^T = W^T . H^T : the MFMA's 16 "rows" are output channels (A = weights
+// from the LDS chunk), its 16 "columns" are the wave's 16 samples (B = activations).  The D fragment
+// of lane (r = lane & 15, g = lane >> 4) then holds channels 16t + 4g + rr (t = 0..7, rr = 0..3) of
+// sample r - and the B operand of the next layer wants, for k-slot g, *some* channel of sample r.  The
+// order in which the reduction runs over channels is free, so k-step (t, rr) simply takes channel
+// 16t + 4g + rr from slot g: the accumulator registers of one layer are the B operands of the next,
+// no transposition through LDS, no activation buffer at all.  The embedding and the colour feature
+// use the same channel -> (step, slot) assignment.  LDS only holds the double-buffered weight chunk
+// (33 KB), so two workgroups share a CU and one's barriers hide behind the other's MFMAs.
+constexpr int kLdw3 = 132;                  // chunk row stride in LDS (floats)
+constexpr int kChunkFloats3 = 32 * kLdw3;
+
+__device__ __forceinline__ void chunk_store3(float* Wb, const ChunkRegs& r) {
   const int t = threadIdx.x;
-  float4* dst = reinterpret_cast<float4*>(Wb + (t >> 4) * kLdw + (t & 15) * 8);
+  float4* dst = reinterpret_cast<float4*>(Wb + (t >> 4) * kLdw3 + (t & 15) * 8);
   dst[0] = r.a;
   dst[1] = r.b;
 }
 
-// acc[t] += a_k * W[k][16t + lane&15] for NS k-steps, A from a register fragment
-template <int A0, int NS, int NREG>
-__device__ __forceinline__ void mma_regs(f32x4 (&acc)[8], const float (&a)[NREG], const float* Wb) {
+// acc[to] += W[16 tt + 4g + rr][16 to + r] * b[T0 + tt][rr]  for tt < NT, rr < 4 (rows relative to the chunk).
+// The columns of a chunk row are stored permuted - column 16 to + r at (to >> 2) * 64 + 4 r + (to & 3) - so
+// the eight A operands of a k-step are two ds_read_b128 (16 lanes read 256 contiguous bytes).
+template <int T0, int NT, int NB>
+__device__ __forceinline__ void mma_t(f32x4 (&acc)[8], const f32x4 (&b)[NB], const float* Wb) {
   const int lane = threadIdx.x & 63;
-  const float* wp = Wb + (lane >> 4) * kLdw + (lane & 15);
+  const float* wp = Wb + (lane >> 4) * 4 * kLdw3 + (lane & 15) * 4;
 #pragma unroll
-  for (int sidx = 0; sidx < NS; ++sidx) {
-    const float av = a[A0 + sidx];
+  for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
-    for (int t = 0; t < 8; ++t)
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wp[sidx * 4 * kLdw + 16 * t], acc[t], 0, 0, 0);
-  }
-}
-// A from this wave's rows of the activation buffer (8 k-steps starting at column h0)
-__device__ __forceinline__ void mma_lds(f32x4 (&acc)[8], const float* Hrow, int h0, const float* Wb) {
-  const int lane = threadIdx.x & 63;
-  const float* wp = Wb + (lane >> 4) * kLdw + (lane & 15);
-  const float* ap = Hrow + h0 + (lane >> 4);
-#pragma unroll
-  for (int sidx = 0; sidx < 8; ++sidx) {
-    const float av = ap[4 * sidx];
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wp[sidx * 4 * kLdw + 16 * t], acc[t], 0, 0, 0);
-  }
+    for (int rr = 0; rr < 4; ++rr) {
+      const float bv = b[T0 + tt][rr];
+      const float4 w0 = *reinterpret_cast<const float4*>(wp + (16 * tt + rr) * kLdw3);
+      const float4 w1 = *reinterpret_cast<const float4*>(wp + (16 * tt + rr) * kLdw3 + 64);
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.x, bv, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.y, bv, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.z, bv, acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.w, bv, acc[3], 0, 0, 0);
+      acc[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.x, bv, acc[4], 0, 0, 0);
+      acc[5] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.y, bv, acc[5], 0, 0, 0);
+      acc[6] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.z, bv, acc[6], 0, 0, 0);
+      acc[7] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.w, bv, acc[7], 0, 0, 0);
+    }
 }
 
-__global__ __launch_bounds__(512) void mlp_col_v2_kernel(ColParams P, const float* __restrict__ Wall,
-                                                         const float* __restrict__ pts,
-                                                         const float* __restrict__ views,
-                                                         const float* __restrict__ c_col, int Q,
-                                                         float* __restrict__ raw) {
+__global__ __launch_bounds__(512, 4) void mlp_col_v3_kernel(ColParams P, const float* __restrict__ Wall,
+                                                            const float* __restrict__ pts,
+                                                            const float* __restrict__ views,
+                                                            const float* __restrict__ c_col, int Q,
+                                                            float* __restrict__ raw) {
   extern __shared__ float smem[];
-  float* Wbuf = smem;                         // [2][32][144]
-  float* H = smem + 2 * kChunkFloats;         // [128][130]
+  float* Wbuf = smem;                         // [2][32][132]
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   const int r = lane & 15, g = lane >> 4;
   const int q0 = blockIdx.x * kTM2;
-  const int q = min(q0 + wv * 16 + r, Q - 1);
-  float* Hrow = H + (wv * 16 + r) * kLdh;     // A-operand row of this lane
-  float* Hw = H + (wv * 16) * kLdh;           // this wave's 16 rows (C/D stores)
+  const int qs = q0 + wv * 16 + r;            // this lane's sample (all four k-slots of a column share it)
+  const int q = min(qs, Q - 1);
 
-  // ---- A fragments held in registers: embedding e[20] (k = 4j + g) and feature c[8]
-  float e[20], c[8];
+  // ---- B fragments: the embedding e (80 channels) stays in registers; the colour feature c (32
+  // channels) is re-read from L2 before each of its five uses (8 registers short of 4 waves / SIMD)
+  f32x4 e[5], c[2];
+  auto load_c = [&]() {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const float4 v = *reinterpret_cast<const float4*>(c_col + (size_t)q * 32 + 16 * t + 4 * g);
+      c[t][0] = v.x; c[t][1] = v.y; c[t][2] = v.z; c[t][3] = v.w;
+    }
+  };
   {
-    const float px = kTwoPi * pts[(size_t)q * 3 + 0], py = kTwoPi * pts[(size_t)q * 3 + 1],
-                pz = kTwoPi * pts[(size_t)q * 3 + 2];
+    // phases in revolutions: the 2 pi of the reference's embedding is the period of v_sin / v_cos
+    const float px = pts[(size_t)q * 3 + 0], py = pts[(size_t)q * 3 + 1], pz = pts[(size_t)q * 3 + 2];
     float vx = views[(size_t)q * 3 + 0], vy = views[(size_t)q * 3 + 1], vz = views[(size_t)q * 3 + 2];
     const float nrm = fmaxf(sqrtf(vx * vx + vy * vy + vz * vz), 1e-12f);
-    vx = kTwoPi * (vx / nrm); vy = kTwoPi * (vy / nrm); vz = kTwoPi * (vz / nrm);
+    vx = vx / nrm; vy = vy / nrm; vz = vz / nrm;
 #pragma unroll
-    for (int j = 0; j < 20; ++j) {
-      const int f = 4 * j + g;             // feature index 0..79
-      const int blk = f / 20, ff = f - blk * 20;
-      const float* Bm = blk < 2 ? P.Bp : P.Bv;
-      const float x = blk < 2 ? px : vx, y = blk < 2 ? py : vy, z = blk < 2 ? pz : vz;
-      const float a = fmaf(z, Bm[40 + ff], fmaf(y, Bm[20 + ff], x * Bm[ff]));
-      e[j] = (blk & 1) ? cosf(a) : sinf(a);
-    }
+    for (int t = 0; t < 5; ++t)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) c[j] = c_col[(size_t)q * 32 + 4 * j + g];
+      for (int rr = 0; rr < 4; ++rr) {
+        const int f = 16 * t + 4 * g + rr;   // feature index 0..79: [sin p | cos p | sin v | cos v] x 20
+        const int blk = f / 20, ff = f - blk * 20;
+        const float* Bm = blk < 2 ? P.Bp : P.Bv;
+        const float x = blk < 2 ? px : vx, y = blk < 2 ? py : vy, z = blk < 2 ? pz : vz;
+        const float a = fmaf(z, Bm[40 + ff], fmaf(y, Bm[20 + ff], x * Bm[ff]));
+        e[t][rr] = (blk & 1) ? cos_rev(a) : sin_rev(a);
+      }
   }
 
-  f32x4 acc[8];
+  f32x4 acc[8], h[8];
   constexpr int NC = 27;
   ChunkRegs nxt = chunk_load(Wall, 0);
-  chunk_store(Wbuf, nxt);
+  chunk_store3(Wbuf, nxt);
   __syncthreads();
 
   auto act = [&](int li) {
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-      const float bb = P.bias[li * 128 + 16 * t + (lane & 15)];
-      const float fb = P.fcb[li * 128 + 16 * t + (lane & 15)];
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) acc[t][rr] = softplus100_fast(acc[t][rr] + bb) + fb;
+      const float4 bb = *reinterpret_cast<const float4*>(P.bias + li * 128 + 16 * t + 4 * g);
+      const float4 fb = *reinterpret_cast<const float4*>(P.fcb + li * 128 + 16 * t + 4 * g);
+      acc[t][0] = softplus100_fast(acc[t][0] + bb.x) + fb.x;
+      acc[t][1] = softplus100_fast(acc[t][1] + bb.y) + fb.y;
+      acc[t][2] = softplus100_fast(acc[t][2] + bb.z) + fb.z;
+      acc[t][3] = softplus100_fast(acc[t][3] + bb.w) + fb.w;
     }
   };
-  auto store_h = [&]() {
+  auto next_layer = [&]() {
 #pragma unroll
-    for (int t = 0; t < 8; ++t)
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) Hw[((lane >> 4) * 4 + rr) * kLdh + 16 * t + (lane & 15)] = acc[t][rr];
+    for (int t = 0; t < 8; ++t) { h[t] = acc[t]; acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   };
 
 #define GL_CHUNK(cidx, BODY)                                        \
   {                                                                 \
     if ((cidx) + 1 < NC) nxt = chunk_load(Wall, (cidx) + 1);        \
-    const float* Wb = Wbuf + ((cidx) & 1) * kChunkFloats;           \
+    const float* Wb = Wbuf + ((cidx) & 1) * kChunkFloats3;          \
     BODY;                                                           \
-    if ((cidx) + 1 < NC) chunk_store(Wbuf + (((cidx) + 1) & 1) * kChunkFloats, nxt); \
+    if ((cidx) + 1 < NC) chunk_store3(Wbuf + (((cidx) + 1) & 1) * kChunkFloats3, nxt); \
     __syncthreads();                                                \
   }
 
   // layer 0: W0 (80 rows -> chunks 0..2), Fc0 (chunk 3)
   zero<8>(acc);
-  GL_CHUNK(0, (mma_regs<0, 8, 20>(acc, e, Wb)))
-  GL_CHUNK(1, (mma_regs<8, 8, 20>(acc, e, Wb)))
-  GL_CHUNK(2, (mma_regs<16, 4, 20>(acc, e, Wb)))
+  GL_CHUNK(0, (mma_t<0, 2, 5>(acc, e, Wb)))
+  GL_CHUNK(1, (mma_t<2, 2, 5>(acc, e, Wb)))
+  GL_CHUNK(2, (mma_t<4, 1, 5>(acc, e, Wb)))
+  load_c();
   act(0);
-  GL_CHUNK(3, (mma_regs<0, 8, 8>(acc, c, Wb), store_h()))
+  GL_CHUNK(3, (mma_t<0, 2, 2>(acc, c, Wb)))
   // layer 1
-  zero<8>(acc);
-  GL_CHUNK(4, (mma_lds(acc, Hrow, 0, Wb)))
-  GL_CHUNK(5, (mma_lds(acc, Hrow, 32, Wb)))
-  GL_CHUNK(6, (mma_lds(acc, Hrow, 64, Wb)))
-  GL_CHUNK(7, (mma_lds(acc, Hrow, 96, Wb)))
+  next_layer();
+  GL_CHUNK(4, (mma_t<0, 2, 8>(acc, h, Wb)))
+  GL_CHUNK(5, (mma_t<2, 2, 8>(acc, h, Wb)))
+  GL_CHUNK(6, (mma_t<4, 2, 8>(acc, h, Wb)))
+  GL_CHUNK(7, (mma_t<6, 2, 8>(acc, h, Wb)))
+  load_c();
   act(1);
-  GL_CHUNK(8, (mma_regs<0, 8, 8>(acc, c, Wb), store_h()))
+  GL_CHUNK(8, (mma_t<0, 2, 2>(acc, c, Wb)))
   // layer 2
-  zero<8>(acc);
-  GL_CHUNK(9, (mma_lds(acc, Hrow, 0, Wb)))
-  GL_CHUNK(10, (mma_lds(acc, Hrow, 32, Wb)))
-  GL_CHUNK(11, (mma_lds(acc, Hrow, 64, Wb)))
-  GL_CHUNK(12, (mma_lds(acc, Hrow, 96, Wb)))
+  next_layer();
+  GL_CHUNK(9, (mma_t<0, 2, 8>(acc, h, Wb)))
+  GL_CHUNK(10, (mma_t<2, 2, 8>(acc, h, Wb)))
+  GL_CHUNK(11, (mma_t<4, 2, 8>(acc, h, Wb)))
+  GL_CHUNK(12, (mma_t<6, 2, 8>(acc, h, Wb)))
+  load_c();
   act(2);
-  GL_CHUNK(13, (mma_regs<0, 8, 8>(acc, c, Wb), store_h()))
+  GL_CHUNK(13, (mma_t<0, 2, 2>(acc, c, Wb)))
   // layer 3 (skip): W3e on the embedding, W3h on the hidden state
-  zero<8>(acc);
-  GL_CHUNK(14, (mma_regs<0, 8, 20>(acc, e, Wb)))
-  GL_CHUNK(15, (mma_regs<8, 8, 20>(acc, e, Wb)))
-  GL_CHUNK(16, (mma_regs<16, 4, 20>(acc, e, Wb)))
-  GL_CHUNK(17, (mma_lds(acc, Hrow, 0, Wb)))
-  GL_CHUNK(18, (mma_lds(acc, Hrow, 32, Wb)))
-  GL_CHUNK(19, (mma_lds(acc, Hrow, 64, Wb)))
-  GL_CHUNK(20, (mma_lds(acc, Hrow, 96, Wb)))
+  next_layer();
+  GL_CHUNK(14, (mma_t<0, 2, 5>(acc, e, Wb)))
+  GL_CHUNK(15, (mma_t<2, 2, 5>(acc, e, Wb)))
+  GL_CHUNK(16, (mma_t<4, 1, 5>(acc, e, Wb)))
+  GL_CHUNK(17, (mma_t<0, 2, 8>(acc, h, Wb)))
+  GL_CHUNK(18, (mma_t<2, 2, 8>(acc, h, Wb)))
+  GL_CHUNK(19, (mma_t<4, 2, 8>(acc, h, Wb)))
+  GL_CHUNK(20, (mma_t<6, 2, 8>(acc, h, Wb)))
+  load_c();
   act(3);
-  GL_CHUNK(21, (mma_regs<0, 8, 8>(acc, c, Wb), store_h()))
+  GL_CHUNK(21, (mma_t<0, 2, 2>(acc, c, Wb)))
   // layer 4
-  zero<8>(acc);
-  GL_CHUNK(22, (mma_lds(acc, Hrow, 0, Wb)))
-  GL_CHUNK(23, (mma_lds(acc, Hrow, 32, Wb)))
-  GL_CHUNK(24, (mma_lds(acc, Hrow, 64, Wb)))
-  GL_CHUNK(25, (mma_lds(acc, Hrow, 96, Wb)))
+  next_layer();
+  GL_CHUNK(22, (mma_t<0, 2, 8>(acc, h, Wb)))
+  GL_CHUNK(23, (mma_t<2, 2, 8>(acc, h, Wb)))
+  GL_CHUNK(24, (mma_t<4, 2, 8>(acc, h, Wb)))
+  GL_CHUNK(25, (mma_t<6, 2, 8>(acc, h, Wb)))
+  load_c();
   act(4);
-  GL_CHUNK(26, (mma_regs<0, 8, 8>(acc, c, Wb), store_h()))
+  GL_CHUNK(26, (mma_t<0, 2, 2>(acc, c, Wb)))
 #undef GL_CHUNK
-  // output layer 128 -> 3 (B straight from global: 16 columns, 3 real)
+  // output layer 128 -> 3 (A straight from global: Wout is [128][16], 3 real columns); lanes with g == 0
+  // end up with channels 0..3 of their sample
   f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
   {
-    const float* ap = Hrow + g;
-    const float* wp = P.Wout + g * 16 + r;
-#pragma unroll 8
-    for (int sidx = 0; sidx < 32; ++sidx)
-      o = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * sidx], wp[sidx * 64], o, 0, 0, 0);
-  }
-  if (r < 3) {
+    const float* wp = P.Wout + (4 * g) * 16 + r;
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const int qq = q0 + wv * 16 + g * 4 + rr;
-      if (qq < Q) raw[(size_t)qq * 4 + r] = 1.0f / (1.0f + __expf(-(o[rr] + P.bout[r])));
-    }
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr)
+        o = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[(16 * t + rr) * 16], acc[t][rr], o, 0, 0, 0);
+  }
+  if (g == 0 && qs < Q) {
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch)
+      raw[(size_t)qs * 4 + ch] = 1.0f / (1.0f + __expf(-(o[ch] + P.bout[ch])));
   }
 }
 
-// per-neighbour F_theta, v2: W1 (52 x 128) resident in LDS for the whole workgroup
-__global__ __launch_bounds__(512, 2) void mlp_nb_v2_kernel(NbParams P, const float* __restrict__ pts,
-                                                        const float* __restrict__ cloud,
-                                                        const float* __restrict__ col_feats,
-                                                        const int64_t* __restrict__ I,
-                                                        const float* __restrict__ wts,
-                                                        const uint8_t* __restrict__ has, int Q,
-                                                        float* __restrict__ c_col) {
-  constexpr int LDX = 66;
+// per-neighbour F_theta, transposed formulation (see mlp_col_v3_kernel): W1 (52 x 128) resident in LDS with
+// the permuted column order, the 52 input channels of neighbour k built directly as B fragments - lane
+// (r, g) owns sample r and supplies, for k-slot g, colour-feature channels 16t + 4g + rr (two 16-byte loads
+// of the neighbour's feature row) and embedding features 4s + g (s = 0..4; sin for feature < 10, cos
+// otherwise).  No staging buffer and no barrier inside the neighbour loop; the weighted sum of the eight
+// softplus outputs stays in the accumulator layout, which is again the B layout of the second layer.
+__global__ __launch_bounds__(512, 4) void mlp_nb_v3_kernel(NbParams P, const float* __restrict__ pts,
+                                                           const float* __restrict__ cloud,
+                                                           const float* __restrict__ col_feats,
+                                                           const int64_t* __restrict__ I,
+                                                           const float* __restrict__ wts,
+                                                           const uint8_t* __restrict__ has, int Q,
+                                                           float* __restrict__ c_col) {
   extern __shared__ float smem[];
-  // 72 KB of LDS -> 2 workgroups (16 waves) per CU: the gather latency of one workgroup's staging phase
-  // is covered by the other's MFMAs.  The [128][130] buffer of the second layer reuses the whole region
-  // once the neighbour loop is over (the IDW weight sums it would overwrite are taken before).
-  float* W1s = smem;                          // [52][144]
-  float* X = W1s + 52 * kLdw;                 // [128][66]
-  float* wbuf = X + kTM2 * LDX;               // [128][8]
-  int* ibuf = reinterpret_cast<int*>(wbuf + kTM2 * 8);  // [128][8]
-  float* Y = smem;                            // [128][130], aliases W1s | X | wbuf | ibuf
+  float* W1s = smem;                          // [52][132], columns permuted like the colour chunks
+  float* b1s = W1s + 52 * kLdw3;              // [128]
+  float* wbuf = b1s + 128;                    // [128][8] IDW weights (0 for an absent neighbour)
+  int* ibuf = reinterpret_cast<int*>(wbuf + kTM2 * 8);  // [128][8] neighbour ids (0 for an absent one)
+  float* bs = reinterpret_cast<float*>(ibuf + kTM2 * 8);  // [20][4] B[:, f mod 10] (revolutions per metre)
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   const int r = lane & 15, g = lane >> 4;
   const int q0 = blockIdx.x * kTM2;
-  for (int idx = tid; idx < 52 * 128; idx += 512) W1s[(idx >> 7) * kLdw + (idx & 127)] = P.W1[idx];
+  if (tid < 80) {
+    const int f = tid >> 2, d = tid & 3;
+    bs[tid] = d < 3 ? P.B[d * 10 + (f < 10 ? f : f - 10)] : 0.0f;
+  }
+  for (int idx = tid; idx < 52 * 128; idx += 512) {
+    const int col = idx & 127, to = col >> 4, rc = col & 15;
+    W1s[(idx >> 7) * kLdw3 + (to >> 2) * 64 + rc * 4 + (to & 3)] = P.W1[idx];
+  }
+  if (tid < 128) b1s[tid] = P.b1[tid];
   for (int idx = tid; idx < kTM2 * 8; idx += 512) {
     const int row = idx >> 3;
     const int q = min(q0 + row, Q - 1);
@@ -561,82 +438,104 @@ __global__ __launch_bounds__(512, 2) void mlp_nb_v2_kernel(NbParams P, const flo
     ibuf[idx] = ii < 0 ? 0 : ii;
   }
   __syncthreads();
+  const int srow = wv * 16 + r;               // this lane's sample row inside the workgroup
+  const int qs = q0 + srow;
+  const int q = min(qs, Q - 1);
+  const float qx = pts[(size_t)q * 3 + 0], qy = pts[(size_t)q * 3 + 1], qz = pts[(size_t)q * 3 + 2];
+  // embedding features of this lane: f = 4s + g; frequency column (f mod 10), sin for f < 10.  The
+  // frequency vectors sit in LDS as [20][4] (15 registers short otherwise); phases in revolutions.
+  const float* bsl = bs + 4 * g;
   f32x4 ysum[8];
   zero<8>(ysum);
-  const float* Xrow = X + (wv * 16 + r) * LDX + g;
-  float b1[8];
-#pragma unroll
-  for (int t = 0; t < 8; ++t) b1[t] = P.b1[16 * t + (lane & 15)];
+  float sw = 0.0f;
+  const float* wpe = W1s + g * kLdw3 + r * 4;               // embedding rows 4s + g
+  const float* wpc = W1s + (20 + 4 * g) * kLdw3 + r * 4;    // colour-feature rows 20 + 16t + 4g + rr
+#pragma unroll 1
   for (int k = 0; k < 8; ++k) {
-    {  // stage x = [sin(rel B) 10 | cos(rel B) 10 | col_feat 32]; 4 threads per sample row
-      const int row = tid >> 2, part = tid & 3;
-      const int q = min(q0 + row, Q - 1);
-      const int pt = ibuf[row * 8 + k];
-      const float rx = kTwoPi * (cloud[(size_t)pt * 3 + 0] - pts[(size_t)q * 3 + 0]);
-      const float ry = kTwoPi * (cloud[(size_t)pt * 3 + 1] - pts[(size_t)q * 3 + 1]);
-      const float rz = kTwoPi * (cloud[(size_t)pt * 3 + 2] - pts[(size_t)q * 3 + 2]);
-      for (int f = part; f < 10; f += 4) {
-        const float a = fmaf(rz, P.B[20 + f], fmaf(ry, P.B[10 + f], rx * P.B[f]));
-        float sn, cs;
-        sincosf(a, &sn, &cs);
-        X[row * LDX + f] = sn;
-        X[row * LDX + 10 + f] = cs;
-      }
-      const float4* src = reinterpret_cast<const float4*>(col_feats + (size_t)pt * 32 + part * 8);
-      const float4 v0 = src[0], v1 = src[1];
-      float* dst = X + row * LDX + 20 + part * 8;
-      dst[0] = v0.x; dst[1] = v0.y; dst[2] = v0.z; dst[3] = v0.w;
-      dst[4] = v1.x; dst[5] = v1.y; dst[6] = v1.z; dst[7] = v1.w;
-    }
-    __syncthreads();
+    const int pt = ibuf[srow * 8 + k];
+    const float w = wbuf[srow * 8 + k];
+    const float4 c0 = *reinterpret_cast<const float4*>(col_feats + (size_t)pt * 32 + 4 * g);
+    const float4 c1 = *reinterpret_cast<const float4*>(col_feats + (size_t)pt * 32 + 16 + 4 * g);
+    const float rx = cloud[(size_t)pt * 3 + 0] - qx, ry = cloud[(size_t)pt * 3 + 1] - qy,
+                rz = cloud[(size_t)pt * 3 + 2] - qz;
     f32x4 acc[8];
     zero<8>(acc);
-    {
-      const float* wp = W1s + g * kLdw + (lane & 15);
-#pragma unroll
-      for (int sidx = 0; sidx < 13; ++sidx) {
-        const float av = Xrow[4 * sidx];
-#pragma unroll
-        for (int t = 0; t < 8; ++t)
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wp[sidx * 4 * kLdw + 16 * t], acc[t], 0, 0, 0);
-      }
+    // 13 k-steps, software pipelined by hand: the two 16-byte weight reads of step i + 1 are issued before
+    // the eight MFMAs of step i; the scheduling barrier keeps the compiler from hoisting all 26 reads
+    // (104 registers) to the top.  Embedding steps first: they only need the neighbour position, the
+    // colour-feature loads (a full L2 round trip behind the index) complete meanwhile.
+#define NB_LOAD(WP) w0n = *reinterpret_cast<const float4*>(WP); w1n = *reinterpret_cast<const float4*>((WP) + 64);
+#define NB_STEP(BV, NEXT)                                                                \
+    {                                                                                    \
+      const float4 w0 = w0n, w1 = w1n;                                                   \
+      const float bv = (BV);                                                             \
+      NEXT                                                                               \
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.x, bv, acc[0], 0, 0, 0);          \
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.y, bv, acc[1], 0, 0, 0);          \
+      acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.z, bv, acc[2], 0, 0, 0);          \
+      acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.w, bv, acc[3], 0, 0, 0);          \
+      acc[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.x, bv, acc[4], 0, 0, 0);          \
+      acc[5] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.y, bv, acc[5], 0, 0, 0);          \
+      acc[6] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.z, bv, acc[6], 0, 0, 0);          \
+      acc[7] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.w, bv, acc[7], 0, 0, 0);          \
+      __builtin_amdgcn_sched_barrier(0);                                                 \
     }
+    float4 w0n, w1n;
+    NB_LOAD(wpe)
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const float w = wbuf[(wv * 16 + g * 4 + rr) * 8 + k];
-#pragma unroll
-      for (int t = 0; t < 8; ++t) ysum[t][rr] += w * softplus100_fast(acc[t][rr] + b1[t]);
+    for (int sidx = 0; sidx < 5; ++sidx) {
+      const float4 bf = *reinterpret_cast<const float4*>(bsl + 16 * sidx);
+      const float a = fmaf(rz, bf.z, fmaf(ry, bf.y, rx * bf.x));
+      const float ev = (4 * sidx + g >= 10) ? cos_rev(a) : sin_rev(a);
+      if (sidx < 4) NB_STEP(ev, NB_LOAD(wpe + 4 * (sidx + 1) * kLdw3))
+      else NB_STEP(ev, NB_LOAD(wpc))
     }
-    __syncthreads();
+    NB_STEP(c0.x, NB_LOAD(wpc + 1 * kLdw3))
+    NB_STEP(c0.y, NB_LOAD(wpc + 2 * kLdw3))
+    NB_STEP(c0.z, NB_LOAD(wpc + 3 * kLdw3))
+    NB_STEP(c0.w, NB_LOAD(wpc + 16 * kLdw3))
+    NB_STEP(c1.x, NB_LOAD(wpc + 17 * kLdw3))
+    NB_STEP(c1.y, NB_LOAD(wpc + 18 * kLdw3))
+    NB_STEP(c1.z, NB_LOAD(wpc + 19 * kLdw3))
+    NB_STEP(c1.w, )
+#undef NB_STEP
+#undef NB_LOAD
+    sw += w;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const float4 bb = *reinterpret_cast<const float4*>(b1s + 16 * t + 4 * g);
+      ysum[t][0] += w * softplus100_fast(acc[t][0] + bb.x);
+      ysum[t][1] += w * softplus100_fast(acc[t][1] + bb.y);
+      ysum[t][2] += w * softplus100_fast(acc[t][2] + bb.z);
+      ysum[t][3] += w * softplus100_fast(acc[t][3] + bb.w);
+    }
   }
-  float sw[4];                                // sum of the IDW weights of this lane's 4 rows
-#pragma unroll
-  for (int rr = 0; rr < 4; ++rr) {
-    sw[rr] = 0.0f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) sw[rr] += wbuf[(wv * 16 + g * 4 + rr) * 8 + k];
-  }
-  __syncthreads();                            // everybody is done with W1s / X / wbuf: Y may overwrite them
-  float* Yw = Y + (wv * 16) * kLdh;
-#pragma unroll
-  for (int t = 0; t < 8; ++t)
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) Yw[(g * 4 + rr) * kLdh + 16 * t + (lane & 15)] = ysum[t][rr];
-  __syncthreads();
+  // second layer 128 -> 32 (A = W2 straight from global / L2, 16 KB shared by everybody)
   f32x4 o[2];
   zero<2>(o);
-  gemm16<2>(o, Yw, kLdh, 128, P.W2, 32, 0);
+  {
+    const float* wp = P.W2 + (4 * g) * 32 + r;
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < 8; ++t)
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const int row = wv * 16 + g * 4 + rr;
-      const int q = q0 + row;
-      if (q < Q) {
-        const int col = 16 * t + (lane & 15);
-        c_col[(size_t)q * 32 + col] = has[q] ? o[t][rr] + P.b2[col] * sw[rr] : 0.0f;
+      for (int rr = 0; rr < 4; ++rr) {
+        o[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[(16 * t + rr) * 32], ysum[t][rr], o[0], 0, 0, 0);
+        o[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[(16 * t + rr) * 32 + 16], ysum[t][rr], o[1], 0, 0, 0);
       }
+  }
+  if (qs < Q) {
+    const bool h = has[qs] != 0;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const float4 b2 = *reinterpret_cast<const float4*>(P.b2 + 16 * t + 4 * g);
+      float4 v;
+      v.x = h ? o[t][0] + b2.x * sw : 0.0f;
+      v.y = h ? o[t][1] + b2.y * sw : 0.0f;
+      v.z = h ? o[t][2] + b2.z * sw : 0.0f;
+      v.w = h ? o[t][3] + b2.w * sw : 0.0f;
+      *reinterpret_cast<float4*>(c_col + (size_t)qs * 32 + 16 * t + 4 * g) = v;
     }
+  }
 }
 
 }  // namespace glorie
@@ -690,21 +589,19 @@ extern "C" int glorie_render_mlp(const float* packed, const float* pts, const fl
   hipLaunchKernelGGL(mlp_geo_kernel, dim3(blocks), dim3(256), 0, st, g, pts, c_geo, has, Q, raw);
   if (stage_color) {
     const int blocks2 = (Q + kTM2 - 1) / kTM2;
-    const size_t nb_work = sizeof(float) * (52 * kLdw + kTM2 * 66 + kTM2 * 8) + sizeof(int) * kTM2 * 8;
-    const size_t nb_y = sizeof(float) * kTM2 * kLdh;
-    const size_t nb_lds = nb_work > nb_y ? nb_work : nb_y;
-    const size_t col_lds = sizeof(float) * (2 * kChunkFloats + kTM2 * kLdh);
+    const size_t nb_lds = sizeof(float) * (52 * kLdw3 + 128 + kTM2 * 8 + 80) + sizeof(int) * kTM2 * 8;
+    const size_t col_lds = sizeof(float) * 2 * kChunkFloats3;
     static bool attr = false;
     if (!attr) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_nb_v2_kernel),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_nb_v3_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)nb_lds);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_col_v2_kernel),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_col_v3_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)col_lds);
       attr = true;
     }
-    hipLaunchKernelGGL(mlp_nb_v2_kernel, dim3(blocks2), dim3(512), nb_lds, st, n, pts, cloud_pos, col_feats,
+    hipLaunchKernelGGL(mlp_nb_v3_kernel, dim3(blocks2), dim3(512), nb_lds, st, n, pts, cloud_pos, col_feats,
                        I, weights, has, Q, c_col_scratch);
-    hipLaunchKernelGGL(mlp_col_v2_kernel, dim3(blocks2), dim3(512), col_lds, st, k, col_chunks, pts, views,
+    hipLaunchKernelGGL(mlp_col_v3_kernel, dim3(blocks2), dim3(512), col_lds, st, k, col_chunks, pts, views,
                        c_col_scratch, Q, raw);
   }
   return check_launch();

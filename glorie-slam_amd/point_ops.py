@@ -177,8 +177,10 @@ def pack_decoders(decoders):
     parts.append(torch.cat([f(l.bias) for l in c.pts_linears]))
     parts.append(torch.cat([f(l.bias) for l in c.fc_c]))
     parts.append(torch.cat([f(c.output_linear.bias), torch.zeros(1, device=dev)]))
-    # colour weights once more, in the 32-row chunk order the v2 kernel streams through LDS:
-    # W0(80->96) Fc0 | W1 Fc1 | W2 Fc2 | W3e(80->96) W3h Fc3 | W4 Fc4   = 27 chunks of [32,128]
+    # colour weights once more, in the 32-row chunk order the colour kernel streams through LDS:
+    # W0(80->96) Fc0 | W1 Fc1 | W2 Fc2 | W3e(80->96) W3h Fc3 | W4 Fc4   = 27 chunks of [32,128];
+    # inside a row, output column 16*to + r sits at (to >> 2) * 64 + 4*r + (to & 3) (two 16-byte LDS
+    # reads per lane fetch the eight MFMA A operands of a k-step)
     w3 = _t(c.pts_linears[3].weight)
     fc = [_t(l.weight) for l in c.fc_c]
     seq = [_pad_rows(_t(c.pts_linears[0].weight), 96), fc[0], _t(c.pts_linears[1].weight), fc[1],
@@ -186,6 +188,7 @@ def pack_decoders(decoders):
            _t(c.pts_linears[4].weight), fc[4]]
     chunks = torch.cat([m.to(dev) for m in seq], 0)
     assert chunks.shape == (27 * 32, 128), chunks.shape
+    chunks = chunks.reshape(-1, 2, 4, 16).permute(0, 1, 3, 2).reshape(-1, 128)
     parts.append(f(chunks))
     packed = torch.cat(parts).contiguous()
     expect = int(L.load().glorie_decoder_pack_floats())
