@@ -4,7 +4,7 @@
 //   MLP_geometry.forward   /root/reference/src/modules/conv_onet/models/decoder.py:175-225
 //   MLP_color.get_feature_at_pos (per-neighbour F_theta)              decoder.py:340-389, 228-243
 //   MLP_color.forward                                                 decoder.py:391-433
-// with three kernels that keep every activation in LDS/registers:
+// with three kernels that keep every activation in registers:
 //   geo  : Fourier(93, sin) -> 5 x (Linear(32) ReLU + fc_c(c)) with the skip at layer 2 -> occ
 //   nb   : per neighbour [sin,cos](rel B)(20) ++ col_feat(32) -> Linear(128) softplus -> IDW sum
 //          -> Linear(32).  The second layer is linear, so it is applied ONCE to the weighted
@@ -12,14 +12,12 @@
 //   col  : [sin,cos](p B)(40) ++ [sin,cos](v B)(40) -> 5 x (Linear(128) softplus + fc_c(c)),
 //          skip at layer 2 -> sigmoid rgb
 //
-// All GEMMs are exact fp32 on v_mfma_f32_16x16x4_f32 (the reference runs fp32; no xf32 on
-// gfx950).  A workgroup = 4 waves = 64 samples; wave w owns rows 16w..16w+15 for the whole
-// network, so activations never cross waves: A operands come from the wave's own LDS rows
-// (leading dimension = 2 mod 32 -> conflict-free ds_read_b32 for the (row = lane&15,
-// k = lane>>4) fragment), B operands (weights, K-major [K][N], L1/L2 resident) are read
-// straight from global memory as coalesced 64-byte rows.  The skip connection is two GEMMs
-// on the split weight (embedding rows / hidden rows) -- the concatenated activation is never
-// built.
+// All GEMMs are exact fp32 on v_mfma_f32_16x16x4_f32 (the reference runs fp32; no xf32 on gfx950), in the
+// transposed form  H'^T = W^T H^T : the 16 MFMA rows are output channels (A = weights from LDS), the 16
+// columns are a wave's 16 samples (B = activations).  The accumulator fragment of one layer is then
+// directly the B fragment of the next (see mlp_col_v3_kernel), so no activation ever touches LDS.  A
+// workgroup = 8 waves = 128 samples; the skip connection is two GEMMs on the split weight (embedding
+// rows / hidden rows) - the concatenated activation is never built.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -28,54 +26,6 @@
 namespace glorie {
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
-
-constexpr int kTM = 64;            // samples per workgroup
-constexpr float kTwoPi = 6.283185307179586f;
-
-// acc[t] += A[16 rows x K] * W[K x (16*NT cols starting at col0)]
-// A_lds points at row 0 of this wave's 16-row tile; W is K-major with leading dimension ldw.
-// K must be a multiple of 4 (packed weights / staged activations are zero padded).
-template <int NT>
-__device__ __forceinline__ void gemm16(f32x4 (&acc)[NT], const float* __restrict__ A_lds, int lda,
-                                       int K, const float* __restrict__ W, int ldw, int col0) {
-  const int lane = threadIdx.x & 63;
-  const float* ap = A_lds + (lane & 15) * lda + (lane >> 4);
-  const float* wp = W + (size_t)(lane >> 4) * ldw + col0 + (lane & 15);
-#pragma unroll 4
-  for (int k0 = 0; k0 < K; k0 += 4) {
-    const float a = ap[k0];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const float b = wp[(size_t)k0 * ldw + 16 * t];
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
-    }
-  }
-}
-
-__device__ __forceinline__ float softplus100(float x) {
-  // torch.nn.Softplus(beta=100, threshold=20): x if beta*x > 20
-  const float bx = 100.0f * x;
-  return bx > 20.0f ? x : log1pf(expf(bx)) * 0.01f;
-}
-
-// C/D fragment of 16x16x4: col = lane & 15, row = (lane >> 4) * 4 + reg
-template <int NT, typename F>
-__device__ __forceinline__ void for_each_out(f32x4 (&acc)[NT], F f) {
-  const int lane = threadIdx.x & 63;
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc[t][r] = f(acc[t][r], (lane >> 4) * 4 + r, 16 * t + (lane & 15));
-}
-
-template <int NT>
-__device__ __forceinline__ void store_tile(const f32x4 (&acc)[NT], float* __restrict__ H_lds, int ldh) {
-  const int lane = threadIdx.x & 63;
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) H_lds[((lane >> 4) * 4 + r) * ldh + 16 * t + (lane & 15)] = acc[t][r];
-}
 
 template <int NT>
 __device__ __forceinline__ void zero(f32x4 (&acc)[NT]) {
@@ -123,71 +73,9 @@ struct ColParams {
   const float* bout;       // [4]       output bias (rgb)
 };
 
-// ------------------------------------------------------------------------------------
-// geometry decoder
-// ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void mlp_geo_kernel(GeoParams P, const float* __restrict__ pts,
-                                                      const float* __restrict__ c_geo,
-                                                      const uint8_t* __restrict__ has, int Q,
-                                                      float* __restrict__ raw) {
-  constexpr int LDE = 98, LDH = 34;
-  __shared__ float emb[kTM * LDE];
-  __shared__ float hbuf[kTM * LDH];
-  __shared__ float cbuf[kTM * LDH];
-  const int tid = threadIdx.x, wv = tid >> 6;
-  const int q0 = blockIdx.x * kTM;
-  // stage: Fourier embedding (sin only) and the interpolated feature c
-  for (int idx = tid; idx < kTM * 96; idx += 256) {
-    const int r = idx / 96, f = idx - r * 96;
-    const int q = min(q0 + r, Q - 1);
-    float v = 0.0f;
-    if (f < 93) {
-      const float x = kTwoPi * pts[(size_t)q * 3 + 0], y = kTwoPi * pts[(size_t)q * 3 + 1],
-                  z = kTwoPi * pts[(size_t)q * 3 + 2];
-      v = sinf(fmaf(z, P.B[2 * 96 + f], fmaf(y, P.B[96 + f], x * P.B[f])));
-    }
-    emb[r * LDE + f] = v;
-  }
-  for (int idx = tid; idx < kTM * 32; idx += 256) {
-    const int r = idx >> 5, f = idx & 31;
-    const int q = min(q0 + r, Q - 1);
-    cbuf[r * LDH + f] = c_geo[(size_t)q * 32 + f];
-  }
-  __syncthreads();
-  const float* E = emb + wv * 16 * LDE;
-  float* H = hbuf + wv * 16 * LDH;
-  const float* C = cbuf + wv * 16 * LDH;
-  f32x4 acc[2];
-  auto layer_tail = [&](int li) {
-    for_each_out<2>(acc, [&](float v, int, int col) { return fmaxf(v + P.bias[li * 32 + col], 0.0f) + P.fcb[li * 32 + col]; });
-    gemm16<2>(acc, C, LDH, 32, P.Fc + li * 32 * 32, 32, 0);
-    __syncthreads();
-    store_tile<2>(acc, H, LDH);
-    __syncthreads();
-  };
-  zero<2>(acc); gemm16<2>(acc, E, LDE, 96, P.W0, 32, 0); layer_tail(0);
-  zero<2>(acc); gemm16<2>(acc, H, LDH, 32, P.W1, 32, 0); layer_tail(1);
-  zero<2>(acc); gemm16<2>(acc, H, LDH, 32, P.W2, 32, 0); layer_tail(2);
-  zero<2>(acc); gemm16<2>(acc, E, LDE, 96, P.W3e, 32, 0); gemm16<2>(acc, H, LDH, 32, P.W3h, 32, 0); layer_tail(3);
-  zero<2>(acc); gemm16<2>(acc, H, LDH, 32, P.W4, 32, 0); layer_tail(4);
-  f32x4 o[1];
-  zero<1>(o);
-  gemm16<1>(o, H, LDH, 32, P.Wout, 16, 0);
-  const int lane = tid & 63;
-  if ((lane & 15) == 0) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int q = q0 + wv * 16 + (lane >> 4) * 4 + r;
-      if (q < Q) raw[(size_t)q * 4 + 3] = has[q] ? o[0][r] + P.bout[0] : -100.0f;  // Renderer.py:206-207
-    }
-  }
-}
-
 // ====================================================================================
-// v2 kernels: 128 samples / 8 waves per workgroup, weights streamed through LDS in 32-row
-// chunks (double buffered, shared by the 8 waves), embedding / feature A-fragments kept in
-// registers, fast softplus.  Same arithmetic (exact fp32 MFMA); only the transcendental
-// approximations of softplus differ (v_exp/v_log, |err| < 1e-6).
+// 128 samples / 8 waves per workgroup.  The colour weights (442 KB) are streamed through LDS in 32-row
+// chunks (double buffered, shared by the 8 waves); the geometry and per-neighbour weights are resident.
 // ====================================================================================
 constexpr int kTM2 = 128;
 
@@ -215,6 +103,103 @@ __device__ __forceinline__ ChunkRegs chunk_load(const float* __restrict__ Wall, 
   r.b = src[1];
   return r;
 }
+// ---- geometry decoder, transposed formulation (see the colour decoder below for the idea) ----------------
+// All weights of the network (480 K-rows of 32 outputs, 61 KB, + the 32 x 16 output layer) are staged once per
+// workgroup as the LDS image built by point_ops.pack_decoders: row k holds output 16 to + r at 2 r + to, so
+// one ds_read_b64 per lane fetches the A operands of the two 16-channel output blocks.  Embedding (96, sin),
+// feature c (32) and hidden state (32) live in registers as B fragments; no barrier after the staging.
+constexpr int kGeoRows = 480;
+constexpr int kGeoImage = kGeoRows * 32 + 32 * 16;   // floats
+
+template <int NT, int NB>
+__device__ __forceinline__ void mma_geo(f32x4 (&acc)[2], const f32x4 (&b)[NB], const float* Wrows) {
+  const int lane = threadIdx.x & 63;
+  const float* wp = Wrows + (lane >> 4) * 4 * 32 + (lane & 15) * 2;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const float2 w = *reinterpret_cast<const float2*>(wp + (16 * t + rr) * 32);
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, b[t][rr], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, b[t][rr], acc[1], 0, 0, 0);
+    }
+}
+
+__global__ __launch_bounds__(512, 4) void mlp_geo_v3_kernel(GeoParams P, const float* __restrict__ image,
+                                                            const float* __restrict__ pts,
+                                                            const float* __restrict__ c_geo,
+                                                            const uint8_t* __restrict__ has, int Q,
+                                                            float* __restrict__ raw) {
+  extern __shared__ float smem[];
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  const int r = lane & 15, g = lane >> 4;
+  const int qs = blockIdx.x * kTM2 + wv * 16 + r;
+  const int q = min(qs, Q - 1);
+  for (int idx = tid; idx < kGeoImage / 4; idx += 512)
+    reinterpret_cast<float4*>(smem)[idx] = reinterpret_cast<const float4*>(image)[idx];
+  // B fragments: channel 16t + 4g + rr of sample r
+  f32x4 e[6], c[2], h[2], acc[2];
+  {
+    const float x = pts[(size_t)q * 3 + 0], y = pts[(size_t)q * 3 + 1], z = pts[(size_t)q * 3 + 2];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+      const float4 b0 = *reinterpret_cast<const float4*>(P.B + 16 * t + 4 * g);
+      const float4 b1 = *reinterpret_cast<const float4*>(P.B + 96 + 16 * t + 4 * g);
+      const float4 b2 = *reinterpret_cast<const float4*>(P.B + 192 + 16 * t + 4 * g);
+      e[t][0] = sin_rev(fmaf(z, b2.x, fmaf(y, b1.x, x * b0.x)));
+      e[t][1] = sin_rev(fmaf(z, b2.y, fmaf(y, b1.y, x * b0.y)));
+      e[t][2] = sin_rev(fmaf(z, b2.z, fmaf(y, b1.z, x * b0.z)));
+      e[t][3] = sin_rev(fmaf(z, b2.w, fmaf(y, b1.w, x * b0.w)));
+    }
+    // columns 93..95 of B are zero padding (sin 0 = 0) and so are the matching weight rows
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const float4 v = *reinterpret_cast<const float4*>(c_geo + (size_t)q * 32 + 16 * t + 4 * g);
+      c[t][0] = v.x; c[t][1] = v.y; c[t][2] = v.z; c[t][3] = v.w;
+    }
+  }
+  __syncthreads();
+  auto act = [&](int li) {   // ReLU(acc + bias) + fc_c bias
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const float4 bb = *reinterpret_cast<const float4*>(P.bias + li * 32 + 16 * t + 4 * g);
+      const float4 fb = *reinterpret_cast<const float4*>(P.fcb + li * 32 + 16 * t + 4 * g);
+      acc[t][0] = fmaxf(acc[t][0] + bb.x, 0.0f) + fb.x;
+      acc[t][1] = fmaxf(acc[t][1] + bb.y, 0.0f) + fb.y;
+      acc[t][2] = fmaxf(acc[t][2] + bb.z, 0.0f) + fb.z;
+      acc[t][3] = fmaxf(acc[t][3] + bb.w, 0.0f) + fb.w;
+    }
+  };
+  auto next_layer = [&]() {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { h[t] = acc[t]; acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  };
+  const float* W = smem;   // row offsets: W0 0 | Fc0 96 | W1 128 | Fc1 160 | W2 192 | Fc2 224 | W3e 256 | W3h 352
+                           //              | Fc3 384 | W4 416 | Fc4 448 | Wout 480 (16 columns, natural order)
+  zero<2>(acc);
+  mma_geo<6, 6>(acc, e, W);               act(0); mma_geo<2, 2>(acc, c, W + 96 * 32);
+  next_layer();
+  mma_geo<2, 2>(acc, h, W + 128 * 32);    act(1); mma_geo<2, 2>(acc, c, W + 160 * 32);
+  next_layer();
+  mma_geo<2, 2>(acc, h, W + 192 * 32);    act(2); mma_geo<2, 2>(acc, c, W + 224 * 32);
+  next_layer();
+  mma_geo<6, 6>(acc, e, W + 256 * 32);
+  mma_geo<2, 2>(acc, h, W + 352 * 32);    act(3); mma_geo<2, 2>(acc, c, W + 384 * 32);
+  next_layer();
+  mma_geo<2, 2>(acc, h, W + 416 * 32);    act(4); mma_geo<2, 2>(acc, c, W + 448 * 32);
+  // output layer 32 -> 1 (16 padded columns): lanes with g == 0 get channel 0 of their sample in o[0]
+  f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+  {
+    const float* wp = W + kGeoRows * 32 + (4 * g) * 16 + r;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr)
+        o = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[(16 * t + rr) * 16], acc[t][rr], o, 0, 0, 0);
+  }
+  if (g == 0 && qs < Q) raw[(size_t)qs * 4 + 3] = has[qs] ? o[0] + P.bout[0] : -100.0f;  // Renderer.py:206-207
+}
+
 // ---- colour decoder, transposed formulation ------------------------------------------------
 // Every layer is evaluated as  H'^T = W^T . H^T : the MFMA's 16 "rows" are output channels (A = weights
 // from the LDS chunk), its 16 "columns" are the wave's 16 samples (B = activations).  The D fragment
@@ -556,7 +541,7 @@ extern "C" size_t glorie_decoder_pack_floats(void) {
   size_t nb = 3 * 10 + 2 + 52 * 128 + 128 + 128 * 32 + 32;
   size_t col = 3 * 20 * 2 + 80 * 128 + 128 * 128 * 2 + 80 * 128 + 128 * 128 * 2 + 128 * 16 + 5 * 32 * 128 +
                5 * 128 * 2 + 4;
-  return geo + nb + col + (size_t)27 * 32 * 128;
+  return geo + nb + col + (size_t)27 * 32 * 128 + (size_t)(480 * 32 + 32 * 16);
 }
 
 extern "C" int glorie_render_mlp(const float* packed, const float* pts, const float* views,
@@ -585,10 +570,18 @@ extern "C" int glorie_render_mlp(const float* packed, const float* pts, const fl
   k.Wout = c.take(128 * 16); k.Fc = c.take(5 * 32 * 128); k.bias = c.take(5 * 128); k.fcb = c.take(5 * 128);
   k.bout = c.take(4);
   const float* col_chunks = c.take((size_t)27 * 32 * 128);
-  const int blocks = (Q + kTM - 1) / kTM;
-  hipLaunchKernelGGL(mlp_geo_kernel, dim3(blocks), dim3(256), 0, st, g, pts, c_geo, has, Q, raw);
+  const float* geo_image = c.take((size_t)kGeoImage);
+  const int blocks2 = (Q + kTM2 - 1) / kTM2;
+  const size_t geo_lds = sizeof(float) * kGeoImage;
+  static bool geo_attr = false;
+  if (!geo_attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_geo_v3_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)geo_lds);
+    geo_attr = true;
+  }
+  hipLaunchKernelGGL(mlp_geo_v3_kernel, dim3(blocks2), dim3(512), geo_lds, st, g, geo_image, pts, c_geo, has, Q,
+                     raw);
   if (stage_color) {
-    const int blocks2 = (Q + kTM2 - 1) / kTM2;
     const size_t nb_lds = sizeof(float) * (52 * kLdw3 + 128 + kTM2 * 8 + 80) + sizeof(int) * kTM2 * 8;
     const size_t col_lds = sizeof(float) * 2 * kChunkFloats3;
     static bool attr = false;

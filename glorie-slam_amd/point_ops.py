@@ -190,6 +190,18 @@ def pack_decoders(decoders):
     assert chunks.shape == (27 * 32, 128), chunks.shape
     chunks = chunks.reshape(-1, 2, 4, 16).permute(0, 1, 3, 2).reshape(-1, 128)
     parts.append(f(chunks))
+    # geometry weights once more, as the LDS image of the geometry kernel: 480 K-rows
+    # W0(93->96) Fc0 | W1 Fc1 | W2 Fc2 | W3e(93->96) W3h Fc3 | W4 Fc4, output 16*to + r of a row at 2*r + to,
+    # followed by the output layer [32,16] in natural order
+    w3 = _t(g.pts_linears[3].weight)
+    fc = [_t(l.weight) for l in g.fc_c]
+    seq = [_pad_rows(_t(g.pts_linears[0].weight), 96), fc[0], _t(g.pts_linears[1].weight), fc[1],
+           _t(g.pts_linears[2].weight), fc[2], _pad_rows(w3[:93], 96), w3[93:], fc[3],
+           _t(g.pts_linears[4].weight), fc[4]]
+    rows = torch.cat([m.to(dev) for m in seq], 0)
+    assert rows.shape == (480, 32), rows.shape
+    parts.append(f(rows.reshape(480, 2, 16).permute(0, 2, 1)))
+    parts.append(f(_pad_cols(_t(g.output_linear.weight), 16)))
     packed = torch.cat(parts).contiguous()
     expect = int(L.load().glorie_decoder_pack_floats())
     if packed.numel() != expect:
