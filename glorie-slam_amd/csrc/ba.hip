@@ -704,6 +704,375 @@ __global__ __launch_bounds__(256) void chol_damp_kernel(BaWork wk, int n, float 
   }
 }
 
+// ---- banded systems: unblocked LDL^T-style elimination on band storage in LDS -------------------------
+// A sliding-window graph (edges |i - j| <= r) couples poses at most 2r apart, so the reduced camera system
+// is banded (half bandwidth bw = 41 for r = 3) and Cholesky fill stays inside the band: n bw^2 / 2 work and
+// n (bw + 1) doubles of storage (99 KB at n = 294) instead of n^3 / 6 and n^2.  One workgroup of 256 threads:
+//   * bw = largest r - c with H[r][c] != 0 (entries nobody accumulated into are exact zeros) comes from
+//     ba_bandwidth_kernel through status[3]; ba_solve_fused_kernel does the work instead if the band does
+//     not fit into LDS or bw >= 64.  H itself is never modified here.
+//   * elimination: column j updates the (bw x bw) window below it and the right-hand side, ONE barrier per
+//     column.  Columns stay unscaled (U[r][j] = L[r][j] sqrt(d_j)); only 1 / d_j is needed, from
+//     v_rcp_f64 + two Newton steps - no square root and no division on the critical path.  Every thread
+//     owns the same <= 9 window positions (dr, dc) in every step, decoded once.
+//   * back substitution x_j = (u_j - sum_k U[j + k][j] x_{j + k}) / d_j in ONE wave without barriers: lane
+//     (r mod 64) keeps the running sum of row r in a register (bw < 64: rows sharing a lane are never
+//     active together), x_j is broadcast with v_readlane.
+// Same operation order on every rank of a sharded run -> bit-identical pose updates.
+constexpr int kBandThreads = 256;
+
+// half bandwidth of the system: one wave per row looks for its first non-zero; result in status[3] = bw << 1
+// (status[3] is 0 between solves: ba_solve_fused_kernel resets it)
+__global__ __launch_bounds__(64) void ba_bandwidth_kernel(BaWork wk, int n) {
+  const int r = blockIdx.x, lane = threadIdx.x;
+  const double* row = wk.Hd + (size_t)r * n;
+  int first = r;
+  for (int c0 = 0; c0 < r; c0 += 256) {     // 4 independent loads per lane and round
+    bool nz[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = c0 + q * 64 + lane;
+      nz[q] = c < r && row[c] != 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const unsigned long long m = __ballot(nz[q]);
+      if (m && first == r) first = c0 + q * 64 + __ffsll((long long)m) - 1;
+    }
+    if (first != r) break;
+  }
+  if (lane == 0 && first < r) atomicMax(&wk.status[3], (r - first) << 1);
+}
+
+__device__ __forceinline__ double rcp_f64(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = fma(fma(-d, r, 1.0), r, r);
+  r = fma(fma(-d, r, 1.0), r, r);
+  return r;
+}
+
+template <int NQ>
+__device__ __forceinline__ void band_eliminate(double* B, double* u, double* rinv, int* fail, int n, int bw) {
+  const int tid = threadIdx.x;
+  const int S = bw + 1;
+  // window positions of this thread, the same in every step: triangle entries (dr, dc), dc <= dr < bw, as LDS
+  // offsets relative to row j of the band (element e = tid + 256 q of the packed triangle), and at most one
+  // entry of the right-hand side (bw < 256)
+  const int T1 = bw * (bw + 1) / 2;
+  int o_lr[NQ], o_lc[NQ], o_w[NQ], e_dr[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int e = tid + q * kBandThreads;
+    int dr = 1 << 20, dc = 0;        // inactive: never inside the matrix
+    if (e < T1) {
+      dr = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+      while ((dr + 1) * (dr + 2) / 2 <= e) ++dr;
+      while (dr * (dr + 1) / 2 > e) --dr;
+      dc = e - dr * (dr + 1) / 2;
+    }
+    e_dr[q] = dr;
+    o_lr[q] = (1 + dr) * S + dr + 1;     // U[r][j]
+    o_lc[q] = (1 + dc) * S + dc + 1;     // U[c][j]
+    o_w[q] = (1 + dr) * S + dr - dc;     // H[r][c]
+  }
+  const int rhs_dc = tid < bw ? tid : (1 << 20);
+  const int o_rc = (1 + rhs_dc) * S + rhs_dc + 1;
+  __syncthreads();
+  for (int j = 0; j < n; ++j) {
+    // all loads of the step are issued before anything is used: the chain per column is one LDS round trip,
+    // the reciprocal, two multiplies and the write-back (branchy code would serialise a round trip per entry)
+    const double* Bj = B + j * S;
+    const double d = Bj[0];
+    double lr[NQ], lc[NQ], cur[NQ];
+    bool ok[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      ok[q] = j + 1 + e_dr[q] < n;
+      lr[q] = Bj[ok[q] ? o_lr[q] : 0];
+      lc[q] = Bj[ok[q] ? o_lc[q] : 0];
+      cur[q] = Bj[ok[q] ? o_w[q] : 0];
+    }
+    const bool rok = j + 1 + rhs_dc < n;
+    const double rl = Bj[rok ? o_rc : 0];
+    const double ru = u[rok ? j + 1 + rhs_dc : 0];
+    const double uj = u[j];
+    if (!(d > 0.0) && tid == 0) *fail = 1;   // also NaN; the (garbage) result is discarded below
+    const double ri = rcp_f64(d);
+    if (tid == 0) rinv[j] = ri;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+      if (ok[q]) B[j * S + o_w[q]] = cur[q] - lr[q] * ri * lc[q];
+    if (rok) u[j + 1 + rhs_dc] = ru - uj * ri * rl;
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(kBandThreads) void ba_solve_band_kernel(BaWork wk, int n, float lm, float ep,
+                                                                    int lds_doubles) {
+  extern __shared__ double bsm[];
+  __shared__ int fail, bw_s;
+  const int tid = threadIdx.x;
+  const double* A = wk.Hd;          // (n + 1) x n row-major, lower triangle; row n = right-hand side
+  if (tid == 0) { fail = (wk.status[0] & BA_ST_M_MISMATCH) ? 1 : 0; bw_s = wk.status[3] >> 1; }
+  __syncthreads();
+  const int bw = bw_s;
+  const int S = bw + 1;             // band row: B[r][k] = H[r][r - k], k = 0 .. bw
+  if (bw >= 64 || (size_t)n * S + 2 * (size_t)n > (size_t)lds_doubles) {
+    return;                                                   // not solved: the fused kernel takes over
+  }
+  double* B = bsm;
+  double* u = B + (size_t)n * S;    // right-hand side
+  double* rinv = u + n;             // 1 / d_j
+  for (int base = tid; base < n * S; base += kBandThreads * 8) {
+    double v[8];
+    int rr[8], kk[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int idx = base + q * kBandThreads;
+      const int r = idx / S, k = S - 1 - (idx - r * S);       // consecutive threads -> consecutive columns
+      rr[q] = r; kk[q] = k;
+      v[q] = (idx < n * S && k <= r) ? A[(size_t)r * n + r - k] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      if (base + q * kBandThreads >= n * S) continue;
+      double x = v[q];
+      if (kk[q] == 0) x += (double)ep + (double)lm * x;
+      B[rr[q] * S + kk[q]] = x;
+    }
+  }
+  for (int i = tid; i < n; i += kBandThreads) u[i] = A[(size_t)n * n + i];
+  if (bw * (bw + 1) / 2 <= 4 * kBandThreads) band_eliminate<4>(B, u, rinv, &fail, n, bw);
+  else band_eliminate<8>(B, u, rinv, &fail, n, bw);
+  if (fail) {
+    for (int i = tid; i < n; i += kBandThreads) wk.dx[i] = 0.0f;
+    if (tid == 0) {
+      atomicOr(&wk.status[0], BA_ST_CHOL_FAILED);
+      atomicAdd(&wk.status[2], 1);
+      wk.status[3] = (bw << 1) | 1;
+    }
+    return;
+  }
+  if (tid < 64) {
+    double srow = 0.0;                               // running sum of the row (mod 64) this lane owns
+    // operands of column j are fetched one iteration ahead: the chain per column is sub, mul, readlane, fma
+    double un = u[n - 1], rn = rinv[n - 1];
+    int dn = (n - 1 - tid) & 63;                     // row (n - 1) - dn lives in this lane
+    double bn = B[(n - 1) * S + min(dn, bw)];
+    for (int j = n - 1; j >= 0; --j) {
+      const double uc = un, rc = rn, bc = bn;
+      const int dist = dn;
+      if (j > 0) {
+        un = u[j - 1]; rn = rinv[j - 1];
+        dn = (j - 1 - tid) & 63;
+        bn = B[(j - 1) * S + min(dn, bw)];
+      }
+      const int lo = j & 63;
+      const double xj_own = (uc - srow) * rc;
+      const unsigned lo32 = __builtin_amdgcn_readlane((int)__double2loint(xj_own), lo);
+      const unsigned hi32 = __builtin_amdgcn_readlane((int)__double2hiint(xj_own), lo);
+      const double xj = __hiloint2double((int)hi32, (int)lo32);
+      if (tid == lo) { srow = 0.0; wk.dx[j] = (float)xj; }
+      if (dist >= 1 && dist <= bw && j - dist >= 0) srow = fma(bc, xj, srow);
+    }
+  }
+  if (tid == 0) wk.status[3] = (bw << 1) | 1;         // solved: ba_solve_fused_kernel returns at once
+}
+
+// ---- medium systems (kSolveMaxN < n <= kFusedMaxN): the whole solve in ONE workgroup of 1024 threads -------------
+// Blocked right-looking Cholesky (32-column blocks) on the fp64 system in HBM (it is L2 resident: 0.7 MB at
+// n = 294), one launch instead of ~3 per block.  The right-hand side is row n of the same buffer (vd follows
+// Hd), so it is carried through the panel / trailing update like any other row and ends up as y = L^-1 b;
+// the back substitution is blocked the same way.  Fixed operation order: every rank of a sharded run
+// factors the same all-reduced system to the same bits.
+//   prologue:   damping; the half bandwidth bw comes from ba_solve_band_kernel (which solved the system itself
+//               if the band fits into LDS - then this kernel returns at once).  Cholesky fill stays inside
+//               the band, so every block only touches the bw rows below it (+ the rhs row); a graph with
+//               loop closures degrades to the dense cost.
+//   per block:  diagonal block -> LDS, 32 elimination steps with ONE barrier each on unscaled columns; the
+//               same row operations applied to an identity give L11^-1 for free (threads (r, c <= j) are
+//               idle otherwise), the square roots are taken once at the end.  L11^-1 is parked in the unused
+//               strict upper triangle of the block for the back substitution.
+//               panel X = A21 L11^-T as a small GEMM (row in registers, 8 independent dot products per
+//               thread against L11^-1 read as LDS broadcasts) - a forward substitution per row is one long
+//               dependent chain of LDS reads.
+//               trailing update: 8 x 4 register tiles, the panel read from LDS (columns interleaved across
+//               lanes: conflict-free reads, coalesced updates).
+constexpr int kCB = 32;           // block size
+constexpr int kCBP = kCB + 1;     // padded row of the LDS copies
+constexpr int kFusedMaxN = 540;   // panel (n + 1 - 32 rows) x 33 doubles must fit into LDS next to the blocks
+
+__global__ __launch_bounds__(1024) void ba_solve_fused_kernel(BaWork wk, int n, float lm, float ep) {
+  extern __shared__ double fsm[];
+  double* Dl = fsm;                 // [32][33] diagonal block (unscaled columns), then L11
+  double* Wl = Dl + kCB * kCBP;     // [32][33] row operations applied to I, then L11^-1
+  double* P = Wl + kCB * kCBP;      // [rows below][33] panel of the current block; later x[n]
+  __shared__ int fail, bw_s;
+  const int tid = threadIdx.x;
+  double* A = wk.Hd;                // (n + 1) x n row-major; row n = right-hand side (wk.vd)
+  // status[3] = (half bandwidth << 1) | solved, left by ba_solve_band_kernel which always runs first
+  if (tid == 0) { fail = (wk.status[0] & BA_ST_M_MISMATCH) ? 1 : 0; bw_s = wk.status[3]; }
+  __syncthreads();
+  if (tid == 0) wk.status[3] = 0;      // consumed (everybody has read it above)
+  if (bw_s & 1) return;
+  for (int i = tid; i < n; i += 1024) {
+    const double v = A[(size_t)i * n + i];
+    A[(size_t)i * n + i] = v + (double)ep + (double)lm * v;
+  }
+  __syncthreads();
+  const int bw = bw_s >> 1;
+  const int br = tid >> 5, bc = tid & 31;   // element of the 32 x 32 block owned during the diagonal phase
+  for (int j0 = 0; j0 < n; j0 += kCB) {
+    const int nb = min(kCB, n - j0);
+    const int rem = min(n - j0 - nb, bw);   // matrix rows below the block that can be non-zero; + the rhs row
+    const int base = j0 + nb;
+    // ---- diagonal block
+    if (br < nb && bc <= br) {
+      Dl[br * kCBP + bc] = A[(size_t)(j0 + br) * n + j0 + bc];
+      Wl[br * kCBP + bc] = br == bc ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    for (int j = 0; j < nb; ++j) {
+      const double d = Dl[j * kCBP + j];
+      if (!(d > 0.0) && tid == 0) fail = 1;   // also NaN; the (garbage) result is discarded below
+      if (br < nb && br > j) {
+        const double mlt = Dl[br * kCBP + j] / d;
+        if (bc > j && bc <= br) Dl[br * kCBP + bc] -= mlt * Dl[bc * kCBP + j];
+        else if (bc <= j) Wl[br * kCBP + bc] -= mlt * Wl[j * kCBP + bc];
+      }
+      __syncthreads();
+    }
+    double lval = 0.0, wval = 0.0;
+    if (br < nb && bc <= br) {
+      const double sc = sqrt(Dl[bc * kCBP + bc]), sr = sqrt(Dl[br * kCBP + br]);
+      lval = (br == bc) ? sc : Dl[br * kCBP + bc] / sc;
+      wval = Wl[br * kCBP + bc] / sr;
+    }
+    __syncthreads();
+    if (br < nb && bc <= br) {
+      Dl[br * kCBP + bc] = lval;
+      Wl[br * kCBP + bc] = wval;
+      A[(size_t)(j0 + br) * n + j0 + bc] = lval;
+      if (bc < br) A[(size_t)(j0 + bc) * n + j0 + br] = wval;   // L11^-1 (strictly lower part), transposed
+    }
+    // ---- panel: X = A21 L11^-T.  Thread = (row t, parity g of its 16 columns); rows base .. base + rem - 1
+    // and the rhs row n (t == rem)
+    for (int idx = tid; idx < (rem + 1) * kCB; idx += 1024) {   // A21 (+ rhs row) -> LDS, coalesced
+      const int t = idx >> 5, m = idx & 31;
+      P[t * kCBP + m] = m < nb ? A[(size_t)(t < rem ? base + t : n) * n + j0 + m] : 0.0;
+    }
+    __syncthreads();                         // A21 staged, L11^-1 complete
+    for (int t0 = 0; t0 <= rem; t0 += 256) {
+      const int t = min(t0 + (tid & 255), rem), g = tid >> 8;   // columns 4 q + g: wave-uniform -> broadcast reads
+      const bool on = t0 + (tid & 255) <= rem;
+      double x[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) x[q] = 0.0;
+      const double* wg = Wl + g * kCBP;
+      const double* ap = P + t * kCBP;
+#pragma unroll 2
+      for (int m = 0; m < kCB; ++m) {          // (not fully unrolled: the 288 LDS reads get hoisted and spill)
+        const double am = ap[m];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) x[q] = fma(am, (m <= 4 * q + g) ? wg[4 * q * kCBP + m] : 0.0, x[q]);
+      }
+      __syncthreads();                       // every reader of these rows is done: overwrite them with X
+      if (on) {
+        double* arow = A + (size_t)(t < rem ? base + t : n) * n + j0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int c = 4 * q + g;
+          if (c < nb) arow[c] = x[q];
+          P[t * kCBP + c] = c < nb ? x[q] : 0.0;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- trailing update A22 -= X X^T on the lower triangle (+ the rhs row): tile = rows 8 tr .. 8 tr + 7,
+    // columns tc + {0, 1, 2, 3} * TC
+    if (rem > 0) {
+      const int TR = (rem + 1 + 7) / 8, TC = (rem + 3) / 4;
+      for (int t = tid; t < TR * TC; t += 1024) {
+        const int tr = t / TC, tc = t - tr * TC;
+        const int r0 = 8 * tr, rmax = min(r0 + 7, rem);
+        if (tc > rmax) continue;              // entirely above the diagonal
+        double acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[i][q] = 0.0;
+        int roff[8], coff[4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) roff[i] = min(r0 + i, rem) * kCBP;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) coff[q] = min(tc + q * TC, rem - 1) * kCBP;
+        for (int k = 0; k < kCB; ++k) {
+          double av[8], bv[4];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) av[i] = P[roff[i] + k];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) bv[q] = P[coff[q] + k];
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[i][q] = fma(av[i], bv[q], acc[i][q]);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int r = r0 + i;
+          if (r > rem) continue;
+          double* arow = A + (size_t)(r < rem ? base + r : n) * n + base;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int c = tc + q * TC;
+            if (c < rem && c <= r) arow[c] -= acc[i][q];
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (fail) {
+    for (int i = tid; i < n; i += 1024) wk.dx[i] = 0.0f;
+    if (tid == 0) {
+      atomicOr(&wk.status[0], BA_ST_CHOL_FAILED);
+      atomicAdd(&wk.status[2], 1);
+    }
+    return;
+  }
+  // ---- back substitution L^T x = y (y = row n), blocked from the last block up:
+  // x_blk = L11^-T y_blk (L11^-1 from the upper triangle of the block), then y[r] -= sum_c L[j0 + c][r] x[j0 + c]
+  // for the rows r < j0 inside the band
+  double* xs = P;
+  for (int i = tid; i < n; i += 1024) xs[i] = A[(size_t)n * n + i];
+  __syncthreads();
+  for (int j0 = ((n - 1) / kCB) * kCB; j0 >= 0; j0 -= kCB) {
+    const int nb = min(kCB, n - j0);
+    if (br < nb && bc < nb) {   // Wl[r][c] = L11^-1[r][c] for r >= c
+      double v = 0.0;
+      if (bc < br) v = A[(size_t)(j0 + bc) * n + j0 + br];
+      else if (bc == br) v = 1.0 / A[(size_t)(j0 + br) * n + j0 + br];
+      Wl[br * kCBP + bc] = v;
+    }
+    __syncthreads();
+    if (tid < nb) {             // x[c] = sum_{r >= c} L11^-1[r][c] y[r]
+      double v = 0.0;
+      for (int r = tid; r < nb; ++r) v = fma(Wl[r * kCBP + tid], xs[j0 + r], v);
+      Dl[tid] = v;
+    }
+    __syncthreads();
+    if (tid < nb) xs[j0 + tid] = Dl[tid];
+    __syncthreads();
+    for (int r = max(0, j0 - bw) + tid; r < j0; r += 1024) {   // rows of L: coalesced in r
+      double v = xs[r];
+      for (int c = 0; c < nb; ++c) v -= A[(size_t)(j0 + c) * n + r] * xs[j0 + c];
+      xs[r] = v;
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < n; i += 1024) wk.dx[i] = (float)xs[i];
+}
+
 // triangular solves on the factored matrix in HBM (1 WG of 1024 threads; row-block sweeps)
 __global__ __launch_bounds__(1024) void chol_solve_kernel(BaWork wk, int n) {
   extern __shared__ double xs[];  // [n]
@@ -881,6 +1250,10 @@ static int ba_plan(glorie_ctx* ctx, int B, int N, int M, int h, int w, int t0, i
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_solve_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ba_solve_fused_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ba_solve_band_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
     attr_set = true;
   }
   return GLORIE_OK;
@@ -912,6 +1285,14 @@ static int ba_solve_update(const BaPlan& pl, float* poses, float* disps, const i
   if (n6 <= kSolveMaxN) {
     const size_t lds = sizeof(double) * ((size_t)(n6 + 1) * (n6 + 2) / 2 + n6);
     hipLaunchKernelGGL(ba_solve_lds_kernel, dim3(1), dim3(256), lds, st, wk, n6, lm, ep);
+  } else if (n6 <= kFusedMaxN) {
+    const size_t rows = (size_t)(n6 + 1 > kCB ? n6 + 1 - kCB : 1);
+    const size_t lds = sizeof(double) * (2 * kCB * kCBP + (rows * kCBP > (size_t)n6 ? rows * kCBP : (size_t)n6));
+    const int band_doubles = (160 * 1024 - 256) / (int)sizeof(double);
+    hipLaunchKernelGGL(ba_bandwidth_kernel, dim3(n6), dim3(64), 0, st, wk, n6);
+    hipLaunchKernelGGL(ba_solve_band_kernel, dim3(1), dim3(kBandThreads), sizeof(double) * (size_t)band_doubles, st,
+                       wk, n6, lm, ep, band_doubles);
+    hipLaunchKernelGGL(ba_solve_fused_kernel, dim3(1), dim3(1024), lds, st, wk, n6, lm, ep);
   } else {
     if ((size_t)n6 * sizeof(double) > 128 * 1024) return GLORIE_EUNSUPPORTED;
     hipLaunchKernelGGL(chol_damp_kernel, dim3((n6 + 255) / 256), dim3(256), 0, st, wk, n6, lm, ep);

@@ -136,7 +136,7 @@ def test_ba_cholesky_failure_gives_zero_update(gpu):
 
 
 def test_ba_large_window_uses_blocked_solver(gpu):
-    """6P > 192 switches to the blocked Cholesky in HBM"""
+    """6P = 234 with loop closures (dense system): the one-workgroup blocked Cholesky (ba_solve_fused_kernel)"""
     g = synth.loop_graph(K=40, h=12, w=16)
     coords, _ = ogeom.reproject(g["poses"], g["disps"], g["intrinsics"], g["ii"], g["jj"])
     g["target"] = (coords.transpose(0, 3, 1, 2) + g["noise"]).astype(np.float32)
@@ -169,7 +169,7 @@ def test_ba_full_size_fixed_point_and_descent(gpu):
 def test_ba_sharded_equals_unsharded(gpu, K, h, w, world):
     """build_system on `world` source-frame shards (one context each, on one GPU), summed like the
     RCCL all-reduce would, then solve_update on each shard == glorie_ba on the whole graph.
-    K = 38: 6P = 222 unknowns -> the blocked HBM Cholesky, as in the multi-GPU bench."""
+    K = 38: 6P = 222 unknowns, half bandwidth 41 -> the banded LDS solver, as in the multi-GPU bench."""
     from glorie_slam_amd import _lib as L, dist as gdist
     g = make_problem(K, h, w, radius=3)
     t0, t1, lm, ep = 1, K, 1e-4, 0.1

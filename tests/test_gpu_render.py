@@ -80,6 +80,23 @@ def test_knn_coarse_grid_forced(gpu):
     _check_knn(gpu, pts, q, cell=0.01, max_cells=64)
 
 
+def test_knn_ray_ordered_queries_cooperative_path(gpu):
+    """Consecutive queries = consecutive samples of neighbouring rays (the renderer's order): the waves take
+    the cooperative box scan.  Also a ragged tail (Q not a multiple of 64) and a mixed batch in which
+    some waves are coherent and some are not."""
+    import glorie_slam_amd.synth as synth
+    pts, _, _ = synth.box_cloud(n_hits=30000)
+    ro, rd, depth, _, _ = synth.box_rays(H=48, W=64, fx=32.0, fy=32.0, cx=31.5, cy=23.5)
+    sel = np.arange(20 * 64, 20 * 64 + 333)                       # 333 neighbouring pixels
+    z = depth[sel, None] * np.linspace(0.95, 1.05, 10, dtype=np.float32)[None]
+    q = (ro[sel, None] + rd[sel, None] * z[..., None]).reshape(-1, 3).astype(np.float32)
+    _check_knn(gpu, pts, q, cell=0.08)
+    _check_knn(gpu, pts, q[:1001], cell=0.05)
+    rng = np.random.default_rng(7)
+    mixed = np.concatenate([q[:640], rng.uniform(-3, 3, (200, 3)).astype(np.float32), q[640:1500]])
+    _check_knn(gpu, pts, mixed, cell=0.08)
+
+
 def test_knn_point_permutation_invariance(gpu):
     rng = np.random.default_rng(4)
     pts = rng.uniform(0, 1, (2000, 3)).astype(np.float32)
