@@ -443,7 +443,7 @@ def main():
                          "achieved": knn_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": knn_gbs / HBM_PEAK_GBS, "traffic": knn_traffic if world == 1 else None,
                          "alg_bytes_per_launch": knn_bytes, "ms_per_launch": knn_ms},
-        "roofline_mlp": {"bound": "mfma", "kernel": "mlp_geo + mlp_nb_v2 + mlp_col_v2 (fp32 MFMA 16x16x4)",
+        "roofline_mlp": {"bound": "mfma", "kernel": "mlp_geo_v3 + mlp_nb_v3 + mlp_col_v3 (fp32 MFMA 16x16x4, transposed form)",
                          "achieved": mlp_tf, "peak": 157.3, "unit": "TFLOP/s", "frac": mlp_tf / 157.3,
                          "traffic": None, "flops_per_launch": mlp_flops, "ms_per_launch": mlp_ms},
     }

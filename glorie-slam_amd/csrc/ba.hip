@@ -516,95 +516,10 @@ __global__ __launch_bounds__(64) void ba_assemble_kernel(BaWork wk, const int64_
 }
 
 // ------------------------------------------------------------------------------------
-// solve: (H + damping) dx = v, fp64 Cholesky in LDS (packed lower), n <= kSolveMaxN
+// solve: (H + damping) dx = v in fp64.  n <= kSolveMaxN and banded systems: ba_solve_band_kernel (LDS);
+// dense systems up to kFusedMaxN: ba_solve_fused_kernel (one workgroup, matrix in L2); above: the
+// multi-kernel blocked Cholesky below.
 // ------------------------------------------------------------------------------------
-__device__ __forceinline__ int tri(int r, int c) { return r * (r + 1) / 2 + c; }  // r >= c
-
-__global__ __launch_bounds__(256) void ba_solve_lds_kernel(BaWork wk, int n, float lm, float ep) {
-  // The right-hand side rides along as row n of the packed lower triangle: the factorisation of
-  // the augmented matrix leaves y = L^-1 b in that row (same operations, in the same order, as a
-  // column-oriented forward substitution), so the solve costs 2 barriers per column instead of
-  // 4 + 2 + 2.  The back substitution runs in one wave without barriers when n <= 64.
-  extern __shared__ double Ls[];  // packed lower triangle of the (n+1) x (n+1) augmented matrix
-  double* x = Ls + (n + 1) * (n + 2) / 2;
-  __shared__ int fail;
-  const int tid = threadIdx.x;
-  const int n1 = n + 1;
-  if (tid == 0) fail = (wk.status[0] & BA_ST_M_MISMATCH) ? 1 : 0;
-  for (int idx = tid; idx < n * (n + 1) / 2; idx += 256) {
-    int r = (int)((sqrtf(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
-    while ((r + 1) * (r + 2) / 2 <= idx) ++r;
-    while (r * (r + 1) / 2 > idx) --r;
-    const int c = idx - r * (r + 1) / 2;
-    double v = wk.Hd[(size_t)r * n + c];
-    if (r == c) v += (double)ep + (double)lm * v;
-    Ls[idx] = v;
-  }
-  for (int i = tid; i < n; i += 256) Ls[tri(n, i)] = wk.vd[i];
-  __syncthreads();
-  // right-looking Cholesky; the diagonal keeps d_j (not sqrt) until the end of its column step
-  for (int j = 0; j < n; ++j) {
-    const double d = Ls[tri(j, j)];
-    if (!(d > 0.0) && tid == 0) fail = 1;  // also catches NaN; checked after the loop (result discarded)
-    const double dj = sqrt(d);
-    for (int r = j + 1 + tid; r < n1; r += 256) Ls[tri(r, j)] = Ls[tri(r, j)] / dj;
-    __syncthreads();
-    // trailing update: rows j < r <= n (row n = rhs), cols j < c <= min(r, n - 1)
-    const int m = n - j - 1;               // remaining matrix rows/cols
-    const int cnt = m * (m + 1) / 2;
-    for (int idx = tid; idx < cnt + m; idx += 256) {
-      int r, c;
-      if (idx < cnt) {
-        // triangular index decode in fp32 (exact after the two correction loops for idx < 2^23)
-        int rr = (int)((sqrtf(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
-        while ((rr + 1) * (rr + 2) / 2 <= idx) ++rr;
-        while (rr * (rr + 1) / 2 > idx) --rr;
-        const int cc = idx - rr * (rr + 1) / 2;
-        r = j + 1 + rr;
-        c = j + 1 + cc;
-      } else {
-        r = n;
-        c = j + 1 + (idx - cnt);
-      }
-      Ls[tri(r, c)] -= Ls[tri(r, j)] * Ls[tri(c, j)];
-    }
-    if (tid == 0) Ls[tri(j, j)] = dj;
-    __syncthreads();
-  }
-  if (fail) {
-    for (int i = tid; i < n; i += 256) wk.dx[i] = 0.0f;
-    if (tid == 0) {
-      atomicOr(&wk.status[0], BA_ST_CHOL_FAILED);
-      atomicAdd(&wk.status[2], 1);
-    }
-    return;
-  }
-  // backward substitution L^T x = y, y = row n of the factor
-  if (n <= 64) {
-    if (tid < 64) {                                     // one wave, lane r owns x[r]
-      double xr = tid < n ? Ls[tri(n, tid)] : 0.0;
-      for (int j = n - 1; j >= 0; --j) {
-        const double ljj = Ls[tri(j, j)];
-        const double xj = __shfl(xr, j, 64) / ljj;
-        if (tid == j) xr = xj;
-        if (tid < j) xr -= Ls[tri(j, tid)] * xj;
-      }
-      if (tid < n) wk.dx[tid] = (float)xr;
-    }
-    return;
-  }
-  for (int i = tid; i < n; i += 256) x[i] = Ls[tri(n, i)];
-  __syncthreads();
-  for (int j = n - 1; j >= 0; --j) {
-    if (tid == 0) x[j] = x[j] / Ls[tri(j, j)];
-    __syncthreads();
-    const double xj = x[j];
-    for (int r = tid; r < j; r += 256) x[r] -= Ls[tri(j, r)] * xj;
-    __syncthreads();
-  }
-  for (int i = tid; i < n; i += 256) wk.dx[i] = (float)x[i];
-}
-
 // ---- large systems: blocked right-looking Cholesky on the dense fp64 matrix in HBM ----
 constexpr int kNB = 32;
 
@@ -808,12 +723,14 @@ __device__ __forceinline__ void band_eliminate(double* B, double* u, double* rin
 }
 
 __global__ __launch_bounds__(kBandThreads) void ba_solve_band_kernel(BaWork wk, int n, float lm, float ep,
-                                                                    int lds_doubles) {
+                                                                    int lds_doubles, int force_bw) {
   extern __shared__ double bsm[];
   __shared__ int fail, bw_s;
   const int tid = threadIdx.x;
   const double* A = wk.Hd;          // (n + 1) x n row-major, lower triangle; row n = right-hand side
-  if (tid == 0) { fail = (wk.status[0] & BA_ST_M_MISMATCH) ? 1 : 0; bw_s = wk.status[3] >> 1; }
+  // force_bw >= 0: small dense systems (n <= 64) come here directly as a band of width n - 1, without the
+  // bandwidth kernel and without the status[3] handshake
+  if (tid == 0) { fail = (wk.status[0] & BA_ST_M_MISMATCH) ? 1 : 0; bw_s = force_bw >= 0 ? force_bw : wk.status[3] >> 1; }
   __syncthreads();
   const int bw = bw_s;
   const int S = bw + 1;             // band row: B[r][k] = H[r][r - k], k = 0 .. bw
@@ -849,7 +766,7 @@ __global__ __launch_bounds__(kBandThreads) void ba_solve_band_kernel(BaWork wk, 
     if (tid == 0) {
       atomicOr(&wk.status[0], BA_ST_CHOL_FAILED);
       atomicAdd(&wk.status[2], 1);
-      wk.status[3] = (bw << 1) | 1;
+      if (force_bw < 0) wk.status[3] = (bw << 1) | 1;
     }
     return;
   }
@@ -876,7 +793,7 @@ __global__ __launch_bounds__(kBandThreads) void ba_solve_band_kernel(BaWork wk, 
       if (dist >= 1 && dist <= bw && j - dist >= 0) srow = fma(bc, xj, srow);
     }
   }
-  if (tid == 0) wk.status[3] = (bw << 1) | 1;         // solved: ba_solve_fused_kernel returns at once
+  if (tid == 0 && force_bw < 0) wk.status[3] = (bw << 1) | 1;   // solved: ba_solve_fused_kernel returns at once
 }
 
 // ---- medium systems (kSolveMaxN < n <= kFusedMaxN): the whole solve in ONE workgroup of 1024 threads -------------
@@ -1246,8 +1163,6 @@ static int ba_plan(glorie_ctx* ctx, int B, int N, int M, int h, int w, int t0, i
   wk.dx = reinterpret_cast<float*>(base + o_dx);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ba_solve_lds_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_solve_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ba_solve_fused_kernel),
@@ -1283,15 +1198,17 @@ static int ba_solve_update(const BaPlan& pl, float* poses, float* disps, const i
   const BaWork& wk = pl.wk;
   const int n6 = pl.n6;
   if (n6 <= kSolveMaxN) {
-    const size_t lds = sizeof(double) * ((size_t)(n6 + 1) * (n6 + 2) / 2 + n6);
-    hipLaunchKernelGGL(ba_solve_lds_kernel, dim3(1), dim3(256), lds, st, wk, n6, lm, ep);
+    const int bwf = n6 > 1 ? n6 - 1 : 1;
+    const int need = n6 * (bwf + 1) + 2 * n6;
+    hipLaunchKernelGGL(ba_solve_band_kernel, dim3(1), dim3(kBandThreads), sizeof(double) * (size_t)need, st, wk, n6,
+                       lm, ep, need, bwf);
   } else if (n6 <= kFusedMaxN) {
     const size_t rows = (size_t)(n6 + 1 > kCB ? n6 + 1 - kCB : 1);
     const size_t lds = sizeof(double) * (2 * kCB * kCBP + (rows * kCBP > (size_t)n6 ? rows * kCBP : (size_t)n6));
     const int band_doubles = (160 * 1024 - 256) / (int)sizeof(double);
     hipLaunchKernelGGL(ba_bandwidth_kernel, dim3(n6), dim3(64), 0, st, wk, n6);
     hipLaunchKernelGGL(ba_solve_band_kernel, dim3(1), dim3(kBandThreads), sizeof(double) * (size_t)band_doubles, st,
-                       wk, n6, lm, ep, band_doubles);
+                       wk, n6, lm, ep, band_doubles, -1);
     hipLaunchKernelGGL(ba_solve_fused_kernel, dim3(1), dim3(1024), lds, st, wk, n6, lm, ep);
   } else {
     if ((size_t)n6 * sizeof(double) > 128 * 1024) return GLORIE_EUNSUPPORTED;

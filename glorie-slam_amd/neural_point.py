@@ -56,7 +56,7 @@ class NeuralPointCloud(object):
         self.geo_feats = None
         self.col_feats = None
         self.video = video
-        self.index = point_ops.KnnIndex(self.device, cell_size=pc.get('knn_cell_size', 0.08),
+        self.index = point_ops.KnnIndex(self.device, cell_size=pc.get('knn_cell_size', 0.06),
                                         max_cells=pc.get('knn_max_cells', 1 << 21))
 
     # ---- accessors (same names as the reference) --------------------------------------
