@@ -60,6 +60,8 @@ SIGNATURES = {
     "glorie_decoder_pack_floats": (_sz, []),
     "glorie_render_mlp": (_c_int, [_vp] * 9 + [_c_int, _vp, _vp, _c_int, _vp]),
     "glorie_composite": (_c_int, [_vp, _vp, _c_int, _c_int, _c_f, _vp, _vp, _vp, _vp, _vp]),
+    "glorie_ray_samples": (_c_int, [_vp] * 5 + [_c_int, _c_int, _c_f, _c_f] + [_vp] * 6),
+    "glorie_ray_counts": (_c_int, [_vp, _c_int, _c_int, _c_int, _vp, _vp, _vp]),
     "glorie_ba_status": (_c_int, [_vp, ctypes.POINTER(_c_int), _vp]),
 }
 

@@ -103,9 +103,77 @@ __global__ __launch_bounds__(256) void composite_kernel(
   var[r] = vv;
 }
 
+// sample placement of Renderer.render_batch_ray for rays with a depth prior (Renderer.py:106-125, 177-179):
+//   z = near_s * d * (1 - t) + far_s * d * t  (t = linspace(0, 1, S), every product and the sum rounded
+//   separately like the chain of torch ops), pts = o + dir * z, and the per-ray view direction / query
+//   radius repeated per sample.  Rays with d <= 0 get z = 0 and are counted in *n_zero: the host sends such a
+//   batch through the general path (they need the 25-probe search of sample_near_pcl).
+__global__ __launch_bounds__(256) void ray_samples_kernel(
+    const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ depth,
+    const float* __restrict__ radius, const float* __restrict__ t_lin, int R, int S, float near_s, float far_s,
+    float* __restrict__ z_vals, float* __restrict__ pts, float* __restrict__ views,
+    float* __restrict__ radius_s, int* __restrict__ n_zero) {
+#pragma clang fp contract(off)
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)R * S) return;
+  const int r = (int)(idx / S), sidx = (int)(idx - (long)r * S);
+  const float d = depth[r], t = t_lin[sidx];
+  const float a = near_s * d, c = far_s * d;
+  const float omt = 1.0f - t;
+  const float p1 = a * omt, p2 = c * t;
+  const float z = d > 0.0f ? p1 + p2 : 0.0f;
+  if (sidx == 0 && !(d > 0.0f)) atomicAdd(n_zero, 1);
+  z_vals[idx] = z;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float dir = rays_d[(size_t)r * 3 + k];
+    const float m = dir * z;
+    pts[idx * 3 + k] = rays_o[(size_t)r * 3 + k] + m;
+    views[idx * 3 + k] = dir;
+  }
+  if (radius_s) radius_s[idx] = radius[r];
+}
+
+// per-ray number of samples that have neighbours and the valid-ray flag (decoder.py:202-204)
+__global__ __launch_bounds__(256) void ray_counts_kernel(const uint8_t* __restrict__ has, int R, int S,
+                                                         int min_samples, int64_t* __restrict__ counts,
+                                                         uint8_t* __restrict__ valid) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= R) return;
+  int c = 0;
+  for (int s = 0; s < S; ++s) c += has[(size_t)r * S + s] ? 1 : 0;
+  counts[r] = c;
+  valid[r] = c >= min_samples ? 1 : 0;
+}
+
 }  // namespace glorie
 
 using namespace glorie;
+
+extern "C" int glorie_ray_samples(const float* rays_o, const float* rays_d, const float* depth,
+                                  const float* radius, const float* t_lin, int R, int S, float near_s,
+                                  float far_s, float* z_vals, float* pts, float* views, float* radius_s,
+                                  int* n_zero, void* stream) {
+  if (R < 0 || S < 1) return GLORIE_EINVAL;
+  if (R == 0) return GLORIE_OK;
+  if (!rays_o || !rays_d || !depth || !t_lin || !z_vals || !pts || !views || !n_zero) return GLORIE_EINVAL;
+  if ((radius == nullptr) != (radius_s == nullptr)) return GLORIE_EINVAL;
+  const long total = (long)R * S;
+  hipLaunchKernelGGL(ray_samples_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     rays_o, rays_d, depth, radius, t_lin, R, S, near_s, far_s, z_vals, pts, views, radius_s,
+                     n_zero);
+  return check_launch();
+}
+
+extern "C" int glorie_ray_counts(const uint8_t* has, int R, int S, int min_samples, int64_t* counts,
+                                 uint8_t* valid, void* stream) {
+  if (R < 0 || S < 1) return GLORIE_EINVAL;
+  if (R == 0) return GLORIE_OK;
+  if (!has || !counts || !valid) return GLORIE_EINVAL;
+  hipLaunchKernelGGL(ray_counts_kernel, dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream, has, R, S,
+                     min_samples, counts, valid);
+  return check_launch();
+}
 
 extern "C" int glorie_idw_gather(const float* D, const int64_t* I, const int* nn,
                                  const float* feats, int Q, int k, int c_dim, float radius,

@@ -79,7 +79,7 @@ class KnnIndex:
 
 
 def idw_gather(D, I, nn, feats, radius=0.0, radius_per_query=None, min_nn=2, expo=False,
-               return_weights=False):
+               return_weights=False, raw_mask=False):
     """decoder.py:130-173: c [Q,32], has_neighbors [Q] bool (, weights [Q,8])"""
     L.need_cuda(D, I, nn, feats)
     Q, k = D.shape
@@ -92,7 +92,51 @@ def idw_gather(D, I, nn, feats, radius=0.0, radius_per_query=None, min_nn=2, exp
                                        L.ptr(feats), Q, k, feats.shape[1], float(radius), L.ptr(rp),
                                        int(min_nn), int(bool(expo)), L.ptr(c), L.ptr(w), L.ptr(has),
                                        L.stream_ptr()), "glorie_idw_gather")
-    return (c, has.bool(), w) if return_weights else (c, has.bool())
+    if not raw_mask:
+        has = has.bool()
+    return (c, has, w) if return_weights else (c, has)
+
+
+_T_LIN = {}
+
+
+def ray_samples(rays_o, rays_d, depth, radius, S, near_s, far_s):
+    """Renderer.py:106-125,177-184 for rays with a depth prior -> z_vals [R,S], pts [R*S,3],
+    views [R*S,3], radius per sample [R*S] (None without `radius`), n_zero (device int32 [1]: rays with
+    depth <= 0, which need the general path)."""
+    L.need_cuda(rays_o, rays_d, depth)
+    dev = rays_o.device
+    R = rays_o.shape[0]
+    key = (str(dev), int(S))
+    if key not in _T_LIN:
+        _T_LIN[key] = torch.linspace(0.0, 1.0, steps=S, device=dev)
+    f = lambda t: t.detach().reshape(-1).contiguous().float()
+    z = torch.empty(R, S, device=dev)
+    pts = torch.empty(R * S, 3, device=dev)
+    views = torch.empty(R * S, 3, device=dev)
+    rs = torch.empty(R * S, device=dev) if radius is not None else None
+    nz = torch.zeros(1, dtype=torch.int32, device=dev)
+    o, d, g = f(rays_o), f(rays_d), f(depth)
+    r = f(radius) if radius is not None else None
+    if g.shape[0] != R or (r is not None and r.shape[0] != R):
+        raise RuntimeError("ray_samples: depth / radius must have one entry per ray")
+    L.check(L.load().glorie_ray_samples(L.ptr(o), L.ptr(d), L.ptr(g), L.ptr(r), L.ptr(_T_LIN[key]), R, int(S),
+                                        float(near_s), float(far_s), L.ptr(z), L.ptr(pts), L.ptr(views),
+                                        L.ptr(rs), L.ptr(nz), L.stream_ptr()), "glorie_ray_samples")
+    return z, pts, views, rs, nz
+
+
+def ray_counts(has, S, min_samples=3):
+    """decoder.py:202-204: has [R*S] (bool / uint8) -> counts [R] int64, valid [R] bool"""
+    L.need_cuda(has)
+    h8 = has if has.dtype == torch.uint8 else has.to(torch.uint8)
+    h8 = h8.contiguous()
+    R = h8.numel() // S
+    counts = torch.empty(R, dtype=torch.int64, device=has.device)
+    valid = torch.empty(R, dtype=torch.bool, device=has.device)
+    L.check(L.load().glorie_ray_counts(L.ptr(h8), R, int(S), int(min_samples), L.ptr(counts), L.ptr(valid),
+                                       L.stream_ptr()), "glorie_ray_counts")
+    return counts, valid
 
 
 def composite(raw, z_vals, coef=0.1, return_weights=True):
@@ -215,10 +259,12 @@ def render_mlp(packed, pts, views, cloud_pos, col_feats, c_geo, I, weights, has,
     L.need_cuda(packed, pts, c_geo)
     Q = pts.shape[0]
     dev = pts.device
-    raw = torch.zeros(Q, 4, dtype=torch.float32, device=dev)
     color = stage == "color"
+    # the colour kernel writes rgb of every sample, the geometry kernel the occupancy: only the geometry
+    # stage needs the zero fill
+    raw = (torch.empty if color else torch.zeros)(Q, 4, dtype=torch.float32, device=dev)
     scratch = torch.empty(Q, 32, dtype=torch.float32, device=dev) if color else None
-    has8 = has.to(torch.uint8).contiguous()
+    has8 = (has if has.dtype == torch.uint8 else has.to(torch.uint8)).contiguous()
     L.check(L.load().glorie_render_mlp(
         L.ptr(packed), L.ptr(pts.contiguous().float()),
         L.ptr(views.contiguous().float()) if color else None,

@@ -8,6 +8,8 @@ import warnings
 
 import torch
 
+from . import point_ops
+
 from .common import get_rays, raw2outputs_nerf_color
 
 
@@ -72,12 +74,47 @@ class Renderer(object):
                 z[~nz] = torch.linspace(self.near_end, torch.max(far), steps=S, device=device).repeat((~nz).sum(), 1)
         return z, near_mask, nz
 
+    def _render_fast(self, npc, decoders, rays_d, rays_o, stage, gt_depth, npc_geo_feats, npc_col_feats,
+                     cloud_pos, dynamic_r_query):
+        """Inference path of render_batch_ray for batches in which every ray has a depth prior: seven HIP
+        launches (samples, KNN, IDW gather, three decoders, per-ray counts, compositing) and no torch glue.
+        Returns None when a ray has no depth (sample_near_pcl is needed: general path)."""
+        S = self.N_surface
+        R = rays_o.shape[0]
+        g = decoders.geo_decoder
+        rad = dynamic_r_query if self.use_dynamic_radius else None
+        z_vals, pts, views, rq, n_zero = point_ops.ray_samples(rays_o, rays_d, gt_depth, rad, S,
+                                                               self.near_end_surface, self.far_end_surface)
+        if int(n_zero.item()) != 0:
+            return None
+        D, I, nn_num = npc.find_neighbors_faiss(pts, step='query', dynamic_radius=rq)
+        radius = 0.0 if g.use_dynamic_radius else npc.get_radius_query()
+        c_geo, has, w = point_ops.idw_gather(D, I, nn_num, npc_geo_feats, radius=radius,
+                                             radius_per_query=rq if g.use_dynamic_radius else None,
+                                             min_nn=g.min_nn_num, return_weights=True, raw_mask=True)
+        cp = cloud_pos if cloud_pos is not None else npc.cloud_pos()
+        raw = point_ops.render_mlp(decoders._packed(), pts, views, cp, npc_col_feats, c_geo, I, w, has,
+                                   stage=stage)
+        counts, valid = point_ops.ray_counts(has, S, 3)
+        depth, var, rgb, _ = point_ops.composite(raw.view(R, S, 4), z_vals, self.sigmoid_coefficient,
+                                                 return_weights=False)
+        return depth, var, rgb, valid, counts
+
     def render_batch_ray(self, npc, decoders, rays_d, rays_o, device, stage, gt_depth=None,
                          npc_geo_feats=None, npc_col_feats=None, is_tracker=False, cloud_pos=None,
                          dynamic_r_query=None):
         """Renderer.py:80-219 -> depth, uncertainty, color, valid_ray_mask, valid_ray_counts"""
         S = self.N_surface
         R = rays_o.shape[0]
+        if (gt_depth is not None and R > 0 and torch.numel(gt_depth) == R and stage in ('geometry', 'color')
+                and getattr(self, "use_fast_path", True)
+                and (dynamic_r_query is not None or not self.use_dynamic_radius)
+                and decoders._fused_ok(rays_o, npc_geo_feats, npc_col_feats, is_tracker, stage)
+                and decoders.geo_decoder.use_dynamic_radius == self.use_dynamic_radius):
+            out = self._render_fast(npc, decoders, rays_d, rays_o, stage, gt_depth, npc_geo_feats,
+                                    npc_col_feats, cloud_pos, dynamic_r_query)
+            if out is not None:
+                return out
         z_vals, near_mask, nz = self.sample_z(npc, rays_o, rays_d, gt_depth, device)
         pts = (rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]).reshape(-1, 3)
         rays_d_pts = rays_d.repeat_interleave(S, dim=0).reshape(-1, 3)

@@ -364,6 +364,24 @@ int glorie_render_mlp(const float* packed, const float* pts, const float* views,
                       const int64_t* I, const float* weights, const uint8_t* has, int Q,
                       float* c_col_scratch, float* raw, int stage_color, void* stream);
 
+/* Sample placement of Renderer.render_batch_ray for rays with a depth prior
+ *   reference: src/utils/Renderer.py:106-125 (z_vals), 177-179 (pts, per-sample view directions),
+ *   183-184 (per-sample query radius)
+ * z[r][s] = near_s*d*(1 - t[s]) + far_s*d*t[s] (t_lin = linspace(0,1,S), [S] device floats; each op rounded
+ * separately like the torch chain), pts = o + dir*z [R*S,3], views [R*S,3] = dir, radius_s [R*S] = radius[r]
+ * (both NULL or both given).  *n_zero (device int, accumulated) counts rays with d <= 0: those get z = 0 and
+ * need the reference's sample_near_pcl path (Renderer.py:127-174), which the host handles. */
+int glorie_ray_samples(const float* rays_o, const float* rays_d, const float* depth,
+                       const float* radius, const float* t_lin, int R, int S, float near_s, float far_s,
+                       float* z_vals, float* pts, float* views, float* radius_s, int* n_zero,
+                       void* stream);
+
+/* Per-ray count of samples with neighbours and the valid-ray flag (count >= min_samples)
+ *   reference: src/modules/conv_onet/models/decoder.py:202-204 (ray_counter, ~(counter < 3))
+ * has [R*S] uint8 -> counts [R] int64, valid [R] uint8. */
+int glorie_ray_counts(const uint8_t* has, int R, int S, int min_samples, int64_t* counts,
+                      uint8_t* valid, void* stream);
+
 /* raw2outputs_nerf_color(raw, z_vals, rays_d, coef)
  *   reference: src/utils/common.py:261-299
  * raw [R,S,4] (rgb, occupancy), z_vals [R,S] -> depth [R], var [R], rgb [R,3],

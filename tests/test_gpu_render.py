@@ -203,6 +203,62 @@ def test_render_batch_ray_end_to_end(gpu):
     assert (c.cpu().numpy() >= 0).all() and (c.cpu().numpy() <= 1).all()
 
 
+def test_render_fast_path_equals_general_path(gpu):
+    """all rays with a depth prior: render_batch_ray takes the HIP-only path (ray_samples, KNN, gather,
+    decoders, ray_counts, compositing); same numbers as the general path built from torch ops.  One ray
+    without depth sends the batch back to the general path."""
+    import glorie_slam_amd.synth as synth
+    from glorie_slam_amd import point_ops
+    from glorie_slam_amd.decoder import POINT
+    from glorie_slam_amd.neural_point import NeuralPointCloud
+    from glorie_slam_amd.renderer import Renderer
+    cfg = _cfg(gpu)
+    pts, geo, col = synth.box_cloud(n_hits=40000)
+    H, W = 24, 32
+    ro, rd, depth, radius, c2w = synth.box_rays(H, W, fx=16.0, fy=16.0, cx=15.5, cy=11.5)
+    t = lambda x: torch.from_numpy(x).to(gpu)
+    npc = NeuralPointCloud(cfg)
+    npc.add_points(t(pts), t(geo), t(col))
+    torch.manual_seed(43)
+    dec = POINT(cfg, use_view_direction=True).eval().to(gpu)
+
+    class Cam:
+        H, W, fx, fy, cx, cy = 24, 32, 16.0, 16.0, 15.5, 11.5
+    ren = Renderer(cfg, Cam())
+    kw = dict(npc_geo_feats=npc.geo_feats, npc_col_feats=npc.col_feats, cloud_pos=npc.cloud_pos(),
+              dynamic_r_query=t(radius * 2.5))
+    # the sampling kernel reproduces the torch chain bit for bit
+    z, p, v, rs, nzero = point_ops.ray_samples(t(ro), t(rd), t(depth), t(radius), 10, 0.95, 1.05)
+    tl = torch.linspace(0.0, 1.0, steps=10, device=gpu)
+    g = t(depth).reshape(-1, 1)
+    z_ref = 0.95 * g * (1. - tl) + 1.05 * g * tl
+    assert torch.equal(z, z_ref) and int(nzero) == 0
+    assert torch.equal(p, (t(ro)[:, None, :] + t(rd)[:, None, :] * z_ref[:, :, None]).reshape(-1, 3))
+    assert torch.equal(v, t(rd).repeat_interleave(10, dim=0)) and torch.equal(rs, t(radius).repeat_interleave(10))
+    with torch.no_grad():
+        for stage in ("color", "geometry"):
+            ren.use_fast_path = True
+            fast = ren.render_batch_ray(npc, dec, t(rd), t(ro), gpu, stage, gt_depth=t(depth), **kw)
+            ren.use_fast_path = False
+            gen = ren.render_batch_ray(npc, dec, t(rd), t(ro), gpu, stage, gt_depth=t(depth), **kw)
+            for a, b in zip(fast, gen):
+                assert a.dtype == b.dtype and a.shape == b.shape
+                if a.dtype.is_floating_point:
+                    torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-7)
+                else:
+                    assert torch.equal(a, b)
+        gt0 = depth.copy()
+        gt0[5] = 0.0
+        ren.use_fast_path = True
+        a = ren.render_batch_ray(npc, dec, t(rd), t(ro), gpu, "color", gt_depth=t(gt0), **kw)
+        ren.use_fast_path = False
+        b = ren.render_batch_ray(npc, dec, t(rd), t(ro), gpu, "color", gt_depth=t(gt0), **kw)
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    c, vld = point_ops.ray_counts(torch.tensor([1, 1, 1, 0, 0, 1, 0, 0], dtype=torch.bool, device=gpu), 4, 3)
+    assert c.tolist() == [3, 1] and vld.tolist() == [True, False]
+
+
 def test_fused_mlp_matches_torch_path_and_reference(gpu):
     """the MFMA decoder kernels == the torch nn.Linear path == the reference fixture"""
     from glorie_slam_amd.decoder import POINT
