@@ -80,13 +80,14 @@ struct ColParams {
 constexpr int kTM2 = 128;
 
 // torch.nn.Softplus(beta=100, threshold=20) on the bare base-2 hardware transcendentals (v_exp_f32 /
-// v_log_f32, 1 ulp each):  ln(1 + e^(100 x)) / 100 = (ln 2 / 100) log2(1 + 2^(100 log2(e) x)).
-// On this chip VALU work does not hide behind fp32 MFMAs of the same SIMD (tools/probes/
-// mfma_valu_overlap.hip: the two add up), and expf / logf cost 3.7x these two instructions.
+// v_log_f32, 1 ulp each), in the overflow-free form
+//   softplus(x) = max(x, 0) + (ln 2 / 100) log2(1 + 2^(-100 log2(e) |x|))
+// which needs no threshold branch: for 100 x > 20 the second term is log2(1 + < 2^-28) = 0 in fp32, i.e.
+// exactly x like torch's threshold.  On this chip VALU work does not hide behind fp32 MFMAs of the same
+// SIMD (tools/probes/mfma_valu_overlap.hip: the two add up), and expf / logf cost 3.7x these two instructions.
 __device__ __forceinline__ float softplus100_fast(float x) {
-  const float e = __builtin_amdgcn_exp2f(144.26950408889634f * x);
-  const float y = 0.006931471805599453f * __builtin_amdgcn_logf(1.0f + e);
-  return x > 0.2f ? x : y;
+  const float e = __builtin_amdgcn_exp2f(-144.26950408889634f * __builtin_fabsf(x));
+  return fmaf(0.006931471805599453f, __builtin_amdgcn_logf(1.0f + e), fmaxf(x, 0.0f));
 }
 // sin / cos of 2 pi rev on v_sin_f32 / v_cos_f32 (argument in revolutions, reduced with v_fract_f32)
 __device__ __forceinline__ float sin_rev(float rev) { return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(rev)); }

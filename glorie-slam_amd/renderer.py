@@ -85,8 +85,12 @@ class Renderer(object):
         rad = dynamic_r_query if self.use_dynamic_radius else None
         z_vals, pts, views, rq, n_zero = point_ops.ray_samples(rays_o, rays_d, gt_depth, rad, S,
                                                                self.near_end_surface, self.far_end_surface)
-        if int(n_zero.item()) != 0:
-            return None
+        # the zero-depth count travels to pinned host memory behind the sampling kernel; it is looked at after
+        # the rest of the batch has been enqueued, so the device never waits for the host
+        flag = self._pinned_flag()
+        flag.copy_(n_zero, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
         D, I, nn_num = npc.find_neighbors_faiss(pts, step='query', dynamic_radius=rq)
         radius = 0.0 if g.use_dynamic_radius else npc.get_radius_query()
         c_geo, has, w = point_ops.idw_gather(D, I, nn_num, npc_geo_feats, radius=radius,
@@ -98,7 +102,15 @@ class Renderer(object):
         counts, valid = point_ops.ray_counts(has, S, 3)
         depth, var, rgb, _ = point_ops.composite(raw.view(R, S, 4), z_vals, self.sigmoid_coefficient,
                                                  return_weights=False)
+        ev.synchronize()
+        if int(flag[0]) != 0:
+            return None
         return depth, var, rgb, valid, counts
+
+    def _pinned_flag(self):
+        if getattr(self, "_flag", None) is None:
+            self._flag = torch.zeros(1, dtype=torch.int32).pin_memory()
+        return self._flag
 
     def render_batch_ray(self, npc, decoders, rays_d, rays_o, device, stage, gt_depth=None,
                          npc_geo_feats=None, npc_col_feats=None, is_tracker=False, cloud_pos=None,
