@@ -150,6 +150,26 @@ def test_ba_large_window_uses_blocked_solver(gpu):
     np.testing.assert_allclose(d, rd, atol=DISP_TOL)
 
 
+@pytest.mark.parametrize("K,extra,path", [
+    (12, (), "band, 6P = 66 (just above the dense-band limit of 64)"),
+    (12, ((0, 11), (11, 0), (2, 10)), "loop closure: half bandwidth >= 64 -> one-workgroup blocked Cholesky"),
+    (30, (), "band, 6P = 174, several waves of window positions"),
+    (30, ((1, 28), (28, 1)), "dense, 6P = 174: several 32-column blocks incl. a partial one"),
+    (92, (), "6P = 546 > 540: multi-kernel blocked Cholesky in HBM"),
+])
+def test_ba_solver_paths_match_oracle(gpu, K, extra, path):
+    """every branch of the fp64 solve (csrc/ba.hip: ba_solve_update) against the oracle's dense Cholesky"""
+    g = make_problem(K, 8, 12, radius=3, extra_edges=extra)
+    rp, rd, rdx, rdz, info = oba.ba(g["poses"], g["disps"], g["intrinsics"][0], g["target"], g["weight"],
+                                    g["eta"], g["ii"], g["jj"], 1, K, 2, 1e-4, 0.1)
+    assert info["failed"] == 0
+    p, d, dx, dz, st = run_gpu(g, gpu, 1, K, 2)
+    assert st[0] == 0 and st[3] == 0, path
+    np.testing.assert_allclose(dx, rdx, rtol=5e-3, atol=5e-6, err_msg=path)
+    np.testing.assert_allclose(p, rp, atol=POSE_TOL, err_msg=path)
+    np.testing.assert_allclose(d, rd, atol=DISP_TOL, err_msg=path)
+
+
 def test_ba_full_size_fixed_point_and_descent(gpu):
     """BASELINE size G8 (60x80, 36 edges): noise-free targets are a fixed point; from a
     perturbed state two GN iterations cut the reprojection cost by > 5x."""
