@@ -106,6 +106,9 @@ def ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
+BA_TARGETS_HWC = 2   # GLORIE_BA_TARGETS_HWC (include/glorie_hip.h)
+
+
 def need_cuda(*tensors):
     for t in tensors:
         if t is not None and not t.is_cuda:

@@ -179,7 +179,7 @@ __global__ __launch_bounds__(kBaThreads) void ba_jacobian_kernel(
     const float* __restrict__ intr, const float* __restrict__ disps_sens,
     const float* __restrict__ targets, const float* __restrict__ weights,
     const float* __restrict__ eta, const int64_t* __restrict__ ii,
-    const int64_t* __restrict__ jj, int HW, int w, int nchunks, int ppt, int motion_only) {
+    const int64_t* __restrict__ jj, int HW, int w, int nchunks, int ppt, int motion_only, int hwc) {
   __shared__ float red[4][28];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wv = tid >> 6;
@@ -218,9 +218,16 @@ __global__ __launch_bounds__(kBaThreads) void ba_jacobian_kernel(
       if (t < ppt && px < HW) {
         const int yy = px / w, xx = px - yy * w;
         PixJ J;
-        pixel_terms(g, fx, fy, cx, cy, (float)xx, (float)yy, disps[(size_t)k * HW + px],
-                    targets[((size_t)n * 2 + 0) * HW + px], targets[((size_t)n * 2 + 1) * HW + px],
-                    weights[((size_t)n * 2 + 0) * HW + px], weights[((size_t)n * 2 + 1) * HW + px], J);
+        float2 tg, wg;
+        if (hwc) {                   // [N][h][w][2]: the layout FactorGraph keeps them in
+          tg = reinterpret_cast<const float2*>(targets)[(size_t)n * HW + px];
+          wg = reinterpret_cast<const float2*>(weights)[(size_t)n * HW + px];
+        } else {                     // [N][2][h][w]: the layout of droid_backends.ba
+          tg = make_float2(targets[((size_t)n * 2 + 0) * HW + px], targets[((size_t)n * 2 + 1) * HW + px]);
+          wg = make_float2(weights[((size_t)n * 2 + 0) * HW + px], weights[((size_t)n * 2 + 1) * HW + px]);
+        }
+        pixel_terms(g, fx, fy, cx, cy, (float)xx, (float)yy, disps[(size_t)k * HW + px], tg.x, tg.y, wg.x,
+                    wg.y, J);
         Cacc[t] += J.wu * J.Jzu * J.Jzu + J.wv * J.Jzv * J.Jzv;
         Wacc[t] += J.wu * J.ru * J.Jzu + J.wv * J.rv * J.Jzv;
         const float wu = stereo ? 0.0f : J.wu;
@@ -1178,12 +1185,13 @@ static int ba_plan(glorie_ctx* ctx, int B, int N, int M, int h, int w, int t0, i
 static int ba_build_system(const BaPlan& pl, const float* poses, const float* disps,
                            const float* intrinsics, const float* disps_sens, const float* targets,
                            const float* weights, const float* eta, const int64_t* ii,
-                           const int64_t* jj, int motion_only, hipStream_t st) {
+                           const int64_t* jj, int flags, hipStream_t st) {
   const BaWork& wk = pl.wk;
+  const int motion_only = flags & 1, hwc = (flags & GLORIE_BA_TARGETS_HWC) ? 1 : 0;
   GLORIE_TRY(check_hip(hipMemsetAsync(wk.Hd, 0, sizeof(double) * ((size_t)pl.n6 * pl.n6 + pl.n6), st)));
   hipLaunchKernelGGL(ba_jacobian_kernel, dim3(pl.nchunks, pl.M), dim3(kBaThreads), 0, st, wk, poses,
                      disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, pl.HW, pl.w,
-                     pl.nchunks, pl.ppt, motion_only);
+                     pl.nchunks, pl.ppt, motion_only, hwc);
   if (!motion_only)
     hipLaunchKernelGGL(ba_gram_kernel, dim3(pl.nchunks, pl.M), dim3(kBaThreads), 0, st, wk, jj, pl.HW,
                        pl.chunk_px, pl.t0, pl.t1);
@@ -1240,6 +1248,8 @@ extern "C" int glorie_ba(glorie_ctx* ctx, float* poses, float* disps, const floa
                          int motion_only, int depth_only, float* dx_out, float* dz_out,
                          void* stream) {
   if (iterations < 0) return GLORIE_EINVAL;
+  const int flags = motion_only;          // bit 0: motion only, GLORIE_BA_TARGETS_HWC: target layout
+  motion_only = flags & 1;
   BaPlan pl;
   GLORIE_TRY(ba_plan(ctx, B, N, M, h, w, t0, t1, nullptr, pl));
   if (N == 0 || pl.P == 0 || pl.HW == 0 || iterations == 0) return GLORIE_OK;
@@ -1249,7 +1259,7 @@ extern "C" int glorie_ba(glorie_ctx* ctx, float* poses, float* disps, const floa
   GLORIE_TRY(ba_prepare(pl.wk, ii, B, N, M, t0, t1, st));
   for (int it = 0; it < iterations; ++it) {
     GLORIE_TRY(ba_build_system(pl, poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj,
-                               motion_only, st));
+                               flags, st));
     GLORIE_TRY(ba_solve_update(pl, poses, disps, ii, jj, lm, ep, motion_only, depth_only, dx_out,
                                dz_out, st));
   }
@@ -1271,7 +1281,7 @@ extern "C" int glorie_ba_build_system(glorie_ctx* ctx, const float* poses, const
     return check_hip(hipMemsetAsync(hv_out, 0, sizeof(double) * ((size_t)pl.n6 * pl.n6 + pl.n6), st));
   }
   if (!poses || !disps || !intrinsics || !targets || !weights || !ii || !jj) return GLORIE_EINVAL;
-  if (!motion_only && !eta) return GLORIE_EINVAL;
+  if (!(motion_only & 1) && !eta) return GLORIE_EINVAL;
   GLORIE_TRY(ba_prepare(pl.wk, ii, B, N, M, t0, t1, st));
   return ba_build_system(pl, poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj,
                          motion_only, st);

@@ -187,17 +187,19 @@ class DepthVideo:
                 t1 = max(ii.max().item(), jj.max().item()) + 1
             h, w = self.ht // self.down_scale, self.wd // self.down_scale
             if opt_type == "pose_depth":
-                target = target.view(-1, h, w, 2).permute(0, 3, 1, 2).contiguous()
-                weight = weight.view(-1, h, w, 2).permute(0, 3, 1, 2).contiguous()
+                # the kernels read the [N,h,w,2] layout the graph keeps them in: no permute + copy
+                # (depth_video.py:215-216 of the reference)
+                target = target.reshape(-1, h, w, 2).contiguous()
+                weight = weight.reshape(-1, h, w, 2).contiguous()
                 if self.shard is not None and self.shard["world"] > 1:
                     from . import dist as gdist
                     gdist.ba_sharded(self.ctx(), self.poses, self.disps, self.intrinsics[0].contiguous(),
                                      target, weight, eta.contiguous(), ii, jj, t0, t1, itrs, lm, ep,
-                                     motion_only, False, group=self.shard["group"])
+                                     motion_only, False, group=self.shard["group"], targets_hwc=True)
                 else:
                     droid_backends.ba(self.poses, self.disps, self.intrinsics[0].contiguous(), None,
                                       target, weight, eta, ii, jj, t0, t1, itrs, lm, ep, motion_only,
-                                      False, ctx=self.ctx(), want_updates=False)
+                                      False, ctx=self.ctx(), want_updates=False, targets_hwc=True)
                 self.disps.clamp_(min=1e-5)
                 return True
             elif opt_type == "depth_scale":

@@ -50,9 +50,9 @@ def allreduce_system(hv, group=None):
 
 
 def ba_sharded(ctx, poses, disps, intrinsics, targets, weights, eta, ii, jj, t0, t1, iterations,
-               lm, ep, motion_only=False, depth_only=False, group=None):
+               lm, ep, motion_only=False, depth_only=False, group=None, targets_hwc=False):
     """Distributed droid_backends.ba: arguments are this rank's LOCAL edges (targets/weights
-    [N,2,h,w], eta rows of unique(cat(arange(t0,t1), ii_local))); poses/disps are full replicas,
+    [N,2,h,w], or [N,h,w,2] with targets_hwc; eta rows of unique(cat(arange(t0,t1), ii_local))); poses/disps are full replicas,
     updated in place (poses everywhere, disps for locally owned source frames)."""
     B, h, w = disps.shape
     N = int(ii.shape[0])
@@ -65,7 +65,8 @@ def ba_sharded(ctx, poses, disps, intrinsics, targets, weights, eta, ii, jj, t0,
     for _ in range(iterations):
         L.check(lib.glorie_ba_build_system(ctx.handle, L.ptr(poses), L.ptr(disps), L.ptr(intrinsics), None,
                                            L.ptr(targets), L.ptr(weights), L.ptr(eta), L.ptr(ii), L.ptr(jj),
-                                           B, N, M, h, w, int(t0), int(t1), int(bool(motion_only)),
+                                           B, N, M, h, w, int(t0), int(t1),
+                                           int(bool(motion_only)) | (L.BA_TARGETS_HWC if targets_hwc else 0),
                                            L.ptr(hv), L.stream_ptr()), "glorie_ba_build_system")
         allreduce_system(hv, group)
         L.check(lib.glorie_ba_solve_update(ctx.handle, L.ptr(poses), L.ptr(disps), L.ptr(ii), L.ptr(jj),

@@ -272,10 +272,11 @@ def cvx_upsample(disps, ix, mask, disps_up, softmax_f32=False):
 # bundle adjustment
 # --------------------------------------------------------------------------------------
 def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, t1,
-       iterations, lm, ep, motion_only, depth_only=False, ctx=None, want_updates=True):
+       iterations, lm, ep, motion_only, depth_only=False, ctx=None, want_updates=True, targets_hwc=False):
     """reference: droid.cpp:89-119, droid_kernels.cu:1314-1437.  Returns [dx, dz] of the last
     iteration (the reference's return value, unused by its caller).  poses/disps updated in
-    place."""
+    place.  targets_hwc=True: targets / weights are [N,h,w,2] (FactorGraph's own layout) instead of the
+    binding's [N,2,h,w]."""
     L.need_cuda(poses, disps, intrinsics, targets, weights, ii, jj)
     L.need_contiguous(targets=targets, weights=weights, poses=poses, disps=disps,
                       intrinsics=intrinsics, disps_sens=disps_sens, ii=ii, jj=jj)
@@ -301,7 +302,8 @@ def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, 
     L.check(L.load().glorie_ba(ctx.handle, L.ptr(poses), L.ptr(disps), L.ptr(intrinsics),
                                L.ptr(disps_sens), L.ptr(targets), L.ptr(weights), L.ptr(eta),
                                L.ptr(ii), L.ptr(jj), B, N, M, h, w, int(t0), int(t1),
-                               int(iterations), float(lm), float(ep), int(bool(motion_only)),
+                               int(iterations), float(lm), float(ep),
+                               int(bool(motion_only)) | (L.BA_TARGETS_HWC if targets_hwc else 0),
                                int(bool(depth_only)), L.ptr(dx),
                                L.ptr(dz) if (dz is not None and dz.numel()) else None,
                                L.stream_ptr()), "glorie_ba")

@@ -241,7 +241,12 @@ int glorie_cvx_upsample_nhwc(const float* disps, const int64_t* ix, const void* 
  * eta [M,h,w] with M = #unique(cat(arange(t0,t1), ii)) (sorted order), disps_sens may be
  * NULL (= all zeros, which is what the reference passes, depth_video.py:217).
  * dx_out [t1-t0,6] / dz_out [M,h*w] receive the last iteration's updates (may be NULL).
- * Whole Gauss-Newton loop runs on the device with no host synchronisation. */
+ * Whole Gauss-Newton loop runs on the device with no host synchronisation.
+ * `motion_only` is a flag word: bit 0 = the reference's motion_only; GLORIE_BA_TARGETS_HWC set =
+ * targets/weights are given as [N,h,w,2] - the layout FactorGraph.target / .weight have before the
+ * permute(0,3,1,2).contiguous() of depth_video.py:215-216 - which saves those two copies per call.
+ * A caller that passes the reference's bool gets the reference's layout. */
+#define GLORIE_BA_TARGETS_HWC 2
 int glorie_ba(glorie_ctx* ctx, float* poses, float* disps, const float* intrinsics,
               const float* disps_sens, const float* targets, const float* weights,
               const float* eta, const int64_t* ii, const int64_t* jj,

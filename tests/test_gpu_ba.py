@@ -64,6 +64,23 @@ def test_ba_matches_oracle(gpu, K, h, w, iters):
     assert np.array_equal(p[0], g["poses"][0])  # pose 0 is fixed (t0 = 1)
 
 
+def test_ba_hwc_target_layout_is_bit_identical(gpu):
+    """GLORIE_BA_TARGETS_HWC: targets / weights as [N,h,w,2] (FactorGraph's layout) == the binding's [N,2,h,w]"""
+    from glorie_slam_amd import droid_backends as db
+    g = make_problem(6, 12, 16)
+    outs = []
+    for hwc in (False, True):
+        poses, disps = _t(g["poses"], gpu), _t(g["disps"], gpu)
+        tg, wg = _t(g["target"], gpu), _t(g["weight"], gpu)
+        if hwc:
+            tg, wg = tg.permute(0, 2, 3, 1).contiguous(), wg.permute(0, 2, 3, 1).contiguous()
+        dx, dz = db.ba(poses, disps, _t(g["intrinsics"][0], gpu), None, tg, wg, _t(g["eta"], gpu),
+                       _t(g["ii"], gpu), _t(g["jj"], gpu), 1, 6, 2, 1e-4, 0.1, False, False, targets_hwc=hwc)
+        outs.append((poses.clone(), disps.clone(), dx.clone(), dz.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 def test_ba_window_inside_graph(gpu):
     """t0 > 1: frames below t0 are fixed but still own depth maps (kx = unique(cat(ts, ii)))"""
     K = 7
