@@ -296,12 +296,23 @@ class FactorGraph:
         self.damping[uniq] = damping.to(self.damping.dtype)
         sharded = getattr(self.video, "shard", None) is not None and self.video.shard["world"] > 1
         if use_inactive:
-            m = (self.ii_inac >= t0 - 3) & (self.jj_inac >= t0 - 3)
-            ii = torch.cat([self.ii_inac[m], self.ii], 0)
-            jj = torch.cat([self.jj_inac[m], self.jj], 0)
-            target = torch.cat([self.target_inac[:, m], self.target], 1)
-            weight = torch.cat([self.weight_inac[:, m], self.weight], 1)
-            uq = torch.unique(ii)
+            # the inactive factors that still touch the window (factor_graph.py:232-238) do not change while
+            # the edge set stays the same: their indices, the frame list and one [inactive | active] buffer
+            # per tensor are kept, every iteration only refreshes the active tail (the reference gathers
+            # and concatenates ~4x the active data per iteration)
+            ck = ("inac", t0)
+            c = self._graphs.get(ck)
+            if c is None:
+                m = (self.ii_inac >= t0 - 3) & (self.jj_inac >= t0 - 3)
+                ii_c = torch.cat([self.ii_inac[m], self.ii], 0)
+                jj_c = torch.cat([self.jj_inac[m], self.jj], 0)
+                tgt = torch.cat([self.target_inac[:, m], self.target], 1)
+                wgt = torch.cat([self.weight_inac[:, m], self.weight], 1)
+                c = (ii_c, jj_c, torch.unique(ii_c), tgt, wgt, tgt.shape[1] - self.target.shape[1])
+                self._graphs[ck] = c
+            ii, jj, uq, target, weight, n_inac = c
+            target[:, n_inac:] = self.target
+            weight[:, n_inac:] = self.weight
         else:
             ii, jj, target, weight, uq = self.ii, self.jj, self.target, self.weight, uniq
         if sharded and opt_type == "pose_depth":
