@@ -241,8 +241,16 @@ class FactorGraph:
     def _capture(self, key, args):
         """capture one update() on static copies of the recurrent state (net, target, weight);
         everything else it touches (video buffers, damping, age) is updated in place already"""
-        s_net = self.net.clone(memory_format=torch.preserve_format)
-        s_target, s_weight = self.target.clone(), self.weight.clone()
+        # one set of static buffers per edge set, shared by every graph captured for it (the pose_depth and
+        # depth_scale graphs alternate: private copies would cost three device copies per replay)
+        st = self._graphs.get("static")
+        if st is None:
+            st = (self.net.clone(memory_format=torch.preserve_format), self.target.clone(), self.weight.clone())
+            self._graphs["static"] = st
+        s_net, s_target, s_weight = st
+        for dst, src in ((s_net, self.net), (s_target, self.target), (s_weight, self.weight)):
+            if src is not dst:
+                dst.copy_(src)
         keep = (self.net, self.target, self.weight)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
@@ -258,7 +266,8 @@ class FactorGraph:
                 # the BA arguments alias the recurrent state: keep them pointing at the static copies
                 ba_args = tuple(s_target if a is self.target else (s_weight if a is self.weight else a)
                                 for a in self._ba_args)
-                s_target.copy_(self.target)
+                if self.target is not s_target:                 # (the eager step adds in place when it can)
+                    s_target.copy_(self.target)
                 s_weight.copy_(self.weight)
         finally:
             # the capture did not execute anything: restore the state the caller had
@@ -291,7 +300,10 @@ class FactorGraph:
                     self.update_op(self.net, self.inp, corr, motn, self.ii, self.jj)
         if t0 is None:
             t0 = max(1, self._uniq_cache[2] + 1)
-        self.target = coords1 + delta.to(dtype=torch.float)
+        if self.target.shape == coords1.shape and self.target.dtype == torch.float32 and self.target.is_contiguous():
+            torch.add(coords1, delta.to(dtype=torch.float), out=self.target)   # no new tensor, no copy when captured
+        else:
+            self.target = coords1 + delta.to(dtype=torch.float)
         self.weight = weight.to(dtype=torch.float)
         self.damping[uniq] = damping.to(self.damping.dtype)
         sharded = getattr(self.video, "shard", None) is not None and self.video.shard["world"] > 1

@@ -182,7 +182,10 @@ def test_graph_replay_matches_eager(gpu):
         for i in range(8):
             graph.update(t0=1, t1=6, itrs=2, opt_type="pose_depth" if i % 2 == 0 else "depth_scale")
         if use_graphs:
-            assert sum(1 for v in graph._graphs.values() if v != "seen") == 2     # both stages replayed
+            captured = [v for v in graph._graphs.values()
+                        if isinstance(v, tuple) and isinstance(v[0], torch.cuda.CUDAGraph)]
+            assert len(captured) == 2                                              # both stages replayed
+            assert captured[0][1] is captured[1][1]                                # ... on shared static state
         outs.append([t.float().clone() for t in (video.poses, video.disps, video.disps_up, video.depth_scale,
                                                   graph.net, graph.target, graph.weight, graph.damping)])
     names = ["poses", "disps", "disps_up", "depth_scale", "net", "target", "weight", "damping"]
