@@ -633,8 +633,8 @@ __global__ __launch_bounds__(256) void chol_damp_kernel(BaWork wk, int n, float 
 //   * bw = largest r - c with H[r][c] != 0 (entries nobody accumulated into are exact zeros) comes from
 //     ba_bandwidth_kernel through status[3]; ba_solve_fused_kernel does the work instead if the band does
 //     not fit into LDS or bw >= 64.  H itself is never modified here.
-//   * elimination: column j updates the (bw x bw) window below it and the right-hand side, ONE barrier per
-//     column.  Columns stay unscaled (U[r][j] = L[r][j] sqrt(d_j)); only 1 / d_j is needed, from
+//   * elimination: columns j, j + 1 update the window below / right of them and the right-hand side, ONE
+//     barrier per TWO columns (band_eliminate).  Columns stay unscaled (U[r][j] = L[r][j] sqrt(d_j)); only 1 / d_j is needed, from
 //     v_rcp_f64 + two Newton steps - no square root and no division on the critical path.  Every thread
 //     owns the same <= 9 window positions (dr, dc) in every step, decoded once.
 //   * back substitution x_j = (u_j - sum_k U[j + k][j] x_{j + k}) / d_j in ONE wave without barriers: lane
@@ -673,15 +673,21 @@ __device__ __forceinline__ double rcp_f64(double d) {
   return r;
 }
 
+// Two columns per barrier.  With a = U[.][j] (column j, unscaled), a1 = a[j + 1], the next column after
+// eliminating j is b[x] = H[x][j + 1] - a[x] a1 / d0 (d1 = b[j + 1]), and every entry right of it gets
+//   H[r][c] -= a[r] a[c] / d0 + b[r] b[c] / d1 .
+// Each thread forms the b's it needs itself (two more LDS reads per entry), so the dependent chain
+// read -> 1/d0 -> d1 -> 1/d1 -> update -> write -> barrier is paid once per TWO columns; entries of column
+// j + 1 itself (dc == 0) only take the first term, which is exactly b.
 template <int NQ>
 __device__ __forceinline__ void band_eliminate(double* B, double* u, double* rinv, int* fail, int n, int bw) {
   const int tid = threadIdx.x;
   const int S = bw + 1;
-  // window positions of this thread, the same in every step: triangle entries (dr, dc), dc <= dr < bw, as LDS
-  // offsets relative to row j of the band (element e = tid + 256 q of the packed triangle), and at most one
-  // entry of the right-hand side (bw < 256)
-  const int T1 = bw * (bw + 1) / 2;
-  int o_lr[NQ], o_lc[NQ], o_w[NQ], e_dr[NQ];
+  // window positions of this thread, the same in every step: entries (dr, dc), dc <= dr <= bw, of the triangle
+  // below / right of (j + 1, j + 1), as LDS offsets relative to row j of the band (entry e = tid + 256 q of
+  // the packed triangle); threads 0 .. bw also own one entry of the right-hand side
+  const int T1 = (bw + 1) * (bw + 2) / 2;
+  int o_ar[NQ], o_ac[NQ], o_w[NQ], e_dr[NQ], e_dc[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
     const int e = tid + q * kBandThreads;
@@ -692,39 +698,69 @@ __device__ __forceinline__ void band_eliminate(double* B, double* u, double* rin
       while (dr * (dr + 1) / 2 > e) --dr;
       dc = e - dr * (dr + 1) / 2;
     }
-    e_dr[q] = dr;
-    o_lr[q] = (1 + dr) * S + dr + 1;     // U[r][j]
-    o_lc[q] = (1 + dc) * S + dc + 1;     // U[c][j]
+    e_dr[q] = dr; e_dc[q] = dc;
+    o_ar[q] = (1 + dr) * S + dr + 1;     // U[r][j]     (one to the left: H[r][j + 1])
+    o_ac[q] = (1 + dc) * S + dc + 1;     // U[c][j]     (one to the left: H[c][j + 1])
     o_w[q] = (1 + dr) * S + dr - dc;     // H[r][c]
   }
-  const int rhs_dc = tid < bw ? tid : (1 << 20);
+  const int rhs_dc = tid <= bw ? tid : (1 << 20);
   const int o_rc = (1 + rhs_dc) * S + rhs_dc + 1;
   __syncthreads();
-  for (int j = 0; j < n; ++j) {
-    // all loads of the step are issued before anything is used: the chain per column is one LDS round trip,
-    // the reciprocal, two multiplies and the write-back (branchy code would serialise a round trip per entry)
+  int j = 0;
+  for (; j + 1 < n; j += 2) {
+    // every load of the step is issued before anything is used (branchy code would serialise an LDS round
+    // trip per entry); entries in row j + 1 + bw lie outside the band of column j: a = 0 there
     const double* Bj = B + j * S;
-    const double d = Bj[0];
-    double lr[NQ], lc[NQ], cur[NQ];
+    const double d0 = Bj[0], a1 = Bj[S + 1], h11 = Bj[S];
+    double ar[NQ], ac[NQ], hr[NQ], hc[NQ], cur[NQ];
     bool ok[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       ok[q] = j + 1 + e_dr[q] < n;
-      lr[q] = Bj[ok[q] ? o_lr[q] : 0];
-      lc[q] = Bj[ok[q] ? o_lc[q] : 0];
+      const bool inr = ok[q] && e_dr[q] < bw, inc = ok[q] && e_dc[q] < bw;
+      ar[q] = Bj[inr ? o_ar[q] : 0];
+      ac[q] = Bj[inc ? o_ac[q] : 0];
+      hr[q] = Bj[ok[q] ? o_ar[q] - 1 : 0];
+      hc[q] = Bj[ok[q] ? o_ac[q] - 1 : 0];
       cur[q] = Bj[ok[q] ? o_w[q] : 0];
+      if (!inr) ar[q] = 0.0;
+      if (!inc) ac[q] = 0.0;
     }
-    const bool rok = j + 1 + rhs_dc < n;
-    const double rl = Bj[rok ? o_rc : 0];
+    const bool rok = j + 1 + rhs_dc < n, rin = rok && rhs_dc < bw;
+    double ra = Bj[rin ? o_rc : 0];
+    const double rh = Bj[rok ? o_rc - 1 : 0];
     const double ru = u[rok ? j + 1 + rhs_dc : 0];
-    const double uj = u[j];
-    if (!(d > 0.0) && tid == 0) *fail = 1;   // also NaN; the (garbage) result is discarded below
-    const double ri = rcp_f64(d);
-    if (tid == 0) rinv[j] = ri;
+    const double u0 = u[j], u1h = u[j + 1];
+    if (!rin) ra = 0.0;
+    const double ri0 = rcp_f64(d0);
+    const double d1 = h11 - a1 * ri0 * a1;
+    if ((!(d0 > 0.0) || !(d1 > 0.0)) && tid == 0) *fail = 1;   // also NaN; the (garbage) result is discarded
+    const double ri1 = rcp_f64(d1);
+    if (tid == 0) { rinv[j] = ri0; rinv[j + 1] = ri1; }
 #pragma unroll
-    for (int q = 0; q < NQ; ++q)
-      if (ok[q]) B[j * S + o_w[q]] = cur[q] - lr[q] * ri * lc[q];
-    if (rok) u[j + 1 + rhs_dc] = ru - uj * ri * rl;
+    for (int q = 0; q < NQ; ++q) {
+      if (!ok[q]) continue;
+      double v = cur[q] - ar[q] * ri0 * ac[q];
+      if (e_dc[q] > 0) {
+        const double br = hr[q] - ar[q] * ri0 * a1, bc = hc[q] - ac[q] * ri0 * a1;
+        v -= br * ri1 * bc;
+      }
+      B[j * S + o_w[q]] = v;
+    }
+    if (rok) {
+      double v = ru - u0 * ri0 * ra;
+      if (rhs_dc > 0) {
+        const double u1 = u1h - u0 * ri0 * a1, bc = rh - ra * ri0 * a1;
+        v -= u1 * ri1 * bc;
+      }
+      u[j + 1 + rhs_dc] = v;
+    }
+    __syncthreads();
+  }
+  if (j < n) {                       // odd n: the last column has nothing below it
+    const double d = B[j * S];
+    if (!(d > 0.0) && tid == 0) *fail = 1;
+    if (tid == 0) rinv[j] = rcp_f64(d);
     __syncthreads();
   }
 }
@@ -766,8 +802,8 @@ __global__ __launch_bounds__(kBandThreads) void ba_solve_band_kernel(BaWork wk, 
     }
   }
   for (int i = tid; i < n; i += kBandThreads) u[i] = A[(size_t)n * n + i];
-  if (bw * (bw + 1) / 2 <= 4 * kBandThreads) band_eliminate<4>(B, u, rinv, &fail, n, bw);
-  else band_eliminate<8>(B, u, rinv, &fail, n, bw);
+  if ((bw + 1) * (bw + 2) / 2 <= 4 * kBandThreads) band_eliminate<4>(B, u, rinv, &fail, n, bw);
+  else band_eliminate<9>(B, u, rinv, &fail, n, bw);      // bw <= 63: 2080 window entries at most
   if (fail) {
     for (int i = tid; i < n; i += kBandThreads) wk.dx[i] = 0.0f;
     if (tid == 0) {
