@@ -148,20 +148,23 @@ def _pmc_traffic():
 
 def gru_gate_conv_workload(device, N, ht, wd):
     """the dominant kernel of a BA-update step in isolation: the merged convz|convr 3x3 convolution
-    of the ConvGRU (448 -> 256 channels, gate epilogue) on the step's shapes; returns a launcher and
-    its algorithmic FLOPs (2 * pixels * 9 * 448 * 256; SURVEY.md 8(d): the update operator is MFMA work)"""
+    of the ConvGRU as the step launches it - 320 -> 256 channels ([net | corr | flow]; the 128 context
+    channels are folded into the per-pixel `pre` term once per edge set) with the gate
+    epilogue - on the step's shapes; returns a launcher and its executed FLOPs
+    (2 * pixels * 9 * 320 * 256; SURVEY.md 8(d): the update operator is MFMA work)"""
     from glorie_slam_amd import update_ops as U
     gen = torch.Generator(device="cpu").manual_seed(5)
     cl = lambda c: torch.randn(N, c, ht, wd, generator=gen).to(device).half().contiguous(memory_format=torch.channels_last)
-    net, hx = cl(128), cl(320)
-    wzr = U.pack_conv_igemm((torch.randn(256, 448, 3, 3, generator=gen) / 63.0).to(device))
+    net, hx, pre = cl(128), cl(320), cl(384)
+    wzr = U.pack_conv_igemm((torch.randn(256, 320, 3, 3, generator=gen) / 53.0).to(device))
     terms = torch.randn(N, 384, generator=gen).to(device)
     z, rnet = torch.empty_like(net), torch.empty_like(net)
 
     def launch():
-        U.conv_igemm(net, hx, wzr, 9, 256, z, epilogue=U.EPI_GRU_ZR, terms=terms[:, :256], net=net, out2=rnet)
+        U.conv_igemm(net, hx[:, 128:320], wzr, 9, 256, z, epilogue=U.EPI_GRU_ZR, terms=terms[:, :256], net=net,
+                     out2=rnet, pre=pre[:, 0:256])
 
-    return launch, 2.0 * N * ht * wd * 9 * 448 * 256
+    return launch, 2.0 * N * ht * wd * 9 * 320 * 256
 
 
 def cpu_baseline_rays(n_rays=192):
@@ -292,6 +295,12 @@ def main():
     def step():
         # DSPO schedule of the frontend (frontend.py:50-53): stages alternate
         opt = "pose_depth" if step_no[0] % 2 == 0 else "depth_scale"
+        if step_no[0] % 12 == 0 and graph.fast_update is not None and graph.fast_update._pre is not None:
+            # The gate convolutions over the context features are evaluated once per edge set, not per
+            # iteration (FusedUpdate.precompute_context).  The frontend changes a few edges per keyframe =
+            # every 12 iterations (frontend.py:23-24); the bench graph never changes, so that cost is
+            # charged here explicitly, conservatively for ALL edges, every 12 timed steps.
+            graph.fast_update.precompute_context()
         step_no[0] += 1
         graph.update(t0=1, t1=K, itrs=2, use_inactive=False, opt_type=opt)
 
@@ -418,7 +427,8 @@ def main():
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f16 corr/ConvGRU, f32 Jacobians, f64 solve", "data": "synthetic",
-        "config": {"workload": (f"G8: 8 keyframes, 36 edges, 60x80 (640x480/8), BA itrs=2, DSPO stages alternating"
+        "config": {"workload": (f"G8: 8 keyframes, 36 edges, 60x80 (640x480/8), BA itrs=2, DSPO stages alternating, "
+                                 f"context part of the GRU gates re-evaluated for all edges every 12 steps"
                                 if world == 1 else
                                 f"G8 topology over {K_graph} keyframes = {len(g['ii'])} edges (36 per GPU), 60x80, BA itrs=2, "
                                 f"DSPO stages alternating; value = G8-sized (36-edge) updates per second")
@@ -428,10 +438,13 @@ def main():
                    "parallelism": ("single GPU" if world == 1 else
                                    f"edges sharded by source keyframe over {world} GPUs + RCCL all-reduce of the "
                                    f"reduced normal equations; rays of the one frame sharded {world} ways")},
-        "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel<EPI_GRU_ZR,4,64> (ConvGRU convz|convr, 448->256, 3x3)",
+        "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel<EPI_GRU_ZR,4,64> (ConvGRU convz|convr over [net|corr|flow], 320->256, 3x3, + hoisted context term)",
                      "achieved": conv_tf, "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s",
                      "frac": conv_tf / MFMA_F16_PEAK_TF, "traffic": conv_traffic if full else None,
-                     "flops_per_launch": conv_flops, "ms_per_launch": conv_ms},
+                     "flops_per_launch": conv_flops, "ms_per_launch": conv_ms,
+                     # the reference evaluates all 448 input channels in every iteration (gru.py:20-24)
+                     "reference_formulation": {"flops_per_launch": conv_flops * 448.0 / 320.0,
+                                               "equiv_frac": conv_tf * 448.0 / 320.0 / MFMA_F16_PEAK_TF}},
         "roofline_corr": {"bound": "hbm", "kernel": "corr_lookup_r3_tiled_kernel (fp16, 4x8-tiled pyramid)",
                           "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": achieved / HBM_PEAK_GBS, "traffic": corr_traffic if full else None,

@@ -54,6 +54,7 @@ struct ConvArgs {
   const float* terms; int terms_stride; int act;
   const _Float16* net; int net_stride;
   const _Float16* z; int z_stride;
+  const _Float16* pre; int pre_stride;          // per-pixel term added before the gate non-linearity (or null)
 };
 
 constexpr int kTileN = 128;       // output channels per workgroup
@@ -193,6 +194,22 @@ __global__ __launch_bounds__(64 * NW, ST == 1 ? 3 : 2) void conv_igemm_kernel(Co
   const int wbase = XBYTES + wm * (16 * MB) * RB, xbase_l = wn * (16 * NB) * RB;
 
   stage(0, 0);
+  if (EPI != EPI_BIAS_ACT && a.pre) {
+    // the hoisted per-pixel term seeds the accumulators: its loads travel together with the first tile
+    // (an add in the epilogue would be an exposed round trip at the tail of every workgroup)
+#pragma unroll
+    for (int ni = 0; ni < NB; ++ni) {
+      const long p = p0 + wn * (16 * NB) + ni * 16 + col;
+#pragma unroll
+      for (int mi = 0; mi < MB; ++mi) {
+        const int n = n0 + wm * (16 * MB) + mi * 16 + kg * 4;
+        if (p < a.P && n < a.nout) {
+          const f16x4 pv = *reinterpret_cast<const f16x4*>(a.pre + p * a.pre_stride + n);
+          acc[mi][ni] = f32x4{(float)pv[0], (float)pv[1], (float)pv[2], (float)pv[3]};
+        }
+      }
+    }
+  }
   int cur = 0;                                 // LDS stage holding tile t
   for (int t = 0; t < T; ++t) {
     __syncthreads();                           // tile t landed (vmcnt(0) + barrier); ST = 2: the other stage is free
@@ -320,7 +337,8 @@ extern "C" int glorie_conv_igemm(const void* xa, int xa_stride, int ca, const vo
                                  int cb, const void* w_packed, int taps, int nout, int epilogue,
                                  const float* terms, int terms_stride, int act, const void* net,
                                  int net_stride, const void* z, int z_stride, void* out, int out_stride,
-                                 void* out2, int out2_stride, int N, int H, int W, void* stream) {
+                                 void* out2, int out2_stride, const void* pre, int pre_stride, int N, int H,
+                                 int W, void* stream) {
   if (N < 0 || H <= 0 || W <= 0 || (taps != 1 && taps != 9) || nout <= 0 || (nout & 3)) return GLORIE_EINVAL;
   if (ca < 0 || cb < 0 || (ca % 64) || (cb % 64) || ca + cb == 0) return GLORIE_EINVAL;
   if (epilogue < 0 || epilogue > 2) return GLORIE_EINVAL;
@@ -329,8 +347,7 @@ extern "C" int glorie_conv_igemm(const void* xa, int xa_stride, int ca, const vo
   if (!w_packed || !out || (out_stride & 3)) return GLORIE_EINVAL;
   if (epilogue == EPI_GRU_ZR && (nout != 256 || !terms || !net || !out2 || (terms_stride & 3))) return GLORIE_EINVAL;
   if (epilogue == EPI_GRU_Q && (nout != 128 || !terms || !net || !z || (terms_stride & 3))) return GLORIE_EINVAL;
-  if (epilogue < 0 || epilogue > 2) return GLORIE_EINVAL;
-  if (N == 0) return GLORIE_OK;
+  if (pre && (epilogue == EPI_BIAS_ACT || (pre_stride & 3))) return GLORIE_EINVAL;
   ConvArgs a;
   a.xa = reinterpret_cast<const _Float16*>(xa); a.xa_stride = xa_stride; a.cha = ca / 64;
   a.xb = reinterpret_cast<const _Float16*>(xb); a.xb_stride = xb_stride; a.chb = cb / 64;
@@ -342,6 +359,7 @@ extern "C" int glorie_conv_igemm(const void* xa, int xa_stride, int ca, const vo
   a.terms = terms; a.terms_stride = terms_stride; a.act = act;
   a.net = reinterpret_cast<const _Float16*>(net); a.net_stride = net_stride;
   a.z = reinterpret_cast<const _Float16*>(z); a.z_stride = z_stride;
+  a.pre = reinterpret_cast<const _Float16*>(pre); a.pre_stride = pre_stride;
   // buffer-descriptor addressing: 31-bit byte offsets per input segment and for the weights
   const long lim = 0x7fffffffL;
   if (((a.P + W + 2) * (long)xa_stride + 64) * 2 > lim || ((a.P + W + 2) * (long)xb_stride + 64) * 2 > lim ||

@@ -162,10 +162,11 @@ def pack_conv_igemm(weight):
 
 
 def conv_igemm(xa, xb, w_packed, taps, nout, out, epilogue=EPI_BIAS_ACT, terms=None, act=ACT_NONE,
-               net=None, z=None, out2=None):
+               net=None, z=None, out2=None, pre=None):
     """Implicit-GEMM convolution with fused epilogue (csrc/conv.hip, include/glorie_hip.h).
     xa / xb: channels-last fp16 maps [N,Ca,h,w] / [N,Cb,h,w] (either may be None); writes `out`
-    (and `out2` for the GRU gates) and returns `out`."""
+    (and `out2` for the GRU gates) and returns `out`.  pre: fp16 channels-last [N,nout,h,w] added before the
+    gate non-linearity (the hoisted convolution over the context features)."""
     ref = xa if xa is not None else xb
     L.need_cuda(ref, w_packed, out)
     n, _, h, w = ref.shape
@@ -185,11 +186,14 @@ def conv_igemm(xa, xb, w_packed, taps, nout, out, epilogue=EPI_BIAS_ACT, terms=N
     opt = lambda t, name: (L.ptr(t), _rows(t, name) if t is not None else 0)
     (pa, sa), (pb, sb) = opt(xa, "xa"), opt(xb, "xb")
     (pn, sn), (pz, sz), (po2, so2) = opt(net, "net"), opt(z, "z"), opt(out2, "out2")
+    pp, sp = opt(pre, "pre")
+    if pre is not None and (epilogue == EPI_BIAS_ACT or pre.shape[0] != n or pre.shape[1] != nout):
+        raise RuntimeError("conv_igemm: pre needs a gate epilogue and the shape [N,nout,h,w]")
     if out.shape[1] != (128 if epilogue != EPI_BIAS_ACT else nout) or out.shape[0] != n:
         raise RuntimeError("conv_igemm: bad output shape")
     L.check(L.load().glorie_conv_igemm(pa, sa, ca, pb, sb, cb, L.ptr(w_packed), taps, nout, epilogue,
                                        L.ptr(terms), ts, act, pn, sn, pz, sz, L.ptr(out), _rows(out, "out"),
-                                       po2, so2, n, h, w, L.stream_ptr()), "glorie_conv_igemm")
+                                       po2, so2, pp, sp, n, h, w, L.stream_ptr()), "glorie_conv_igemm")
     return out
 
 

@@ -164,12 +164,17 @@ int glorie_conv3x3_small(const void* x, int x_stride, const float* in_bias, int 
  * epilogue 2: GRU blend, nout = 128 (gru.py:31-33):
  *             out[p][c] = (1 - z[p][c]) * net[p][c] + z[p][c] * tanh(acc[c] + terms[e][c])
  * e = p / (H*W) is the map (edge) index; terms rows are terms_stride floats apart (gates) and come
- * from glorie_gru_glo_terms.  out / out2 / net / z are fp16 rows with their own strides (halfs). */
+ * from glorie_gru_glo_terms.  out / out2 / net / z are fp16 rows with their own strides (halfs).
+ * pre (may be NULL; gate epilogues only): fp16 rows [p][nout] added to the accumulator before the
+ * non-linearity, like terms but per pixel -- the convolution over the context features `inp` of an edge,
+ * which never change while the edge lives (factor_graph.py:125-130: inp = video.inps[ii] at add_factors) and
+ * is therefore evaluated once per edge instead of once per iteration (a convolution is linear in its input
+ * channels: conv([net|inp|corr|flow]) = conv_dyn([net|corr|flow]) + conv_inp(inp)). */
 int glorie_conv_igemm(const void* xa, int xa_stride, int ca, const void* xb, int xb_stride, int cb,
                       const void* w_packed, int taps, int nout, int epilogue, const float* terms,
                       int terms_stride, int act, const void* net, int net_stride, const void* z,
-                      int z_stride, void* out, int out_stride, void* out2, int out2_stride, int N,
-                      int H, int W, void* stream);
+                      int z_stride, void* out, int out_stride, void* out2, int out2_stride,
+                      const void* pre, int pre_stride, int N, int H, int W, void* stream);
 
 /* flow_encoder[0] (droid_net.py:79-81): 7x7 convolution, zero padding 3, 4 -> 128 channels, + bias
  * + ReLU.  flow: float32 channels-last motion map [N*H*W][4]; out: fp16 rows of 128 channels,

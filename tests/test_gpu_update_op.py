@@ -134,6 +134,34 @@ def test_fused_update_matches_fp32_module(gpu, n, h, w):
         assert err_f <= 2.0 * err_h + 2e-3 * scale, (name, err_f, err_h)
 
 
+def test_hoisted_context_term_equals_full_gate_convolution(gpu):
+    """conv([net|inp|corr|flow]) == conv([net|corr|flow]) + conv_inp(inp): the gates with the context part
+    evaluated once (FusedUpdate.precompute_context, fp16 per-pixel term added in the epilogue) against the
+    448-channel convolution; refreshed when `inp` or a GRU weight changes"""
+    from glorie_slam_amd.droid_net import UpdateModule, FusedUpdate
+    torch.manual_seed(11)
+    mod = UpdateModule().to(gpu).eval()
+    net, inp, corr, flow = _inputs(gpu, 5, 12, 16, seed=5)
+    ii = torch.tensor([0, 0, 1, 1, 2], device=gpu)
+    full, hoist = FusedUpdate(mod), FusedUpdate(mod)
+    full.hoist_inp = False
+    a = full(net, inp, corr, flow, ii, None)
+    b = hoist(net, inp, corr, flow, ii, None)
+    assert hoist._pre is not None and full._pre is None
+    for name, x, y in zip(["net", "delta", "weight", "eta", "upmask"], a, b):
+        scale = max(1.0, float(x.float().abs().max()))
+        assert float((x.float() - y.float()).abs().max()) <= 4e-3 * scale, name
+    # a new context tensor and a weight update are both picked up
+    inp2 = (inp.float() * 0.5 + 0.1).to(inp.dtype)
+    with torch.no_grad():
+        mod.gru.convz.weight.mul_(0.9)
+    a = full(net, inp2, corr, flow, ii, None)
+    b = hoist(net, inp2, corr, flow, ii, None)
+    for name, x, y in zip(["net", "delta", "weight", "eta", "upmask"], a, b):
+        scale = max(1.0, float(x.float().abs().max()))
+        assert float((x.float() - y.float()).abs().max()) <= 4e-3 * scale, name
+
+
 def test_fused_update_without_graph_aggregation_and_repack(gpu):
     from glorie_slam_amd.droid_net import UpdateModule, FusedUpdate
     torch.manual_seed(9)
