@@ -359,13 +359,22 @@ class FactorGraph:
                       enable_wq=True):
         """factor_graph.py:259-309 -- alt-corr, 8 source frames per chunk"""
         num, rig, ch, ht, wd = self.video.fmaps.shape
-        corr_op = AltCorrBlock(self.video.fmaps.view(1, num * rig, ch, ht, wd))
+        # on-the-fly correlation: the MFMA operator (csrc/corr_otf.hip; the values of the volume lookup up to
+        # fp16 rounding) unless lowmem_corr == "alt" asks for the literal fp32 alt_cuda_corr formulation
+        if getattr(self, "lowmem_corr", "otf") == "otf" and str(self.device).startswith("cuda"):
+            corr_op = self._otf_block()
+        else:
+            corr_op = AltCorrBlock(self.video.fmaps.view(1, num * rig, ch, ht, wd))
         hjj = self._host(self.jj)
         hii = self._host(self.ii)
         for step in range(steps):
             coords1, mask = self.video.reproject(self.ii, self.jj)
             motn = self._motion(coords1)
-            s = 8
+            # The reference walks the source frames 8 at a time to bound the activations of the update operator
+            # (factor_graph.py:279).  All edges of a source frame share a chunk, so the chunk size does not
+            # change any value (GraphAgg averages per source frame); with 288 GB of HBM one chunk takes the
+            # whole graph unless lowmem_chunk asks for less: 16x fewer launches at 128 keyframes.
+            s = int(getattr(self, "lowmem_chunk", 1 << 30))
             for i in range(0, int(hjj.max()) + 1, s):
                 vh = (hii >= i) & (hii < i + s)
                 if vh.sum() < 1:

@@ -139,6 +139,25 @@ def test_update_lowmem_backend_path(gpu):
     assert graph.net.dtype == torch.float16 and torch.isfinite(graph.target).all()
 
 
+def test_update_lowmem_chunking_and_correlation_operator(gpu):
+    """one chunk over the whole graph == the reference's 8-source-frame chunks (all edges of a source frame
+    share a chunk, GraphAgg is per source frame); the MFMA on-the-fly correlation stays within fp16 rounding
+    of the fp32 alt-corr formulation"""
+    outs = {}
+    for name, chunk, corr in (("one", 1 << 30, "otf"), ("eight", 8, "otf"), ("alt", 8, "alt")):
+        g, video = make_video(gpu, 20, 16, 24, graph="loop")
+        graph = make_graph(gpu, video, corr_impl="alt", max_factors=200)
+        graph.lowmem_chunk, graph.lowmem_corr = chunk, corr
+        n = graph.add_backend_proximity_factors(0, 20, nms=2, radius=1, thresh=50.0, max_factors=200, beta=0.75)
+        assert n > 0 and int(graph.ii.max()) >= 16          # more than two chunks of 8 source frames
+        graph.update_lowmem(t0=1, t1=20, itrs=2, steps=1)
+        outs[name] = [t.float().clone() for t in (graph.target, graph.weight, graph.net, video.disps[:20])]
+    for a, b in zip(outs["one"], outs["eight"]):
+        torch.testing.assert_close(a, b, atol=1e-3, rtol=1e-3)
+    tgt_o, tgt_a = outs["eight"][0], outs["alt"][0]
+    assert float((tgt_o - tgt_a).abs().max()) < 0.05          # flow targets in pixels
+
+
 def test_rm_factors_and_rm_keyframe(gpu):
     g, video = make_video(gpu, 6, 16, 24, buffer=8)
     graph = make_graph(gpu, video)
