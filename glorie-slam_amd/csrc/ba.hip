@@ -530,90 +530,30 @@ __global__ __launch_bounds__(64) void ba_assemble_kernel(BaWork wk, const int64_
 // ---- large systems: blocked right-looking Cholesky on the dense fp64 matrix in HBM ----
 constexpr int kNB = 32;
 
-// factor the diagonal block A[j0:j0+nb, j0:j0+nb] in place (1 WG), apply damping first
-__global__ __launch_bounds__(256) void chol_diag_kernel(BaWork wk, int n, int j0, int nb) {
-  __shared__ double A[kNB][kNB + 1];
-  __shared__ int fail;
-  const int tid = threadIdx.x;
-  if (tid == 0) fail = 0;
-  if (wk.status[0] & (BA_ST_CHOL_FAILED | BA_ST_M_MISMATCH)) return;
-  for (int idx = tid; idx < nb * nb; idx += 256) {
-    const int r = idx / nb, c = idx % nb;
-    A[r][c] = (r >= c) ? wk.Hd[(size_t)(j0 + r) * n + j0 + c] : 0.0;
-  }
-  __syncthreads();
-  for (int j = 0; j < nb; ++j) {
-    const double d = A[j][j];
-    if (!(d > 0.0) && tid == 0) fail = 1;
-    __syncthreads();
-    if (fail) break;
-    const double dj = sqrt(d);
-    __syncthreads();
-    for (int r = j + tid; r < nb; r += 256) A[r][j] = (r == j) ? dj : A[r][j] / dj;
-    __syncthreads();
-    for (int idx = tid; idx < (nb - j - 1) * (nb - j - 1); idx += 256) {
-      const int r = j + 1 + idx / (nb - j - 1), c = j + 1 + idx % (nb - j - 1);
-      if (r >= c) A[r][c] -= A[r][j] * A[c][j];
-    }
-    __syncthreads();
-  }
-  if (fail) {
-    if (tid == 0) {
-      atomicOr(&wk.status[0], BA_ST_CHOL_FAILED);
-      atomicAdd(&wk.status[2], 1);
-    }
-    return;
-  }
-  for (int idx = tid; idx < nb * nb; idx += 256) {
-    const int r = idx / nb, c = idx % nb;
-    if (r >= c) wk.Hd[(size_t)(j0 + r) * n + j0 + c] = A[r][c];
-  }
-}
-
-// panel: rows below the diagonal block: X L11^T = A21  (each WG takes 64 rows)
-__global__ __launch_bounds__(64) void chol_panel_kernel(BaWork wk, int n, int j0, int nb) {
-  __shared__ double L11[kNB][kNB + 1];
-  if (wk.status[0] & (BA_ST_CHOL_FAILED | BA_ST_M_MISMATCH)) return;
-  const int tid = threadIdx.x;
-  for (int idx = tid; idx < nb * nb; idx += 64) {
-    const int r = idx / nb, c = idx % nb;
-    L11[r][c] = (r >= c) ? wk.Hd[(size_t)(j0 + r) * n + j0 + c] : 0.0;
-  }
-  __syncthreads();
-  const int r = j0 + nb + blockIdx.x * 64 + tid;
-  if (r >= n) return;
-  double row[kNB];
-  for (int c = 0; c < nb; ++c) row[c] = wk.Hd[(size_t)r * n + j0 + c];
-  for (int c = 0; c < nb; ++c) {
-    double v = row[c];
-    for (int m = 0; m < c; ++m) v -= row[m] * L11[c][m];
-    row[c] = v / L11[c][c];
-  }
-  for (int c = 0; c < nb; ++c) wk.Hd[(size_t)r * n + j0 + c] = row[c];
-}
-
-// trailing update A22 -= L21 L21^T (lower part), 32x32 output tile per WG
+// trailing update A22 -= X X^T (lower part) + the right-hand side row n, 32 x 32 output tile per workgroup;
+// row index t of the (rem + 1)-row panel: t < rem -> matrix row j0 + nb + t, t == rem -> row n
 __global__ __launch_bounds__(256) void chol_trail_kernel(BaWork wk, int n, int j0, int nb) {
   __shared__ double Ar[32][kNB + 1], Ac[32][kNB + 1];
   if (wk.status[0] & (BA_ST_CHOL_FAILED | BA_ST_M_MISMATCH)) return;
-  const int base = j0 + nb;
+  const int base = j0 + nb, rem = n - base;
   const int tr = blockIdx.y, tc = blockIdx.x;
   if (tc > tr) return;
-  const int r0 = base + tr * 32, c0 = base + tc * 32;
+  const int r0 = tr * 32, c0 = tc * 32;
   const int tid = threadIdx.x;
   for (int idx = tid; idx < 32 * nb; idx += 256) {
     const int r = idx / nb, m = idx % nb;
-    Ar[r][m] = (r0 + r < n) ? wk.Hd[(size_t)(r0 + r) * n + j0 + m] : 0.0;
-    Ac[r][m] = (c0 + r < n) ? wk.Hd[(size_t)(c0 + r) * n + j0 + m] : 0.0;
+    const int tr_ = r0 + r, tc_ = c0 + r;
+    Ar[r][m] = (tr_ <= rem) ? wk.Hd[(size_t)(tr_ < rem ? base + tr_ : n) * n + j0 + m] : 0.0;
+    Ac[r][m] = (tc_ < rem) ? wk.Hd[(size_t)(base + tc_) * n + j0 + m] : 0.0;
   }
   __syncthreads();
   for (int idx = tid; idx < 32 * 32; idx += 256) {
     const int r = idx / 32, c = idx % 32;
-    const int gr = r0 + r, gc = c0 + c;
-    if (gr < n && gc < n && gr >= gc) {
+    const int t_r = r0 + r, t_c = c0 + c;
+    if (t_r <= rem && t_c < rem && t_r >= t_c) {
       double acc = 0.0;
       for (int m = 0; m < nb; ++m) acc += Ar[r][m] * Ac[c][m];
-      wk.Hd[(size_t)gr * n + gc] -= acc;
+      wk.Hd[(size_t)(t_r < rem ? base + t_r : n) * n + base + t_c] -= acc;
     }
   }
 }
@@ -1033,29 +973,124 @@ __global__ __launch_bounds__(1024) void ba_solve_fused_kernel(BaWork wk, int n, 
   for (int i = tid; i < n; i += 1024) wk.dx[i] = (float)xs[i];
 }
 
-// triangular solves on the factored matrix in HBM (1 WG of 1024 threads; row-block sweeps)
-__global__ __launch_bounds__(1024) void chol_solve_kernel(BaWork wk, int n) {
-  extern __shared__ double xs[];  // [n]
-  const int tid = threadIdx.x;
-  const bool failed = wk.status[0] & (BA_ST_CHOL_FAILED | BA_ST_M_MISMATCH);
-  if (failed) {
+// ---- large systems (n > kFusedMaxN): the same blocked algorithm, one launch per phase and block so that the
+// O(n^3) trailing update spreads over the chip.  The right-hand side rides along as row n here too.
+
+// diagonal block: elimination on unscaled columns + the same row operations on an identity (L11^-1), like the
+// diagonal phase of ba_solve_fused_kernel; L11 goes back into the lower triangle, L11^-1 (strictly lower
+// part, transposed) into the unused upper triangle of the block
+__global__ __launch_bounds__(1024) void chol_diag_inv_kernel(BaWork wk, int n, int j0, int nb) {
+  __shared__ double Dl[kCB * kCBP], Wl[kCB * kCBP];
+  __shared__ int fail;
+  const int tid = threadIdx.x, br = tid >> 5, bc = tid & 31;
+  double* A = wk.Hd;
+  if (tid == 0) fail = 0;
+  if (wk.status[0] & (BA_ST_CHOL_FAILED | BA_ST_M_MISMATCH)) return;
+  if (br < nb && bc <= br) {
+    Dl[br * kCBP + bc] = A[(size_t)(j0 + br) * n + j0 + bc];
+    Wl[br * kCBP + bc] = br == bc ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  for (int j = 0; j < nb; ++j) {
+    const double d = Dl[j * kCBP + j];
+    if (!(d > 0.0) && tid == 0) fail = 1;
+    if (br < nb && br > j) {
+      const double mlt = Dl[br * kCBP + j] / d;
+      if (bc > j && bc <= br) Dl[br * kCBP + bc] -= mlt * Dl[bc * kCBP + j];
+      else if (bc <= j) Wl[br * kCBP + bc] -= mlt * Wl[j * kCBP + bc];
+    }
+    __syncthreads();
+  }
+  if (fail) {
+    if (tid == 0) {
+      atomicOr(&wk.status[0], BA_ST_CHOL_FAILED);
+      atomicAdd(&wk.status[2], 1);
+    }
+    return;
+  }
+  if (br < nb && bc <= br) {
+    const double sc = sqrt(Dl[bc * kCBP + bc]), sr = sqrt(Dl[br * kCBP + br]);
+    A[(size_t)(j0 + br) * n + j0 + bc] = (br == bc) ? sc : Dl[br * kCBP + bc] / sc;
+    if (bc < br) A[(size_t)(j0 + bc) * n + j0 + br] = Wl[br * kCBP + bc] / sr;
+  }
+}
+
+// panel X = A21 L11^-T as a GEMM, 128 rows per workgroup (row t: matrix row j0 + nb + t, t == rem: rhs row n);
+// thread = (row, residue g of its 4 columns 8 q + g): wave-uniform columns -> the L11^-1 reads are broadcasts
+constexpr int kPanelRows = 128;
+__global__ __launch_bounds__(1024) void chol_panel_gemm_kernel(BaWork wk, int n, int j0, int nb) {
+  __shared__ double Wl[kCB * kCBP], P[kPanelRows * kCBP];
+  if (wk.status[0] & (BA_ST_CHOL_FAILED | BA_ST_M_MISMATCH)) return;
+  const int tid = threadIdx.x, br = tid >> 5, bc = tid & 31;
+  double* A = wk.Hd;
+  const int base = j0 + nb, rem = n - base;
+  if (br < nb && bc < nb) {              // Wl[r][c] = L11^-1[r][c], r >= c
+    double v = 0.0;
+    if (bc < br) v = A[(size_t)(j0 + bc) * n + j0 + br];
+    else if (bc == br) v = 1.0 / A[(size_t)(j0 + br) * n + j0 + br];
+    Wl[br * kCBP + bc] = v;
+  }
+  const int t0 = blockIdx.x * kPanelRows;
+  for (int idx = tid; idx < kPanelRows * kCB; idx += 1024) {
+    const int tl = idx >> 5, m = idx & 31, t = t0 + tl;
+    P[tl * kCBP + m] = (t <= rem && m < nb) ? A[(size_t)(t < rem ? base + t : n) * n + j0 + m] : 0.0;
+  }
+  __syncthreads();
+  const int tl = tid & (kPanelRows - 1), g = tid >> 7, t = t0 + tl;
+  double x[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) x[q] = 0.0;
+  const double* wg = Wl + g * kCBP;
+  const double* ap = P + tl * kCBP;
+#pragma unroll 4
+  for (int m = 0; m < kCB; ++m) {
+    const double am = ap[m];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) x[q] = fma(am, (m <= 8 * q + g) ? wg[8 * q * kCBP + m] : 0.0, x[q]);
+  }
+  if (t <= rem) {
+    double* arow = A + (size_t)(t < rem ? base + t : n) * n + j0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = 8 * q + g;
+      if (c < nb) arow[c] = x[q];
+    }
+  }
+}
+
+// back substitution L^T x = y (y = row n) with the L11^-1 blocks, one workgroup; zero update after a failure
+__global__ __launch_bounds__(1024) void chol_backsub_kernel(BaWork wk, int n) {
+  extern __shared__ double xs[];      // [n]
+  __shared__ double Wl[kCB * kCBP], xb[kCB];
+  const int tid = threadIdx.x, br = tid >> 5, bc = tid & 31;
+  const double* A = wk.Hd;
+  if (wk.status[0] & (BA_ST_CHOL_FAILED | BA_ST_M_MISMATCH)) {
     for (int i = tid; i < n; i += 1024) wk.dx[i] = 0.0f;
     return;
   }
-  for (int i = tid; i < n; i += 1024) xs[i] = wk.vd[i];
+  for (int i = tid; i < n; i += 1024) xs[i] = A[(size_t)n * n + i];
   __syncthreads();
-  for (int j = 0; j < n; ++j) {
-    if (tid == 0) xs[j] = xs[j] / wk.Hd[(size_t)j * n + j];
+  for (int j0 = ((n - 1) / kCB) * kCB; j0 >= 0; j0 -= kCB) {
+    const int nb = min(kCB, n - j0);
+    if (br < nb && bc < nb) {
+      double v = 0.0;
+      if (bc < br) v = A[(size_t)(j0 + bc) * n + j0 + br];
+      else if (bc == br) v = 1.0 / A[(size_t)(j0 + br) * n + j0 + br];
+      Wl[br * kCBP + bc] = v;
+    }
     __syncthreads();
-    const double xj = xs[j];
-    for (int r = j + 1 + tid; r < n; r += 1024) xs[r] -= wk.Hd[(size_t)r * n + j] * xj;
+    if (tid < nb) {                   // x[c] = sum_{r >= c} L11^-1[r][c] y[r]
+      double v = 0.0;
+      for (int r = tid; r < nb; ++r) v = fma(Wl[r * kCBP + tid], xs[j0 + r], v);
+      xb[tid] = v;
+    }
     __syncthreads();
-  }
-  for (int j = n - 1; j >= 0; --j) {
-    if (tid == 0) xs[j] = xs[j] / wk.Hd[(size_t)j * n + j];
-    __syncthreads();
-    const double xj = xs[j];
-    for (int r = tid; r < j; r += 1024) xs[r] -= wk.Hd[(size_t)j * n + r] * xj;
+    if (tid < nb) xs[j0 + tid] = xb[tid];
+    for (int r = tid; r < j0; r += 1024) {   // rows of L: coalesced in r
+      double v = xs[r];
+      for (int c = 0; c < nb; ++c) v -= A[(size_t)(j0 + c) * n + r] * xb[c];
+      xs[r] = v;
+    }
     __syncthreads();
   }
   for (int i = tid; i < n; i += 1024) wk.dx[i] = (float)xs[i];
@@ -1206,7 +1241,7 @@ static int ba_plan(glorie_ctx* ctx, int B, int N, int M, int h, int w, int t0, i
   wk.dx = reinterpret_cast<float*>(base + o_dx);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_solve_kernel),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_backsub_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ba_solve_fused_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
@@ -1257,17 +1292,17 @@ static int ba_solve_update(const BaPlan& pl, float* poses, float* disps, const i
   } else {
     if ((size_t)n6 * sizeof(double) > 128 * 1024) return GLORIE_EUNSUPPORTED;
     hipLaunchKernelGGL(chol_damp_kernel, dim3((n6 + 255) / 256), dim3(256), 0, st, wk, n6, lm, ep);
-    for (int j0 = 0; j0 < n6; j0 += kNB) {
-      const int nb = (n6 - j0 < kNB) ? (n6 - j0) : kNB;
-      hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, st, wk, n6, j0, nb);
-      const int rem = n6 - j0 - nb;
+    for (int j0 = 0; j0 < n6; j0 += kCB) {
+      const int nb = (n6 - j0 < kCB) ? (n6 - j0) : kCB;
+      const int rem = n6 - j0 - nb;                     // + the rhs row
+      hipLaunchKernelGGL(chol_diag_inv_kernel, dim3(1), dim3(1024), 0, st, wk, n6, j0, nb);
+      hipLaunchKernelGGL(chol_panel_gemm_kernel, dim3((rem + kPanelRows) / kPanelRows), dim3(1024), 0, st, wk, n6, j0, nb);
       if (rem > 0) {
-        hipLaunchKernelGGL(chol_panel_kernel, dim3((rem + 63) / 64), dim3(64), 0, st, wk, n6, j0, nb);
-        const int tl = (rem + 31) / 32;
+        const int tl = (rem + 1 + 31) / 32;
         hipLaunchKernelGGL(chol_trail_kernel, dim3(tl, tl), dim3(256), 0, st, wk, n6, j0, nb);
       }
     }
-    hipLaunchKernelGGL(chol_solve_kernel, dim3(1), dim3(1024), sizeof(double) * (size_t)n6, st, wk, n6);
+    hipLaunchKernelGGL(chol_backsub_kernel, dim3(1), dim3(1024), sizeof(double) * (size_t)n6, st, wk, n6);
   }
   const int upd_chunks = (pl.HW + kBaThreads - 1) / kBaThreads;
   hipLaunchKernelGGL(ba_update_kernel, dim3(upd_chunks, pl.M), dim3(kBaThreads), 0, st, wk, poses,

@@ -179,14 +179,19 @@ __global__ __launch_bounds__(256) void gru_gate_q_kernel(const _Float16* __restr
 }
 
 // out[g][p][c] = mean over the edges e with ix[e] == g of act(x[e][p][c] + bias[c])
-// (scatter_mean of GraphAgg, droid_net.py:53-59).  Every thread walks the edge list in order ->
-// fixed summation order, no atomics, no zero fill.  grid (HW*16/256, G).
+// (scatter_mean of GraphAgg, droid_net.py:53-59).  The workgroup first compacts the ids of its group's edges,
+// 256 candidates at a time and in ascending order (ballot + prefix count), then every thread walks that
+// short list: fixed summation order, no atomics, no zero fill, and no O(N) scan per thread on graphs with
+// thousands of edges.  grid (HW*16/256, G).
 __global__ __launch_bounds__(256) void segment_mean_kernel(const _Float16* __restrict__ x, int xs,
                                                            const float* __restrict__ bias, int relu,
                                                            const int64_t* __restrict__ ix, int N,
                                                            _Float16* __restrict__ out, int os, int HW) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= HW * 16) return;
+  __shared__ int elist[256];
+  __shared__ int wcnt[4];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int idx = blockIdx.x * 256 + tid;
+  const bool live = idx < HW * 16;
   const int p = idx >> 4, c = (idx & 15) * 8, g = blockIdx.y;
   float b[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (bias) {
@@ -195,17 +200,35 @@ __global__ __launch_bounds__(256) void segment_mean_kernel(const _Float16* __res
   }
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int cnt = 0;
-  for (int e = 0; e < N; ++e) {
-    if (ix[e] != g) continue;   // wave-uniform
-    const h8 v = *reinterpret_cast<const h8*>(x + ((long)e * HW + p) * xs + c);
+  for (int base = 0; base < N; base += 256) {
+    const int e = base + tid;
+    const bool hit = e < N && ix[e] == g;
+    const unsigned long long m = __ballot(hit);
+    if (lane == 0) wcnt[wv] = __popcll(m);
+    __syncthreads();
+    int off = 0, total = 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      float f = (float)v[k] + b[k];
-      if (relu) f = fmaxf(f, 0.0f);
-      acc[k] += f;
+    for (int q = 0; q < 4; ++q) {
+      if (q < wv) off += wcnt[q];
+      total += wcnt[q];
     }
-    ++cnt;
+    if (hit) elist[off + __popcll(m & ((1ull << lane) - 1ull))] = e;
+    __syncthreads();
+    if (live) {
+      for (int q = 0; q < total; ++q) {
+        const h8 v = *reinterpret_cast<const h8*>(x + ((long)elist[q] * HW + p) * xs + c);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          float f = (float)v[k] + b[k];
+          if (relu) f = fmaxf(f, 0.0f);
+          acc[k] += f;
+        }
+      }
+    }
+    cnt += total;
+    __syncthreads();              // elist / wcnt are rewritten by the next batch
   }
+  if (!live) return;
   const float inv = 1.0f / (float)max(cnt, 1);
   h8 o;
 #pragma unroll

@@ -367,37 +367,63 @@ class FactorGraph:
             corr_op = AltCorrBlock(self.video.fmaps.view(1, num * rig, ch, ht, wd))
         hjj = self._host(self.jj)
         hii = self._host(self.ii)
+        # The reference walks the source frames 8 at a time to bound the activations of the update operator
+        # (factor_graph.py:279).  All edges of a source frame share a chunk, so the chunk size does not change
+        # any value (GraphAgg averages per source frame); with 288 GB of HBM one chunk takes the whole graph
+        # unless lowmem_chunk asks for less: 16x fewer launches at 128 keyframes.  Everything about a chunk
+        # that does not depend on the iteration (edge selection, frame list, context features) is set up once.
+        s = int(getattr(self, "lowmem_chunk", 1 << 30))
+        # ... and within what the kernels can address: the convolutions use 31-bit buffer offsets, i.e. at most
+        # ~2 M pixel rows of the widest (576-channel fp16) map per launch
+        max_edges = max(1, (3 << 19) // (ht * wd))
+        per_frame = np.bincount(hii, minlength=int(hii.max()) + 1) if hii.size else np.zeros(1, np.int64)
+        bounds, lo, acc = [], 0, 0
+        for f in range(len(per_frame)):
+            if f > lo and (f - lo >= s or acc + per_frame[f] > max_edges):
+                bounds.append((lo, f))
+                lo, acc = f, 0
+            acc += int(per_frame[f])
+        bounds.append((lo, len(per_frame)))
+        chunks = []
+        for i, i_end in bounds:
+            vh = (hii >= i) & (hii < i_end)
+            if vh.sum() < 1:
+                continue
+            v = slice(None) if bool(vh.all()) else torch.as_tensor(vh, device=self.device)
+            iis, jjs = self.ii[v], self.jj[v]
+            chunks.append((v, iis, jjs, rig * iis, rig * jjs + (iis == jjs).long(), torch.unique(iis),
+                           self.video.inps[None, iis]))
+        if self.fast_update is not None and self._lowmem_update is None:
+            self._lowmem_update = [FusedUpdate(self.update_op)]
+        while self.fast_update is not None and len(self._lowmem_update) < min(len(chunks), 4):
+            self._lowmem_update.append(FusedUpdate(self.update_op))     # own context cache per chunk
         for step in range(steps):
             coords1, mask = self.video.reproject(self.ii, self.jj)
             motn = self._motion(coords1)
-            # The reference walks the source frames 8 at a time to bound the activations of the update operator
-            # (factor_graph.py:279).  All edges of a source frame share a chunk, so the chunk size does not
-            # change any value (GraphAgg averages per source frame); with 288 GB of HBM one chunk takes the
-            # whole graph unless lowmem_chunk asks for less: 16x fewer launches at 128 keyframes.
-            s = int(getattr(self, "lowmem_chunk", 1 << 30))
-            for i in range(0, int(hjj.max()) + 1, s):
-                vh = (hii >= i) & (hii < i + s)
-                if vh.sum() < 1:
-                    continue
-                v = torch.as_tensor(vh, device=self.device)
-                iis, jjs = self.ii[v], self.jj[v]
-                corr1 = corr_op(coords1[:, v], rig * iis, rig * jjs + (iis == jjs).long())
-                uq = torch.unique(iis)
+            for ci, (v, iis, jjs, ci1, cj1, uq, inp) in enumerate(chunks):
+                whole = isinstance(v, slice)
+                corr1 = corr_op(coords1 if whole else coords1[:, v], ci1, cj1)
+                net_in = self.net if whole else self.net[:, v]
+                mot_in = motn if whole else motn[:, v].contiguous()
                 if self.fast_update is not None:
-                    # chunks differ in size: a second FusedUpdate (own buffers, never in place) serves them
-                    if self._lowmem_update is None:
-                        self._lowmem_update = FusedUpdate(self.update_op)
-                    net, delta, weight, damping, upmask = self._lowmem_update(
-                        self.net[:, v], self.video.inps[None, iis], corr1, motn[:, v].contiguous(), iis, jjs)
+                    # chunks differ in size: separate FusedUpdate objects (own buffers, never in place); the
+                    # first four chunks keep their hoisted context term across the steps
+                    fu = self._lowmem_update[min(ci, len(self._lowmem_update) - 1)]
+                    net, delta, weight, damping, upmask = fu(net_in, inp, corr1, mot_in, iis, jjs)
                     self.video.upsample(uq, upmask, softmax_f32=True)   # inside autocast in the reference: fp32 softmax
                 else:
                     with torch.autocast("cuda", enabled=True):
                         net, delta, weight, damping, upmask = \
-                            self.update_op(self.net[:, v], self.video.inps[None, iis], corr1, motn[:, v], iis, jjs)
+                            self.update_op(net_in, inp, corr1, mot_in, iis, jjs)
                     self.video.upsample(uq, upmask, softmax_f32=True)
-                self.net[:, v] = net
-                self.target[:, v] = coords1[:, v] + delta.float()
-                self.weight[:, v] = weight.float()
+                if whole:
+                    self.net = net if net.dtype == self.net.dtype else net.to(self.net.dtype)
+                    self.target = coords1 + delta.float()
+                    self.weight = weight.float()
+                else:
+                    self.net[:, v] = net
+                    self.target[:, v] = coords1[:, v] + delta.float()
+                    self.weight[:, v] = weight.float()
                 self.damping[uq] = damping.to(self.damping.dtype)
             damping = .2 * self.damping[self._unique_ii()].contiguous() + EP
             opt_type = ("pose_depth" if step % 2 == 0 else "depth_scale") if enable_wq else "pose_depth"
