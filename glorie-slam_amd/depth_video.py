@@ -127,6 +127,21 @@ class DepthVideo:
         for nme in names:
             gdist.allgather_owned_rows(getattr(self, nme), self.shard["owner"], self.shard["rank"],
                                        self.shard["world"], self.shard["group"])
+            if nme == "disps_up":
+                self.shard["stale_up"] = False
+
+    def mark_upsampled(self):
+        """a sharded BA-update wrote the full-resolution disparities of this rank's frames only.  Nothing
+        inside the update loop reads another rank's disps_up (61 MB at 50 keyframes), so their exchange is
+        left to the consumers - the valid-depth mask, the mapper's accessors, save_video - via
+        `fresh_disps_up()`; a COLLECTIVE call: every rank has to reach the same consumer."""
+        if self.shard is not None and self.shard["world"] > 1:
+            self.shard["stale_up"] = True
+
+    def fresh_disps_up(self):
+        if self.shard is not None and self.shard.get("stale_up"):
+            self.sync_owned("disps_up")
+        return self.disps_up
 
     def ctx(self):
         if self._ctx is None:
@@ -231,7 +246,7 @@ class DepthVideo:
                 return
         else:
             dirty_index = torch.arange(self.counter.value, device=self.device)
-        src = self.disps_up if up else self.disps
+        src = self.fresh_disps_up() if up else self.disps
         intr = (self.intrinsics[0].detach() * (self.down_scale if up else 1.0)).contiguous()
         mv = self.cfg['tracking']['multiview_filter']
         if fused and src.is_cuda:
@@ -268,7 +283,7 @@ class DepthVideo:
     def get_depth_and_pose(self, index, device):
         """(depth [H,W], valid mask [H,W], c2w [4,4]) of keyframe `index` (depth_video.py:318-324)"""
         with self.get_lock():
-            est_depth = 1.0 / self.disps_up[index].clone().to(device)
+            est_depth = 1.0 / self.fresh_disps_up()[index].clone().to(device)
             depth_mask = self.valid_depth_mask[index].clone().to(device)
             c2w = self.get_pose(index, device)
         return est_depth, depth_mask, c2w

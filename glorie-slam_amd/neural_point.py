@@ -169,7 +169,7 @@ class NeuralPointCloud(object):
         if isinstance(video_idxs, int):
             video_idxs = torch.tensor([video_idxs], dtype=torch.long, device=self.device)
         if self._full_pcl is None:
-            B, H, W = v.disps_up.shape
+            B, H, W = v.fresh_disps_up().shape
             self._full_pcl = torch.zeros(B, H, W, 3, device=self.device, dtype=torch.float)
             self._full_mask = torch.zeros(B, H, W, device=self.device, dtype=torch.bool)
         intrinsic = (v.intrinsics[0].detach() * float(v.down_scale)).contiguous()
