@@ -130,6 +130,24 @@ class DepthVideo:
             if nme == "disps_up":
                 self.shard["stale_up"] = False
 
+    def sync_owned_state(self):
+        """disps, depth_scale and depth_shift of every rank's frames in ONE collective (three small
+        exchanges per BA-update are three collective latencies)"""
+        if self.shard is None or self.shard["world"] <= 1:
+            return
+        from . import dist as gdist
+        nf = min(len(self.shard["owner"]), self.disps.shape[0])
+        hw = self.disps.shape[1] * self.disps.shape[2]
+        pack = torch.empty(nf, hw + 2, dtype=self.disps.dtype, device=self.disps.device)
+        pack[:, :hw] = self.disps[:nf].reshape(nf, hw)
+        pack[:, hw] = self.depth_scale[:nf]
+        pack[:, hw + 1] = self.depth_shift[:nf]
+        gdist.allgather_owned_rows(pack, self.shard["owner"], self.shard["rank"], self.shard["world"],
+                                   self.shard["group"])
+        self.disps[:nf] = pack[:, :hw].reshape(nf, *self.disps.shape[1:])
+        self.depth_scale[:nf] = pack[:, hw]
+        self.depth_shift[:nf] = pack[:, hw + 1]
+
     def mark_upsampled(self):
         """a sharded BA-update wrote the full-resolution disparities of this rank's frames only.  Nothing
         inside the update loop reads another rank's disps_up (61 MB at 50 keyframes), so their exchange is

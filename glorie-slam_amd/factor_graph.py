@@ -351,7 +351,7 @@ class FactorGraph:
                       motion_only=motion_only, opt_type=opt_type)
         self.video.upsample(uniq, upmask)
         if getattr(self.video, "shard", None) is not None and self.video.shard["world"] > 1:
-            self.video.sync_owned("disps", "depth_scale", "depth_shift")
+            self.video.sync_owned_state()
             self.video.mark_upsampled()
         self.age += 1
 
