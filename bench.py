@@ -448,14 +448,19 @@ def main():
         "roofline_corr": {"bound": "hbm", "kernel": "corr_lookup_r3_tiled_kernel (fp16, 4x8-tiled pyramid)",
                           "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": achieved / HBM_PEAK_GBS, "traffic": corr_traffic if full else None,
-                          "alg_bytes_per_launch": alg_bytes, "ms_per_launch": corr_ms},
+                          "alg_bytes_per_launch": alg_bytes, "ms_per_launch": corr_ms,
+                          # bytes the hardware really moved (PMC) over the same time: the rocprof HBM GB/s
+                          "measured_hbm_gbs": (corr_traffic / (corr_ms * 1e-3) / 1e9) if (full and corr_traffic) else None,
+                          "measured_hbm_frac": (corr_traffic / (corr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
+                          if (full and corr_traffic) else None},
         "rays_per_sec": rays_per_s,
         "render": {"rays_local": int(n_r // render_reps), "samples_per_ray": int(S), "cloud_points": int(npc.pts_num()),
                    "ms_per_frame_shard": 1e3 * t_r / render_reps},
         "roofline_knn": {"bound": "hbm", "kernel": "knn_query_kernel<8> + 2x idw_gather_kernel",
                          "achieved": knn_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": knn_gbs / HBM_PEAK_GBS, "traffic": knn_traffic if world == 1 else None,
-                         "alg_bytes_per_launch": knn_bytes, "ms_per_launch": knn_ms},
+                         "alg_bytes_per_launch": knn_bytes, "ms_per_launch": knn_ms,
+                         "measured_hbm_gbs": (knn_traffic / (knn_ms * 1e-3) / 1e9) if (world == 1 and knn_traffic) else None},
         "roofline_mlp": {"bound": "mfma", "kernel": "mlp_geo_v3 + mlp_nb_v3 + mlp_col_v3 (fp32 MFMA 16x16x4, transposed form)",
                          "achieved": mlp_tf, "peak": 157.3, "unit": "TFLOP/s", "frac": mlp_tf / 157.3,
                          "traffic": None, "flops_per_launch": mlp_flops, "ms_per_launch": mlp_ms},
