@@ -6,16 +6,18 @@
 // without ever materialising the 61 MB/edge correlation volume whose per-pixel planes make the
 // windowed gather fetch 4.3x its useful bytes (profiles/r01_pmc_gathers.json).
 //
-// Structure.  A wave owns 16 consecutive source pixels; its four 16-byte A fragments (128
+// Structure.  A workgroup owns an 8 x 8 block of source pixels, each of its four waves a 4 x 4 sub-block
+// (a 16 x 1 run of pixels has a ~23 x 8 bounding box at level 0, a 4 x 4 block ~11 x 11: a third fewer
+// targets to multiply and to pull through L2); the wave's four 16-byte A fragments (128
 // channels) stay in registers.  Per level the wave takes the bounding box of the 16 windows
-// (smooth flow -> ~24 x 10 target pixels at level 0), evaluates the dense 16 x |bbox| block of dot
+// (smooth flow -> ~11 x 11 target pixels at level 0), evaluates the dense 16 x |bbox| block of dot
 // products with v_mfma_f32_16x16x32_f16 (B fragments are 16-byte channel runs of the pooled,
 // channel-last feature map, L2 resident), rounds to fp16 like the reference volume and parks it in
 // LDS; every pixel then picks and blends its own window from LDS with the reference's fp16
 // rounding sequence.  If the 16 windows do not share a compact bbox (bbox > 256 targets: flow
 // discontinuities, random coords) the wave falls back to one 8x8 bbox per pixel -- 16x the MFMA
 // work for that tile, still correct.  Outputs of the 4 levels are staged in LDS and written as
-// full 128-byte channel rows.
+// 16-byte runs (8 pixels of a block row) per channel.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "common.hiph"
@@ -62,7 +64,7 @@ __device__ __forceinline__ int wave_max_i(int v) {
   return v;
 }
 
-// grid (ceil(HW/64), N), 256 threads.  C = 128 channels.
+// grid (ceil(w/8) * ceil(h/8), N), 256 threads.  C = 128 channels.
 __global__ __launch_bounds__(256) void corr_otf_kernel(
     const _Float16* __restrict__ f1, OtfLevels lv, int num_levels, const float* __restrict__ coords,
     const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, _Float16* __restrict__ out,
@@ -73,12 +75,17 @@ __global__ __launch_bounds__(256) void corr_otf_kernel(
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   const int col = lane & 15, kg = lane >> 4;
   const int n = blockIdx.y;
-  const int pblock = blockIdx.x * kOtfPx;
-  const int p0 = pblock + wv * 16;
+  const int W0 = lv.w[0], H0 = lv.h[0];
+  const int nbx = (W0 + 7) >> 3;
+  const int by = blockIdx.x / nbx, bx = blockIdx.x - by * nbx;
+  // pixel `q` (0..15) of wave `v`: row 8 by + 4 (v >> 1) + (q >> 2), column 8 bx + 4 (v & 1) + (q & 3);
+  // its slot in the staged output is (local row) * 8 + (local column)
+  auto lslot = [](int v, int q) { return ((4 * (v >> 1) + (q >> 2)) << 3) + 4 * (v & 1) + (q & 3); };
+  const int sy = 8 * by + 4 * (wv >> 1) + (col >> 2), sx = 8 * bx + 4 * (wv & 1) + (col & 3);
   const int fi = (int)ii[n], fj = (int)jj[n];
 
-  // A fragments: source pixel (p0 + col), channels 32*kk + 8*kg .. +7
-  const int pa = min(p0 + col, HW - 1);
+  // A fragments: this lane's source pixel (clamped into the map), channels 32*kk + 8*kg .. +7
+  const int pa = min(sy, H0 - 1) * W0 + min(sx, W0 - 1);
   f16x8 afrag[4];
   {
     const f16x8* src = reinterpret_cast<const f16x8*>(f1 + ((size_t)fi * HW + pa) * C + kg * 8);
@@ -111,7 +118,7 @@ __global__ __launch_bounds__(256) void corr_otf_kernel(
     const _Float16 w11 = otf_weight(dx * dy);
 
     if (empty) {   // all windows outside the map: the reference leaves zeros
-      for (int o = lane; o < 16 * 49; o += 64) obuf[l * 49 + (o >> 4)][wv * 16 + (o & 15)] = (_Float16)0.0f;
+      for (int o = lane; o < 16 * 49; o += 64) obuf[l * 49 + (o >> 4)][lslot(wv, o & 15)] = (_Float16)0.0f;
     }
     for (int sub = 0; sub < nsub; ++sub) {
       int sx0 = bx0, sx1 = bx1, sy0 = by0, sy1 = by1;
@@ -171,25 +178,29 @@ __global__ __launch_bounds__(256) void corr_otf_kernel(
         const _Float16 pw10 = __builtin_bit_cast(_Float16, (unsigned short)(wpk1 & 0xffff));
         const _Float16 pw11 = __builtin_bit_cast(_Float16, (unsigned short)((unsigned)wpk1 >> 16));
         const _Float16 v = otf_blend4(s00, s01, s10, s11, pw00, pw01, pw10, pw11);
-        if (o < 16 * 49 && (grouped || px == sub)) obuf[l * 49 + ch][wv * 16 + px] = v;
+        if (o < 16 * 49 && (grouped || px == sub)) obuf[l * 49 + ch][lslot(wv, px)] = v;
       }
       __builtin_amdgcn_wave_barrier();
     }
   }
   __syncthreads();
-  // coalesced write-out: channel rows of 64 pixels = 128 bytes (8 lanes x 16 B)
-  const int npx = min(kOtfPx, HW - pblock);
+  // write-out: per channel and block row 8 pixels = 16 bytes
   const int total_ch = num_levels * 49;
-  if (npx == kOtfPx && (HW & 7) == 0) {
+  const int rows = min(8, H0 - 8 * by), cols = min(8, W0 - 8 * bx);
+  if (cols == 8 && (W0 & 7) == 0) {
     for (int idx = tid; idx < total_ch * 8; idx += 256) {
-      const int ch = idx >> 3, seg = idx & 7;
-      const uint4 v = *reinterpret_cast<const uint4*>(&obuf[ch][seg * 8]);
-      *reinterpret_cast<uint4*>(out + ((size_t)n * out_channels + ch) * HW + pblock + seg * 8) = v;
+      const int ch = idx >> 3, ry = idx & 7;
+      if (ry < rows) {
+        const uint4 v = *reinterpret_cast<const uint4*>(&obuf[ch][ry * 8]);
+        *reinterpret_cast<uint4*>(out + ((size_t)n * out_channels + ch) * HW + (size_t)(8 * by + ry) * W0 + 8 * bx) = v;
+      }
     }
   } else {
     for (int idx = tid; idx < total_ch * kOtfPx; idx += 256) {
-      const int ch = idx / kOtfPx, px = idx - ch * kOtfPx;
-      if (px < npx) out[((size_t)n * out_channels + ch) * HW + pblock + px] = obuf[ch][px];
+      const int ch = idx / kOtfPx, q = idx - ch * kOtfPx;
+      const int ry = q >> 3, rx = q & 7;
+      if (ry < rows && rx < cols)
+        out[((size_t)n * out_channels + ch) * HW + (size_t)(8 * by + ry) * W0 + 8 * bx + rx] = obuf[ch][q];
     }
   }
 }
@@ -212,7 +223,7 @@ extern "C" int glorie_corr_otf(const void* fmap1, const void* const* fmap2_level
     lv.h[l] = h >> l;
     lv.w[l] = w >> l;
   }
-  dim3 grid((h * w + kOtfPx - 1) / kOtfPx, N);
+  dim3 grid(((w + 7) / 8) * ((h + 7) / 8), N);
   hipLaunchKernelGGL(corr_otf_kernel, grid, dim3(256), 0, (hipStream_t)stream,
                      reinterpret_cast<const _Float16*>(fmap1), lv, num_levels, coords, ii, jj,
                      reinterpret_cast<_Float16*>(out), h * w, num_levels * 49);
