@@ -375,8 +375,8 @@ class FactorGraph:
         # that does not depend on the iteration (edge selection, frame list, context features) is set up once.
         s = int(getattr(self, "lowmem_chunk", 1 << 30))
         # ... and within what the kernels can address: the convolutions use 31-bit buffer offsets, i.e. at most
-        # ~2 M pixel rows of the widest (576-channel fp16) map per launch
-        max_edges = max(1, (3 << 19) // (ht * wd))
+        # 2^31 / (2 * 448) = 2.39 M pixel rows of the widest per-edge fp16 map per launch
+        max_edges = max(1, (9 << 18) // (ht * wd))
         per_frame = np.bincount(hii, minlength=int(hii.max()) + 1) if hii.size else np.zeros(1, np.int64)
         bounds, lo, acc = [], 0, 0
         for f in range(len(per_frame)):
