@@ -530,30 +530,52 @@ __global__ __launch_bounds__(64) void ba_assemble_kernel(BaWork wk, const int64_
 // ---- large systems: blocked right-looking Cholesky on the dense fp64 matrix in HBM ----
 constexpr int kNB = 32;
 
-// trailing update A22 -= X X^T (lower part) + the right-hand side row n, 32 x 32 output tile per workgroup;
-// row index t of the (rem + 1)-row panel: t < rem -> matrix row j0 + nb + t, t == rem -> row n
+// trailing update A22 -= X X^T (lower part) + the right-hand side row n, 64 x 64 output tile per workgroup,
+// 4 x 4 outputs per thread (rows ty + 16 i, columns tx + 16 j: broadcast / conflict-free LDS reads, coalesced
+// updates); row index t of the (rem + 1)-row panel: t < rem -> matrix row j0 + nb + t, t == rem -> row n
+constexpr int kTrailTile = 64;
 __global__ __launch_bounds__(256) void chol_trail_kernel(BaWork wk, int n, int j0, int nb) {
-  __shared__ double Ar[32][kNB + 1], Ac[32][kNB + 1];
+  __shared__ double Ar[kTrailTile][kNB + 1], Ac[kTrailTile][kNB + 1];
   if (wk.status[0] & (BA_ST_CHOL_FAILED | BA_ST_M_MISMATCH)) return;
   const int base = j0 + nb, rem = n - base;
   const int tr = blockIdx.y, tc = blockIdx.x;
   if (tc > tr) return;
-  const int r0 = tr * 32, c0 = tc * 32;
+  const int r0 = tr * kTrailTile, c0 = tc * kTrailTile;
   const int tid = threadIdx.x;
-  for (int idx = tid; idx < 32 * nb; idx += 256) {
-    const int r = idx / nb, m = idx % nb;
-    const int tr_ = r0 + r, tc_ = c0 + r;
-    Ar[r][m] = (tr_ <= rem) ? wk.Hd[(size_t)(tr_ < rem ? base + tr_ : n) * n + j0 + m] : 0.0;
-    Ac[r][m] = (tc_ < rem) ? wk.Hd[(size_t)(base + tc_) * n + j0 + m] : 0.0;
+  for (int idx = tid; idx < kTrailTile * kNB; idx += 256) {
+    const int r = idx >> 5, m = idx & 31;
+    const int t_r = r0 + r, t_c = c0 + r;
+    Ar[r][m] = (t_r <= rem && m < nb) ? wk.Hd[(size_t)(t_r < rem ? base + t_r : n) * n + j0 + m] : 0.0;
+    Ac[r][m] = (t_c < rem && m < nb) ? wk.Hd[(size_t)(base + t_c) * n + j0 + m] : 0.0;
   }
   __syncthreads();
-  for (int idx = tid; idx < 32 * 32; idx += 256) {
-    const int r = idx / 32, c = idx % 32;
-    const int t_r = r0 + r, t_c = c0 + c;
-    if (t_r <= rem && t_c < rem && t_r >= t_c) {
-      double acc = 0.0;
-      for (int m = 0; m < nb; ++m) acc += Ar[r][m] * Ac[c][m];
-      wk.Hd[(size_t)(t_r < rem ? base + t_r : n) * n + base + t_c] -= acc;
+  const int ty = tid >> 4, tx = tid & 15;
+  double acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+#pragma unroll 4
+  for (int m = 0; m < kNB; ++m) {
+    double a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = Ar[ty + 16 * i][m];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b[j] = Ac[tx + 16 * j][m];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = fma(a[i], b[j], acc[i][j]);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int t_r = r0 + ty + 16 * i;
+    if (t_r > rem) continue;
+    double* row = wk.Hd + (size_t)(t_r < rem ? base + t_r : n) * n + base;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int t_c = c0 + tx + 16 * j;
+      if (t_c < rem && t_c <= t_r) row[t_c] -= acc[i][j];
     }
   }
 }
@@ -1058,42 +1080,43 @@ __global__ __launch_bounds__(1024) void chol_panel_gemm_kernel(BaWork wk, int n,
   }
 }
 
-// back substitution L^T x = y (y = row n) with the L11^-1 blocks, one workgroup; zero update after a failure
-__global__ __launch_bounds__(1024) void chol_backsub_kernel(BaWork wk, int n) {
-  extern __shared__ double xs[];      // [n]
-  __shared__ double Wl[kCB * kCBP], xb[kCB];
-  const int tid = threadIdx.x, br = tid >> 5, bc = tid & 31;
-  const double* A = wk.Hd;
+// back substitution L^T x = y (y = row n of the buffer), one launch per 32-column block from the last block up:
+// every workgroup forms x_blk = L11^-T y_blk itself (32 x 32, L11^-1 from the block's upper triangle) and
+// subtracts L[blk rows][r] x_blk from its slice of y (rows of L: coalesced in r) - the O(n^2) part of the sweep
+// spread over the chip instead of one workgroup; workgroup 0 also stores x_blk (and zeros after a failure).
+__global__ __launch_bounds__(256) void chol_backsub_block_kernel(BaWork wk, int n, int j0, int nb) {
+  __shared__ double Wl[kCB * kCBP], yb[kCB], xb[kCB];
+  const int tid = threadIdx.x;
+  double* A = wk.Hd;
+  double* y = A + (size_t)n * n;
   if (wk.status[0] & (BA_ST_CHOL_FAILED | BA_ST_M_MISMATCH)) {
-    for (int i = tid; i < n; i += 1024) wk.dx[i] = 0.0f;
+    if (blockIdx.x == 0 && tid < nb) wk.dx[j0 + tid] = 0.0f;
     return;
   }
-  for (int i = tid; i < n; i += 1024) xs[i] = A[(size_t)n * n + i];
-  __syncthreads();
-  for (int j0 = ((n - 1) / kCB) * kCB; j0 >= 0; j0 -= kCB) {
-    const int nb = min(kCB, n - j0);
-    if (br < nb && bc < nb) {
-      double v = 0.0;
-      if (bc < br) v = A[(size_t)(j0 + bc) * n + j0 + br];
-      else if (bc == br) v = 1.0 / A[(size_t)(j0 + br) * n + j0 + br];
-      Wl[br * kCBP + bc] = v;
+  for (int idx = tid; idx < kCB * kCB; idx += 256) {
+    const int r = idx >> 5, c = idx & 31;
+    double v = 0.0;
+    if (r < nb && c < nb) {
+      if (c < r) v = A[(size_t)(j0 + c) * n + j0 + r];
+      else if (c == r) v = 1.0 / A[(size_t)(j0 + r) * n + j0 + r];
     }
-    __syncthreads();
-    if (tid < nb) {                   // x[c] = sum_{r >= c} L11^-1[r][c] y[r]
-      double v = 0.0;
-      for (int r = tid; r < nb; ++r) v = fma(Wl[r * kCBP + tid], xs[j0 + r], v);
-      xb[tid] = v;
-    }
-    __syncthreads();
-    if (tid < nb) xs[j0 + tid] = xb[tid];
-    for (int r = tid; r < j0; r += 1024) {   // rows of L: coalesced in r
-      double v = xs[r];
-      for (int c = 0; c < nb; ++c) v -= A[(size_t)(j0 + c) * n + r] * xb[c];
-      xs[r] = v;
-    }
-    __syncthreads();
+    Wl[r * kCBP + c] = v;
   }
-  for (int i = tid; i < n; i += 1024) wk.dx[i] = (float)xs[i];
+  if (tid < kCB) yb[tid] = tid < nb ? y[j0 + tid] : 0.0;
+  __syncthreads();
+  if (tid < kCB) {                     // x[c] = sum_{r >= c} L11^-1[r][c] y[r]
+    double v = 0.0;
+    for (int r = tid; r < nb; ++r) v = fma(Wl[r * kCBP + tid], yb[r], v);
+    xb[tid] = v;
+  }
+  __syncthreads();
+  if (blockIdx.x == 0 && tid < nb) wk.dx[j0 + tid] = (float)xb[tid];
+  const int r = blockIdx.x * 256 + tid;
+  if (r < j0) {
+    double v = y[r];
+    for (int c = 0; c < nb; ++c) v -= A[(size_t)(j0 + c) * n + r] * xb[c];
+    y[r] = v;
+  }
 }
 
 // ------------------------------------------------------------------------------------
@@ -1241,8 +1264,6 @@ static int ba_plan(glorie_ctx* ctx, int B, int N, int M, int h, int w, int t0, i
   wk.dx = reinterpret_cast<float*>(base + o_dx);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_backsub_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ba_solve_fused_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ba_solve_band_kernel),
@@ -1290,7 +1311,6 @@ static int ba_solve_update(const BaPlan& pl, float* poses, float* disps, const i
                        wk, n6, lm, ep, band_doubles, -1);
     hipLaunchKernelGGL(ba_solve_fused_kernel, dim3(1), dim3(1024), lds, st, wk, n6, lm, ep);
   } else {
-    if ((size_t)n6 * sizeof(double) > 128 * 1024) return GLORIE_EUNSUPPORTED;
     hipLaunchKernelGGL(chol_damp_kernel, dim3((n6 + 255) / 256), dim3(256), 0, st, wk, n6, lm, ep);
     for (int j0 = 0; j0 < n6; j0 += kCB) {
       const int nb = (n6 - j0 < kCB) ? (n6 - j0) : kCB;
@@ -1298,11 +1318,15 @@ static int ba_solve_update(const BaPlan& pl, float* poses, float* disps, const i
       hipLaunchKernelGGL(chol_diag_inv_kernel, dim3(1), dim3(1024), 0, st, wk, n6, j0, nb);
       hipLaunchKernelGGL(chol_panel_gemm_kernel, dim3((rem + kPanelRows) / kPanelRows), dim3(1024), 0, st, wk, n6, j0, nb);
       if (rem > 0) {
-        const int tl = (rem + 1 + 31) / 32;
+        const int tl = (rem + kTrailTile) / kTrailTile;
         hipLaunchKernelGGL(chol_trail_kernel, dim3(tl, tl), dim3(256), 0, st, wk, n6, j0, nb);
       }
     }
-    hipLaunchKernelGGL(chol_backsub_kernel, dim3(1), dim3(1024), sizeof(double) * (size_t)n6, st, wk, n6);
+    for (int j0 = ((n6 - 1) / kCB) * kCB; j0 >= 0; j0 -= kCB) {
+      const int nb = (n6 - j0 < kCB) ? (n6 - j0) : kCB;
+      hipLaunchKernelGGL(chol_backsub_block_kernel, dim3(j0 > 0 ? (j0 + 255) / 256 : 1), dim3(256), 0, st, wk, n6, j0,
+                         nb);
+    }
   }
   const int upd_chunks = (pl.HW + kBaThreads - 1) / kBaThreads;
   hipLaunchKernelGGL(ba_update_kernel, dim3(upd_chunks, pl.M), dim3(kBaThreads), 0, st, wk, poses,

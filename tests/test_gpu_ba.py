@@ -246,7 +246,7 @@ def test_ba_sharded_equals_unsharded(gpu, K, h, w, world):
 
 @pytest.mark.parametrize("P,bw", [(1, 5), (7, 41), (7, 5), (11, 41), (11, 65), (25, 41), (25, 63), (25, 64),
                                   (25, 149), (49, 41), (49, 293), (90, 41), (90, 539), (91, 41), (91, 545),
-                                  (167, 200)])
+                                  (167, 200), (300, 41), (300, 700)])
 def test_solver_kernels_on_synthetic_spd_systems(gpu, P, bw):
     """the fp64 solve in isolation: glorie_ba_solve_update (N = 0: no depth frames) on a random banded SPD
     system written straight into the [H | v] buffer, against numpy.  Covers the dense-band kernel (6P <= 64),
