@@ -279,3 +279,25 @@ def test_empty_inputs_are_no_ops(gpu):
     assert eo.numel() == 0 and int(any_on) == 0
     assert db.motion(torch.empty(0, 6, 8, 2, device=gpu), torch.zeros(6, 8, 2, device=gpu),
                      torch.empty(0, 6, 8, 2, device=gpu)).shape == (0, 6, 8, 4)
+
+
+def test_update_operator_full_size_edge_permutation(gpu):
+    """BASELINE size (36 edges of 60x80): the per-edge outputs of the update operator (recurrent state, flow
+    revision, confidence) do not depend on the position of the edge in the batch - a permuted batch gives the
+    permuted result bit for bit - and the per-keyframe outputs (eta, upsampling mask: means over the edges of a
+    source frame, summed in edge order) agree to fp16 rounding."""
+    from glorie_slam_amd.droid_net import UpdateModule, FusedUpdate
+    torch.manual_seed(13)
+    mod = UpdateModule().to(gpu).eval()
+    n, h, w = 36, 60, 80
+    net, inp, corr, flow = _inputs(gpu, n, h, w, seed=21)
+    ii = torch.tensor([i // 5 for i in range(n)], device=gpu)           # 8 source frames
+    perm = torch.randperm(n, generator=torch.Generator().manual_seed(2)).to(gpu)
+    a = FusedUpdate(mod)(net, inp, corr, flow, ii, None)
+    b = FusedUpdate(mod)(net[:, perm].contiguous(), inp[:, perm].contiguous(), corr[:, perm].contiguous(),
+                         flow[:, perm].contiguous(), ii[perm], None)
+    for name, x, y in zip(["net", "delta", "weight"], a[:3], b[:3]):
+        assert torch.equal(x[:, perm], y), name
+    for name, x, y in zip(["eta", "upmask"], a[3:], b[3:]):
+        torch.testing.assert_close(x.float(), y.float(), atol=4e-3, rtol=4e-3, msg=lambda m, n=name: f"{n}: {m}")
+    assert all(torch.isfinite(t.float()).all() for t in a)
