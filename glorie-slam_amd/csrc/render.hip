@@ -134,6 +134,31 @@ __global__ __launch_bounds__(256) void ray_samples_kernel(
   if (radius_s) radius_s[idx] = radius[r];
 }
 
+// z-buffer projection of a point set into a pinhole view (neural_point.py:446-506, proj_depth_map): camera
+// coordinates X_c = w2c X (OpenGL convention: the camera looks along -z; the x axis is flipped before the
+// projection), pixel (u, v) = trunc(K X_c / z), depth = -z; the closest point per pixel wins.  The reference
+// sorts all points by depth and takes the first of every unique pixel; here every point does one atomicMin on
+// the bit pattern of its (positive) depth.  depth_bits must be pre-filled with +inf (0x7f800000).
+__global__ __launch_bounds__(256) void proj_depth_kernel(const float* __restrict__ pts,
+                                                         const uint8_t* __restrict__ mask, long n,
+                                                         const float* __restrict__ w2c, float fx, float fy,
+                                                         float cx, float cy, int H, int W,
+                                                         unsigned* __restrict__ depth_bits) {
+#pragma clang fp contract(off)
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n || (mask && !mask[i])) return;
+  const float x = pts[i * 3 + 0], y = pts[i * 3 + 1], z = pts[i * 3 + 2];
+  float xc = w2c[0] * x + w2c[1] * y + w2c[2] * z + w2c[3];
+  const float yc = w2c[4] * x + w2c[5] * y + w2c[6] * z + w2c[7];
+  const float zc = w2c[8] * x + w2c[9] * y + w2c[10] * z + w2c[11];
+  xc = -xc;
+  const float zz = zc + 1e-6f;
+  const float u = (fx * xc + cx * zc) / zz, v = (fy * yc + cy * zc) / zz;
+  if (!(u < (float)W && u >= 0.0f && v < (float)H && v >= 0.0f && -zz > 0.0f)) return;
+  const int ui = (int)u, vi = (int)v;
+  atomicMin(&depth_bits[(size_t)vi * W + ui], __float_as_uint(-zz));
+}
+
 // per-ray number of samples that have neighbours and the valid-ray flag (decoder.py:202-204)
 __global__ __launch_bounds__(256) void ray_counts_kernel(const uint8_t* __restrict__ has, int R, int S,
                                                          int min_samples, int64_t* __restrict__ counts,
@@ -162,6 +187,16 @@ extern "C" int glorie_ray_samples(const float* rays_o, const float* rays_d, cons
   hipLaunchKernelGGL(ray_samples_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      rays_o, rays_d, depth, radius, t_lin, R, S, near_s, far_s, z_vals, pts, views, radius_s,
                      n_zero);
+  return check_launch();
+}
+
+extern "C" int glorie_proj_depth(const float* points, const uint8_t* mask, long n, const float* w2c, float fx,
+                                 float fy, float cx, float cy, int H, int W, float* depth_inf, void* stream) {
+  if (n < 0 || H <= 0 || W <= 0) return GLORIE_EINVAL;
+  if (n == 0) return GLORIE_OK;
+  if (!points || !w2c || !depth_inf) return GLORIE_EINVAL;
+  hipLaunchKernelGGL(proj_depth_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, points,
+                     mask, n, w2c, fx, fy, cx, cy, H, W, reinterpret_cast<unsigned*>(depth_inf));
   return check_launch();
 }
 

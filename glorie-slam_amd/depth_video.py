@@ -285,6 +285,15 @@ class DepthVideo:
             self.valid_depth_mask_small[dirty_index] = masks
 
     # ---- outputs ------------------------------------------------------
+    def get_depth_scale_and_shift(self, index, mono_depth, est_depth, weights):
+        """depth_video.py:301-311: weighted least-squares alignment of a mono depth map to the estimated depth
+        of keyframe `index`; stores and returns [scale, shift]"""
+        from .common import align_scale_and_shift
+        scale, shift, _ = align_scale_and_shift(mono_depth, est_depth, weights)
+        self.depth_scale[index] = scale
+        self.depth_shift[index] = shift
+        return [self.depth_scale[index], self.depth_shift[index]]
+
     def get_pose(self, index, device):
         """camera-to-world 4x4 matrix of keyframe `index` (depth_video.py:313-316: SE3(pose).inv().matrix());
         poses are stored world-to-camera as [tx ty tz qx qy qz qw]"""

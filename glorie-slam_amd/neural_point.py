@@ -7,12 +7,16 @@ Point-cloud maintenance: `add_neural_points` (radius
 along the rays of a keyframe, neural_point.py:165-262), `add_points(video_idxs)` (full-resolution
 unprojection of keyframes, :145-162), `update_points_pos` (deformation after a pose/depth update,
 :378-438) and `retrain_updated_points`.  Every index (re)build is one counting sort on the device
-(`glorie_knn_build`), where the reference re-trains an IVF k-means.  Proxy-depth rendering
-(`proj_depth_map`, `get_proxy_render_depth`, :446-575) is not part of this module yet.
+(`glorie_knn_build`), where the reference re-trains an IVF k-means.  The module-level functions of the
+reference follow at the end: `proj_depth_map` (one z-buffer launch), `get_proxy_render_depth`,
+`update_points_pos(npc, video)` (:446-575).
 """
+import os
+
 import numpy as np
 import torch
 
+from . import _lib as L
 from . import point_ops
 
 
@@ -286,3 +290,80 @@ class NeuralPointCloud(object):
             c = np.nonzero(occ_np[r])[0]
             z_total[r] = np.linspace(z_section[c[0]], z_section[c[1]], num=num)
         return torch.from_numpy(z_total).float().to(self.device), invalid
+
+
+# ---- module-level helpers of the reference's neural_point.py (proxy depth, deformation driver) ----------
+def proj_depth_map(c2w, npc, device, cfg, neural_pcl=False):
+    """neural_point.py:446-506: depth map of the point set seen from `c2w` (closest point per pixel, 0 where
+    no point lands).  neural_pcl=False projects the unprojected keyframe point maps (`npc.full_pcl()`) minus the
+    frame `mapping_window_size` behind the newest one, True the neural points themselves.  One z-buffer
+    launch (`glorie_proj_depth`, atomicMin) instead of a global sort + unique of all projected points."""
+    from .common import update_cam
+    H, W, fx, fy, cx, cy = update_cam(cfg)
+    dev = npc.get_device()
+    if neural_pcl:
+        points, mask = npc.cloud_pos().contiguous(), None
+    else:
+        full_mask = npc.full_mask().clone()
+        full_mask[npc.video.counter.value - cfg["mapping"]["mapping_window_size"]] = False
+        points, mask = npc.full_pcl().reshape(-1, 3), full_mask.reshape(-1).view(torch.uint8)
+    w2c = torch.linalg.inv(c2w.to(dev, torch.float32)).contiguous()
+    depth = torch.full((H, W), float("inf"), device=dev, dtype=torch.float32)
+    n = points.shape[0]
+    if n:
+        L.check(L.load().glorie_proj_depth(L.ptr(points), L.ptr(mask), n, L.ptr(w2c), float(fx), float(fy),
+                                           float(cx), float(cy), H, W, L.ptr(depth), L.stream_ptr()),
+                "glorie_proj_depth")
+    return torch.where(torch.isinf(depth), torch.zeros_like(depth), depth).to(device)
+
+
+def get_proxy_render_depth(npc, cfg, c2w, droid_depth, mono_depth, device, idx=None, use_mono_to_complete=True):
+    """neural_point.py:539-575: the proxy depth of the paper - the tracker's depth where it is valid, else the
+    depth of the point cloud projected into the view, else (optionally) the aligned mono prior"""
+    proxy = droid_depth.clone()
+    proj = proj_depth_map(c2w, npc, device, cfg)
+    take = (~(droid_depth > 0.0)) & (proj > 0.0)
+    proxy[take] = proj[take]
+    if cfg["mapping"].get("save_depth", False) and idx is not None:
+        out = f"{cfg['data']['output']}/{cfg['setting']}/{cfg['scene']}/semi_dense_depth"
+        p_droid, p_proj = f"{out}/droid/{idx:05d}.npy", f"{out}/project/{idx:05d}.npy"
+        if not os.path.isfile(p_droid):
+            os.makedirs(os.path.dirname(p_droid), exist_ok=True)
+            os.makedirs(os.path.dirname(p_proj), exist_ok=True)
+            np.save(p_droid, droid_depth.detach().cpu().float().numpy())
+            np.save(p_proj, proxy.detach().cpu().float().numpy())
+    if use_mono_to_complete:
+        hole = proxy == 0
+        proxy[hole] = mono_depth[hole]
+    return proxy
+
+
+def update_points_pos(npc, video, mono_depth_loader=None):
+    """neural_point.py:509-537: deform the cloud after the tracker moved keyframes - for every keyframe whose
+    `npc_dirty` flag is set, re-place the points that were created from it with its current depth map and pose,
+    refresh its unprojected point map and rebuild the search structure.  `mono_depth_loader(dataset_idx)` is
+    only needed for cfg['mapping']['render_depth'] == 'mono' (the reference reads the prior from disk there)."""
+    with video.get_lock():
+        video_idx, = torch.where(video.npc_dirty.clone())
+    if len(video_idx) == 0 or npc.pts_num() == 0:
+        return
+    video.npc_dirty[video_idx] = False
+    device = npc.get_device()
+    for v_idx in video_idx:
+        est_depth, est_mask, c2w = video.get_depth_and_pose(v_idx, device)
+        est_depth[~est_mask] = 0
+        c2w[:3, 1:3] *= -1
+        mode = video.cfg["mapping"]["render_depth"]
+        if mode == "proxy":
+            render_depth = est_depth
+        elif mode == "mono":
+            if mono_depth_loader is None:
+                raise RuntimeError("render_depth == 'mono' needs a mono_depth_loader")
+            mono = mono_depth_loader(int(video.timestamp[v_idx])).to(device)
+            scale, shift = video.get_depth_scale_and_shift(v_idx, mono, est_depth, est_depth > 0)
+            render_depth = mono * scale + shift
+        else:
+            raise NotImplementedError(mode)
+        npc.update_points_pos(v_idx, render_depth.clone(), c2w.clone(), video.cfg)
+    npc.add_points(video_idx)
+    npc.retrain_updated_points()

@@ -386,6 +386,15 @@ int glorie_ray_samples(const float* rays_o, const float* rays_d, const float* de
                        float* z_vals, float* pts, float* views, float* radius_s, int* n_zero,
                        void* stream);
 
+/* proj_depth_map(c2w, npc, ...): z-buffer projection of a point set into a view
+ *   reference: src/neural_point.py:446-506
+ * points [n,3] world coordinates, mask [n] uint8 (NULL = all points), w2c = inverse of the camera-to-world
+ * matrix, row-major [>= 12 floats] on the device; camera looks along -z, x flipped before the projection,
+ * pixel = trunc(u, v), depth = -z.  depth_inf [H,W] must hold +inf on entry; on return every pixel hit by a
+ * point holds the smallest depth, the rest still +inf (the caller writes 0 there). */
+int glorie_proj_depth(const float* points, const uint8_t* mask, long n, const float* w2c, float fx, float fy,
+                      float cx, float cy, int H, int W, float* depth_inf, void* stream);
+
 /* Per-ray count of samples with neighbours and the valid-ray flag (count >= min_samples)
  *   reference: src/modules/conv_onet/models/decoder.py:202-204 (ray_counter, ~(counter < 3))
  * has [R*S] uint8 -> counts [R] int64, valid [R] uint8. */

@@ -403,6 +403,91 @@ def test_add_points_from_video_unprojects_keyframes(gpu):
     np.testing.assert_allclose(npc.full_pcl()[3, v, u].cpu().numpy(), Xw[:3], rtol=1e-4, atol=1e-4)
 
 
+def test_proxy_depth_projection_and_deformation_driver(gpu):
+    """proj_depth_map (neural_point.py:446-506) against a scatter-min restatement of the same projection;
+    get_proxy_render_depth (:539-575) fills holes of the tracker depth from the projected cloud, then from the
+    mono prior; update_points_pos(npc, video) (:509-537) consumes the npc_dirty flags"""
+    from test_gpu_graph import make_video
+    from glorie_slam_amd import neural_point as NP
+    H, W = 48, 64
+    cfg = _npc_cfg(gpu, H, W)
+    cfg["mapping"] = {"mapping_window_size": 5, "render_depth": "proxy", "save_depth": False}
+    npc = NP.NeuralPointCloud(cfg)
+    rng = np.random.default_rng(5)
+    pts = np.concatenate([rng.uniform(-2, 2, (20000, 2)), rng.uniform(-4, -1, (20000, 1))], 1).astype(np.float32)
+    pts[:50, 2] = 1.0                                           # behind the camera: never projected
+    npc.add_points(torch.from_numpy(pts).to(gpu))
+    c2w = torch.eye(4)
+    c2w[:3, 3] = torch.tensor([0.05, -0.02, 0.1])
+    ang = 0.1
+    c2w[:3, :3] = torch.tensor([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]])
+    proj = NP.proj_depth_map(c2w, npc, gpu, cfg, neural_pcl=True)
+    # restatement: X_c = w2c X, x flipped, (u, v) = trunc(K X_c / z), depth = -z, per-pixel minimum
+    w2c = torch.linalg.inv(c2w.double())
+    X = torch.from_numpy(pts).double()
+    Xc = (w2c[:3, :3] @ X.T).T + w2c[:3, 3]
+    z = Xc[:, 2] + 1e-6
+    u = (40.0 * -Xc[:, 0] + (W / 2 - 0.5) * Xc[:, 2]) / z
+    v = (40.0 * Xc[:, 1] + (H / 2 - 0.5) * Xc[:, 2]) / z
+    m = (u < W) & (u >= 0) & (v < H) & (v >= 0) & (-z > 0)
+    ref = torch.full((H * W,), float("inf"), dtype=torch.float64)
+    ref.scatter_reduce_(0, (v[m].long() * W + u[m].long()), -z[m], reduce="amin")
+    ref = torch.where(torch.isinf(ref), torch.zeros_like(ref), ref).reshape(H, W)
+    got = proj.cpu().double()
+    differ = (got - ref).abs() > 1e-4 * (1 + ref.abs())
+    assert differ.float().mean() < 2e-3                         # fp32 vs fp64 pixel assignment at cell borders
+    assert (got > 0).float().mean() > 0.5 and float(got.max()) < 4.2
+    # proxy depth: tracker depth wins, then the projection, then the mono prior
+    class V:
+        pass
+    droid = torch.zeros(H, W, device=gpu)
+    droid[:, : W // 2] = 2.5
+    mono = torch.full((H, W), 7.0, device=gpu)
+    npc.video = V()
+    npc.video.counter = type("C", (), {"value": 3})()
+    npc._full_pcl = torch.from_numpy(pts[:H * W * 2]).to(gpu).reshape(2, H, W, 3).contiguous()
+    npc._full_pcl = torch.cat([npc._full_pcl, torch.zeros(6, H, W, 3, device=gpu)])
+    npc._full_mask = torch.zeros(8, H, W, dtype=torch.bool, device=gpu)
+    npc._full_mask[:2] = True
+    proxy = NP.get_proxy_render_depth(npc, cfg, c2w, droid, mono, gpu)
+    p2 = NP.proj_depth_map(c2w, npc, gpu, cfg)
+    assert torch.equal(proxy[:, : W // 2], droid[:, : W // 2])
+    right = proxy[:, W // 2:]
+    exp = torch.where(p2[:, W // 2:] > 0, p2[:, W // 2:], mono[:, W // 2:])
+    assert torch.equal(right, exp) and bool((right == 7.0).any()) and bool((right < 7.0).any())
+    # the frame mapping_window_size behind the newest is left out: counter 3 -> index -2 = frame 6 (empty): same map;
+    # counter 6 -> frame 1 dropped: fewer hits
+    npc.video.counter.value = 6
+    p3 = NP.proj_depth_map(c2w, npc, gpu, cfg)
+    assert int((p3 > 0).sum()) < int((p2 > 0).sum())
+
+    # deformation driver on a real video
+    g, video = make_video(gpu, 5, 6, 8)
+    n = video.counter.value
+    video.cfg["mapping"] = {"render_depth": "proxy", "mapping_window_size": 5}
+    video.cfg["cam"] = _npc_cfg(gpu, 48, 64)["cam"]
+    video.disps_up[:n] = torch.nn.functional.interpolate(video.disps[:n, None], scale_factor=8, mode="nearest")[:, 0]
+    video.valid_depth_mask[:n] = True
+    npc2 = NP.NeuralPointCloud(_npc_cfg(gpu, 48, 64), video)
+    jj, ii = torch.meshgrid(torch.arange(48), torch.arange(64), indexing="ij")
+    ii, jj = ii.reshape(-1).to(gpu), jj.reshape(-1).to(gpu)
+    from glorie_slam_amd.common import get_rays_from_uv
+    est_depth, est_mask, c2w1 = video.get_depth_and_pose(1, gpu)
+    c2w1[:3, 1:3] *= -1
+    ro, rd = get_rays_from_uv(ii.float(), jj.float(), c2w1, 40.0, 40.0, 31.5, 23.5, gpu)
+    npc2.add_neural_points(ro, rd, est_depth[jj, ii], torch.rand(48 * 64, 3, device=gpu), 1, ii, jj)
+    before = npc2.cloud_pos().clone()
+    video.npc_dirty[:] = False
+    NP.update_points_pos(npc2, video)                             # nothing dirty: no-op
+    assert torch.equal(npc2.cloud_pos(), before)
+    video.disps_up[1] *= 0.9                                      # the tracker revised keyframe 1
+    video.npc_dirty[1] = True
+    NP.update_points_pos(npc2, video)
+    assert not bool(video.npc_dirty.any())
+    assert float((npc2.cloud_pos() - before).abs().max()) > 1e-3 and npc2.index.ntotal == npc2.pts_num()
+    assert bool(npc2.full_mask()[1].all())
+
+
 def test_full_frame_render_is_order_independent(gpu):
     """BASELINE size (307,200 rays x 10 samples against the 524k-point cloud): a ray's result does not depend on
     where in which batch it is evaluated - rendering a random permutation of the rays and un-permuting gives
