@@ -282,14 +282,22 @@ class NeuralPointCloud(object):
         _, _, nn_num = self.find_neighbors_faiss(pts, step='query')
         occ = nn_num.reshape(n_rays, intervals) > 0
         invalid = occ.sum(-1) < 2
-        z_section = np.linspace(near, far, intervals)
-        z_total = np.tile(np.linspace(near, far, num), (n_rays, 1))
-        occ_np = occ.cpu().numpy()
-        inv_np = invalid.cpu().numpy()
-        for r in np.nonzero(~inv_np)[0]:
-            c = np.nonzero(occ_np[r])[0]
-            z_total[r] = np.linspace(z_section[c[0]], z_section[c[1]], num=num)
-        return torch.from_numpy(z_total).float().to(self.device), invalid
+        # first and second occupied probe of every ray, then num samples between them - the reference walks the
+        # rays in a numpy loop on the host (neural_point.py:355-372); same float64 linspace arithmetic here,
+        # evaluated for all rays at once on the device
+        z_section = torch.linspace(near, far, steps=intervals, device=self.device, dtype=torch.float64)
+        first = torch.argmax(occ.to(torch.uint8), dim=1)
+        occ2 = occ.clone()
+        occ2[torch.arange(n_rays, device=self.device), first] = False
+        second = torch.argmax(occ2.to(torch.uint8), dim=1)
+        lo = torch.where(invalid, torch.full_like(z_section[first], near), z_section[first])
+        hi = torch.where(invalid, torch.full_like(z_section[second], far), z_section[second])
+        steps = torch.arange(num, device=self.device, dtype=torch.float64)
+        z_total = lo[:, None] + ((hi - lo) / max(num - 1, 1))[:, None] * steps[None]
+        if num > 1:
+            z_total[:, -1] = hi                      # numpy.linspace pins the end point
+        return z_total.float(), invalid
+
 
 
 # ---- module-level helpers of the reference's neural_point.py (proxy depth, deformation driver) ----------
