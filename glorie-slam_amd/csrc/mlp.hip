@@ -129,6 +129,9 @@ __device__ __forceinline__ void mma_geo(f32x4 (&acc)[2], const f32x4 (&b)[NB], c
 __global__ __launch_bounds__(512, 4) void mlp_geo_v3_kernel(GeoParams P, const float* __restrict__ image,
                                                             const float* __restrict__ pts,
                                                             const float* __restrict__ c_geo,
+                                                            const float* __restrict__ geo_feats,
+                                                            const int64_t* __restrict__ I,
+                                                            const float* __restrict__ wts,
                                                             const uint8_t* __restrict__ has, int Q,
                                                             float* __restrict__ raw) {
   extern __shared__ float smem[];
@@ -153,10 +156,30 @@ __global__ __launch_bounds__(512, 4) void mlp_geo_v3_kernel(GeoParams P, const f
       e[t][3] = sin_rev(fmaf(z, b2.w, fmaf(y, b1.w, x * b0.w)));
     }
     // columns 93..95 of B are zero padding (sin 0 = 0) and so are the matching weight rows
+    if (geo_feats) {
+      // IDW interpolation of the neighbours' features right here (decoder.py:130-173; same summation order
+      // as idw_gather_kernel): the loads travel with the weight image, c_geo never exists in HBM
+      c[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+      c[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const bool on = has[q] != 0;
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const float4 v = *reinterpret_cast<const float4*>(c_geo + (size_t)q * 32 + 16 * t + 4 * g);
-      c[t][0] = v.x; c[t][1] = v.y; c[t][2] = v.z; c[t][3] = v.w;
+      for (int k = 0; k < 8; ++k) {
+        const float wk = wts[(size_t)q * 8 + k];
+        const long ik = I[(size_t)q * 8 + k];
+        if (on && wk != 0.0f) {
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const float4 v = *reinterpret_cast<const float4*>(geo_feats + (size_t)ik * 32 + 16 * t + 4 * g);
+            c[t][0] += wk * v.x; c[t][1] += wk * v.y; c[t][2] += wk * v.z; c[t][3] += wk * v.w;
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const float4 v = *reinterpret_cast<const float4*>(c_geo + (size_t)q * 32 + 16 * t + 4 * g);
+        c[t][0] = v.x; c[t][1] = v.y; c[t][2] = v.z; c[t][3] = v.w;
+      }
     }
   }
   __syncthreads();
@@ -547,12 +570,13 @@ extern "C" size_t glorie_decoder_pack_floats(void) {
 
 extern "C" int glorie_render_mlp(const float* packed, const float* pts, const float* views,
                                  const float* cloud_pos, const float* col_feats,
-                                 const float* c_geo, const int64_t* I, const float* weights,
-                                 const uint8_t* has, int Q, float* c_col_scratch, float* raw,
-                                 int stage_color, void* stream) {
+                                 const float* c_geo, const float* geo_feats, const int64_t* I,
+                                 const float* weights, const uint8_t* has, int Q, float* c_col_scratch,
+                                 float* raw, int stage_color, void* stream) {
   if (Q < 0) return GLORIE_EINVAL;
   if (Q == 0) return GLORIE_OK;
-  if (!packed || !pts || !c_geo || !has || !raw) return GLORIE_EINVAL;
+  if (!packed || !pts || !has || !raw) return GLORIE_EINVAL;
+  if (!c_geo && !(geo_feats && I && weights)) return GLORIE_EINVAL;   // interpolated feature, or what it takes
   if (stage_color && (!views || !cloud_pos || !col_feats || !I || !weights || !c_col_scratch))
     return GLORIE_EINVAL;
   hipStream_t st = (hipStream_t)stream;
@@ -580,8 +604,8 @@ extern "C" int glorie_render_mlp(const float* packed, const float* pts, const fl
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)geo_lds);
     geo_attr = true;
   }
-  hipLaunchKernelGGL(mlp_geo_v3_kernel, dim3(blocks2), dim3(512), geo_lds, st, g, geo_image, pts, c_geo, has, Q,
-                     raw);
+  hipLaunchKernelGGL(mlp_geo_v3_kernel, dim3(blocks2), dim3(512), geo_lds, st, g, geo_image, pts, c_geo,
+                     c_geo ? nullptr : geo_feats, I, weights, has, Q, raw);
   if (stage_color) {
     const size_t nb_lds = sizeof(float) * (52 * kLdw3 + 128 + kTM2 * 8 + 80) + sizeof(int) * kTM2 * 8;
     const size_t col_lds = sizeof(float) * 2 * kChunkFloats3;

@@ -47,19 +47,49 @@ __global__ __launch_bounds__(256) void idw_gather_kernel(
   for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);  // stays inside the half
   wgt = wgt / fmaxf(s, 1e-12f);
   float acc = 0.0f;
+  if (cout) {                     // cout == NULL: weights / mask only (the geometry decoder gathers itself)
 #pragma unroll
-  for (int k = 0; k < K; ++k) {
-    const float wk = __shfl(wgt, half * 32 + k, 64);
-    const int ik = __shfl(idx, half * 32 + k, 64);
-    if (wk != 0.0f) acc += wk * feats[(size_t)ik * C + ch];
+    for (int k = 0; k < K; ++k) {
+      const float wk = __shfl(wgt, half * 32 + k, 64);
+      const int ik = __shfl(idx, half * 32 + k, 64);
+      if (wk != 0.0f) acc += wk * feats[(size_t)ik * C + ch];
+    }
   }
   if (!live) return;
   const bool has = nn[q] > min_nn - 1;
   // samples without enough neighbours get a N(0, 0.01) random feature in the reference
   // (decoder.py:170-171); here they get zeros (their occupancy is forced to -100 anyway)
-  cout[(size_t)q * C + ch] = has ? acc : 0.0f;
+  if (cout) cout[(size_t)q * C + ch] = has ? acc : 0.0f;
   if (wout && ch < K) wout[(size_t)q * K + ch] = wgt;
   if (has_out && ch == 0) has_out[q] = has ? 1 : 0;
+}
+
+// the weights and the mask of idw_gather_kernel without the feature interpolation: one thread per sample
+// (same arithmetic: w = [idx >= 0 and D <= r^2] / (D + 1e-10), L1-normalised with eps 1e-12)
+__global__ __launch_bounds__(256) void idw_weights_kernel(
+    const float* __restrict__ D, const int64_t* __restrict__ I, const int* __restrict__ nn, int Q, float radius,
+    const float* __restrict__ radius_ptr, int min_nn, int expo_weighting, float* __restrict__ wout,
+    uint8_t* __restrict__ has_out) {
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= Q) return;
+  const float r = radius_ptr ? radius_ptr[q] : radius;
+  const float r2 = r * r;
+  float w[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float d = D[(size_t)q * 8 + k];
+    const long idx = I[(size_t)q * 8 + k];
+    w[k] = (idx >= 0 && !(d > r2)) ? (expo_weighting ? expf(-20.0f * sqrtf(d)) : 1.0f / (d + 1e-10f)) : 0.0f;
+  }
+  // the L1 norm in the summation order of idw_gather_kernel's butterfly (xor 4, 2, 1 over the 8 weights), so
+  // that both kernels produce the same bits
+  const float s4[4] = {w[0] + w[4], w[1] + w[5], w[2] + w[6], w[3] + w[7]};
+  const float s2[2] = {s4[0] + s4[2], s4[1] + s4[3]};
+  const float s = s2[0] + s2[1];
+  const float den = fmaxf(s, 1e-12f);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) wout[(size_t)q * 8 + k] = w[k] / den;
+  if (has_out) has_out[q] = nn[q] > min_nn - 1 ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------------
@@ -216,8 +246,13 @@ extern "C" int glorie_idw_gather(const float* D, const int64_t* I, const int* nn
                                  float* c_out, float* w_out, uint8_t* has_out, void* stream) {
   if (Q < 0) return GLORIE_EINVAL;
   if (Q == 0) return GLORIE_OK;
-  if (!D || !I || !nn || !feats || !c_out) return GLORIE_EINVAL;
+  if (!D || !I || !nn || (c_out && !feats) || (!c_out && !w_out)) return GLORIE_EINVAL;
   if (k != 8 || c_dim != 32) return GLORIE_EUNSUPPORTED;
+  if (!c_out) {                 // weights + mask only
+    hipLaunchKernelGGL(idw_weights_kernel, dim3((Q + 255) / 256), dim3(256), 0, (hipStream_t)stream, D, I, nn, Q,
+                       radius, radius_ptr, min_nn, expo_weighting, w_out, has_out);
+    return check_launch();
+  }
   const long threads = (long)Q * 32;
   dim3 grid((unsigned)((threads + 255) / 256));
   hipLaunchKernelGGL((idw_gather_kernel<8, 32>), grid, dim3(256), 0, (hipStream_t)stream, D, I, nn,

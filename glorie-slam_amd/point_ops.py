@@ -81,15 +81,16 @@ class KnnIndex:
 def idw_gather(D, I, nn, feats, radius=0.0, radius_per_query=None, min_nn=2, expo=False,
                return_weights=False, raw_mask=False):
     """decoder.py:130-173: c [Q,32], has_neighbors [Q] bool (, weights [Q,8])"""
-    L.need_cuda(D, I, nn, feats)
+    L.need_cuda(D, I, nn)
     Q, k = D.shape
-    feats = feats.contiguous()
-    c = torch.empty(Q, feats.shape[1], dtype=torch.float32, device=D.device)
+    weights_only = feats is None                      # weights + mask only (the geometry kernel interpolates)
+    feats = feats.contiguous() if feats is not None else None
+    c = torch.empty(Q, feats.shape[1], dtype=torch.float32, device=D.device) if not weights_only else None
     has = torch.empty(Q, dtype=torch.uint8, device=D.device)
     w = torch.empty(Q, k, dtype=torch.float32, device=D.device) if return_weights else None
     rp = radius_per_query.reshape(-1).contiguous().float() if radius_per_query is not None else None
     L.check(L.load().glorie_idw_gather(L.ptr(D.contiguous()), L.ptr(I.contiguous()), L.ptr(nn.contiguous()),
-                                       L.ptr(feats), Q, k, feats.shape[1], float(radius), L.ptr(rp),
+                                       L.ptr(feats), Q, k, 32 if weights_only else feats.shape[1], float(radius), L.ptr(rp),
                                        int(min_nn), int(bool(expo)), L.ptr(c), L.ptr(w), L.ptr(has),
                                        L.stream_ptr()), "glorie_idw_gather")
     if not raw_mask:
@@ -253,10 +254,11 @@ def pack_decoders(decoders):
     return packed
 
 
-def render_mlp(packed, pts, views, cloud_pos, col_feats, c_geo, I, weights, has, stage="color"):
+def render_mlp(packed, pts, views, cloud_pos, col_feats, c_geo, I, weights, has, stage="color", geo_feats=None):
     """raw [Q,4] = (rgb, occ) for samples `pts` given their neighbours; occ = -100 where
-    has == False.  stage 'geometry' leaves rgb = 0."""
-    L.need_cuda(packed, pts, c_geo)
+    has == False.  stage 'geometry' leaves rgb = 0.  c_geo: the interpolated geometry feature [Q,32], or None
+    with geo_feats [Np,32]: the geometry kernel interpolates it itself from (I, weights)."""
+    L.need_cuda(packed, pts, c_geo if c_geo is not None else geo_feats)
     Q = pts.shape[0]
     dev = pts.device
     color = stage == "color"
@@ -269,7 +271,9 @@ def render_mlp(packed, pts, views, cloud_pos, col_feats, c_geo, I, weights, has,
         L.ptr(packed), L.ptr(pts.contiguous().float()),
         L.ptr(views.contiguous().float()) if color else None,
         L.ptr(cloud_pos.contiguous()) if color else None, L.ptr(col_feats.contiguous()) if color else None,
-        L.ptr(c_geo.contiguous()), L.ptr(I.contiguous()) if color else None,
-        L.ptr(weights.contiguous()) if color else None, L.ptr(has8), Q, L.ptr(scratch), L.ptr(raw),
-        int(color), L.stream_ptr()), "glorie_render_mlp")
+        L.ptr(c_geo.contiguous()) if c_geo is not None else None,
+        L.ptr(geo_feats.contiguous()) if c_geo is None else None,
+        L.ptr(I.contiguous()) if (color or c_geo is None) else None,
+        L.ptr(weights.contiguous()) if (color or c_geo is None) else None, L.ptr(has8), Q, L.ptr(scratch),
+        L.ptr(raw), int(color), L.stream_ptr()), "glorie_render_mlp")
     return raw

@@ -93,12 +93,13 @@ class Renderer(object):
         ev.record()
         D, I, nn_num = npc.find_neighbors_faiss(pts, step='query', dynamic_radius=rq)
         radius = 0.0 if g.use_dynamic_radius else npc.get_radius_query()
-        c_geo, has, w = point_ops.idw_gather(D, I, nn_num, npc_geo_feats, radius=radius,
-                                             radius_per_query=rq if g.use_dynamic_radius else None,
-                                             min_nn=g.min_nn_num, return_weights=True, raw_mask=True)
+        # weights and mask only: the geometry kernel interpolates its feature itself (no [Q,32] round trip)
+        _, has, w = point_ops.idw_gather(D, I, nn_num, None, radius=radius,
+                                         radius_per_query=rq if g.use_dynamic_radius else None,
+                                         min_nn=g.min_nn_num, return_weights=True, raw_mask=True)
         cp = cloud_pos if cloud_pos is not None else npc.cloud_pos()
-        raw = point_ops.render_mlp(decoders._packed(), pts, views, cp, npc_col_feats, c_geo, I, w, has,
-                                   stage=stage)
+        raw = point_ops.render_mlp(decoders._packed(), pts, views, cp, npc_col_feats, None, I, w, has,
+                                   stage=stage, geo_feats=npc_geo_feats)
         counts, valid = point_ops.ray_counts(has, S, 3)
         depth, var, rgb, _ = point_ops.composite(raw.view(R, S, 4), z_vals, self.sigmoid_coefficient,
                                                  return_weights=False)
