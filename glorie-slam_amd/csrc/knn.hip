@@ -310,9 +310,43 @@ __global__ __launch_bounds__(256) void knn_query_kernel(
     const KnnGrid* __restrict__ gp, const float* __restrict__ q, int Q, float radius,
     const float* __restrict__ radius_ptr, float* __restrict__ D, int64_t* __restrict__ I,
     int* __restrict__ nn) {
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= Q) return;
+  // The 256 queries of a workgroup are processed in the order of their grid cells: lanes that sit in the same
+  // cell walk the same shells over the same point ranges - identical trip counts and identical addresses
+  // (one L1 transaction per wave instead of one per lane) - where in ray order a wave straddles ~5 cells
+  // along its rays and every loop runs for the longest lane.  Each query is still searched by one lane and
+  // written to its own row, so the result does not depend on the order.  Sort key = (cell id, local index)
+  // in 30 bits (the build caps the grid at 2^22 cells), bitonic in LDS.
+  __shared__ unsigned skey[256];
+  const int tid = threadIdx.x;
+  const int base = blockIdx.x * 256;
   const KnnGrid g = *gp;
+  {
+    const int t = base + tid;
+    unsigned key = 0xffffffffu;
+    if (t < Q && g.npoints > 0) {
+      const int cx = cell_coord(q[(size_t)t * 3 + 0], g.ox, g.inv_cs, g.nx);
+      const int cy = cell_coord(q[(size_t)t * 3 + 1], g.oy, g.inv_cs, g.ny);
+      const int cz = cell_coord(q[(size_t)t * 3 + 2], g.oz, g.inv_cs, g.nz);
+      key = ((unsigned)((cz * g.ny + cy) * g.nx + cx) << 8) | (unsigned)tid;
+    } else if (t < Q) {
+      key = 0xffffff00u | (unsigned)tid;
+    }
+    skey[tid] = key;
+  }
+  __syncthreads();
+  for (int k = 2; k <= 256; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const int p = tid ^ j;
+      if (p > tid) {
+        const unsigned a = skey[tid], b = skey[p];
+        const bool up = (tid & k) == 0;
+        if ((a > b) == up) { skey[tid] = b; skey[p] = a; }
+      }
+      __syncthreads();
+    }
+  const unsigned mine = skey[tid];
+  if (mine == 0xffffffffu) return;           // past the end of the query array
+  const int t = base + (int)(mine & 255u);
   TopK<K> top;
   knn_search<K>(sorted, starts, g, q[(size_t)t * 3 + 0], q[(size_t)t * 3 + 1], q[(size_t)t * 3 + 2], top);
   const float r = radius_ptr ? radius_ptr[t] : radius;
