@@ -13,9 +13,10 @@
 // synchronisation, rebuilt in well under a millisecond for 0.5 M points (the reference
 // re-trains the IVF k-means on every insertion, neural_point.py:257,443).
 // Query = one lane per query, expanding Chebyshev shells of cells around the query cell until
-// the k-th best distance is provably inside the scanned cube.  Consecutive lanes hold
-// consecutive samples of the same ray, so a wave touches a handful of neighbouring cells and
-// the sorted point array (16 B per point, x y z + original index) stays L1/L2 resident.
+// the k-th best distance is provably inside the scanned cube.  The 256 queries of a workgroup
+// (consecutive samples of ~25 neighbouring rays) are processed in the order of their cells, so
+// the lanes of a wave share 2-3 cells and the sorted point array (16 B per point, x y z +
+// original index) stays L1/L2 resident.
 //
 // Distances are evaluated as ((dx*dx + dy*dy) + dz*dz) with every operation rounded to fp32
 // (no FMA contraction), which is what the numpy oracle computes.
