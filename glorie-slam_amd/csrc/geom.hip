@@ -9,6 +9,12 @@
 //   /root/reference/src/modules/droid_net/droid_net.py:9-23 (cvx_upsample)
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
+// Every fp32 operation of this file (and of the SE3 helpers it inlines) is rounded on its own, in the
+// source order of the reference kernels: hipcc's default -ffp-contract=fast would fuse mul+add pairs where
+// IT likes (nvcc fuses where nvcc likes - neither is reproducible from the source).  Without contraction the
+// integer-valued results (depth_filter counts, validity masks) and the thresholded ones (frame_distance,
+// on which graph topology depends) are bit-identical to oracle/geom.py; the kernels are bandwidth-bound.
+#pragma clang fp contract(off)
 #include "common.hiph"
 #include "se3.hiph"
 

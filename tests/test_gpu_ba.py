@@ -48,9 +48,10 @@ def run_gpu(g, dev, t0, t1, iters, lm=1e-4, ep=0.1, motion_only=False, depth_onl
     return poses.cpu().numpy(), disps.cpu().numpy(), dx.cpu().numpy(), dz.cpu().numpy(), st
 
 
-@pytest.mark.parametrize("K,h,w,iters", [(4, 12, 16, 1), (5, 24, 32, 2), (8, 30, 40, 2)])
-def test_ba_matches_oracle(gpu, K, h, w, iters):
-    g = make_problem(K, h, w)
+@pytest.mark.parametrize("K,h,w,iters,radius", [(4, 12, 16, 1, 2), (5, 24, 32, 2, 2), (8, 30, 40, 2, 2),
+                                                (8, 60, 80, 2, 3)])          # last: BASELINE graph G8
+def test_ba_matches_oracle(gpu, K, h, w, iters, radius):
+    g = make_problem(K, h, w, radius=radius)
     t0, t1 = 1, K
     rp, rd, rdx, rdz, info = oba.ba(g["poses"], g["disps"], g["intrinsics"][0], g["target"], g["weight"],
                                     g["eta"], g["ii"], g["jj"], t0, t1, iters, 1e-4, 0.1)

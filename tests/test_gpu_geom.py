@@ -26,8 +26,9 @@ def test_reproject(gpu, graph):
     ref_c, ref_v = ogeom.reproject(g["poses"], g["disps"], g["intrinsics"], ii, jj)
     c, v = db.reproject(_t(g["poses"], gpu), _t(g["disps"], gpu), _t(g["intrinsics"], gpu),
                         _t(ii, gpu), _t(jj, gpu))
-    np.testing.assert_allclose(c.cpu().numpy(), ref_c, rtol=1e-5, atol=2e-4)
-    assert (v.cpu().numpy() != ref_v).mean() < 1e-4
+    # strict fp32 (no contraction) in the reference's operation order: bit-identical to the oracle
+    assert np.array_equal(c.cpu().numpy(), ref_c)
+    assert np.array_equal(v.cpu().numpy(), ref_v)
 
 
 def test_frame_distance(gpu, graph):
@@ -40,9 +41,9 @@ def test_frame_distance(gpu, graph):
         ref = ogeom.frame_distance(g["poses"], g["disps"], g["intrinsics"][0], ii, jj, beta)
         got = db.frame_distance(_t(g["poses"], gpu), _t(g["disps"], gpu), _t(g["intrinsics"][0], gpu),
                                 _t(ii, gpu), _t(jj, gpu), beta).cpu().numpy()
-        np.testing.assert_allclose(got, ref, rtol=2e-5, atol=1e-5)
-        assert np.array_equal(np.argsort(got, kind="stable"), np.argsort(ref, kind="stable")) or \
-            np.allclose(np.sort(got), np.sort(ref), rtol=2e-5)
+        # same per-thread accumulation order, same tree, no contraction: the distances graph topology is
+        # thresholded on are bit-identical to the oracle
+        assert np.array_equal(got, ref), float(np.abs(got - ref).max())
 
 
 def test_frame_distance_invalid_returns_1000(gpu, graph):
@@ -73,8 +74,9 @@ def test_depth_filter(gpu):
     ref = ogeom.depth_filter(g["poses"], g["disps"], g["intrinsics"][0], ix, thresh)
     got = db.depth_filter(_t(g["poses"], gpu), _t(g["disps"], gpu), _t(g["intrinsics"][0], gpu),
                           _t(ix, gpu), _t(thresh, gpu)).cpu().numpy()
-    assert ref.max() >= 1
-    assert (got != ref).mean() < 2e-3
+    assert ref.max() >= 2 and (ref > 0).mean() > 0.2
+    # integer counts: bit-exact (the kernels of geom.hip round every fp32 operation on its own, like the oracle)
+    assert np.array_equal(got, ref)
 
 
 @pytest.mark.parametrize("half", [True, False])

@@ -134,6 +134,34 @@ def test_fused_update_matches_fp32_module(gpu, n, h, w):
         assert err_f <= 2.0 * err_h + 2e-3 * scale, (name, err_f, err_h)
 
 
+def test_fused_update_on_reference_fixture(gpu):
+    """FusedUpdate on the inputs of tests/golden/update_module.npz against the outputs the REFERENCE's
+    UpdateModule produced for them (fixture F1, minted from /root/reference/src/modules/droid_net by
+    tests/golden/make_golden.py; fp32 on CPU).  Tolerance = SURVEY 8(d) for the fp16 path: rel 2e-2 / abs 1e-2."""
+    import os
+    import numpy as np
+    from glorie_slam_amd.droid_net import UpdateModule, FusedUpdate
+    f = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "update_module.npz"))
+    torch.manual_seed(43)
+    mod = UpdateModule().eval()
+    psum = float(sum(p.detach().double().abs().sum() for p in mod.parameters()))
+    assert abs(psum - float(f["param_abs_sum"])) < 1e-6 * psum          # the fixture's weights
+    mod = mod.to(gpu)
+    g = torch.Generator().manual_seed(3)                                # the fixture's inputs (make_golden.py)
+    N, h, w = 3, 8, 10
+    x_net = torch.tanh(torch.randn(1, N, 128, h, w, generator=g)).to(gpu)
+    x_inp = torch.relu(torch.randn(1, N, 128, h, w, generator=g)).to(gpu)
+    x_corr = torch.randn(1, N, 196, h, w, generator=g).to(gpu)
+    x_flow = (torch.randn(1, N, 4, h, w, generator=g) * 3).to(gpu)
+    ii = torch.from_numpy(f["ii"]).to(gpu)
+    out = FusedUpdate(mod)(x_net, x_inp, x_corr, x_flow, ii, torch.from_numpy(f["jj"]).to(gpu))
+    for got, key in zip(out, ("net", "delta", "weight", "eta", "upmask")):
+        ref = torch.from_numpy(f[key].astype(np.float32)).to(gpu)
+        assert tuple(got.shape) == tuple(ref.shape), key
+        torch.testing.assert_close(got.float(), ref, rtol=2e-2, atol=1e-2 if key != "eta" else 2e-4,
+                                   msg=lambda m, k=key: f"{k}: {m}")
+
+
 def test_hoisted_context_term_equals_full_gate_convolution(gpu):
     """conv([net|inp|corr|flow]) == conv([net|corr|flow]) + conv_inp(inp): the gates with the context part
     evaluated once (FusedUpdate.precompute_context, fp16 per-pixel term added in the epilogue) against the
