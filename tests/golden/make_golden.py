@@ -94,9 +94,96 @@ class BruteNPC:
         return Dk, I, (Dk < r2).sum(-1).int()
 
 
+def render_cfg():
+    cfg = decoder_cfg()
+    cfg["rendering"] = {"N_surface": 10, "near_end_surface": 0.95, "far_end_surface": 1.05,
+                        "sample_near_pcl": True, "sigmoid_coef": 0.1, "near_end": 0.3}
+    return cfg
+
+
+def render_scene():
+    """a wall at x = 2 m seen from the origin (camera looking along +x, OpenGL rays of get_rays):
+    4000 surface hits x 3 along-ray copies (N_add = 3), 12x16 image whose top / bottom rows miss the wall"""
+    g = torch.Generator().manual_seed(11)
+    hits = torch.stack([torch.full((4000,), 2.0), torch.rand(4000, generator=g) * 3.0 - 1.5,
+                        torch.rand(4000, generator=g) * 2.0 - 1.0], -1)
+    cloud = torch.cat([hits * s for s in (0.95, 1.0, 1.05)], 0) + 0.005 * torch.randn(12000, 3, generator=g)
+    geo = torch.randn(12000, 32, generator=g) * 0.1
+    col = torch.randn(12000, 32, generator=g) * 0.1
+    c2w = torch.eye(4)
+    c2w[:3, :3] = torch.tensor([[0.0, 0.0, -1.0], [-1.0, 0.0, 0.0], [0.0, 1.0, 0.0]])
+    cam = dict(H=12, W=16, fx=10.0, fy=10.0, cx=7.5, cy=5.5)
+    depth = 2.0 * (1.0 + 0.01 * torch.randn(12 * 16, generator=g))
+    radius = (torch.rand(12 * 16, generator=g) * 0.12 + 0.04) * depth / 3.0
+    depth_zero = depth.clone()
+    depth_zero[torch.tensor([5, 40, 41, 77, 100, 150, 191])] = 0.0         # rays without a depth prior
+    return cloud, geo, col, c2w, cam, depth, depth_zero, radius
+
+
+def make_render():
+    """F11: Renderer.render_batch_ray / render_img of the reference (src/utils/Renderer.py:80-306) on CPU with the
+    exact-KNN fake npc; zero-depth rays go through the reference's own NeuralPointCloud.sample_near_pcl
+    (src/neural_point.py:315-375), borrowed as an unbound method (its class needs faiss to construct)."""
+    for name in ("faiss", "faiss.contrib", "faiss.contrib.torch_utils", "cv2"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    ds = types.ModuleType("src.utils.datasets")
+    ds.load_mono_depth = None
+    sys.modules.setdefault("src.utils.datasets", ds)
+    from src.utils.Renderer import Renderer
+    from src.utils.common import get_rays
+    from src.neural_point import NeuralPointCloud as RefNPC
+    from src.modules.conv_onet.models.decoder import POINT
+
+    class NPC(BruteNPC):
+        device = "cpu"
+        radius_query = 0.08
+        sample_near_pcl = RefNPC.sample_near_pcl
+
+    class Cam:
+        pass
+
+    cfg = render_cfg()
+    cloud, geo, col, c2w, cam, depth, depth_zero, radius = render_scene()
+    slam = Cam()
+    for k, v in cam.items():
+        setattr(slam, k, v)
+    torch.manual_seed(43)
+    dec = POINT(cfg, c_dim=32, hidden_size=128, use_view_direction=True).eval()
+    ren = Renderer(cfg, slam, ray_batch_size=50)
+    npc = NPC(cloud)
+    ro, rd = get_rays(cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"], cam["cy"], c2w, "cpu")
+    ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
+    out = {}
+    with torch.no_grad():
+        for tag, gt in (("a", depth), ("b", depth_zero)):
+            torch.manual_seed(0)
+            d, u, c, vm, vc = ren.render_batch_ray(npc, dec, rd, ro, "cpu", "color", gt_depth=gt, npc_geo_feats=geo,
+                                                   npc_col_feats=col, cloud_pos=cloud, dynamic_r_query=radius)
+            out.update({f"{tag}_depth": d.numpy(), f"{tag}_unc": u.numpy(), f"{tag}_color": c.numpy(),
+                        f"{tag}_mask": vm.numpy(), f"{tag}_count": vc.numpy()})
+        torch.manual_seed(0)
+        d, u, c, vm, vc = ren.render_img(npc, dec, c2w, "cpu", "color", gt_depth=depth_zero.reshape(12, 16),
+                                         npc_geo_feats=geo, npc_col_feats=col, dynamic_r_query=radius.reshape(12, 16),
+                                         cloud_pos=cloud)
+        out.update(img_depth=d.numpy(), img_unc=u.numpy(), img_color=c.numpy(), img_mask=vm.numpy(),
+                   img_count=vc.numpy())
+    psum = float(sum(p.detach().double().abs().sum() for p in dec.parameters()))
+    # the scene itself is NOT stored: tests call render_scene() (seeded) and check these sums
+    np.savez_compressed(os.path.join(OUT, "render.npz"),
+                        scene_sums=np.array([cloud.double().sum(), geo.double().abs().sum(),
+                                             col.double().abs().sum(), depth.double().sum(),
+                                             radius.double().sum()], np.float64),
+                        rays_o=ro.numpy(), rays_d=rd.numpy(), param_abs_sum=np.float64(psum), **out)
+    print("render.npz: valid rays", int(out["a_mask"].sum()), "/", out["a_mask"].size,
+          "| zero-depth variant", int(out["b_mask"].sum()))
+
+
 def main():
     install_stubs()
     torch.set_num_threads(4)
+    if "--only-render" in sys.argv:
+        make_render()
+        return
     from src.modules.droid_net.corr import CorrBlock
     from src.modules.droid_net.droid_net import UpdateModule, cvx_upsample, GraphAgg
     from src.modules.droid_net.gru import ConvGRU
@@ -214,6 +301,7 @@ def main():
                         color_B_pos=dec.color_decoder.embedder._B.numpy(),
                         color_B_view=dec.color_decoder.embedder_view_direction._B.numpy(),
                         **{"sd__" + k: v for k, v in sd.items()})
+    make_render()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KB")

@@ -203,6 +203,79 @@ def test_render_batch_ray_end_to_end(gpu):
     assert (c.cpu().numpy() >= 0).all() and (c.cpu().numpy() <= 1).all()
 
 
+def _reference_render_setup(gpu, ray_batch_size=65536):
+    """scene, decoders and renderer of fixture F11 (tests/golden/render.npz, minted from the reference's
+    Renderer by tests/golden/make_golden.py::make_render)"""
+    from golden.make_golden import render_scene, render_cfg
+    from glorie_slam_amd.decoder import POINT
+    from glorie_slam_amd.neural_point import NeuralPointCloud
+    from glorie_slam_amd.renderer import Renderer
+    f = np.load(os.path.join(GOLD, "render.npz"))
+    cloud, geo, col, c2w, cam, depth, depth_zero, radius = render_scene()
+    sums = [cloud.double().sum(), geo.double().abs().sum(), col.double().abs().sum(), depth.double().sum(),
+            radius.double().sum()]
+    np.testing.assert_allclose([float(v) for v in sums], f["scene_sums"], rtol=1e-12)
+    cfg = dict(_cfg(gpu))
+    cfg["rendering"] = render_cfg()["rendering"]
+    torch.manual_seed(43)
+    dec = POINT(cfg, c_dim=32, hidden_size=128, use_view_direction=True).eval()
+    psum = float(sum(p.detach().double().abs().sum() for p in dec.parameters()))
+    assert abs(psum - float(f["param_abs_sum"])) < 1e-9 * psum           # the fixture's decoder weights
+    dec = dec.to(gpu)
+    npc = NeuralPointCloud(cfg)
+    npc.add_points(cloud.to(gpu), geo.to(gpu), col.to(gpu))
+
+    class Cam:
+        pass
+    c = Cam()
+    for k, v in cam.items():
+        setattr(c, k, v)
+    ren = Renderer(cfg, c, ray_batch_size=ray_batch_size)
+    t = lambda k: torch.from_numpy(f[k]).to(gpu)
+    return f, npc, dec, ren, t("rays_o"), t("rays_d"), c2w.to(gpu), depth.to(gpu), depth_zero.to(gpu), radius.to(gpu)
+
+
+def _check_render(got, f, tag, sel=None):
+    """rendered colours 1e-3; depth / variance rel 1e-3; masks and counts exact"""
+    d, u, c, vm, cnt = [x.detach().cpu().numpy() for x in got]
+    pick = (lambda a: a) if sel is None else (lambda a: a[sel])
+    ref = {k: pick(f[f"{tag}_{k}"].reshape((-1, 3) if k == "color" else (-1,)))
+           for k in ("depth", "unc", "color", "mask", "count")}
+    assert np.array_equal(pick(vm.reshape(-1)).astype(bool), ref["mask"].astype(bool)), tag + " valid_ray_mask"
+    assert np.array_equal(pick(cnt.reshape(-1)).astype(np.int64), ref["count"].astype(np.int64)), tag + " counts"
+    np.testing.assert_allclose(pick(c.reshape(-1, 3)), ref["color"], atol=1e-3, err_msg=tag + " colour")
+    np.testing.assert_allclose(pick(d.reshape(-1)), ref["depth"], rtol=1e-3, atol=1e-4, err_msg=tag + " depth")
+    np.testing.assert_allclose(pick(u.reshape(-1)), ref["unc"], rtol=5e-3, atol=1e-5, err_msg=tag + " uncertainty")
+
+
+def test_render_batch_ray_matches_reference_renderer(gpu):
+    """Renderer.render_batch_ray (Renderer.py:80-219) against the outputs of the REFERENCE's Renderer on the
+    same cloud / decoders / rays (fixture F11): the HIP-only fast path (every ray has a depth prior), the
+    general path, and the batch with zero-depth rays (sample_near_pcl branch, neural_point.py:315-375)."""
+    f, npc, dec, ren, ro, rd, c2w, depth, depth_zero, radius = _reference_render_setup(gpu)
+    kw = dict(npc_geo_feats=npc.geo_feats, npc_col_feats=npc.col_feats, cloud_pos=npc.cloud_pos(),
+              dynamic_r_query=radius)
+    with torch.no_grad():
+        ren.use_fast_path = True
+        _check_render(ren.render_batch_ray(npc, dec, rd, ro, gpu, "color", gt_depth=depth, **kw), f, "a")
+        ren.use_fast_path = False
+        _check_render(ren.render_batch_ray(npc, dec, rd, ro, gpu, "color", gt_depth=depth, **kw), f, "a")
+        ren.use_fast_path = True
+        _check_render(ren.render_batch_ray(npc, dec, rd, ro, gpu, "color", gt_depth=depth_zero, **kw), f, "b")
+    assert 100 < int(f["a_mask"].sum()) < 192 and int((f["a_count"] == 0).sum()) > 10   # a non-trivial fixture
+
+
+def test_render_img_matches_reference_renderer(gpu):
+    """Renderer.render_img (Renderer.py:222-306) with the reference's 50-ray batches: get_rays, per-batch `far`,
+    float64 outputs -- against the image the reference rendered (fixture F11)"""
+    f, npc, dec, ren, ro, rd, c2w, depth, depth_zero, radius = _reference_render_setup(gpu, ray_batch_size=50)
+    H, W = ren.H, ren.W
+    out = ren.render_img(npc, dec, c2w, gpu, "color", gt_depth=depth_zero.reshape(H, W), npc_geo_feats=npc.geo_feats,
+                         npc_col_feats=npc.col_feats, dynamic_r_query=radius.reshape(H, W), cloud_pos=npc.cloud_pos())
+    assert out[0].dtype == torch.float64 and out[0].shape == (H, W) and out[2].shape == (H, W, 3)
+    _check_render(out, f, "img")
+
+
 def test_render_fast_path_equals_general_path(gpu):
     """all rays with a depth prior: render_batch_ray takes the HIP-only path (ray_samples, KNN, gather,
     decoders, ray_counts, compositing); same numbers as the general path built from torch ops.  One ray
