@@ -243,7 +243,10 @@ def _check_render(got, f, tag, sel=None):
            for k in ("depth", "unc", "color", "mask", "count")}
     assert np.array_equal(pick(vm.reshape(-1)).astype(bool), ref["mask"].astype(bool)), tag + " valid_ray_mask"
     assert np.array_equal(pick(cnt.reshape(-1)).astype(np.int64), ref["count"].astype(np.int64)), tag + " counts"
-    np.testing.assert_allclose(pick(c.reshape(-1, 3)), ref["color"], atol=1e-3, err_msg=tag + " colour")
+    # a ray none of whose samples has neighbours is coloured from the reference's RANDOM placeholder features
+    # (decoder.py:170-171,386-387: N(0, 0.01) per call) - not reproducible, and masked invalid either way
+    seen = ref["count"] > 0
+    np.testing.assert_allclose(pick(c.reshape(-1, 3))[seen], ref["color"][seen], atol=1e-3, err_msg=tag + " colour")
     np.testing.assert_allclose(pick(d.reshape(-1)), ref["depth"], rtol=1e-3, atol=1e-4, err_msg=tag + " depth")
     np.testing.assert_allclose(pick(u.reshape(-1)), ref["unc"], rtol=5e-3, atol=1e-5, err_msg=tag + " uncertainty")
 
@@ -270,6 +273,10 @@ def test_render_img_matches_reference_renderer(gpu):
     float64 outputs -- against the image the reference rendered (fixture F11)"""
     f, npc, dec, ren, ro, rd, c2w, depth, depth_zero, radius = _reference_render_setup(gpu, ray_batch_size=50)
     H, W = ren.H, ren.W
+    from glorie_slam_amd.common import get_rays
+    go, gd = get_rays(H, W, ren.fx, ren.fy, ren.cx, ren.cy, c2w, gpu)         # R7 on the device == reference rays
+    np.testing.assert_allclose(gd.reshape(-1, 3).cpu().numpy(), f["rays_d"], atol=1e-6)
+    np.testing.assert_allclose(go.reshape(-1, 3).cpu().numpy(), f["rays_o"], atol=1e-6)
     out = ren.render_img(npc, dec, c2w, gpu, "color", gt_depth=depth_zero.reshape(H, W), npc_geo_feats=npc.geo_feats,
                          npc_col_feats=npc.col_feats, dynamic_r_query=radius.reshape(H, W), cloud_pos=npc.cloud_pos())
     assert out[0].dtype == torch.float64 and out[0].shape == (H, W) and out[2].shape == (H, W, 3)
