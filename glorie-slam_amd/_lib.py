@@ -25,6 +25,8 @@ SIGNATURES = {
     "glorie_last_hip_error": (_c_int, []),
     "glorie_ctx_create": (_c_int, [ctypes.POINTER(_vp), _sz]),
     "glorie_ctx_destroy": (_c_int, [_vp]),
+    "glorie_ctx_reserve": (_c_int, [_vp, _sz]),
+    "glorie_ctx_generation": (ctypes.c_ulonglong, [_vp]),
     "glorie_corr_index_fwd": (_c_int, [_vp, _vp, _vp] + [_c_int] * 7 + [_vp]),
     "glorie_corr_lookup_pyramid": (_c_int, [_vp, _c_int, _vp, _vp] + [_c_int] * 7 + [_vp]),
     "glorie_corr_otf": (_c_int, [_vp, _vp, _c_int, _vp, _vp, _vp, _vp] + [_c_int] * 4 + [_vp]),
@@ -140,6 +142,13 @@ class Context:
         h = ctypes.c_void_p()
         check(lib.glorie_ctx_create(ctypes.byref(h), scratch_bytes), "glorie_ctx_create")
         self.handle = h
+
+    def generation(self):
+        """how often the scratch arena moved (launches recorded before a move point into freed memory)"""
+        return int(load().glorie_ctx_generation(self.handle))
+
+    def reserve(self, scratch_bytes):
+        check(load().glorie_ctx_reserve(self.handle, scratch_bytes), "glorie_ctx_reserve")
 
     def ba_status(self):
         out = (ctypes.c_int * 4)()

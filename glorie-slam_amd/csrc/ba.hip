@@ -536,7 +536,7 @@ constexpr int kNB = 32;
 constexpr int kTrailTile = 64;
 __global__ __launch_bounds__(256) void chol_trail_kernel(BaWork wk, int n, int j0, int nb) {
   __shared__ double Ar[kTrailTile][kNB + 1], Ac[kTrailTile][kNB + 1];
-  if (wk.status[0] & (BA_ST_CHOL_FAILED | BA_ST_M_MISMATCH)) return;
+  if (wk.status[0] & (BA_ST_SOLVE_ABORT | BA_ST_M_MISMATCH)) return;
   const int base = j0 + nb, rem = n - base;
   const int tr = blockIdx.y, tc = blockIdx.x;
   if (tc > tr) return;
@@ -582,6 +582,7 @@ __global__ __launch_bounds__(256) void chol_trail_kernel(BaWork wk, int n, int j
 
 __global__ __launch_bounds__(256) void chol_damp_kernel(BaWork wk, int n, float lm, float ep) {
   const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i == 0) atomicAnd(&wk.status[0], ~BA_ST_SOLVE_ABORT);     // first launch of a large-system solve
   if (i < n) {
     double v = wk.Hd[(size_t)i * n + i];
     wk.Hd[(size_t)i * n + i] = v + (double)ep + (double)lm * v;
@@ -1007,7 +1008,7 @@ __global__ __launch_bounds__(1024) void chol_diag_inv_kernel(BaWork wk, int n, i
   const int tid = threadIdx.x, br = tid >> 5, bc = tid & 31;
   double* A = wk.Hd;
   if (tid == 0) fail = 0;
-  if (wk.status[0] & (BA_ST_CHOL_FAILED | BA_ST_M_MISMATCH)) return;
+  if (wk.status[0] & (BA_ST_SOLVE_ABORT | BA_ST_M_MISMATCH)) return;
   if (br < nb && bc <= br) {
     Dl[br * kCBP + bc] = A[(size_t)(j0 + br) * n + j0 + bc];
     Wl[br * kCBP + bc] = br == bc ? 1.0 : 0.0;
@@ -1025,7 +1026,7 @@ __global__ __launch_bounds__(1024) void chol_diag_inv_kernel(BaWork wk, int n, i
   }
   if (fail) {
     if (tid == 0) {
-      atomicOr(&wk.status[0], BA_ST_CHOL_FAILED);
+      atomicOr(&wk.status[0], BA_ST_CHOL_FAILED | BA_ST_SOLVE_ABORT);
       atomicAdd(&wk.status[2], 1);
     }
     return;
@@ -1042,7 +1043,7 @@ __global__ __launch_bounds__(1024) void chol_diag_inv_kernel(BaWork wk, int n, i
 constexpr int kPanelRows = 128;
 __global__ __launch_bounds__(1024) void chol_panel_gemm_kernel(BaWork wk, int n, int j0, int nb) {
   __shared__ double Wl[kCB * kCBP], P[kPanelRows * kCBP];
-  if (wk.status[0] & (BA_ST_CHOL_FAILED | BA_ST_M_MISMATCH)) return;
+  if (wk.status[0] & (BA_ST_SOLVE_ABORT | BA_ST_M_MISMATCH)) return;
   const int tid = threadIdx.x, br = tid >> 5, bc = tid & 31;
   double* A = wk.Hd;
   const int base = j0 + nb, rem = n - base;
@@ -1089,7 +1090,7 @@ __global__ __launch_bounds__(256) void chol_backsub_block_kernel(BaWork wk, int 
   const int tid = threadIdx.x;
   double* A = wk.Hd;
   double* y = A + (size_t)n * n;
-  if (wk.status[0] & (BA_ST_CHOL_FAILED | BA_ST_M_MISMATCH)) {
+  if (wk.status[0] & (BA_ST_SOLVE_ABORT | BA_ST_M_MISMATCH)) {
     if (blockIdx.x == 0 && tid < nb) wk.dx[j0 + tid] = 0.0f;
     return;
   }

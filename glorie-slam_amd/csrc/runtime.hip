@@ -29,6 +29,7 @@ int ctx_reserve(Ctx* ctx, size_t bytes) {
   }
   ctx->scratch = p;
   ctx->scratch_bytes = want;
+  ctx->generation += 1;
   return GLORIE_OK;
 }
 
@@ -60,6 +61,13 @@ extern "C" int glorie_ctx_create(glorie_ctx** out, size_t scratch_bytes) {
   }
   *out = c;
   return GLORIE_OK;
+}
+
+extern "C" unsigned long long glorie_ctx_generation(const glorie_ctx* ctx) { return ctx ? ctx->generation : 0ull; }
+
+extern "C" int glorie_ctx_reserve(glorie_ctx* ctx, size_t scratch_bytes) {
+  if (!ctx) return GLORIE_EINVAL;
+  return glorie::ctx_reserve(ctx, scratch_bytes);
 }
 
 extern "C" int glorie_ctx_destroy(glorie_ctx* ctx) {

@@ -10,10 +10,14 @@ Extra entry points (fused forms the reference builds out of several torch ops):
 ``corr_lookup_pyramid``, ``reproject``, ``cvx_upsample``.
 """
 import ctypes
+import os
 
 import torch
 
 from . import _lib as L
+
+
+_CHECK_STATUS = os.environ.get("GLORIE_CHECK_STATUS", "0") not in ("", "0")
 
 
 def _i64(t, name):
@@ -307,4 +311,13 @@ def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, 
                                int(bool(depth_only)), L.ptr(dx),
                                L.ptr(dz) if (dz is not None and dz.numel()) else None,
                                L.stream_ptr()), "glorie_ba")
+    if _CHECK_STATUS:
+        # opt-in (GLORIE_CHECK_STATUS=1): surface what the reference raises on the host - a shape mismatch of
+        # eta (droid_kernels.cu:1339-1352) - and report Cholesky failures; costs a device synchronisation
+        st = ctx.ba_status()
+        if st[0] & 1:
+            raise RuntimeError(f"ba: eta has {M} rows but unique(cat(arange(t0, t1), ii)) has {st[1]} frames")
+        if st[0] & 4:
+            import warnings
+            warnings.warn(f"ba: {st[2]} Gauss-Newton iteration(s) had a non positive definite system (zero update)")
     return [dx, dz] if want_updates else []

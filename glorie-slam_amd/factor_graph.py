@@ -195,31 +195,69 @@ class FactorGraph:
         motn = torch.cat([coords1 - self.coords0, self.target - coords1], dim=-1)
         return motn.permute(0, 1, 4, 2, 3).clamp(-64.0, 64.0)
 
+    def _window(self, t0, t1, use_inactive):
+        """(t0, t1) as the reference resolves them when the caller passes None (factor_graph.py:229-230:
+        t0 = max(1, ii.min() + 1); depth_video.py:211-212: t1 = max over the BA's edge list + 1), from host
+        mirrors of the edge lists cached with the edge set: no .item() per call, and a captured update
+        contains no host decision"""
+        if t0 is not None and t1 is not None:
+            return t0, t1
+        st = self._graphs.get("edge_stats")
+        if st is None:
+            hi, hj = self._host(self.ii), self._host(self.jj)
+            st = self._graphs["edge_stats"] = (int(hi.min()), int(max(hi.max(), hj.max())),
+                                               self._host(self.ii_inac), self._host(self.jj_inac))
+        if t0 is None:
+            t0 = max(1, st[0] + 1)
+        if t1 is None:
+            top = st[1]
+            if use_inactive and st[2].size:
+                m = (st[2] >= t0 - 3) & (st[3] >= t0 - 3)
+                if m.any():
+                    top = max(top, int(st[2][m].max()), int(st[3][m].max()))
+            t1 = top + 1
+        return t0, t1
+
+    def _arena_generations(self):
+        from . import _lib as L
+        return (self.video.ctx().generation(), L.default_context().generation())
+
     @torch.no_grad()
     def update(self, t0=None, t1=None, itrs=2, use_inactive=False, EP=1e-7, motion_only=False,
                opt_type="pose_depth"):
         """factor_graph.py:212-256.  With use_graphs the launch sequence of one call is captured
         the second time it is seen for the current edge set and replayed afterwards."""
         sharded = getattr(self.video, "shard", None) is not None and self.video.shard["world"] > 1
-        if not self.use_graphs or use_inactive or self.corr_impl == "otf" or self.ii.numel() == 0:
+        if self.ii.numel() == 0:
+            return self._update_eager(t0, t1, itrs, use_inactive, EP, motion_only, opt_type)
+        t0, t1 = self._window(t0, t1, use_inactive)
+        if not self.use_graphs or self.corr_impl == "otf":
             return self._update_eager(t0, t1, itrs, use_inactive, EP, motion_only, opt_type)
         # sharded graphs: everything up to the BA is replayed, the BA (all-reduce of the normal equations,
         # the all-reduced fallback decision) and the row exchange are issued eagerly behind it
-        key = (self._topo, t0, t1, itrs, float(EP), bool(motion_only), opt_type, sharded)
+        key = (self._topo, t0, t1, itrs, bool(use_inactive), float(EP), bool(motion_only), opt_type, sharded)
         ent = self._graphs.get(key)
         if ent is None:                     # first sighting: run eagerly (packs weights, sizes scratch buffers)
             self._graphs[key] = "seen"
             return self._update_eager(t0, t1, itrs, use_inactive, EP, motion_only, opt_type)
         if ent == "seen":
             try:
-                ent = self._capture(key, (t0, t1, itrs, False, EP, motion_only, opt_type, not sharded))
+                ent = self._capture(key, (t0, t1, itrs, use_inactive, EP, motion_only, opt_type, not sharded))
             except Exception as exc:        # a failed capture must not take the step down: stay eager
                 import warnings
                 warnings.warn(f"hipGraph capture of FactorGraph.update failed ({exc!r}); running eagerly")
                 ent = self._graphs[key] = "eager"
         if ent == "eager":
             return self._update_eager(t0, t1, itrs, use_inactive, EP, motion_only, opt_type)
-        graph, s_net, s_target, s_weight, ba_args, deferred = ent
+        if ent[-1] != self._arena_generations():
+            # a scratch arena moved since the capture (another graph, the backend or a bigger KNN build grew
+            # it): the recorded launches point into freed memory.  Drop them; this call runs eagerly and the
+            # edge set is captured again on its next sighting.
+            for k in [k for k, v in self._graphs.items() if isinstance(v, tuple) and k not in ("static", "edge_stats")
+                      and isinstance(v[0], torch.cuda.CUDAGraph)]:
+                self._graphs[k] = "seen"
+            return self._update_eager(t0, t1, itrs, use_inactive, EP, motion_only, opt_type)
+        graph, s_net, s_target, s_weight, ba_args, deferred, _gen = ent
         for dst, src in ((s_net, self.net), (s_target, self.target), (s_weight, self.weight)):
             if src is not dst:
                 dst.copy_(src)
@@ -272,7 +310,8 @@ class FactorGraph:
         finally:
             # the capture did not execute anything: restore the state the caller had
             self.net, self.target, self.weight = keep
-        ent = (graph, s_net, s_target, s_weight, ba_args, bool(self.video.deferred_fallback))
+        ent = (graph, s_net, s_target, s_weight, ba_args, bool(self.video.deferred_fallback),
+               self._arena_generations())
         self._graphs[key] = ent
         return ent
 
@@ -298,8 +337,8 @@ class FactorGraph:
             with torch.autocast("cuda", enabled=True):
                 self.net, delta, weight, damping, upmask = \
                     self.update_op(self.net, self.inp, corr, motn, self.ii, self.jj)
-        if t0 is None:
-            t0 = max(1, self._uniq_cache[2] + 1)
+        if t0 is None or t1 is None:
+            t0, t1 = self._window(t0, t1, use_inactive)
         if self.target.shape == coords1.shape and self.target.dtype == torch.float32 and self.target.is_contiguous():
             torch.add(coords1, delta.to(dtype=torch.float), out=self.target)   # no new tensor, no copy when captured
         else:
@@ -340,6 +379,16 @@ class FactorGraph:
             damping = damping.reshape(-1, self.ht, self.wd).to(self.damping.dtype).mul(0.2).add_(EP)
         else:
             damping = .2 * self.damping[uq].contiguous() + EP
+        if opt_type == "pose_depth" and not motion_only and not sharded:
+            # ba_cuda views eta as [len(unique(cat(arange(t0, t1), ii))), h*w] and raises when the sizes
+            # disagree (droid_kernels.cu:1339-1352); the device only sets a status bit, so the count is
+            # checked here against the host mirror of the edge list (cached with the edge set)
+            ck = ("slots", t0, t1, bool(use_inactive))
+            if ck not in self._graphs:
+                self._graphs[ck] = int(np.unique(np.concatenate([np.arange(t0, t1), self._host(ii)])).size)
+            if damping.shape[0] != self._graphs[ck]:
+                raise RuntimeError(f"FactorGraph.update: eta has {damping.shape[0]} frames, the BA window "
+                                   f"[{t0}, {t1}) + the source frames of the edges span {self._graphs[ck]}")
         self._ba_args = (target, weight, damping, ii, jj, uniq, upmask, t0, t1)
         if run_ba:
             self._update_finish(itrs, motion_only, opt_type)

@@ -52,6 +52,12 @@ typedef struct glorie_ctx glorie_ctx;
  * stream capture). */
 int glorie_ctx_create(glorie_ctx** out, size_t scratch_bytes);
 int glorie_ctx_destroy(glorie_ctx* ctx);
+/* Grow the arena to at least scratch_bytes now (never inside a stream capture).  Growing re-allocates:
+ * kernels recorded into a hipGraph before the move still point into the old block. */
+int glorie_ctx_reserve(glorie_ctx* ctx, size_t scratch_bytes);
+/* Number of times the arena of `ctx` has moved.  An owner of recorded launches (FactorGraph's hipGraph replay)
+ * compares it with the value at capture time and re-captures when it differs. */
+unsigned long long glorie_ctx_generation(const glorie_ctx* ctx);
 
 /* ------------------------------------------------------------------------------------ */
 /* A. correlation lookup                                                                 */

@@ -283,3 +283,44 @@ def test_solver_kernels_on_synthetic_spd_systems(gpu, P, bw):
     assert st[0] == 0 and st[3] == 0
     got = dx.cpu().numpy().reshape(-1).astype(np.float64)
     np.testing.assert_allclose(got, ref, rtol=2e-5, atol=1e-7 * np.abs(ref).max())
+
+
+def test_large_system_failed_iteration_does_not_poison_the_next(gpu):
+    """n = 546 > 540 (multi-launch Cholesky): a factorisation that fails zeroes ITS update only; the next
+    solve on the same context - the second Gauss-Newton iteration of one glorie_ba call re-uses the status
+    word without another ba_prepare - factorises on its own like SparseBlock::solve (droid_kernels.cu:1192-1213)"""
+    from glorie_slam_amd import _lib as L
+    P = 91
+    n = 6 * P
+    rng = np.random.default_rng(5)
+    A = rng.standard_normal((n, n)) * 0.05
+    H = A @ A.T + np.eye(n)
+    v = rng.standard_normal(n)
+    lm, ep = 1e-4, 0.1
+    ref = np.linalg.solve(H + np.diag(ep + lm * np.diag(H)), v)
+    lib, ctx = L.load(), L.Context()
+    B = P + 1
+    poses = torch.zeros(B, 7, device=gpu)
+    poses[:, 6] = 1.0
+    disps = torch.ones(B, 2, 2, device=gpu)
+    hv = torch.zeros(n * n + n, dtype=torch.float64, device=gpu)
+    L.check(lib.glorie_ba_build_system(ctx.handle, L.ptr(poses), L.ptr(disps), None, None, None, None, None,
+                                       None, None, B, 0, 1, 2, 2, 1, B, 0, L.ptr(hv), L.stream_ptr()), "build")
+
+    def solve(Hm):
+        hv.copy_(torch.from_numpy(np.concatenate([np.tril(Hm).reshape(-1), v])))
+        dx = torch.full((P, 6), 7.0, device=gpu)
+        L.check(lib.glorie_ba_solve_update(ctx.handle, L.ptr(poses), L.ptr(disps), None, None, B, 0, 1, 2, 2, 1, B,
+                                           lm, ep, 0, 0, L.ptr(hv), L.ptr(dx), None, L.stream_ptr()), "solve")
+        torch.cuda.synchronize()
+        return dx.cpu().numpy().reshape(-1).astype(np.float64), ctx.ba_status()
+
+    bad = H.copy()
+    bad[300, 300] = -50.0                                  # not positive definite (fails in the 10th column block)
+    dx, st = solve(bad)
+    assert np.all(dx == 0) and st[0] & 4 and st[2] == 1
+    p_before = poses.clone()
+    dx, st = solve(H)                                      # same context, no ba_prepare in between
+    assert st[2] == 1                                      # no new failure
+    np.testing.assert_allclose(dx, ref, rtol=2e-5, atol=1e-7 * np.abs(ref).max())
+    assert not torch.equal(poses, p_before)                # ... and the update was applied

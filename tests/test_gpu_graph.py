@@ -255,3 +255,64 @@ def test_full_resolution_valid_mask_and_video_npz(gpu, tmp_path):
     assert z["poses"].shape == (n, 4, 4) and z["depths"].shape == (n, 96, 128) and z["timestamps"].shape == (n,)
     assert z["valid_depth_masks"].dtype == np.bool_ and z["valid_depth_masks"].shape == (n, 96, 128)
     np.testing.assert_allclose(z["depths"][1], 1.0 / video.disps_up[1].cpu().numpy(), rtol=1e-6)
+
+
+def _replay_graph(gpu, use_graphs, K=6, h=24, w=32):
+    from glorie_slam_amd.factor_graph import FactorGraph
+    from glorie_slam_amd.droid_net import UpdateModule
+    g, video = make_video(gpu, K, h, w)
+    video.cfg["tracking"]["multiview_filter"]["thresh"] = 0.25
+    torch.manual_seed(43)
+    net = UpdateModule().to(gpu).eval()
+    graph = FactorGraph(video, net, device=str(gpu), use_graphs=use_graphs)
+    graph.add_factors(torch.as_tensor(g["ii"], device=gpu), torch.as_tensor(g["jj"], device=gpu))
+    return video, graph
+
+
+def test_graph_replay_with_inactive_factors_matches_eager(gpu):
+    """the frontend's call (use_inactive=True, t0 = t1 = None: frontend.py:50-53) is captured too: (t0, t1) are
+    resolved from host mirrors of the edge lists and the [inactive | active] buffers are static per edge set"""
+    outs = []
+    for use_graphs in (False, True):
+        video, graph = _replay_graph(gpu, use_graphs, K=7)
+        graph.rm_factors((graph.ii == 0) | (graph.jj == 0), store=True)        # frame 0's edges retire
+        assert graph.ii_inac.numel() > 0
+        for i in range(8):
+            graph.update(None, None, use_inactive=True, opt_type="pose_depth" if i % 2 == 0 else "depth_scale")
+        if use_graphs:
+            captured = [v for v in graph._graphs.values()
+                        if isinstance(v, tuple) and isinstance(v[0], torch.cuda.CUDAGraph)]
+            assert len(captured) == 2
+        assert graph._ba_args[7] == 2 and graph._ba_args[8] == 7             # t0 = max(1, ii.min() + 1), t1 = K
+        outs.append([t.float().clone() for t in (video.poses, video.disps, video.disps_up, graph.net, graph.target,
+                                                  graph.weight)])
+    for name, a, b in zip(["poses", "disps", "disps_up", "net", "target", "weight"], *outs):
+        assert torch.isfinite(a).all(), name
+        torch.testing.assert_close(a, b, atol=2e-3, rtol=2e-3, msg=lambda m, n=name: f"{n}: {m}")
+
+
+def test_graph_replay_survives_a_moved_scratch_arena(gpu):
+    """growing the context's scratch arena re-allocates it; launches recorded into a hipGraph before that hold
+    pointers into the freed block.  The context counts its moves (glorie_ctx_generation) and FactorGraph
+    drops captured updates whose generation is stale instead of replaying them."""
+    video_e, eager = _replay_graph(gpu, False)
+    video_g, graph = _replay_graph(gpu, True)
+    for i in range(4):
+        for gr in (eager, graph):
+            gr.update(t0=1, t1=6, itrs=2, opt_type="pose_depth")
+    key = [k for k, v in graph._graphs.items() if isinstance(v, tuple) and isinstance(v[0], torch.cuda.CUDAGraph)]
+    assert len(key) == 1
+    ctx = video_g.ctx()
+    gen0 = ctx.generation()
+    ctx.reserve(1 << 28)                                     # e.g. the backend's global BA on the same video
+    assert ctx.generation() == gen0 + 1
+    junk = torch.full((1 << 24,), float("nan"), device=gpu)  # make re-use of the freed block likely
+    for i in range(4):
+        for gr in (eager, graph):
+            gr.update(t0=1, t1=6, itrs=2, opt_type="pose_depth")
+    assert graph._graphs[key[0]][-1] == (gen0 + 1, graph._arena_generations()[1])    # captured again
+    torch.cuda.synchronize()
+    del junk
+    for a, b in ((video_e.poses, video_g.poses), (video_e.disps, video_g.disps), (eager.target, graph.target)):
+        assert torch.isfinite(b).all()
+        torch.testing.assert_close(a, b, atol=2e-3, rtol=2e-3)
