@@ -163,15 +163,20 @@ def test_rm_factors_and_rm_keyframe(gpu):
     graph = make_graph(gpu, video)
     graph.add_neighborhood_factors(0, 6, r=2)
     n0 = graph.ii.shape[0]
-    mask = graph.ii == 5
+    mask = (graph.ii == 5) | (graph.jj == 5)
     graph.rm_factors(mask, store=True)
     assert graph.ii.shape[0] == n0 - int(mask.sum()) and graph.ii_inac.shape[0] == int(mask.sum())
     rows_per_edge = graph.ht * graph.wd if graph.corr.tiled else 1
     assert graph.corr.corr_pyramid[0].shape[0] == graph.ii.shape[0] * rows_per_edge
     graph.rm_keyframe(3)
-    assert int(graph.ii.max()) <= 4 and not ((graph.ii == 3) & (graph.jj == 3)).any()
-    graph.update(t0=1, t1=5, itrs=1)
-    assert torch.isfinite(video.poses).all()
+    assert int(graph.ii.max()) <= 3 and not ((graph.ii == 3) & (graph.jj == 3)).any()
+    p0 = video.poses.clone()
+    graph.update(t0=1, t1=4, itrs=1)
+    assert torch.isfinite(video.poses).all() and not torch.equal(video.poses, p0)
+    # a window that contains a frame without outgoing edges: eta has one row less than the BA has frames.  The
+    # reference fails in ba_cuda (eta.view); the device would only set a status bit, so the host mirror raises
+    with pytest.raises(RuntimeError, match="eta has"):
+        graph.update(t0=1, t1=5, itrs=1)
 
 
 def test_normalize_and_valid_mask(gpu):
