@@ -54,6 +54,7 @@ SIGNATURES = {
     "glorie_ba": (_c_int, [_vp] * 10 + [_c_int] * 8 + [_c_f, _c_f, _c_int, _c_int, _vp, _vp, _vp]),
     "glorie_ba_build_system": (_c_int, [_vp] * 10 + [_c_int] * 8 + [_vp, _vp]),
     "glorie_ba_solve_update": (_c_int, [_vp] * 5 + [_c_int] * 7 + [_c_f, _c_f, _c_int, _c_int] + [_vp] * 4),
+    "glorie_ba_pack_system": (_c_int, [_vp, _vp, _c_int, _c_int, _vp]),
     "glorie_dspo_scale_shift": (_c_int, [_vp] * 14 + [_c_int] * 6 + [_c_f, _c_f, _c_f, _vp, _vp]),
     "glorie_knn_build": (_c_int, [_vp, _vp, _c_int, _c_f, _c_int, _vp, _vp, _vp, _vp]),
     "glorie_knn_query": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_f, _vp, _vp, _vp, _vp, _vp]),

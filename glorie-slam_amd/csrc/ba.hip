@@ -1402,6 +1402,35 @@ extern "C" int glorie_ba_solve_update(glorie_ctx* ctx, float* poses, float* disp
   return ba_solve_update(pl, poses, disps, ii, jj, lm, ep, motion_only, depth_only, dx_out, dz_out, st);
 }
 
+// ---- exchange format of the reduced system: lower triangle (row r: columns 0..r) followed by v ----
+namespace glorie {
+__global__ __launch_bounds__(256) void hv_pack_kernel(const double* __restrict__ hv, double* __restrict__ packed,
+                                                      int n, int unpack) {
+  const int r = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+  double* dense = const_cast<double*>(hv);
+  if (r == n) {                                   // right-hand side
+    if (c < n) {
+      const size_t k = (size_t)n * (n + 1) / 2 + c;
+      if (unpack) dense[(size_t)n * n + c] = packed[k];
+      else packed[k] = hv[(size_t)n * n + c];
+    }
+    return;
+  }
+  if (c > r) return;
+  const size_t k = (size_t)r * (r + 1) / 2 + c;
+  if (unpack) dense[(size_t)r * n + c] = packed[k];
+  else packed[k] = hv[(size_t)r * n + c];
+}
+}  // namespace glorie
+
+extern "C" int glorie_ba_pack_system(const double* hv, double* packed, int n6, int unpack, void* stream) {
+  if (!hv || !packed || n6 < 0) return GLORIE_EINVAL;
+  if (n6 == 0) return GLORIE_OK;
+  hipLaunchKernelGGL(glorie::hv_pack_kernel, dim3((n6 + 255) / 256, n6 + 1), dim3(256), 0, (hipStream_t)stream, hv,
+                     packed, n6, unpack);
+  return glorie::check_launch();
+}
+
 // diagnostic: blocks until `stream` drains, then returns the device status word
 // (bit 0: M mismatch, bit 1: degree too large for the gram kernel, bit 2: Cholesky failed)
 extern "C" int glorie_ba_status(glorie_ctx* ctx, int* status_out, void* stream) {

@@ -42,15 +42,34 @@ def local_edges(ii_host, owner, rank):
     return owner[ii_host] == rank
 
 
-def allreduce_system(hv, group=None):
-    """sum the packed [H | v] buffer over ranks (RCCL all-reduce; gloo in the CPU tests)"""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(hv, op=dist.ReduceOp.SUM, group=group)
+PACK_MIN_N6 = 96     # below this the exchange is latency-bound (6P = 42: 14 KB) and two extra launches cost more
+
+
+def _active(group=None):
+    return dist.is_available() and dist.is_initialized()
+
+
+def allreduce_system(hv, group=None, n6=None, force=False):
+    """sum the reduced system [H | v] over ranks (RCCL all-reduce; gloo in the CPU tests).  hv: n6*n6 + n6
+    doubles.  On the device and for n6 >= PACK_MIN_N6 only the lower triangle + v travel
+    (glorie_ba_pack_system): xGMI rings are per-link bound, half the bytes is half the time.
+    force: run the collective even with one rank (exercises the RCCL path on a single GPU)."""
+    if not _active(group) or (dist.get_world_size(group) <= 1 and not force):
+        return hv
+    if hv.is_cuda and n6 is not None and n6 >= PACK_MIN_N6:
+        packed = torch.empty(n6 * (n6 + 1) // 2 + n6, dtype=torch.float64, device=hv.device)
+        lib = L.load()
+        L.check(lib.glorie_ba_pack_system(L.ptr(hv), L.ptr(packed), int(n6), 0, L.stream_ptr()), "glorie_ba_pack_system")
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+        L.check(lib.glorie_ba_pack_system(L.ptr(hv), L.ptr(packed), int(n6), 1, L.stream_ptr()), "glorie_ba_pack_system")
+        return hv
+    dist.all_reduce(hv, op=dist.ReduceOp.SUM, group=group)
     return hv
 
 
 def ba_sharded(ctx, poses, disps, intrinsics, targets, weights, eta, ii, jj, t0, t1, iterations,
-               lm, ep, motion_only=False, depth_only=False, group=None, targets_hwc=False):
+               lm, ep, motion_only=False, depth_only=False, group=None, targets_hwc=False,
+               force_collective=False):
     """Distributed droid_backends.ba: arguments are this rank's LOCAL edges (targets/weights
     [N,2,h,w], or [N,h,w,2] with targets_hwc; eta rows of unique(cat(arange(t0,t1), ii_local))); poses/disps are full replicas,
     updated in place (poses everywhere, disps for locally owned source frames)."""
@@ -68,7 +87,7 @@ def ba_sharded(ctx, poses, disps, intrinsics, targets, weights, eta, ii, jj, t0,
                                            B, N, M, h, w, int(t0), int(t1),
                                            int(bool(motion_only)) | (L.BA_TARGETS_HWC if targets_hwc else 0),
                                            L.ptr(hv), L.stream_ptr()), "glorie_ba_build_system")
-        allreduce_system(hv, group)
+        allreduce_system(hv, group, n6=n6, force=force_collective)
         L.check(lib.glorie_ba_solve_update(ctx.handle, L.ptr(poses), L.ptr(disps), L.ptr(ii), L.ptr(jj),
                                            B, N, M, h, w, int(t0), int(t1), float(lm), float(ep),
                                            int(bool(motion_only)), int(bool(depth_only)), L.ptr(hv),
@@ -76,14 +95,38 @@ def ba_sharded(ctx, poses, disps, intrinsics, targets, weights, eta, ii, jj, t0,
     return dx
 
 
-def allgather_owned_rows(buf, owner, rank, world, group=None):
-    """make `buf[f]` consistent on all ranks: row f is taken from owner[f] (used for disps /
-    disps_up after a sharded BA-update).  Implemented as a masked all-reduce(sum)."""
-    if world <= 1:
+def _owner_blocks(owner, nf, world):
+    """(start, count) per rank if every rank owns one contiguous block of the first nf frames, else None"""
+    own = np.asarray(owner[:nf])
+    if nf == 0 or np.any(np.diff(own) < 0):
+        return None
+    starts = np.searchsorted(own, np.arange(world), side="left")
+    counts = np.searchsorted(own, np.arange(world), side="right") - starts
+    return starts, counts
+
+
+def allgather_owned_rows(buf, owner, rank, world, group=None, force=False):
+    """make `buf[f]` consistent on all ranks: row f is taken from owner[f] (disps / depth_scale / disps_up
+    after a sharded BA-update).  shard_frames hands every rank one contiguous block of frames, so this is an
+    all-gather of the blocks (padded to the largest one): each row crosses a link once, where the masked
+    all-reduce of full buffers it replaces moved every row twice and summed zeros."""
+    if world <= 1 and not force:
         return buf
     nf = min(len(owner), buf.shape[0])
-    mine = torch.as_tensor(owner[:nf] == rank, device=buf.device)
-    contrib = torch.where(mine.view(-1, *([1] * (buf.dim() - 1))), buf[:nf], torch.zeros_like(buf[:nf]))
-    dist.all_reduce(contrib, op=dist.ReduceOp.SUM, group=group)
-    buf[:nf] = contrib
+    blocks = _owner_blocks(owner, nf, world)
+    if blocks is None:                      # non-contiguous ownership: masked all-reduce(sum)
+        mine = torch.as_tensor(np.asarray(owner[:nf]) == rank, device=buf.device)
+        contrib = torch.where(mine.view(-1, *([1] * (buf.dim() - 1))), buf[:nf], torch.zeros_like(buf[:nf]))
+        dist.all_reduce(contrib, op=dist.ReduceOp.SUM, group=group)
+        buf[:nf] = contrib
+        return buf
+    starts, counts = blocks
+    width = int(counts.max())
+    send = torch.zeros((width,) + tuple(buf.shape[1:]), dtype=buf.dtype, device=buf.device)
+    send[:counts[rank]] = buf[starts[rank]:starts[rank] + counts[rank]]
+    recv = torch.empty((world * width,) + tuple(buf.shape[1:]), dtype=buf.dtype, device=buf.device)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    for r in range(world):
+        if r != rank and counts[r]:
+            buf[starts[r]:starts[r] + counts[r]] = recv[r * width:r * width + counts[r]]
     return buf

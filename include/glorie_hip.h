@@ -286,6 +286,12 @@ int glorie_ba_solve_update(glorie_ctx* ctx, float* poses, float* disps, const in
                            float lm, float ep, int motion_only, int depth_only, const double* hv,
                            float* dx_out, float* dz_out, void* stream);
 
+/* Exchange format of the reduced system: the solve reads the lower triangle of H only, so ranks all-reduce
+ * n6*(n6+1)/2 + n6 doubles (row r: columns 0..r, then v) instead of n6*n6 + n6 - 13 MB instead of 26 MB at
+ * P = 300.  unpack = 0: hv -> packed; unpack = 1: packed -> the lower triangle and v of hv (the rest of hv is
+ * left as it is). */
+int glorie_ba_pack_system(const double* hv, double* packed, int n6, int unpack, void* stream);
+
 /* DSPO stage 2, `BA_with_scale_shift(target, weight, eta, poses, disps, intrinsics, ii, jj,
  *                mono_disps, scales, shifts, valid_depth_mask, ignore_frames=0, lm, ep, alpha)`
  *   reference: src/geom/ba.py:127-216, src/geom/chol.py:58-85, call site

@@ -55,6 +55,15 @@ def _worker(rank, world, port, ret):
         gdist.allgather_owned_rows(buf, owner, rank, world)
         expect = torch.as_tensor(owner[:6] + 1, dtype=torch.float32)[:, None].expand(6, 3)
         ok_rows = bool(torch.equal(buf, expect))
+        # uneven blocks (rank 0 owns one frame, rank 1 four) with trailing rows nobody owns, and a
+        # non-contiguous ownership pattern (falls back to the masked all-reduce)
+        for own in (np.array([0, 1, 1, 1, 1]), np.array([1, 0, 1, 0, 0])):
+            b2 = torch.arange(7 * 2, dtype=torch.float32).view(7, 2) + 100.0 * (rank + 1)
+            gdist.allgather_owned_rows(b2, own, rank, world)
+            want = torch.arange(7 * 2, dtype=torch.float32).view(7, 2)
+            want[:5] += 100.0 * torch.as_tensor(own + 1, dtype=torch.float32)[:, None]
+            want[5:] += 100.0 * (rank + 1)                       # rows beyond len(owner) stay local
+            ok_rows = ok_rows and bool(torch.equal(b2, want))
         ret[rank] = (err, ok_rows, int(m.sum()))
     finally:
         dist.destroy_process_group()

@@ -1,0 +1,72 @@
+"""The collectives of glorie_slam_amd.dist through RCCL (torch.distributed backend "nccl") on the one GPU of
+the test box: a world of ONE rank still initialises the communicator, runs ncclAllReduce / ncclAllGather on
+device buffers and orders them against the HIP kernels on the stream.  (The N > 1 logic is covered by the gloo
+tests - tests/test_dist_cpu.py, tests/test_gpu_sharded_update.py; two RCCL ranks cannot share one device.)"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, port, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    try:
+        from glorie_slam_amd import _lib as L, dist as gdist, droid_backends as db
+        from test_gpu_ba import make_problem
+        res = {}
+        for K, tag in ((6, "small"), (20, "packed")):          # 6P = 30 (dense exchange) and 114 (packed triangle)
+            g = make_problem(K, 12, 16, radius=3)
+            t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+            # reference: the single-call BA
+            p0, d0 = t(g["poses"]), t(g["disps"])
+            db.ba(p0, d0, t(g["intrinsics"][0]), None, t(g["target"]), t(g["weight"]), t(g["eta"]), t(g["ii"]),
+                  t(g["jj"]), 1, K, 2, 1e-4, 0.1, False, False)
+            # the sharded form with its all-reduce forced through RCCL
+            p1, d1 = t(g["poses"]), t(g["disps"])
+            ctx = L.Context()
+            gdist.ba_sharded(ctx, p1, d1, t(g["intrinsics"][0]), t(g["target"]), t(g["weight"]), t(g["eta"]),
+                             t(g["ii"]), t(g["jj"]), 1, K, 2, 1e-4, 0.1, force_collective=True)
+            torch.cuda.synchronize()
+            res[tag] = (float((p0 - p1).abs().max()), float((d0 - d1).abs().max()), ctx.ba_status()[0])
+        # pack -> all-reduce -> unpack leaves the lower triangle and v intact
+        n6 = 120
+        hv = torch.randn(n6 * n6 + n6, dtype=torch.float64, device=dev)
+        ref = hv.clone()
+        gdist.allreduce_system(hv, n6=n6, force=True)
+        res["pack_roundtrip"] = bool(torch.equal(hv, ref))
+        # owned-row exchange
+        buf = torch.arange(12, dtype=torch.float32, device=dev).view(6, 2)
+        want = buf.clone()
+        gdist.allgather_owned_rows(buf, np.zeros(6, np.int64), 0, 1, force=True)
+        res["rows"] = bool(torch.equal(buf, want))
+        res["backend"] = dist.get_backend()
+        torch.save(res, out_path)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_collectives_run_through_rccl(gpu, tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "res.pt")
+    mp.spawn(_worker, args=(port, out), nprocs=1, join=True)
+    res = torch.load(out)
+    assert res["backend"] == "nccl"
+    for tag in ("small", "packed"):
+        dp, dd, st = res[tag]
+        assert st == 0 and dp < 2e-6 and dd < 2e-6, (tag, res[tag])
+    assert res["pack_roundtrip"] and res["rows"]

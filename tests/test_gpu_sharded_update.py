@@ -40,11 +40,10 @@ def _worker(rank, world, port, K, use_graphs, out_path):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("use_graphs", [False, True])
-def test_two_rank_update_matches_single_process(gpu, tmp_path, use_graphs):
+@pytest.mark.parametrize("K,use_graphs", [(9, False), (9, True), (18, False)])   # K = 18: 6P = 102, packed triangle
+def test_two_rank_update_matches_single_process(gpu, tmp_path, K, use_graphs):
     sys.path.insert(0, ROOT)
     import bench
-    K = 9
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
