@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+PMC_SUMMARY = "r01_pmc_kernels.json"   # refreshed per round by tools/pmc_passes.sh
 MFMA_F16_PEAK_TF = 2500.0  # same guide: ~2.5 PFLOP/s dense f16/bf16 (not the 2:1-sparsity figure)
 
 
@@ -133,7 +134,7 @@ def _pmc_traffic():
     """per-launch HBM bytes of the profiled kernels from the committed PMC summary (separate
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, corrected as MI355X_MICROARCH.md prescribes;
     see profiles/README.md).  None when the summary is absent.  -> (conv, corr, knn)"""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_kernels.json")
+    path = os.path.join(ROOT, "profiles", PMC_SUMMARY)
     try:
         with open(path) as f:
             d = json.load(f)
@@ -206,46 +207,47 @@ def cpu_baseline_rays(n_rays=192):
     return n_rays / dt, dt
 
 
-def cpu_baseline_step(g, n_edges=12):
-    """Oracle ("port") timing of one step on a bounded sample: `n_edges` edges of the
-    correlation lookup + update operator, and one BA call on a 4-keyframe 30x40 sub-problem;
-    scaled to the full G8 step (36 edges, HW=4800)."""
+def cpu_baseline_step(g):
+    """Oracle ("port") timing of ONE whole BA-update step on the full graph G8 (36 edges, 60x80), un-scaled:
+    oracle reproject + oracle 4-level correlation lookup + the update operator as the plain fp32 torch-CPU
+    module + oracle BA (2 GN iterations) + oracle convex upsampling.  The torch part runs on all host threads,
+    the numpy oracle parts on one (numpy loops)."""
     from oracle import corr as ocorr, ba as oba, geom as ogeom
-    import glorie_slam_amd.synth as synth
     from glorie_slam_amd.droid_net import UpdateModule
-    h, w = g["h"], g["w"]
+    h, w, N, K = g["h"], g["w"], len(g["ii"]), g["K"]
     rng = np.random.default_rng(0)
-    t0 = time.perf_counter()
-    levels = [rng.standard_normal((n_edges, h, w, h >> l, w >> l)).astype(np.float16) for l in range(4)]
-    coords = np.stack([rng.uniform(0, w, (n_edges, h, w)), rng.uniform(0, h, (n_edges, h, w))], 1).astype(np.float32)
-    t1 = time.perf_counter()
-    ocorr.corr_lookup_pyramid(levels, coords, 3)
-    t_corr = (time.perf_counter() - t1) / n_edges
+    t_all = time.perf_counter()
+    # one edge's pyramid stands for all 36 (61 MB each; the values do not change the cost of the lookup)
+    levels = [rng.standard_normal((1, h, w, h >> l, w >> l)).astype(np.float16) for l in range(4)]
     torch.manual_seed(43)
     net = UpdateModule().eval()
-    x = lambda c: torch.randn(1, n_edges, c, h, w)
+    x = lambda c: torch.randn(1, N, c, h, w)
+    xin = (x(128), x(128), x(196), x(4))
+    up = (rng.standard_normal((K, 576, h, w))).astype(np.float16)
+    t0 = time.perf_counter()
+    coords, _ = ogeom.reproject(g["poses"], g["disps"], g["intrinsics"], g["ii"], g["jj"])
+    tgt = (coords.transpose(0, 3, 1, 2) + g["noise"]).astype(np.float32)
+    for n in range(N):
+        ocorr.corr_lookup_pyramid(levels, np.ascontiguousarray(coords[n:n + 1].transpose(0, 3, 1, 2)), 3)
+    t_corr = time.perf_counter() - t0
     with torch.no_grad():
-        ii = torch.arange(n_edges)
+        ii = torch.from_numpy(g["ii"])
         t1 = time.perf_counter()
-        net(x(128), x(128), x(196), x(4), ii, ii)
-        t_upd = (time.perf_counter() - t1) / n_edges
-    gs = synth.keyframe_graph(K=6, h=30, w=40, radius=3)
-    c, _ = ogeom.reproject(gs["poses"], gs["disps"], gs["intrinsics"], gs["ii"], gs["jj"])
-    tgt = (c.transpose(0, 3, 1, 2) + gs["noise"]).astype(np.float32)
+        net(*xin, ii, ii)
+        t_upd = time.perf_counter() - t1
     t1 = time.perf_counter()
-    oba.ba(gs["poses"], gs["disps"], gs["intrinsics"][0], tgt, gs["weight"], gs["eta"], gs["ii"], gs["jj"],
-           1, 6, 2, 1e-4, 0.1)
-    t_ba_small = time.perf_counter() - t1
-    scale = (36 * 4800) / (len(gs["ii"]) * 30 * 40)
-    N = len(g["ii"])
-    step_s = N * (t_corr + t_upd) + t_ba_small * scale
+    oba.ba(g["poses"], g["disps"], g["intrinsics"][0], tgt, g["weight"], g["eta"], g["ii"], g["jj"], 1, K, 2, 1e-4, 0.1)
+    ogeom.cvx_upsample(g["disps"][:K], up, np.float16)
+    t_ba = time.perf_counter() - t1
+    step_s = t_corr + t_upd + t_ba
     rays_s, rays_dt = cpu_baseline_rays()
     return dict(value=1.0 / step_s, unit="BA-update iters/s", cores=torch.get_num_threads(), kind="port",
                 rays_per_sec=rays_s,
-                sample=f"oracle corr lookup + torch-CPU update operator on {n_edges} of {N} edges, "
-                       f"oracle BA (2 GN iterations) on a 6-keyframe 30x40 graph scaled by pixel-edges "
-                       f"(x{scale:.1f}); rays: 192 rays of the frame, brute-force KNN over the 524k-point cloud + "
-                       f"torch-CPU decoders ({rays_dt:.1f}s); {time.perf_counter() - t0:.1f}s of CPU work")
+                sample=f"ONE un-scaled step on G8 ({N} edges, {h}x{w}): oracle reproject + lookup {t_corr:.2f}s "
+                       f"(numpy, 1 thread), fp32 torch-CPU update operator {t_upd:.2f}s ({torch.get_num_threads()} "
+                       f"threads), oracle BA 2 GN iterations + upsampling {t_ba:.2f}s (numpy, 1 thread); rays: 192 "
+                       f"rays of the frame, brute-force KNN over the 524k-point cloud + torch-CPU decoders "
+                       f"({rays_dt:.1f}s); {time.perf_counter() - t_all:.1f}s of CPU work in total")
 
 
 def main():
@@ -326,6 +328,77 @@ def main():
         tmax = torch.tensor([elapsed], device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+    # ---- the timed steps did the work they claim: solver status, finite state, stage-2 fallbacks ----
+    ba_st = video.ctx().ba_status()
+    assert ba_st[0] == 0, f"BA status word after the timed loop: {ba_st} (bit 0 eta/M mismatch, bit 2 Cholesky failed)"
+    assert bool(torch.isfinite(video.poses).all()) and bool(torch.isfinite(video.disps[:K]).all()), "non-finite state"
+    assert bool(torch.isfinite(graph.target).all()) and bool(torch.isfinite(graph.net.float()).all())
+    assert not torch.equal(video.poses[1:K], poses0[1:K]), "the timed steps did not move the poses"
+    fallbacks = int(video.stage2_fallbacks)
+    stage2_steps = (args.steps // 2)
+    # ---- sustained figure: >= 400 back-to-back steps (the K-step figure above runs on boost clocks) ----
+    sustained_steps = max(400, args.steps)
+    reset()
+    barrier()
+    t_s = time.perf_counter()
+    for _ in range(sustained_steps):
+        step()
+    barrier()
+    sustained_ms = 1e3 * (time.perf_counter() - t_s) / sustained_steps
+    if world > 1:
+        tm = torch.tensor([sustained_ms], device=device)
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        sustained_ms = float(tm.item())
+    assert video.ctx().ba_status()[0] == 0 and bool(torch.isfinite(video.poses).all())
+
+    # ---- sub-metric: Gauss-Newton iterations/s of the BA step alone (B2-B7) on G8 ----
+    ba_gn_per_s = None
+    frontend_cfg = None
+    if world == 1:
+        from glorie_slam_amd import droid_backends as db
+        reset()
+        step()                                   # state of a running graph: targets / weights / damping of an update
+        tg, wg, dm, bi, bj = graph._ba_args[:5]
+        tg, wg = tg.reshape(-1, graph.ht, graph.wd, 2).contiguous(), wg.reshape(-1, graph.ht, graph.wd, 2).contiguous()
+        intr0 = video.intrinsics[0].contiguous()
+        pz, dz_ = video.poses.clone(), video.disps.clone()
+
+        def ba_only():
+            pz.copy_(video.poses)
+            dz_.copy_(video.disps)
+            db.ba(pz, dz_, intr0, None, tg, wg, dm.reshape(-1, graph.ht, graph.wd), bi, bj, 1, K, 2, 1e-4, 0.1,
+                  False, False, ctx=video.ctx(), want_updates=False, targets_hwc=True)
+        for _ in range(5):
+            ba_only()
+        b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        b0.record()
+        for _ in range(100):
+            ba_only()
+        b1.record()
+        torch.cuda.synchronize()
+        ba_ms = b0.elapsed_time(b1) / 100
+        ba_gn_per_s = 2.0 / (ba_ms * 1e-3)
+        assert video.ctx().ba_status()[0] == 0
+
+        # ---- the configuration the tracking driver calls (frontend.py:50-53): use_inactive=True, t0 = t1 = None,
+        # on a graph whose oldest edges have retired to the inactive set; eager launches and hipGraph replay
+        fe = {}
+        for tag, ug in (("eager", False), ("replay", True)):
+            _, v2, g2 = build_graph(device, K=K_graph, use_graphs=ug)
+            g2.rm_factors((g2.ii == 0) | (g2.jj == 0), store=True)
+            for i in range(6):
+                g2.update(None, None, use_inactive=True, opt_type="pose_depth" if i % 2 == 0 else "depth_scale")
+            torch.cuda.synchronize()
+            t_f = time.perf_counter()
+            for i in range(40):
+                g2.update(None, None, use_inactive=True, opt_type="pose_depth" if i % 2 == 0 else "depth_scale")
+            torch.cuda.synchronize()
+            fe[tag + "_its_per_s"] = 40 / (time.perf_counter() - t_f)
+            fe["edges_active"], fe["edges_inactive"] = int(g2.ii.numel()), int(g2.ii_inac.numel())
+            assert v2.ctx().ba_status()[0] == 0 and bool(torch.isfinite(v2.poses).all())
+            del g2, v2
+        frontend_cfg = fe
+        torch.cuda.empty_cache()
 
     # ---- roofline of the dominant kernel of a step (GRU gate convolution, 23 % of it): HIP events on
     # the launch stream around back-to-back launches
@@ -378,6 +451,25 @@ def main():
     if world > 1:
         dist.all_reduce(rays_total)
     rays_per_s = float(rays_total.item()) / t_r
+    # M2 on the 5000-ray training batch (mapper.py:390-515 samples 5000 pixels per iteration), forward
+    gsel = torch.Generator(device="cpu").manual_seed(5)
+    pick = torch.randperm(rays["o"].shape[0], generator=gsel)[:5000].to(device)
+    b5 = {k: v[pick].contiguous() for k, v in rays.items()}
+
+    def batch5000():
+        with torch.no_grad():
+            return ren.render_batch_ray(npc, dec, b5["d"], b5["o"], device, "color", gt_depth=b5["depth"],
+                                        npc_geo_feats=npc.geo_feats, npc_col_feats=npc.col_feats,
+                                        cloud_pos=npc.cloud_pos(), dynamic_r_query=b5["radius"])
+    for _ in range(3):
+        batch5000()
+    torch.cuda.synchronize()
+    t_b = time.perf_counter()
+    for _ in range(50):
+        out5 = batch5000()
+    torch.cuda.synchronize()
+    batch_ms = 1e3 * (time.perf_counter() - t_b) / 50
+    assert bool(torch.isfinite(out5[2]).all())
     # KNN + feature gather alone (HIP events), 2156 B per sample
     S = ren.N_surface
     nq = min(rays["o"].shape[0], 65536)
@@ -425,6 +517,12 @@ def main():
         "unit": "BA-update iters/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
+        "sustained_ms_per_step": sustained_ms, "sustained_steps": sustained_steps,
+        "sustained_value": world * 1e3 / sustained_ms,
+        "checks": {"ba_status": ba_st, "stage2_fallbacks": fallbacks, "stage2_steps": stage2_steps,
+                   "state_finite": True},
+        "ba_gn_iters_per_sec": ba_gn_per_s,
+        "frontend_config": frontend_cfg,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f16 corr/ConvGRU, f32 Jacobians, f64 solve", "data": "synthetic",
         "config": {"workload": (f"G8: 8 keyframes, 36 edges, 60x80 (640x480/8), BA itrs=2, DSPO stages alternating, "
@@ -454,6 +552,7 @@ def main():
                           "measured_hbm_frac": (corr_traffic / (corr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
                           if (full and corr_traffic) else None},
         "rays_per_sec": rays_per_s,
+        "rays_per_sec_batch5000": 5000.0 / (batch_ms * 1e-3), "ms_per_batch5000": batch_ms,
         "render": {"rays_local": int(n_r // render_reps), "samples_per_ray": int(S), "cloud_points": int(npc.pts_num()),
                    "ms_per_frame_shard": 1e3 * t_r / render_reps},
         "roofline_knn": {"bound": "hbm", "kernel": "knn_query_kernel<8> + 2x idw_gather_kernel",

@@ -58,6 +58,7 @@ class DepthVideo:
         self.poses[:] = torch.as_tensor([0, 0, 0, 0, 0, 0, 1], **f32)
         self.printer = printer
         self._ctx = None
+        self.stage2_fallbacks = 0      # depth_scale stages that fell back to pose_depth (depth_video.py:290-294)
         # multi-GPU state (glorie_slam_amd.dist): None = single GPU
         self.shard = None
 
@@ -245,6 +246,7 @@ class DepthVideo:
         if self.BA_type == "DSPO":
             ok = self.dspo(target, weight, eta, ii, jj, t0, t1, iters, lm, ep, motion_only, opt_type)
             if not ok:
+                self.stage2_fallbacks += 1
                 self.dspo(target, weight, eta, ii, jj, t0, t1, iters, lm, ep, motion_only, "pose_depth")
         elif self.BA_type == "DBA":
             self.dspo(target, weight, eta, ii, jj, t0, t1, iters, lm, ep, motion_only, "pose_depth")

@@ -271,6 +271,7 @@ class FactorGraph:
             # (dspo.depth_scale_stage): read the flag it left in pinned memory and redo it here
             torch.cuda.current_stream().synchronize()
             if int(self.video.deferred_any_on()[0]) == 0:
+                self.video.stage2_fallbacks += 1
                 target, weight, damping, ii, jj, uniq, upmask, t0_, t1_ = ba_args
                 self.video.dspo(target, weight, damping, ii, jj, t0_, t1_, itrs, 1e-4, 0.1, motion_only,
                                 "pose_depth")
