@@ -30,6 +30,7 @@ SIGNATURES = {
     "glorie_corr_index_fwd": (_c_int, [_vp, _vp, _vp] + [_c_int] * 7 + [_vp]),
     "glorie_corr_lookup_pyramid": (_c_int, [_vp, _c_int, _vp, _vp] + [_c_int] * 7 + [_vp]),
     "glorie_corr_otf": (_c_int, [_vp, _vp, _c_int, _vp, _vp, _vp, _vp] + [_c_int] * 4 + [_vp]),
+    "glorie_corr_otf_encode": (_c_int, [_vp, _vp, _c_int, _vp, _vp, _vp, _vp] + [_c_int] * 4 + [_vp, _vp, _vp, _c_int, _vp]),
     "glorie_altcorr_fwd": (_c_int, [_vp] * 4 + [_c_int] * 8 + [_vp]),
     "glorie_bias_act": (_c_int, [_vp, _c_int, _vp, _vp, _c_int, ctypes.c_long, _c_int, _c_int, _vp]),
     "glorie_gru_glo_terms": (_c_int, [_vp, _c_int, _vp, _vp, _c_int, _vp, _vp, _c_int, _vp, _c_int, _vp, _c_int, _c_int, _vp]),

@@ -516,3 +516,32 @@ class OtfCorrBlock:
                                          self.num_levels, L.ptr(c), L.ptr(ii.contiguous()), L.ptr(jj.contiguous()),
                                          L.ptr(out), batch * num, H, W, C, L.stream_ptr()), "glorie_corr_otf")
         return out.view(batch, num, -1, ht, wd)
+
+    @staticmethod
+    def pack_encoder(weight):
+        """corr_encoder[0].weight [128,196,1,1] -> fp16 [128,224] in the kernel's staging order
+        (k = level*56 + row*8 + tap, tap 7 = zero pad; include/glorie_hip.h: glorie_corr_otf_encode)"""
+        w = weight.detach().reshape(128, 4, 7, 7)                      # [o][l][i][j]
+        p = torch.zeros(128, 4, 7, 8, dtype=torch.float16, device=weight.device)   # [o][l][j][i]
+        p[..., :7] = w.permute(0, 1, 3, 2).half()
+        return p.reshape(128, 224).contiguous()
+
+    def lookup_encode(self, coords, ii, jj, enc_w, enc_b, enc_out, want_corr=False):
+        """lookup + fused corr_encoder[0]: writes relu(W corr + b) into `enc_out`, a channels-last fp16 map
+        [N,128,h,w] (or a 128-channel slice of a wider one); returns the 196-channel map only if asked to"""
+        import ctypes
+        from . import _lib as L
+        from . import update_ops as U
+        batch, num, ht, wd, _ = coords.shape
+        c = coords.permute(0, 1, 4, 2, 3).contiguous().view(batch * num, 2, ht, wd).float()
+        H, W, C = self.shape
+        if self.num_levels != 4 or tuple(enc_out.shape) != (batch * num, 128, ht, wd):
+            raise RuntimeError("lookup_encode: 4 levels and an [N,128,h,w] output map expected")
+        stride = U._rows(enc_out, "enc_out")
+        out = torch.empty(batch * num, 196, ht, wd, dtype=torch.float16, device=c.device) if want_corr else None
+        arr = (ctypes.c_void_p * 4)(*[v.data_ptr() for v in self.levels])
+        L.check(L.load().glorie_corr_otf_encode(L.ptr(self.levels[0]), ctypes.cast(arr, ctypes.c_void_p), 4, L.ptr(c),
+                                                L.ptr(ii.contiguous()), L.ptr(jj.contiguous()), L.ptr(out),
+                                                batch * num, H, W, C, L.ptr(enc_w), L.ptr(enc_b), L.ptr(enc_out),
+                                                stride, L.stream_ptr()), "glorie_corr_otf_encode")
+        return out.view(batch, num, -1, ht, wd) if want_corr else None

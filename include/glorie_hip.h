@@ -103,6 +103,21 @@ int glorie_corr_otf(const void* fmap1, const void* const* fmap2_levels, int num_
                     const float* coords, const int64_t* ii, const int64_t* jj, void* out,
                     int N, int h, int w, int C, void* stream);
 
+/* The same lookup with corr_encoder[0] of the update operator fused behind it
+ *   reference: src/modules/droid_net/droid_net.py:73-77 (1x1 convolution 196 -> 128, bias, ReLU on the looked-up
+ *   features) - the first consumer of CorrBlock.__call__ in UpdateModule.forward (droid_net.py:121)
+ * enc_w: fp16 [128][224], enc_w[o][l*56 + j*8 + i] = W[o][l*49 + i*7 + j] for i < 7, zero for i == 7 (the order the
+ * kernel stages a pixel's looked-up features in LDS); enc_b: f32 [128];
+ * enc_out: fp16 rows of `enc_stride` halfs per edge-pixel (channels-last map or a channel slice of one,
+ * enc_stride % 4 == 0, 8-byte aligned): enc_out[(n*h*w + p) * enc_stride + o] = relu(sum_k W[o][k] corr[n][k][p] + b[o]),
+ * corr rounded to fp16 like the lookup's own output, fp32 accumulation.
+ * corr_out: NULL (the 196-channel map never goes to HBM) or [N,196,h,w] fp16 as for glorie_corr_otf.
+ * num_levels must be 4, C 128. */
+int glorie_corr_otf_encode(const void* fmap1, const void* const* fmap2_levels, int num_levels,
+                           const float* coords, const int64_t* ii, const int64_t* jj, void* corr_out,
+                           int N, int h, int w, int C, const void* enc_w, const float* enc_b,
+                           void* enc_out, int enc_stride, void* stream);
+
 /* droid_backends.altcorr_forward(fmap1, fmap2, coords, radius)
  *   reference: src/lib/droid.cpp:195-205, src/lib/altcorr_kernel.cu:27-149,290-319
  * fmap1 [B,H,W,C], fmap2 [B,H2,W2,C], coords [B,S,H,W,2] f32, out [B,S,(2r+1)^2,H,W].

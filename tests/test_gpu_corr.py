@@ -190,3 +190,29 @@ def test_corr_otf_equals_volume_path(gpu):
     a = vol(c5)[0].float()
     b = OtfCorrBlock(fmt[None])(c5, torch.from_numpy(ii).to(gpu), torch.from_numpy(jj).to(gpu))[0].float()
     assert torch.allclose(a, b, rtol=2e-2, atol=1e-2)   # fp16 path rel 2e-2 / abs 1e-2
+
+
+@pytest.mark.parametrize("smooth,H,W", [(True, 24, 32), (False, 17, 21), (True, 60, 80)])
+def test_corr_otf_fused_encoder(gpu, smooth, H, W):
+    """glorie_corr_otf_encode: the looked-up features of the same launch (bit-identical to the plain lookup) and
+    relu(conv1x1(corr) + b) of corr_encoder[0] (droid_net.py:73-74) against torch on those features"""
+    from glorie_slam_amd.droid_net import OtfCorrBlock
+    rng = np.random.default_rng(8)
+    fm, coords, ii, jj = _otf_inputs(rng, 3, H, W, smooth)
+    blk = OtfCorrBlock(torch.from_numpy(fm).to(gpu)[None])
+    c5 = torch.from_numpy(coords).to(gpu).permute(0, 2, 3, 1)[None].contiguous()
+    it, jt = torch.from_numpy(ii).to(gpu), torch.from_numpy(jj).to(gpu)
+    g = torch.Generator().manual_seed(1)
+    wgt = (torch.randn(128, 196, 1, 1, generator=g) / 14).to(gpu)
+    bias = torch.randn(128, generator=g).to(gpu)
+    N = len(ii)
+    wide = torch.zeros(N, 320, H, W, dtype=torch.float16, device=gpu).contiguous(memory_format=torch.channels_last)
+    plain = blk(c5, it, jt)
+    corr = blk.lookup_encode(c5, it, jt, OtfCorrBlock.pack_encoder(wgt), bias, wide[:, 128:256], want_corr=True)
+    assert torch.equal(corr, plain)
+    ref = torch.relu(torch.nn.functional.conv2d(plain[0].float(), wgt.half().float(), bias))
+    torch.testing.assert_close(wide[:, 128:256].float(), ref, rtol=4e-3, atol=4e-3)
+    assert float(wide[:, :128].abs().max()) == 0.0 and float(wide[:, 256:].abs().max()) == 0.0
+    only = torch.zeros(N, 128, H, W, dtype=torch.float16, device=gpu).contiguous(memory_format=torch.channels_last)
+    assert blk.lookup_encode(c5, it, jt, OtfCorrBlock.pack_encoder(wgt), bias, only) is None
+    assert torch.equal(only, wide[:, 128:256])
