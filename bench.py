@@ -282,6 +282,7 @@ def main():
     # the launches of a step are replayed as a hipGraph per (edge set, stage); when sharded the replay stops
     # before the BA, whose all-reduce and row exchange are issued eagerly (FactorGraph.update)
     g, video, graph = build_graph(device, K=K_graph, rank=rank, world=world,
+                                  corr_impl=os.environ.get("GLORIE_BENCH_CORR", "volume"),
                                   use_graphs=os.environ.get("GLORIE_NO_GRAPHS") is None)
     K = g["K"]
     poses0, disps0 = video.poses.clone(), video.disps.clone()
@@ -417,12 +418,31 @@ def main():
     # ---- roofline of the correlation gather (the HBM-bound kernel north_star names)
     coords1, _ = video.reproject(graph.ii, graph.jj)
     reps = 20
+    if graph.corr_impl == "otf":
+        # volume-free lookup with corr_encoder[0] fused behind it, as the step launches it
+        from glorie_slam_amd.droid_net import FusedLookup
+        blk, rig = graph._otf_block(), graph._otf_rig
+        fl = FusedLookup(blk, coords1, (rig * graph.ii).contiguous(), (rig * graph.jj).contiguous())
+        fu = graph.fast_update
+        c1buf = torch.empty((graph.ii.shape[0], 128, graph.ht, graph.wd), dtype=torch.float16, device=device,
+                            memory_format=torch.channels_last)
+        corr_fn = lambda: fl.encode_into(fu.W["ce1_p"], fu.W["ce1_b"], c1buf)
+        corr_kernel = "corr_otf8_kernel<false,true> (volume-free MFMA lookup, 8x8 source tiles, + fused corr_encoder[0])"
+    else:
+        corr_fn = lambda: graph.corr(coords1)
+        corr_kernel = "corr_lookup_r3_tiled_kernel (fp16, 4x8-tiled pyramid)"
     for _ in range(3):
-        graph.corr(coords1)
+        corr_fn()
+    torch.cuda.synchronize()
+    # device time of the launch: `reps` calls replayed as one hipGraph (the eager Python wrapper is slower than the kernel)
+    cgraph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(cgraph):
+        for _ in range(reps):
+            corr_fn()
+    cgraph.replay()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record()
-    for _ in range(reps):
-        graph.corr(coords1)
+    cgraph.replay()
     ev1.record()
     torch.cuda.synchronize()
     N = graph.ii.shape[0]
@@ -543,7 +563,7 @@ def main():
                      # the reference evaluates all 448 input channels in every iteration (gru.py:20-24)
                      "reference_formulation": {"flops_per_launch": conv_flops * 448.0 / 320.0,
                                                "equiv_frac": conv_tf * 448.0 / 320.0 / MFMA_F16_PEAK_TF}},
-        "roofline_corr": {"bound": "hbm", "kernel": "corr_lookup_r3_tiled_kernel (fp16, 4x8-tiled pyramid)",
+        "roofline_corr": {"bound": "hbm", "kernel": corr_kernel,
                           "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": achieved / HBM_PEAK_GBS, "traffic": corr_traffic if full else None,
                           "alg_bytes_per_launch": alg_bytes, "ms_per_launch": corr_ms,

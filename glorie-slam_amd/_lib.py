@@ -67,6 +67,11 @@ SIGNATURES = {
     "glorie_ray_samples": (_c_int, [_vp] * 5 + [_c_int, _c_int, _c_f, _c_f] + [_vp] * 6),
     "glorie_proj_depth": (_c_int, [_vp, _vp, ctypes.c_long, _vp, _c_f, _c_f, _c_f, _c_f, _c_int, _c_int, _vp, _vp]),
     "glorie_ray_counts": (_c_int, [_vp, _c_int, _c_int, _c_int, _vp, _vp, _vp]),
+    "glorie_render_train_workspace": (_sz, [ctypes.c_long]),
+    "glorie_render_train_fwd": (_c_int, [_vp] * 9 + [ctypes.c_long, _c_int, _vp, _vp, _vp]),
+    "glorie_render_train_bwd": (_c_int, [_vp] * 10 + [ctypes.c_long, _c_int, _vp, _vp, _vp, _vp, _vp]),
+    "glorie_composite_bwd": (_c_int, [_vp, _vp, _c_int, _c_int, _c_f, _vp, _vp, _vp, _vp]),
+    "glorie_adam_step": (_c_int, [_vp, _vp, _vp, _vp, ctypes.c_long, _c_f, _c_f, _c_f, _c_f, _c_int, _vp, _c_int, _vp]),
     "glorie_ba_status": (_c_int, [_vp, ctypes.POINTER(_c_int), _vp]),
 }
 

@@ -1,0 +1,748 @@
+// Training path of the neural-point renderer (scope row N1): forward with saved activations and the
+// hand-written backward of
+//   MLP_geometry.forward / MLP_color.forward / get_feature_at_pos / MLP_col_neighbor
+//       /root/reference/src/modules/conv_onet/models/decoder.py:130-225, 228-243, 340-433
+//   raw2outputs_nerf_color                         /root/reference/src/utils/common.py:261-299
+// which `loss.backward()` of the mapper walks through autograd
+//   /root/reference/src/mapper.py:390-515 (optimizer_update_one_step), :511-512
+// plus the Adam update of the feature rows / decoder parameters (torch.optim.Adam semantics, mapper.py:612-624).
+//
+// The inference kernels of csrc/mlp.hip keep every activation on chip and therefore cannot be differentiated;
+// a mapping iteration renders only 5000 rays (50k samples, 400k neighbour rows), so here every layer is its
+// own launch with activations in HBM (16 KB per sample, ~1 GB of traffic per iteration = 0.2 ms at HBM speed):
+//   mm_rows_kernel    out[q][j] = epilogue( sum_r in[q][r] * W(r, j) )      forward layers and input gradients
+//   mm_wgrad_kernel   dW[n][k] += sum_q dY[q][n] X[q][k],  db[n] += sum_q dY[q][n]     (fp32 atomics)
+// both on v_mfma_f32_16x16x4_f32 (exact fp32: training stays in the reference's precision), one wave = 16 rows
+// (or 16 output rows of dW) x all columns, operands straight from L1/L2 (the matrices have <= 208 columns);
+// and a handful of element-wise / gather kernels (Fourier features with learnable B, IDW gather / scatter,
+// per-neighbour rows, compositing).  The launch sequence lives in glorie_render_train_fwd / _bwd so that one
+// C call = one pass (no Python per layer).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+#include "common.hiph"
+
+namespace glorie {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+enum { TACT_NONE = 0, TACT_RELU = 1, TACT_SOFTPLUS = 2, TACT_SIGMOID = 3 };
+constexpr float kBeta = 100.0f;       // nn.Softplus(beta=100), decoder.py:108,312
+
+__device__ __forceinline__ float t_act(float v, int act) {
+  if (act == TACT_RELU) return fmaxf(v, 0.0f);
+  if (act == TACT_SOFTPLUS) {         // torch: x if beta x > 20 else log1p(exp(beta x)) / beta
+    const float bx = kBeta * v;
+    return bx > 20.0f ? v : log1pf(expf(bx)) / kBeta;
+  }
+  if (act == TACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
+  return v;
+}
+// derivative of the activation expressed through its OUTPUT y (only outputs are saved)
+__device__ __forceinline__ float t_dact(float y, int act) {
+  if (act == TACT_RELU) return y > 0.0f ? 1.0f : 0.0f;
+  if (act == TACT_SOFTPLUS) return 1.0f - expf(-kBeta * y);        // sigmoid(beta z) = 1 - exp(-beta softplus(z))
+  if (act == TACT_SIGMOID) return y * (1.0f - y);
+  return 1.0f;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// out[q][j] = [accumulate: out[q][j] +] act( sum_r in[q][r] W(r, j) + bias[j] ) * dact(saved[q][j]) + res[q][j]
+//   TRANS:  W(r, j) = W[j * ldw + r]   (forward: nn.Linear weight [J][R])
+//   !TRANS: W(r, j) = W[r * ldw + j]   (input gradient: dX = dY W, W [R][J])
+// one wave = 16 rows x J columns (J <= 208: 13 tiles of 16), reduction in chunks of 16 (4 MFMA k-steps)
+// ---------------------------------------------------------------------------------------------------------
+struct MmArgs {
+  const float* in; int ldi;
+  const float* W; int ldw;
+  const float* bias;
+  const float* res; int ldr;
+  const float* saved; int lds; int dact;
+  float* out; int ldo;
+  int Q, R, J, act, accumulate;
+};
+
+constexpr int kMaxJT = 13;
+
+template <bool TRANS>
+__global__ __launch_bounds__(256) void mm_rows_kernel(MmArgs a) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const long q0 = ((long)blockIdx.x * 4 + wv) * 16;
+  if (q0 >= a.Q) return;
+  const int njt = (a.J + 15) >> 4;
+  f32x4 acc[kMaxJT];
+#pragma unroll
+  for (int t = 0; t < kMaxJT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const long qa = q0 + i;
+  const bool qok = qa < a.Q;
+  const float* xrow = a.in + (qok ? qa : 0) * (long)a.ldi;
+  for (int r0 = 0; r0 < a.R; r0 += 16) {
+    float av[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int r = r0 + 4 * s + g;
+      av[s] = (qok && r < a.R) ? xrow[r] : 0.0f;
+    }
+#pragma unroll
+    for (int t = 0; t < kMaxJT; ++t) {
+      if (t < njt) {
+        const int j = t * 16 + i;
+        float bv[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int r = r0 + 4 * s + g;
+          const bool ok = r < a.R && j < a.J;
+          bv[s] = ok ? (TRANS ? a.W[(long)j * a.ldw + r] : a.W[(long)r * a.ldw + j]) : 0.0f;
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s], acc[t], 0, 0, 0);
+      }
+    }
+  }
+  // lane: rows q0 + 4 g + rr, column t * 16 + i
+#pragma unroll
+  for (int t = 0; t < kMaxJT; ++t) {
+    if (t >= njt) continue;
+    const int j = t * 16 + i;
+    if (j >= a.J) continue;
+    const float b = a.bias ? a.bias[j] : 0.0f;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const long q = q0 + 4 * g + rr;
+      if (q >= a.Q) continue;
+      float v = t_act(acc[t][rr] + b, a.act);
+      if (a.saved) v *= t_dact(a.saved[q * a.lds + j], a.dact);
+      if (a.res) v += a.res[q * a.ldr + j];
+      float* o = a.out + q * a.ldo + j;
+      if (a.accumulate) v += *o;
+      *o = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// dW[n][k] += sum_q dY[q][n] X[q][k]   (k < K),   db[n] += sum_q dY[q][n]   (the "k == K" column of ones)
+// grid (ceil(N/16), q-splits); a wave owns 16 rows n of dW and a contiguous q range, 4 rows q per MFMA
+// ---------------------------------------------------------------------------------------------------------
+struct WgArgs {
+  const float* dY; int ldy;
+  const float* X; int ldx;
+  float* dW; int ldw;
+  float* db;
+  long Q; int N, K; long rows_per_wave;
+};
+
+constexpr int kMaxKT = 14;            // 208 columns + the bias column
+
+__global__ __launch_bounds__(256) void mm_wgrad_kernel(WgArgs a) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.x * 16;
+  const long qa = ((long)blockIdx.y * 4 + wv) * a.rows_per_wave;
+  if (qa >= a.Q) return;
+  const long qb = qa + a.rows_per_wave < a.Q ? qa + a.rows_per_wave : a.Q;
+  const int KE = a.K + (a.db ? 1 : 0);
+  const int nkt = (KE + 15) >> 4;
+  f32x4 acc[kMaxKT];
+#pragma unroll
+  for (int t = 0; t < kMaxKT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool nok = n0 + i < a.N;
+  for (long q = qa; q < qb; q += 4) {
+    const long qq = q + g;
+    const bool ok = qq < qb;
+    const float av = (ok && nok) ? a.dY[qq * a.ldy + n0 + i] : 0.0f;
+    const float* xr = a.X + (ok ? qq : 0) * (long)a.ldx;
+#pragma unroll
+    for (int t = 0; t < kMaxKT; ++t) {
+      if (t < nkt) {
+        const int k = t * 16 + i;
+        const float bv = ok ? (k < a.K ? xr[k] : (k == a.K ? 1.0f : 0.0f)) : 0.0f;
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[t], 0, 0, 0);
+      }
+    }
+  }
+  // lane: rows n0 + 4 g + rr of dW, column t * 16 + i
+#pragma unroll
+  for (int t = 0; t < kMaxKT; ++t) {
+    if (t >= nkt) continue;
+    const int k = t * 16 + i;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int n = n0 + 4 * g + rr;
+      if (n >= a.N) continue;
+      const float v = acc[t][rr];
+      if (k < a.K) atomicAdd(a.dW + (long)n * a.ldw + k, v);
+      else if (k == a.K && a.db) atomicAdd(a.db + n, v);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Fourier features  v = (2 pi x) B,  out = sin(v) [| cos(v)]      (decoder.py:8-37)
+// x [Q,3] (row stride ldx; optional L2 normalisation of x: F.normalize(views), decoder.py:404), B [3][M]
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void load_x3(const float* x, long q, int ldx, int normalize, float (&v)[3]) {
+  v[0] = x[q * ldx + 0]; v[1] = x[q * ldx + 1]; v[2] = x[q * ldx + 2];
+  if (normalize) {
+    const float nrm = fmaxf(sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]), 1e-12f);
+    v[0] /= nrm; v[1] /= nrm; v[2] /= nrm;
+  }
+}
+__device__ __forceinline__ float fourier_phase(const float (&x)[3], const float* B, int M, int m) {
+  const float tp = 6.283185307179586f;
+  return (tp * x[0]) * B[m] + (tp * x[1]) * B[M + m] + (tp * x[2]) * B[2 * M + m];
+}
+
+__global__ __launch_bounds__(256) void fourier_fwd_kernel(const float* __restrict__ x, int ldx, int normalize,
+                                                          const float* __restrict__ B, int M, int concat, long Q,
+                                                          float* __restrict__ out, int ldo) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= Q * M) return;
+  const long q = idx / M;
+  const int m = (int)(idx - q * M);
+  float xv[3];
+  load_x3(x, q, ldx, normalize, xv);
+  const float v = fourier_phase(xv, B, M, m);
+  out[q * ldo + m] = sinf(v);
+  if (concat) out[q * ldo + M + m] = cosf(v);
+}
+
+// dB[d][m] += sum_q 2 pi x[q][d] (g_sin[q][m] cos(v) - g_cos[q][m] sin(v));  grid (ceil(M/..), q-chunks)
+__global__ __launch_bounds__(256) void fourier_bwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ B,
+                                                          int M, int concat, long Q, const float* __restrict__ gout,
+                                                          int ldg, float* __restrict__ dB, int rows_per_block) {
+  // thread = (m, q-lane): 256 threads cover min(M, 32) columns x 8.. row lanes; simple strided loops
+  const int m = threadIdx.x % 32, ql = threadIdx.x / 32;          // 32 columns x 8 row lanes
+  const long qa = (long)blockIdx.x * rows_per_block;
+  const long qb = qa + rows_per_block < Q ? qa + rows_per_block : Q;
+  const float tp = 6.283185307179586f;
+  for (int m0 = 0; m0 < M; m0 += 32) {
+    const int mm = m0 + m;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    if (mm < M) {
+      for (long q = qa + ql; q < qb; q += 8) {
+        float xv[3];
+        load_x3(x, q, ldx, 0, xv);
+        const float v = fourier_phase(xv, B, M, mm);
+        float gv = gout[q * ldg + mm] * cosf(v);
+        if (concat) gv -= gout[q * ldg + M + mm] * sinf(v);
+        s0 += tp * xv[0] * gv; s1 += tp * xv[1] * gv; s2 += tp * xv[2] * gv;
+      }
+    }
+    // reduce the 8 row lanes through LDS
+    __shared__ float red[3][8][32];
+    red[0][ql][m] = s0; red[1][ql][m] = s1; red[2][ql][m] = s2;
+    __syncthreads();
+    if (ql < 3 && mm < M) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s += red[ql][k][m];
+      atomicAdd(dB + ql * M + mm, s);
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// inverse-distance interpolation of the feature table:  c[q] = has ? sum_k w[q][k] feats[I[q][k]] : 0
+// and its transpose  dfeats[I[q][k]] += w[q][k] dc[q]     (32 lanes = one 128-byte feature row)
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void idw_fwd_kernel(const float* __restrict__ feats, const int64_t* __restrict__ I,
+                                                      const float* __restrict__ w, const uint8_t* __restrict__ has,
+                                                      long Q, float* __restrict__ c, int ldc) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const long q = t >> 5;
+  const int ch = (int)(t & 31);
+  if (q >= Q) return;
+  float acc = 0.0f;
+  if (has[q]) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float wk = w[q * 8 + k];
+      const long ik = I[q * 8 + k];
+      if (wk != 0.0f && ik >= 0) acc += wk * feats[ik * 32 + ch];
+    }
+  }
+  c[q * ldc + ch] = acc;
+}
+
+__global__ __launch_bounds__(256) void idw_bwd_kernel(const float* __restrict__ dc, int ldc, const int64_t* __restrict__ I,
+                                                      const float* __restrict__ w, const uint8_t* __restrict__ has,
+                                                      long Q, float* __restrict__ dfeats) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const long q = t >> 5;
+  const int ch = (int)(t & 31);
+  if (q >= Q || !has[q]) return;
+  const float g = dc[q * ldc + ch];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float wk = w[q * 8 + k];
+    const long ik = I[q * 8 + k];
+    if (wk != 0.0f && ik >= 0) atomicAdd(dfeats + ik * 32 + ch, wk * g);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// per-neighbour rows of the colour decoder (decoder.py:361-383): row (q, k) = [sin(v) | cos(v) | col_feats[I]],
+// v = 2 pi (cloud_pos[I] - p) B_rel;  64 threads per row group: thread = (row, column 0..51)
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nb_rows_fwd_kernel(const float* __restrict__ pts, const float* __restrict__ cloud,
+                                                          const float* __restrict__ feats, const int64_t* __restrict__ I,
+                                                          const float* __restrict__ Brel, long Q, float* __restrict__ X,
+                                                          int ldx) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const long row = t >> 6;                       // (q, k)
+  const int col = (int)(t & 63);
+  if (row >= Q * 8 || col >= 52) return;
+  const long q = row >> 3;
+  long ik = I[row];
+  if (ik < 0) ik = 0;                            // clamp(min=0) of the reference; its weight is zero
+  float v;
+  if (col < 20) {
+    const int m = col < 10 ? col : col - 10;
+    float rel[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) rel[d] = cloud[ik * 3 + d] - pts[q * 3 + d];
+    const float ph = fourier_phase(rel, Brel, 10, m);
+    v = col < 10 ? sinf(ph) : cosf(ph);
+  } else {
+    v = feats[ik * 32 + (col - 20)];
+  }
+  X[row * ldx + col] = v;
+}
+
+// dX [8Q,52] -> dcol_feats[I] (columns 20..51, atomics) and dB_rel (columns 0..19)
+__global__ __launch_bounds__(256) void nb_rows_bwd_kernel(const float* __restrict__ dX, int ldx, const float* __restrict__ pts,
+                                                          const float* __restrict__ cloud, const int64_t* __restrict__ I,
+                                                          const float* __restrict__ Brel, long Q,
+                                                          float* __restrict__ dfeats, float* __restrict__ dBrel) {
+  __shared__ float red[30];
+  if (threadIdx.x < 30) red[threadIdx.x] = 0.0f;
+  __syncthreads();
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const long row = t >> 6;
+  const int col = (int)(t & 63);
+  if (row < Q * 8 && col < 52) {
+    const long q = row >> 3;
+    long ik = I[row];
+    const bool neg = ik < 0;
+    if (neg) ik = 0;
+    if (col >= 20) {
+      // feats[I.clamp(min=0)]: a missing neighbour (I = -1) reads row 0 and its gradient flows there too; the
+      // weight of such a row is zero, so its gradient row is exactly zero
+      const float g = dX[row * ldx + col];
+      if (g != 0.0f) atomicAdd(dfeats + ik * 32 + (col - 20), g);
+    } else if (col < 10) {
+      float rel[3];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) rel[d] = cloud[ik * 3 + d] - pts[q * 3 + d];
+      const float ph = fourier_phase(rel, Brel, 10, col);
+      const float gv = dX[row * ldx + col] * cosf(ph) - dX[row * ldx + 10 + col] * sinf(ph);
+      const float tp = 6.283185307179586f;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) atomicAdd(&red[d * 10 + col], tp * rel[d] * gv);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 30 && red[threadIdx.x] != 0.0f) atomicAdd(dBrel + threadIdx.x, red[threadIdx.x]);
+}
+
+// c[q][ch] = has ? sum_k w[q][k] F[(q,k)][ch] : 0        and        dF[(q,k)][ch] = has ? w[q][k] dc[q][ch] : 0
+__global__ __launch_bounds__(256) void wsum_fwd_kernel(const float* __restrict__ F, int ldf, const float* __restrict__ w,
+                                                       const uint8_t* __restrict__ has, long Q, float* __restrict__ c,
+                                                       int ldc) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const long q = t >> 5;
+  const int ch = (int)(t & 31);
+  if (q >= Q) return;
+  float acc = 0.0f;
+  if (has[q]) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc += w[q * 8 + k] * F[(q * 8 + k) * ldf + ch];
+  }
+  c[q * ldc + ch] = acc;
+}
+__global__ __launch_bounds__(256) void wsum_bwd_kernel(const float* __restrict__ dc, int ldc, const float* __restrict__ w,
+                                                       const uint8_t* __restrict__ has, long Q, float* __restrict__ dF,
+                                                       int ldf) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const long q = t >> 5;
+  const int ch = (int)(t & 31);
+  if (q >= Q) return;
+  const float g = has[q] ? dc[q * ldc + ch] : 0.0f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) dF[(q * 8 + k) * ldf + ch] = w[q * 8 + k] * g;
+}
+
+// raw[q] = (rgb, has ? occ : -100)      (Renderer.py:206-207)
+__global__ __launch_bounds__(256) void raw_pack_kernel(const float* __restrict__ rgb, int ldrgb, const float* __restrict__ occ,
+                                                       const uint8_t* __restrict__ has, long Q, int color,
+                                                       float* __restrict__ raw) {
+  const long q = (long)blockIdx.x * 256 + threadIdx.x;
+  if (q >= Q) return;
+  float4 v = make_float4(0.f, 0.f, 0.f, has[q] ? occ[q] : -100.0f);
+  if (color) { v.x = rgb[q * ldrgb]; v.y = rgb[q * ldrgb + 1]; v.z = rgb[q * ldrgb + 2]; }
+  reinterpret_cast<float4*>(raw)[q] = v;
+}
+// d_raw [Q,4] -> dz[q][0..2] = g_rgb * rgb (1 - rgb) (sigmoid of the output layer), dz[q][3] = has ? g_occ : 0
+__global__ __launch_bounds__(256) void raw_unpack_bwd_kernel(const float* __restrict__ draw, const float* __restrict__ rgb,
+                                                             int ldrgb, const uint8_t* __restrict__ has, long Q, int color,
+                                                             float* __restrict__ dz) {
+  const long q = (long)blockIdx.x * 256 + threadIdx.x;
+  if (q >= Q) return;
+  const float4 g = reinterpret_cast<const float4*>(draw)[q];
+  float4 o = make_float4(0.f, 0.f, 0.f, has[q] ? g.w : 0.0f);
+  if (color) {
+    const float y0 = rgb[q * ldrgb], y1 = rgb[q * ldrgb + 1], y2 = rgb[q * ldrgb + 2];
+    o.x = g.x * y0 * (1.0f - y0); o.y = g.y * y1 * (1.0f - y1); o.z = g.z * y2 * (1.0f - y2);
+  }
+  reinterpret_cast<float4*>(dz)[q] = o;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// compositing backward (common.py:261-299): one thread per ray
+//   alpha_s = sigmoid(coef occ_s), T_s = prod_{j<s} (1 - alpha_j + 1e-10), w_s = alpha_s T_s, W = sum w + 1e-10
+//   rgb = sum w c / W, depth = sum w z / W
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kMaxS = 32;
+__global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restrict__ raw, const float* __restrict__ z_vals,
+                                                            int R, int S, float coef, const float* __restrict__ g_depth,
+                                                            const float* __restrict__ g_rgb, float* __restrict__ draw) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= R) return;
+  float alpha[kMaxS], wgt[kMaxS];
+  float T = 1.0f, W = 0.0f, cr = 0.f, cg = 0.f, cb = 0.f, dz = 0.f;
+  for (int s = 0; s < S; ++s) {
+    const float4 v = reinterpret_cast<const float4*>(raw)[(size_t)r * S + s];
+    alpha[s] = 1.0f / (1.0f + expf(-coef * v.w));
+    wgt[s] = alpha[s] * T;
+    T *= (1.0f - alpha[s] + 1e-10f);
+    W += wgt[s];
+    cr += wgt[s] * v.x; cg += wgt[s] * v.y; cb += wgt[s] * v.z;
+    dz += wgt[s] * z_vals[(size_t)r * S + s];
+  }
+  const float den = W + 1e-10f;
+  const float mr = cr / den, mg = cg / den, mb = cb / den, md = dz / den;
+  const float gd = g_depth ? g_depth[r] : 0.0f;
+  const float gr = g_rgb ? g_rgb[(size_t)r * 3] : 0.f, gg = g_rgb ? g_rgb[(size_t)r * 3 + 1] : 0.f,
+              gb = g_rgb ? g_rgb[(size_t)r * 3 + 2] : 0.f;
+  float suffix = 0.0f;                 // sum_{s > j} g_w[s] w_s
+  for (int j = S - 1; j >= 0; --j) {
+    const float4 v = reinterpret_cast<const float4*>(raw)[(size_t)r * S + j];
+    const float gw = (gd * (z_vals[(size_t)r * S + j] - md) + gr * (v.x - mr) + gg * (v.y - mg) + gb * (v.z - mb)) / den;
+    // T_j = w_j / alpha_j would divide by ~0 for alpha -> 0: rebuild T_j as prod below instead
+    float Tj = 1.0f;
+    for (int k = 0; k < j; ++k) Tj *= (1.0f - alpha[k] + 1e-10f);
+    const float ga = gw * Tj - suffix / (1.0f - alpha[j] + 1e-10f);
+    float4 o;
+    o.x = gr * wgt[j] / den; o.y = gg * wgt[j] / den; o.z = gb * wgt[j] / den;
+    o.w = ga * coef * alpha[j] * (1.0f - alpha[j]);
+    reinterpret_cast<float4*>(draw)[(size_t)r * S + j] = o;
+    suffix += gw * wgt[j];
+  }
+}
+
+// torch.optim.Adam (amsgrad = False, weight_decay = 0, maximize = False), one element per thread
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
+                                                   float bc1, float bc2_sqrt, const uint8_t* __restrict__ row_mask,
+                                                   int row_len) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  if (row_mask && !row_mask[i / row_len]) return;
+  const float gi = g[i];
+  const float mi = b1 * m[i] + (1.0f - b1) * gi;
+  const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+  m[i] = mi; v[i] = vi;
+  const float denom = sqrtf(vi) / bc2_sqrt + eps;
+  p[i] -= (lr / bc1) * mi / denom;
+}
+
+// dz[q][j] = dy[q][j] * act'(through the saved output y[q][j])
+__global__ __launch_bounds__(256) void dact_kernel(const float* __restrict__ dy, int ldd, const float* __restrict__ y, int ldy,
+                                                   int act, long Q, int J, float* __restrict__ dz, int ldz) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= Q * J) return;
+  const long q = idx / J;
+  const int j = (int)(idx - q * J);
+  dz[q * ldz + j] = dy[q * ldd + j] * t_dact(y[q * ldy + j], act);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host side: launch helpers
+// ---------------------------------------------------------------------------------------------------------
+static int mm(hipStream_t st, bool trans, const float* in, int ldi, const float* W, int ldw, const float* bias, int Q, int R,
+              int J, int act, float* out, int ldo, const float* res = nullptr, int ldr = 0, const float* saved = nullptr,
+              int lds = 0, int dact = 0, int accumulate = 0) {
+  if (Q == 0) return GLORIE_OK;
+  if (J > kMaxJT * 16) return GLORIE_EUNSUPPORTED;
+  MmArgs a{in, ldi, W, ldw, bias, res, ldr, saved, lds, dact, out, ldo, Q, R, J, act, accumulate};
+  const dim3 grid((unsigned)((Q + 63) / 64));
+  if (trans) hipLaunchKernelGGL(mm_rows_kernel<true>, grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(mm_rows_kernel<false>, grid, dim3(256), 0, st, a);
+  return check_launch();
+}
+static int wgrad(hipStream_t st, const float* dY, int ldy, const float* X, int ldx, long Q, int N, int K, float* dW, int ldw,
+                 float* db) {
+  if (Q == 0 || !dW) return GLORIE_OK;
+  if (K + 1 > kMaxKT * 16) return GLORIE_EUNSUPPORTED;
+  // ~256 waves per 16-row slab of dW are plenty; at least 256 rows per wave keep the atomics rare
+  long rpw = (Q + 255) / 256;
+  if (rpw < 256) rpw = 256;
+  rpw = (rpw + 3) / 4 * 4;
+  const long waves = (Q + rpw - 1) / rpw;
+  WgArgs a{dY, ldy, X, ldx, dW, ldw, db, Q, N, K, rpw};
+  hipLaunchKernelGGL(mm_wgrad_kernel, dim3((N + 15) / 16, (unsigned)((waves + 3) / 4)), dim3(256), 0, st, a);
+  return check_launch();
+}
+
+}  // namespace glorie
+
+using namespace glorie;
+
+// workspace layout (floats per sample); every buffer is [Q or 8Q][ld] row-major
+namespace {
+struct Ws {
+  // geometry decoder
+  float *g_c, *g_emb, *g_A[5], *g_H[5], *g_occ;     // H[2] is the tail of g_cat
+  float* g_cat;                                     // [Q,125]: emb | H2
+  // colour decoder
+  float *n_X, *n_Z, *n_F, *c_c, *c_emb, *c_A[5], *c_H[5], *c_cat, *c_rgb;
+  // backward temporaries
+  float *t_a, *t_b, *t_c32, *t_n128, *t_n52, *t_n32, *t_q4, *t_cat, *t_emb;
+  size_t total;
+};
+constexpr int G_HID = 32, G_EMB = 93, G_CAT = 125, C_HID = 128, C_EMB = 80, C_CAT = 208, NB_IN = 52;
+
+Ws carve(float* base, long Q) {
+  Ws w{};
+  size_t off = 0;
+  auto take = [&](size_t n) { float* p = base ? base + off : nullptr; off += (n + 3) / 4 * 4; return p; };
+  const size_t q = (size_t)Q;
+  w.g_c = take(q * 32); w.g_emb = take(q * G_EMB);
+  for (int i = 0; i < 5; ++i) w.g_A[i] = take(q * G_HID);
+  w.g_cat = take(q * G_CAT);
+  for (int i = 0; i < 5; ++i) w.g_H[i] = (i == 2) ? nullptr : take(q * G_HID);
+  w.g_occ = take(q);
+  w.n_X = take(q * 8 * NB_IN); w.n_Z = take(q * 8 * C_HID); w.n_F = take(q * 8 * 32);
+  w.c_c = take(q * 32); w.c_emb = take(q * C_EMB);
+  for (int i = 0; i < 5; ++i) w.c_A[i] = take(q * C_HID);
+  w.c_cat = take(q * C_CAT);
+  for (int i = 0; i < 5; ++i) w.c_H[i] = (i == 2) ? nullptr : take(q * C_HID);
+  w.c_rgb = take(q * 4);
+  w.t_a = take(q * C_CAT); w.t_b = take(q * C_CAT); w.t_c32 = take(q * 32);
+  w.t_n128 = take(q * 8 * C_HID); w.t_n52 = take(q * 8 * NB_IN); w.t_n32 = take(q * 8 * 32);
+  w.t_q4 = take(q * 4); w.t_cat = take(q * C_CAT); w.t_emb = take(q * G_EMB);
+  w.total = off;
+  return w;
+}
+inline unsigned blocks(long n) { return (unsigned)((n + 255) / 256); }
+}  // namespace
+
+extern "C" size_t glorie_render_train_workspace(long Q) { return carve(nullptr, Q < 0 ? 0 : Q).total * sizeof(float); }
+
+static int dact(hipStream_t st, const float* dy, int ldd, const float* y, int ldy, int act, long Q, int J, float* dz, int ldz) {
+  if (Q == 0) return GLORIE_OK;
+  hipLaunchKernelGGL(dact_kernel, dim3(blocks(Q * J)), dim3(256), 0, st, dy, ldd, y, ldy, act, Q, J, dz, ldz);
+  return check_launch();
+}
+
+// the 5-layer trunk shared by both decoders (decoder.py:206-216, 414-426):
+//   A_i = act(lin_i(h)); H_i = A_i + fc_c_i(c); after layer 2: h = cat(emb, H_2) (H_2 lives in the tail of `cat`)
+static int trunk_fwd(hipStream_t st, long Q, int hid, int emb_w, int act, const float* emb, const float* c,
+                     const float* const* Wl, const float* const* bl, const float* const* Ul, const float* const* ul,
+                     float* const* A, float* const* H, float* cat) {
+  const int catw = emb_w + hid;
+  GLORIE_TRY(check_hip(hipMemcpy2DAsync(cat, sizeof(float) * catw, emb, sizeof(float) * emb_w, sizeof(float) * emb_w,
+                                        (size_t)Q, hipMemcpyDeviceToDevice, st)));
+  const float* h = emb;
+  int hw = emb_w, ldh = emb_w;
+  for (int i = 0; i < 5; ++i) {
+    GLORIE_TRY(mm(st, true, h, ldh, Wl[i], hw, bl[i], (int)Q, hw, hid, act, A[i], hid));
+    float* Hi = (i == 2) ? cat + emb_w : H[i];
+    const int ldH = (i == 2) ? catw : hid;
+    GLORIE_TRY(mm(st, true, c, 32, Ul[i], 32, ul[i], (int)Q, 32, hid, TACT_NONE, Hi, ldH, A[i], hid));
+    if (i == 2) { h = cat; hw = catw; ldh = catw; }
+    else { h = Hi; hw = hid; ldh = hid; }
+  }
+  return GLORIE_OK;
+}
+
+// backward of the trunk: dH_4 ([Q,hid] contiguous, destroyed) -> parameter gradients (accumulated), dc [Q,32]
+// (overwritten) and, if demb != NULL, the gradient of the embedding [Q,emb_w] (overwritten).
+// scratch: p0, p1, dz [Q,hid]; dcat [Q,emb_w + hid]
+static int trunk_bwd(hipStream_t st, long Q, int hid, int emb_w, int act, const float* emb, const float* c,
+                     const float* const* Wl, const float* const* Ul, float* const* dWl, float* const* dbl,
+                     float* const* dUl, float* const* dul, float* const* A, float* const* H, const float* cat,
+                     float* dH4, float* p0, float* p1, float* dz, float* dcat, float* dc, float* demb) {
+  const int catw = emb_w + hid;
+  GLORIE_TRY(check_hip(hipMemsetAsync(dc, 0, sizeof(float) * (size_t)Q * 32, st)));
+  const float* dh = dH4;
+  int ldd = hid;
+  for (int i = 4; i >= 0; --i) {
+    // H_i = A_i + c U_i^T + u_i
+    GLORIE_TRY(wgrad(st, dh, ldd, c, 32, Q, hid, 32, dUl[i], 32, dul[i]));
+    GLORIE_TRY(mm(st, false, dh, ldd, Ul[i], 32, nullptr, (int)Q, hid, 32, TACT_NONE, dc, 32, nullptr, 0, nullptr, 0, 0, 1));
+    // A_i = act(Z_i):  dZ_i = dH_i * act'(A_i)
+    GLORIE_TRY(dact(st, dh, ldd, A[i], hid, act, Q, hid, dz, hid));
+    // Z_i = hin W_i^T + b_i
+    const float* hin; int hw, ldh;
+    if (i == 0) { hin = emb; hw = emb_w; ldh = emb_w; }
+    else if (i == 3) { hin = cat; hw = catw; ldh = catw; }
+    else if (i == 4) { hin = H[3]; hw = hid; ldh = hid; }
+    else { hin = H[i - 1]; hw = hid; ldh = hid; }              // i = 1, 2: H_0, H_1
+    GLORIE_TRY(wgrad(st, dz, hid, hin, ldh, Q, hid, hw, dWl[i], hw, dbl[i]));
+    if (i == 0) {
+      if (demb) GLORIE_TRY(mm(st, false, dz, hid, Wl[0], emb_w, nullptr, (int)Q, hid, emb_w, TACT_NONE, demb, emb_w,
+                              nullptr, 0, nullptr, 0, 0, /*accumulate=*/1));
+    } else if (i == 3) {
+      GLORIE_TRY(mm(st, false, dz, hid, Wl[3], catw, nullptr, (int)Q, hid, catw, TACT_NONE, dcat, catw));
+      if (demb)   // the embedding half of the skip connection; layer 0 adds its part on top
+        GLORIE_TRY(check_hip(hipMemcpy2DAsync(demb, sizeof(float) * emb_w, dcat, sizeof(float) * catw,
+                                              sizeof(float) * emb_w, (size_t)Q, hipMemcpyDeviceToDevice, st)));
+      dh = dcat + emb_w; ldd = catw;
+    } else {
+      float* nxt = (i == 4 || i == 2) ? p0 : p1;
+      GLORIE_TRY(mm(st, false, dz, hid, Wl[i], hid, nullptr, (int)Q, hid, hid, TACT_NONE, nxt, hid));
+      dh = nxt; ldd = hid;
+    }
+  }
+  return GLORIE_OK;
+}
+
+static bool params_ok(const glorie_decoder_params* p, bool color) {
+  if (!p || !p->g_B || !p->g_Wo || !p->g_bo) return false;
+  for (int i = 0; i < 5; ++i) if (!p->g_W[i] || !p->g_b[i] || !p->g_U[i] || !p->g_u[i]) return false;
+  if (!color) return true;
+  if (!p->n_B || !p->n_W1 || !p->n_b1 || !p->n_W2 || !p->n_b2 || !p->c_Bp || !p->c_Bv || !p->c_Wo || !p->c_bo) return false;
+  for (int i = 0; i < 5; ++i) if (!p->c_W[i] || !p->c_b[i] || !p->c_U[i] || !p->c_u[i]) return false;
+  return true;
+}
+
+extern "C" int glorie_render_train_fwd(const glorie_decoder_params* P, const float* pts, const float* views,
+                                       const float* cloud_pos, const float* geo_feats, const float* col_feats,
+                                       const int64_t* I, const float* w, const uint8_t* has, long Q, int stage_color,
+                                       float* workspace, float* raw, void* stream) {
+  if (Q < 0) return GLORIE_EINVAL;
+  if (Q == 0) return GLORIE_OK;
+  if (!params_ok(P, stage_color != 0) || !pts || !geo_feats || !I || !w || !has || !workspace || !raw) return GLORIE_EINVAL;
+  if (stage_color && (!views || !cloud_pos || !col_feats)) return GLORIE_EINVAL;
+  if (Q > (1L << 27)) return GLORIE_EUNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  Ws W = carve(workspace, Q);
+  // ---- geometry decoder (decoder.py:175-225) ----
+  hipLaunchKernelGGL(idw_fwd_kernel, dim3(blocks(Q * 32)), dim3(256), 0, st, geo_feats, I, w, has, Q, W.g_c, 32);
+  hipLaunchKernelGGL(fourier_fwd_kernel, dim3(blocks(Q * G_EMB)), dim3(256), 0, st, pts, 3, 0, P->g_B, G_EMB, 0, Q, W.g_emb, G_EMB);
+  GLORIE_TRY(check_launch());
+  float* gH[5] = {W.g_H[0], W.g_H[1], W.g_cat + G_EMB, W.g_H[3], W.g_H[4]};
+  GLORIE_TRY(trunk_fwd(st, Q, G_HID, G_EMB, TACT_RELU, W.g_emb, W.g_c, P->g_W, P->g_b, P->g_U, P->g_u, W.g_A, gH, W.g_cat));
+  GLORIE_TRY(mm(st, true, W.g_H[4], G_HID, P->g_Wo, G_HID, P->g_bo, (int)Q, G_HID, 1, TACT_NONE, W.g_occ, 1));
+  if (stage_color) {
+    // ---- per-neighbour F_theta + IDW sum (decoder.py:340-389, 228-243) ----
+    hipLaunchKernelGGL(nb_rows_fwd_kernel, dim3(blocks(Q * 8 * 64)), dim3(256), 0, st, pts, cloud_pos, col_feats, I, P->n_B, Q, W.n_X, NB_IN);
+    GLORIE_TRY(check_launch());
+    GLORIE_TRY(mm(st, true, W.n_X, NB_IN, P->n_W1, NB_IN, P->n_b1, (int)(Q * 8), NB_IN, C_HID, TACT_SOFTPLUS, W.n_Z, C_HID));
+    GLORIE_TRY(mm(st, true, W.n_Z, C_HID, P->n_W2, C_HID, P->n_b2, (int)(Q * 8), C_HID, 32, TACT_NONE, W.n_F, 32));
+    hipLaunchKernelGGL(wsum_fwd_kernel, dim3(blocks(Q * 32)), dim3(256), 0, st, W.n_F, 32, w, has, Q, W.c_c, 32);
+    // ---- colour decoder (decoder.py:391-433) ----
+    hipLaunchKernelGGL(fourier_fwd_kernel, dim3(blocks(Q * 20)), dim3(256), 0, st, pts, 3, 0, P->c_Bp, 20, 1, Q, W.c_emb, C_EMB);
+    hipLaunchKernelGGL(fourier_fwd_kernel, dim3(blocks(Q * 20)), dim3(256), 0, st, views, 3, 1, P->c_Bv, 20, 1, Q, W.c_emb + 40, C_EMB);
+    GLORIE_TRY(check_launch());
+    float* cH[5] = {W.c_H[0], W.c_H[1], W.c_cat + C_EMB, W.c_H[3], W.c_H[4]};
+    GLORIE_TRY(trunk_fwd(st, Q, C_HID, C_EMB, TACT_SOFTPLUS, W.c_emb, W.c_c, P->c_W, P->c_b, P->c_U, P->c_u, W.c_A, cH, W.c_cat));
+    GLORIE_TRY(mm(st, true, W.c_H[4], C_HID, P->c_Wo, C_HID, P->c_bo, (int)Q, C_HID, 3, TACT_SIGMOID, W.c_rgb, 4));
+  }
+  hipLaunchKernelGGL(raw_pack_kernel, dim3(blocks(Q)), dim3(256), 0, st, W.c_rgb, 4, W.g_occ, has, Q, stage_color ? 1 : 0, raw);
+  return check_launch();
+}
+
+extern "C" int glorie_render_train_bwd(const glorie_decoder_params* P, const glorie_decoder_grads* G, const float* pts,
+                                       const float* views, const float* cloud_pos, const float* geo_feats,
+                                       const float* col_feats, const int64_t* I, const float* w, const uint8_t* has,
+                                       long Q, int stage_color, float* workspace, const float* d_raw,
+                                       float* d_geo_feats, float* d_col_feats, void* stream) {
+  if (Q < 0) return GLORIE_EINVAL;
+  if (Q == 0) return GLORIE_OK;
+  if (!params_ok(P, stage_color != 0) || !G || !pts || !I || !w || !has || !workspace || !d_raw) return GLORIE_EINVAL;
+  if (stage_color && (!views || !cloud_pos || !col_feats)) return GLORIE_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  Ws W = carve(workspace, Q);
+  // d_raw -> d(occ), d(pre-sigmoid rgb)
+  hipLaunchKernelGGL(raw_unpack_bwd_kernel, dim3(blocks(Q)), dim3(256), 0, st, d_raw, W.c_rgb, 4, has, Q, stage_color ? 1 : 0,
+                     W.t_q4);
+  GLORIE_TRY(check_launch());
+  const float* docc = W.t_q4 + 3;         // column 3 of the [Q,4] scratch (row stride 4)
+  // ---- geometry decoder ----
+  {
+    // occ = H_4 Wo^T + bo
+    GLORIE_TRY(wgrad(st, docc, 4, W.g_H[4], G_HID, Q, 1, G_HID, G->g_Wo, G_HID, G->g_bo));
+    float* dH4 = W.t_a;
+    GLORIE_TRY(mm(st, false, docc, 4, P->g_Wo, G_HID, nullptr, (int)Q, 1, G_HID, TACT_NONE, dH4, G_HID));
+    float* gH[5] = {W.g_H[0], W.g_H[1], W.g_cat + G_EMB, W.g_H[3], W.g_H[4]};
+    float* p0 = W.t_b, *p1 = W.t_b + (size_t)Q * G_HID, *dz = W.t_b + (size_t)Q * 2 * G_HID;
+    GLORIE_TRY(trunk_bwd(st, Q, G_HID, G_EMB, TACT_RELU, W.g_emb, W.g_c, P->g_W, P->g_U, G->g_W, G->g_b, G->g_U, G->g_u,
+                         W.g_A, gH, W.g_cat, dH4, p0, p1, dz, W.t_cat, W.t_c32, G->g_B ? W.t_emb : nullptr));
+    if (G->g_B) {
+      const int rpb = 2048;
+      hipLaunchKernelGGL(fourier_bwd_kernel, dim3((unsigned)((Q + rpb - 1) / rpb)), dim3(256), 0, st, pts, 3, P->g_B, G_EMB, 0, Q,
+                         W.t_emb, G_EMB, G->g_B, rpb);
+    }
+    if (d_geo_feats)
+      hipLaunchKernelGGL(idw_bwd_kernel, dim3(blocks(Q * 32)), dim3(256), 0, st, W.t_c32, 32, I, w, has, Q, d_geo_feats);
+    GLORIE_TRY(check_launch());
+  }
+  if (!stage_color) return GLORIE_OK;
+  // ---- colour decoder ----
+  {
+    // rgb = sigmoid(H_4 Wo^T + bo): t_q4[:, 0:3] already holds dZ
+    GLORIE_TRY(wgrad(st, W.t_q4, 4, W.c_H[4], C_HID, Q, 3, C_HID, G->c_Wo, C_HID, G->c_bo));
+    float* dH4 = W.t_a;
+    GLORIE_TRY(mm(st, false, W.t_q4, 4, P->c_Wo, C_HID, nullptr, (int)Q, 3, C_HID, TACT_NONE, dH4, C_HID));
+    float* cH[5] = {W.c_H[0], W.c_H[1], W.c_cat + C_EMB, W.c_H[3], W.c_H[4]};
+    // scratch: t_b holds only C_CAT floats per sample -> p0 there, p1 / dz in the (now free) neighbour temporaries
+    float* p0 = W.t_b, *p1 = W.t_n128, *dz = W.t_n128 + (size_t)Q * C_HID;
+    GLORIE_TRY(trunk_bwd(st, Q, C_HID, C_EMB, TACT_SOFTPLUS, W.c_emb, W.c_c, P->c_W, P->c_U, G->c_W, G->c_b, G->c_U, G->c_u,
+                         W.c_A, cH, W.c_cat, dH4, p0, p1, dz, W.t_cat, W.t_c32, nullptr));
+    // c = has ? sum_k w F : 0;  F = Z L2^T + b2;  Z = softplus(X L1^T + b1)
+    hipLaunchKernelGGL(wsum_bwd_kernel, dim3(blocks(Q * 32)), dim3(256), 0, st, W.t_c32, 32, w, has, Q, W.t_n32, 32);
+    GLORIE_TRY(check_launch());
+    GLORIE_TRY(wgrad(st, W.t_n32, 32, W.n_Z, C_HID, Q * 8, 32, C_HID, G->n_W2, C_HID, G->n_b2));
+    GLORIE_TRY(mm(st, false, W.t_n32, 32, P->n_W2, C_HID, nullptr, (int)(Q * 8), 32, C_HID, TACT_NONE, W.t_n128, C_HID, nullptr, 0,
+                  W.n_Z, C_HID, TACT_SOFTPLUS));
+    GLORIE_TRY(wgrad(st, W.t_n128, C_HID, W.n_X, NB_IN, Q * 8, C_HID, NB_IN, G->n_W1, NB_IN, G->n_b1));
+    GLORIE_TRY(mm(st, false, W.t_n128, C_HID, P->n_W1, NB_IN, nullptr, (int)(Q * 8), C_HID, NB_IN, TACT_NONE, W.t_n52, NB_IN));
+    if (d_col_feats || G->n_B) {
+      // one launch serves both; a NULL target is replaced by a scratch sink
+      float* sinkB = G->n_B ? G->n_B : W.t_q4;          // 30 floats
+      if (!d_col_feats) return GLORIE_EINVAL;
+      hipLaunchKernelGGL(nb_rows_bwd_kernel, dim3(blocks(Q * 8 * 64)), dim3(256), 0, st, W.t_n52, NB_IN, pts, cloud_pos, I,
+                         P->n_B, Q, d_col_feats, sinkB);
+      GLORIE_TRY(check_launch());
+    }
+  }
+  return GLORIE_OK;
+}
+
+extern "C" int glorie_composite_bwd(const float* raw, const float* z_vals, int R, int S, float coef, const float* g_depth,
+                                    const float* g_rgb, float* d_raw, void* stream) {
+  if (R < 0 || S < 1 || S > kMaxS) return GLORIE_EINVAL;
+  if (R == 0) return GLORIE_OK;
+  if (!raw || !z_vals || !d_raw) return GLORIE_EINVAL;
+  hipLaunchKernelGGL(composite_bwd_kernel, dim3(blocks(R)), dim3(256), 0, (hipStream_t)stream, raw, z_vals, R, S, coef,
+                     g_depth, g_rgb, d_raw);
+  return check_launch();
+}
+
+extern "C" int glorie_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr,
+                                float beta1, float beta2, float eps, int step, const uint8_t* row_mask, int row_len,
+                                void* stream) {
+  if (n < 0 || step < 1) return GLORIE_EINVAL;
+  if (n == 0) return GLORIE_OK;
+  if (!param || !grad || !exp_avg || !exp_avg_sq || (row_mask && row_len < 1)) return GLORIE_EINVAL;
+  const float bc1 = 1.0f - powf(beta1, (float)step);
+  const float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks(n)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr,
+                     beta1, beta2, eps, bc1, bc2s, row_mask, row_len > 0 ? row_len : 1);
+  return check_launch();
+}

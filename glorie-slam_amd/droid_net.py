@@ -224,6 +224,7 @@ class FusedUpdate:
         W = {}
         W["ce1_t"] = m.corr_encoder[0].weight.detach().view(128, -1).t().half().contiguous()
         W["ce1_b"] = f32(m.corr_encoder[0].bias)
+        W["ce1_p"] = OtfCorrBlock.pack_encoder(m.corr_encoder[0].weight)
         W["ce2"], W["ce2_b"] = U.pack_conv_igemm(m.corr_encoder[2].weight), f32(m.corr_encoder[2].bias)
         W["fe1"], W["fe1_b"] = U.pack_flow_conv7(m.flow_encoder[0].weight), f32(m.flow_encoder[0].bias)
         W["fe2"], W["fe2_b"] = U.pack_conv_igemm(m.flow_encoder[2].weight), f32(m.flow_encoder[2].bias)
@@ -321,11 +322,17 @@ class FusedUpdate:
             wn = U.conv_igemm(net0, None, W["w"], 1, 128, cl_map(128))
             g = U.gru_glo_terms(wn, W["w_b"], net0, W["G"], W["G_b"])
         # corr_encoder (droid_net.py:73-77): 1x1 as a transposed GEMM on the NCHW lookup output
-        if callable(corr):
-            corr = corr()                              # the lookup itself, issued behind the forks
-        c1 = torch.matmul(corr.reshape(n, -1, hw).half().transpose(1, 2), W["ce1_t"])
-        c1 = c1.view(n, ht, wd, 128).permute(0, 3, 1, 2)
-        U.bias_act(c1, W["ce1_b"], U.ACT_RELU)
+        if hasattr(corr, "encode_into"):
+            # volume-free lookup with corr_encoder[0] fused behind it (csrc/corr_otf.hip): the 196-channel map
+            # never exists in HBM
+            c1 = cl_map(128)
+            corr.encode_into(W["ce1_p"], W["ce1_b"], c1)
+        else:
+            if callable(corr):
+                corr = corr()                          # the lookup itself, issued behind the forks
+            c1 = torch.matmul(corr.reshape(n, -1, hw).half().transpose(1, 2), W["ce1_t"])
+            c1 = c1.view(n, ht, wd, 128).permute(0, 3, 1, 2)
+            U.bias_act(c1, W["ce1_b"], U.ACT_RELU)
         U.conv_igemm(c1, None, W["ce2"], 9, 128, hx[:, 128:256], terms=W["ce2_b"], act=U.ACT_RELU)
         for st in side:
             if st is not main:
@@ -483,6 +490,19 @@ class AltCorrBlock:
         if squeeze:
             corr = corr.squeeze(-1)
         return corr.contiguous()
+
+
+class FusedLookup:
+    """one pending lookup of an OtfCorrBlock that FusedUpdate runs with corr_encoder[0] fused behind it"""
+
+    def __init__(self, block, coords, ii, jj):
+        self.block, self.coords, self.ii, self.jj = block, coords, ii, jj
+
+    def encode_into(self, enc_w, enc_b, out):
+        self.block.lookup_encode(self.coords, self.ii, self.jj, enc_w, enc_b, out)
+
+    def __call__(self):
+        return self.block(self.coords, self.ii, self.jj)
 
 
 class OtfCorrBlock:

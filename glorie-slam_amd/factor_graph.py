@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import droid_backends
-from .droid_net import CorrBlock, AltCorrBlock, FusedUpdate, OtfCorrBlock
+from .droid_net import CorrBlock, AltCorrBlock, FusedUpdate, FusedLookup, OtfCorrBlock
 
 
 def coords_grid(ht, wd, device):
@@ -231,7 +231,7 @@ class FactorGraph:
         if self.ii.numel() == 0:
             return self._update_eager(t0, t1, itrs, use_inactive, EP, motion_only, opt_type)
         t0, t1 = self._window(t0, t1, use_inactive)
-        if not self.use_graphs or self.corr_impl == "otf":
+        if not self.use_graphs:
             return self._update_eager(t0, t1, itrs, use_inactive, EP, motion_only, opt_type)
         # sharded graphs: everything up to the BA is replayed, the BA (all-reduce of the normal equations,
         # the all-reduced fallback decision) and the row exchange are issued eagerly behind it
@@ -324,7 +324,12 @@ class FactorGraph:
         if self.corr_impl == "otf":
             blk = self._otf_block()
             rig = self._otf_rig
-            lookup = lambda: blk(coords1, rig * self.ii, rig * self.jj + (self.ii == self.jj).long())
+            ck = ("otf_idx", rig)
+            if ck not in self._graphs:
+                self._graphs[ck] = ((rig * self.ii).contiguous(), (rig * self.jj + (self.ii == self.jj).long()).contiguous())
+            oi, oj = self._graphs[ck]
+            lookup = FusedLookup(blk, coords1, oi, oj) if (self.fast_update is not None and blk.num_levels == 4) \
+                else (lambda: blk(coords1, oi, oj))
         else:
             lookup = lambda: self.corr(coords1)
         uniq = self._unique_ii()

@@ -1,0 +1,179 @@
+"""Training path of the renderer: `render_batch_ray` under autograd on the HIP kernels of
+csrc/train.hip, and the Adam step of the mapper.
+
+What /root/reference/src/mapper.py:390-515 (`optimizer_update_one_step`) needs from the renderer is the gradient of
+a scalar loss on (depth, colour) with respect to
+  * the neural-point feature tables `npc_geo_feats`, `npc_col_feats` (leaf tensors the mapper clones, mapper.py:586-611)
+  * the decoder parameters (`self.decoders.parameters()`, incl. the learnable Fourier matrices)
+The reference gets it from torch autograd over ~150 small ops per call; here ONE autograd.Function spans
+sampling -> KNN -> decoders -> compositing: its forward is glorie_render_train_fwd + glorie_composite, its backward
+glorie_composite_bwd + glorie_render_train_bwd (no torch op in between, no Python per layer).
+"""
+import ctypes
+
+import torch
+
+from . import _lib as L
+from . import point_ops
+
+
+class _DecoderPtrs(ctypes.Structure):
+    """glorie_decoder_params / glorie_decoder_grads of include/glorie_hip.h: 52 pointers"""
+    _fields_ = [("p", ctypes.c_void_p * 52)]
+
+
+def decoder_tensors(decoders):
+    """the decoder's tensors in the field order of glorie_decoder_params"""
+    g, c = decoders.geo_decoder, decoders.color_decoder
+    n = c.mlp_col_neighbor
+    ts = [g.embedder._B]
+    ts += [l.weight for l in g.pts_linears] + [l.bias for l in g.pts_linears]
+    ts += [l.weight for l in g.fc_c] + [l.bias for l in g.fc_c]
+    ts += [g.output_linear.weight, g.output_linear.bias]
+    ts += [c.embedder_rel_pos._B, n.linear1.weight, n.linear1.bias, n.linear2.weight, n.linear2.bias]
+    ts += [c.embedder._B, c.embedder_view_direction._B]
+    ts += [l.weight for l in c.pts_linears] + [l.bias for l in c.pts_linears]
+    ts += [l.weight for l in c.fc_c] + [l.bias for l in c.fc_c]
+    ts += [c.output_linear.weight, c.output_linear.bias]
+    assert len(ts) == 52
+    return ts
+
+
+_SHAPES = ([(3, 93), (32, 93), (32, 32), (32, 32), (32, 125), (32, 32)] + [(32,)] * 5 + [(32, 32)] * 5 + [(32,)] * 5 +
+           [(1, 32), (1,), (3, 10), (128, 52), (128,), (32, 128), (32,), (3, 20), (3, 20),
+            (128, 80), (128, 128), (128, 128), (128, 208), (128, 128)] + [(128,)] * 5 + [(128, 32)] * 5 +
+           [(128,)] * 5 + [(3, 128), (3,)])
+
+
+def _ptr_struct(tensors):
+    st = _DecoderPtrs()
+    for i, t in enumerate(tensors):
+        st.p[i] = t.data_ptr() if t is not None else None
+    return st
+
+
+def supported(decoders):
+    g, c = decoders.geo_decoder, decoders.color_decoder
+    if not (g.weighting == 'distance' and c.weighting == 'distance' and g.c_dim == 32 and c.c_dim == 32 and
+            c.encode_rel_pos_in_col and c.use_view_direction and c.encode_viewd and g.min_nn_num == c.min_nn_num):
+        return False
+    return all(tuple(t.shape) == s for t, s in zip(decoder_tensors(decoders), _SHAPES))
+
+
+class RenderTrain(torch.autograd.Function):
+    """(geo_feats, col_feats, *decoder tensors) -> (depth, uncertainty, colour) for samples that are already placed"""
+
+    @staticmethod
+    def forward(ctx, meta, geo_feats, col_feats, *params):
+        pts, views, cloud_pos, I, w, has8, z_vals, coef, color = meta
+        dev = pts.device
+        Q = pts.shape[0]
+        R, S = z_vals.shape
+        lib = L.load()
+        f32c = lambda t: t.detach().contiguous().float()
+        geo_feats_c, col_feats_c = f32c(geo_feats), f32c(col_feats)
+        pcs = [f32c(p).to(dev) for p in params]
+        ws = torch.empty(int(lib.glorie_render_train_workspace(Q)) // 4, dtype=torch.float32, device=dev)
+        raw = torch.empty(Q, 4, dtype=torch.float32, device=dev)
+        P = _ptr_struct(pcs)
+        L.check(lib.glorie_render_train_fwd(ctypes.byref(P), L.ptr(pts), L.ptr(views), L.ptr(cloud_pos), L.ptr(geo_feats_c),
+                                            L.ptr(col_feats_c), L.ptr(I), L.ptr(w), L.ptr(has8), Q, int(color),
+                                            L.ptr(ws), L.ptr(raw), L.stream_ptr()), "glorie_render_train_fwd")
+        depth, var, rgb, _ = point_ops.composite(raw.view(R, S, 4), z_vals, coef, return_weights=False)
+        ctx.meta = meta
+        ctx.saved = (geo_feats_c, col_feats_c, pcs, ws, raw)
+        ctx.shapes = (geo_feats.shape, col_feats.shape)
+        ctx.mark_non_differentiable(var)
+        return depth, var, rgb
+
+    @staticmethod
+    def backward(ctx, g_depth, g_var, g_rgb):
+        pts, views, cloud_pos, I, w, has8, z_vals, coef, color = ctx.meta
+        geo_feats_c, col_feats_c, pcs, ws, raw = ctx.saved
+        dev = pts.device
+        Q = pts.shape[0]
+        R, S = z_vals.shape
+        lib = L.load()
+        gd = g_depth.contiguous().float() if g_depth is not None else None
+        gc = g_rgb.contiguous().float() if g_rgb is not None else None
+        d_raw = torch.empty(Q, 4, dtype=torch.float32, device=dev)
+        L.check(lib.glorie_composite_bwd(L.ptr(raw), L.ptr(z_vals), R, S, float(coef), L.ptr(gd), L.ptr(gc), L.ptr(d_raw),
+                                         L.stream_ptr()), "glorie_composite_bwd")
+        need = ctx.needs_input_grad            # (meta, geo_feats, col_feats, *params)
+        d_geo = torch.zeros(ctx.shapes[0], dtype=torch.float32, device=dev) if need[1] else None
+        # the colour table's gradient buffer is needed by the kernel whenever the colour stage runs
+        d_col = torch.zeros(ctx.shapes[1], dtype=torch.float32, device=dev) if (need[2] or color) else None
+        grads = [torch.zeros_like(p) if (need[3 + i] and i not in (28, 29)) else None for i, p in enumerate(pcs)]
+        P, G = _ptr_struct(pcs), _ptr_struct(grads)
+        L.check(lib.glorie_render_train_bwd(ctypes.byref(P), ctypes.byref(G), L.ptr(pts), L.ptr(views), L.ptr(cloud_pos),
+                                            L.ptr(geo_feats_c), L.ptr(col_feats_c), L.ptr(I), L.ptr(w), L.ptr(has8), Q,
+                                            int(color), L.ptr(ws), L.ptr(d_raw), L.ptr(d_geo), L.ptr(d_col),
+                                            L.stream_ptr()), "glorie_render_train_bwd")
+        ctx.saved = None
+        return (None, d_geo, d_col if need[2] else None) + tuple(grads)
+
+
+def render_rays(renderer, npc, decoders, rays_d, rays_o, stage, gt_depth, npc_geo_feats, npc_col_feats, cloud_pos,
+                dynamic_r_query):
+    """render_batch_ray for a batch whose rays all carry a depth prior, differentiable with respect to the feature
+    tables and the decoder parameters.  Returns None if the batch holds a ray without depth (general path)."""
+    S = renderer.N_surface
+    R = rays_o.shape[0]
+    g = decoders.geo_decoder
+    rad = dynamic_r_query if renderer.use_dynamic_radius else None
+    with torch.no_grad():
+        z_vals, pts, views, rq, n_zero = point_ops.ray_samples(rays_o, rays_d, gt_depth, rad, S,
+                                                               renderer.near_end_surface, renderer.far_end_surface)
+        D, I, nn_num = npc.find_neighbors_faiss(pts, step='query', dynamic_radius=rq)
+        radius = 0.0 if g.use_dynamic_radius else npc.get_radius_query()
+        _, has8, w = point_ops.idw_gather(D, I, nn_num, None, radius=radius,
+                                          radius_per_query=rq if g.use_dynamic_radius else None,
+                                          min_nn=g.min_nn_num, return_weights=True, raw_mask=True)
+        counts, valid = point_ops.ray_counts(has8, S, 3)
+        if int(n_zero) != 0:
+            return None
+    cp = (cloud_pos if cloud_pos is not None else npc.cloud_pos()).detach().contiguous().float()
+    meta = (pts, views, cp, I.contiguous(), w.contiguous(), has8.contiguous(), z_vals, renderer.sigmoid_coefficient,
+            stage == "color")
+    depth, var, rgb = RenderTrain.apply(meta, npc_geo_feats, npc_col_feats, *decoder_tensors(decoders))
+    return depth, var, rgb, valid, counts
+
+
+class FeatureAdam:
+    """torch.optim.Adam semantics (mapper.py:612-624) on glorie_adam_step: one launch per tensor, optional row mask
+    for the frustum-selected rows of a feature table (rows outside it keep their value AND their moments)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        self.param_groups = []
+        for g in params:
+            g = dict(g) if isinstance(g, dict) else {"params": list(g)}
+            g.setdefault("lr", lr)
+            g.setdefault("betas", betas)
+            g.setdefault("eps", eps)
+            g["params"] = list(g["params"])
+            self.param_groups.append(g)
+        self.state = {}
+
+    def zero_grad(self):
+        for g in self.param_groups:
+            for p in g["params"]:
+                p.grad = None
+
+    @torch.no_grad()
+    def step(self, row_masks=None):
+        lib = L.load()
+        for g in self.param_groups:
+            for p in g["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state.setdefault(id(p), {"step": 0, "m": torch.zeros_like(p), "v": torch.zeros_like(p)})
+                st["step"] += 1
+                mask = row_masks.get(id(p)) if row_masks else None
+                if not (p.is_contiguous() and p.grad.is_contiguous() and p.dtype == torch.float32):
+                    raise RuntimeError("FeatureAdam: contiguous float32 parameters expected")
+                row_len = p.shape[-1] if mask is not None else 1
+                m8 = mask.to(torch.uint8).contiguous() if mask is not None else None
+                L.check(lib.glorie_adam_step(L.ptr(p), L.ptr(p.grad), L.ptr(st["m"]), L.ptr(st["v"]), p.numel(),
+                                             float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
+                                             int(st["step"]), L.ptr(m8), int(row_len), L.stream_ptr(p.device)),
+                        "glorie_adam_step")

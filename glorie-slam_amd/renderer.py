@@ -128,6 +128,20 @@ class Renderer(object):
                                     npc_col_feats, cloud_pos, dynamic_r_query)
             if out is not None:
                 return out
+        if (torch.is_grad_enabled() and gt_depth is not None and R > 0 and torch.numel(gt_depth) == R and not is_tracker
+                and stage in ('geometry', 'color') and rays_o.is_cuda and getattr(self, "use_train_path", True)
+                and (dynamic_r_query is not None or not self.use_dynamic_radius)
+                and decoders.geo_decoder.use_dynamic_radius == self.use_dynamic_radius):
+            # mapping iteration (mapper.py:390-515): the same kernels chain under autograd - gradients with respect to
+            # the feature tables and the decoder parameters come from csrc/train.hip, not from ~150 torch ops
+            from . import render_train
+            wants = (npc_geo_feats.requires_grad or npc_col_feats.requires_grad
+                     or any(p.requires_grad for p in decoders.parameters()))
+            if wants and render_train.supported(decoders):
+                out = render_train.render_rays(self, npc, decoders, rays_d, rays_o, stage, gt_depth, npc_geo_feats,
+                                               npc_col_feats, cloud_pos, dynamic_r_query)
+                if out is not None:
+                    return out
         z_vals, near_mask, nz = self.sample_z(npc, rays_o, rays_d, gt_depth, device)
         pts = (rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]).reshape(-1, 3)
         rays_d_pts = rays_d.repeat_interleave(S, dim=0).reshape(-1, 3)

@@ -445,6 +445,71 @@ int glorie_composite(const float* raw, const float* z_vals, int R, int S, float 
  * device; [2] = number of failed factorisations. */
 int glorie_ba_status(glorie_ctx* ctx, int* status_out, void* stream);
 
+/* ------------------------------------------------------------------------------------ */
+/* N1. training path of the renderer (forward with saved activations, backward, Adam)   */
+/* ------------------------------------------------------------------------------------ */
+
+/* Parameters of the decoders `POINT` (src/modules/conv_onet/models/decoder.py:436-501) as the tensors of its
+ * state dict, fp32, in torch's own layouts (nn.Linear weight = [out][in]; no packing, no copies):
+ *   geometry decoder (hidden 32): g_B = embedder._B [3][93]; g_W/g_b = pts_linears[i] ([32][93], [32][32],
+ *     [32][32], [32][125], [32][32]); g_U/g_u = fc_c[i] ([32][32]); g_Wo/g_bo = output_linear ([1][32])
+ *   per-neighbour F_theta of the colour decoder: n_B = embedder_rel_pos._B [3][10]; n_W1 [128][52], n_W2 [32][128]
+ *   colour decoder (hidden 128): c_Bp / c_Bv = embedder._B / embedder_view_direction._B [3][20] (not learnable);
+ *     c_W/c_b = pts_linears[i] ([128][80], [128][128], [128][128], [128][208], [128][128]); c_U/c_u = fc_c[i]
+ *     ([128][32]); c_Wo/c_bo = output_linear ([3][128])
+ * glorie_decoder_grads has the same fields; a NULL gradient pointer skips that gradient (c_Bp / c_Bv are ignored).
+ * Gradients are ACCUMULATED (+=) like autograd's .grad. */
+typedef struct glorie_decoder_params {
+  const float* g_B; const float* g_W[5]; const float* g_b[5]; const float* g_U[5]; const float* g_u[5];
+  const float* g_Wo; const float* g_bo;
+  const float* n_B; const float* n_W1; const float* n_b1; const float* n_W2; const float* n_b2;
+  const float* c_Bp; const float* c_Bv; const float* c_W[5]; const float* c_b[5]; const float* c_U[5];
+  const float* c_u[5]; const float* c_Wo; const float* c_bo;
+} glorie_decoder_params;
+typedef struct glorie_decoder_grads {
+  float* g_B; float* g_W[5]; float* g_b[5]; float* g_U[5]; float* g_u[5];
+  float* g_Wo; float* g_bo;
+  float* n_B; float* n_W1; float* n_b1; float* n_W2; float* n_b2;
+  float* c_Bp; float* c_Bv; float* c_W[5]; float* c_b[5]; float* c_U[5];
+  float* c_u[5]; float* c_Wo; float* c_bo;
+} glorie_decoder_grads;
+
+/* bytes of the activation workspace for Q samples (saved forward activations + backward temporaries) */
+size_t glorie_render_train_workspace(long Q);
+
+/* POINT.forward for a training batch: raw [Q,4] = (rgb, occ; occ = -100 where has == 0), every layer's output kept
+ * in `workspace` for the backward pass
+ *   reference: decoder.py:175-225 (MLP_geometry.forward), :340-389 + :228-243 (get_feature_at_pos + F_theta),
+ *   :391-433 (MLP_color.forward), src/utils/Renderer.py:206-207
+ * pts / views [Q,3]; cloud_pos [Np,3]; geo_feats / col_feats [Np,32]; I [Q,8] int64, w [Q,8], has [Q] uint8 from
+ * glorie_knn_query + glorie_idw_gather.  stage_color = 0: geometry stage (rgb = 0; views, cloud_pos, col_feats unused). */
+int glorie_render_train_fwd(const glorie_decoder_params* params, const float* pts, const float* views,
+                            const float* cloud_pos, const float* geo_feats, const float* col_feats,
+                            const int64_t* I, const float* w, const uint8_t* has, long Q, int stage_color,
+                            float* workspace, float* raw, void* stream);
+
+/* what loss.backward() computes below `raw` (src/mapper.py:511): d_raw [Q,4] -> parameter gradients (accumulated
+ * into `grads`), d_geo_feats / d_col_feats [Np,32] (accumulated with fp32 atomics: rows are shared by samples).
+ * Same arguments and the workspace of the matching glorie_render_train_fwd call.  Samples without neighbours pass
+ * no gradient (their feature is a constant; the reference additionally lets a 4.5e-5-weighted gradient of their
+ * overwritten occupancy reach the geometry decoder). */
+int glorie_render_train_bwd(const glorie_decoder_params* params, const glorie_decoder_grads* grads, const float* pts,
+                            const float* views, const float* cloud_pos, const float* geo_feats,
+                            const float* col_feats, const int64_t* I, const float* w, const uint8_t* has, long Q,
+                            int stage_color, float* workspace, const float* d_raw, float* d_geo_feats,
+                            float* d_col_feats, void* stream);
+
+/* backward of raw2outputs_nerf_color (src/utils/common.py:261-299) for depth and colour:
+ * g_depth [R], g_rgb [R,3] (either may be NULL = zero) -> d_raw [R,S,4].  S <= 32. */
+int glorie_composite_bwd(const float* raw, const float* z_vals, int R, int S, float coef, const float* g_depth,
+                         const float* g_rgb, float* d_raw, void* stream);
+
+/* torch.optim.Adam.step() for one tensor (amsgrad off, no weight decay; src/mapper.py:612-624, :512):
+ * step = 1-based step count of this tensor; row_mask [n / row_len] uint8 (may be NULL) restricts the update to the
+ * marked rows of a [rows, row_len] table (the frustum-selected feature rows, mapper.py:586-611). */
+int glorie_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr,
+                     float beta1, float beta2, float eps, int step, const uint8_t* row_mask, int row_len, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

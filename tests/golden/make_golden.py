@@ -178,11 +178,61 @@ def make_render():
           "| zero-depth variant", int(out["b_mask"].sum()))
 
 
+def make_render_grad():
+    """F12: gradients of the mapper's loss (mapper.py:497-505: L1 depth + w * L1 colour) through the reference's
+    render_batch_ray by torch autograd on CPU -> d loss / d {geo_feats, col_feats, every decoder parameter}"""
+    for name in ("faiss", "faiss.contrib", "faiss.contrib.torch_utils", "cv2"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    ds = types.ModuleType("src.utils.datasets")
+    ds.load_mono_depth = None
+    sys.modules.setdefault("src.utils.datasets", ds)
+    from src.utils.Renderer import Renderer
+    from src.utils.common import get_rays
+    from src.modules.conv_onet.models.decoder import POINT
+
+    class NPC(BruteNPC):
+        device = "cpu"
+        radius_query = 0.08
+
+    class Cam:
+        pass
+
+    cfg = render_cfg()
+    cloud, geo, col, c2w, cam, depth, depth_zero, radius = render_scene()
+    slam = Cam()
+    for k, v in cam.items():
+        setattr(slam, k, v)
+    torch.manual_seed(43)
+    dec = POINT(cfg, c_dim=32, hidden_size=128, use_view_direction=True)
+    ren = Renderer(cfg, slam)
+    ro, rd = get_rays(cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"], cam["cy"], c2w, "cpu")
+    ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
+    g = torch.Generator().manual_seed(21)
+    gt_color = torch.rand(ro.shape[0], 3, generator=g)
+    gt_depth = depth * (1.0 + 0.02 * torch.randn(depth.shape[0], generator=g))
+    geo = geo.clone().requires_grad_(True)
+    col = col.clone().requires_grad_(True)
+    torch.manual_seed(0)
+    d, u, c, vm, vc = ren.render_batch_ray(NPC(cloud), dec, rd, ro, "cpu", "color", gt_depth=depth, npc_geo_feats=geo,
+                                           npc_col_feats=col, cloud_pos=cloud, dynamic_r_query=radius)
+    loss = torch.abs(gt_depth - d).sum() + 0.5 * torch.abs(gt_color - c).sum()
+    loss.backward()
+    grads = {"g__" + n: p.grad.numpy() for n, p in dec.named_parameters() if p.grad is not None and float(p.grad.abs().max()) > 0}
+    np.savez_compressed(os.path.join(OUT, "render_grad.npz"), gt_depth=gt_depth.numpy(), gt_color=gt_color.numpy(),
+                        loss=np.float64(loss.item()), d_geo=geo.grad.numpy().astype(np.float32),
+                        d_col=col.grad.numpy().astype(np.float32), **grads)
+    print("render_grad.npz: loss", float(loss), "| parameter gradients", len(grads),
+          "| rows with a gradient", int((geo.grad.abs().sum(1) > 0).sum()), int((col.grad.abs().sum(1) > 0).sum()))
+
+
 def main():
     install_stubs()
     torch.set_num_threads(4)
     if "--only-render" in sys.argv:
         make_render()
+        return
+    if "--only-render-grad" in sys.argv:
+        make_render_grad()
         return
     from src.modules.droid_net.corr import CorrBlock
     from src.modules.droid_net.droid_net import UpdateModule, cvx_upsample, GraphAgg
@@ -302,6 +352,7 @@ def main():
                         color_B_view=dec.color_decoder.embedder_view_direction._B.numpy(),
                         **{"sd__" + k: v for k, v in sd.items()})
     make_render()
+    make_render_grad()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KB")
