@@ -490,6 +490,43 @@ def main():
     torch.cuda.synchronize()
     batch_ms = 1e3 * (time.perf_counter() - t_b) / 50
     assert bool(torch.isfinite(out5[2]).all())
+    # one mapping iteration on that batch (mapper.py:390-515): forward, L1 depth + colour loss, backward to the
+    # feature tables and the decoder parameters, Adam step - on the HIP training path (csrc/train.hip) and, for
+    # comparison, through torch autograd over the plain modules (what the reference's mapper runs)
+    from glorie_slam_amd.render_train import FeatureAdam
+    train = {}
+    gt_col5 = torch.rand(5000, 3, device=device)
+    for tag, hip in (("hip", True), ("torch_autograd", False)):
+        geo_t = npc.geo_feats.detach().clone().requires_grad_(True)
+        col_t = npc.col_feats.detach().clone().requires_grad_(True)
+        dec_t = dec.train()
+        opt = FeatureAdam([{"params": list(dec_t.parameters()), "lr": 1e-3}, {"params": [geo_t], "lr": 1e-3},
+                           {"params": [col_t], "lr": 5e-3}])
+        ren.use_train_path, dec_t.use_fused = hip, hip
+
+        def iteration():
+            opt.zero_grad()
+            d5, _, c5, _, _ = ren.render_batch_ray(npc, dec_t, b5["d"], b5["o"], device, "color", gt_depth=b5["depth"],
+                                                   npc_geo_feats=geo_t, npc_col_feats=col_t, cloud_pos=npc.cloud_pos(),
+                                                   dynamic_r_query=b5["radius"])
+            loss = torch.abs(b5["depth"] - d5).sum() + 0.5 * torch.abs(gt_col5 - c5).sum()
+            loss.backward()
+            opt.step()
+            return loss
+        for _ in range(3):
+            l0 = iteration()
+        torch.cuda.synchronize()
+        t_t = time.perf_counter()
+        n_it = 20
+        for _ in range(n_it):
+            l1 = iteration()
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t_t) / n_it
+        assert bool(torch.isfinite(l1)) and float(l1) < float(l0), "the mapping iterations must reduce the loss"
+        train[tag + "_ms_per_iteration"] = ms
+        train[tag + "_rays_per_sec"] = 5000.0 / (ms * 1e-3)
+    ren.use_train_path, dec.use_fused = True, True
+    dec.eval()
     # KNN + feature gather alone (HIP events), 2156 B per sample
     S = ren.N_surface
     nq = min(rays["o"].shape[0], 65536)
@@ -573,6 +610,7 @@ def main():
                           if (full and corr_traffic) else None},
         "rays_per_sec": rays_per_s,
         "rays_per_sec_batch5000": 5000.0 / (batch_ms * 1e-3), "ms_per_batch5000": batch_ms,
+        "train_batch5000": train,
         "render": {"rays_local": int(n_r // render_reps), "samples_per_ray": int(S), "cloud_points": int(npc.pts_num()),
                    "ms_per_frame_shard": 1e3 * t_r / render_reps},
         "roofline_knn": {"bound": "hbm", "kernel": "knn_query_kernel<8> + 2x idw_gather_kernel",

@@ -385,14 +385,17 @@ __global__ __launch_bounds__(256) void raw_pack_kernel(const float* __restrict__
   if (color) { v.x = rgb[q * ldrgb]; v.y = rgb[q * ldrgb + 1]; v.z = rgb[q * ldrgb + 2]; }
   reinterpret_cast<float4*>(raw)[q] = v;
 }
-// d_raw [Q,4] -> dz[q][0..2] = g_rgb * rgb (1 - rgb) (sigmoid of the output layer), dz[q][3] = has ? g_occ : 0
+// d_raw [Q,4] -> dz[q][0..2] = g_rgb * rgb (1 - rgb) (sigmoid of the output layer), dz[q][3] = g_occ
 __global__ __launch_bounds__(256) void raw_unpack_bwd_kernel(const float* __restrict__ draw, const float* __restrict__ rgb,
                                                              int ldrgb, const uint8_t* __restrict__ has, long Q, int color,
                                                              float* __restrict__ dz) {
   const long q = (long)blockIdx.x * 256 + threadIdx.x;
   if (q >= Q) return;
   const float4 g = reinterpret_cast<const float4*>(draw)[q];
-  float4 o = make_float4(0.f, 0.f, 0.f, has[q] ? g.w : 0.0f);
+  // the occupancy of a sample without neighbours is overwritten with -100 under no_grad (Renderer.py:206-207):
+  // autograd does not see that assignment, the gradient computed at -100 still flows into the geometry decoder.
+  // It matters: a ray whose samples ALL lack neighbours has weights ~4.5e-5 that are normalised by their sum.
+  float4 o = make_float4(0.f, 0.f, 0.f, g.w);
   if (color) {
     const float y0 = rgb[q * ldrgb], y1 = rgb[q * ldrgb + 1], y2 = rgb[q * ldrgb + 2];
     o.x = g.x * y0 * (1.0f - y0); o.y = g.y * y1 * (1.0f - y1); o.z = g.z * y2 * (1.0f - y2);

@@ -491,8 +491,8 @@ int glorie_render_train_fwd(const glorie_decoder_params* params, const float* pt
 /* what loss.backward() computes below `raw` (src/mapper.py:511): d_raw [Q,4] -> parameter gradients (accumulated
  * into `grads`), d_geo_feats / d_col_feats [Np,32] (accumulated with fp32 atomics: rows are shared by samples).
  * Same arguments and the workspace of the matching glorie_render_train_fwd call.  Samples without neighbours pass
- * no gradient (their feature is a constant; the reference additionally lets a 4.5e-5-weighted gradient of their
- * overwritten occupancy reach the geometry decoder). */
+ * no gradient to the feature tables (their feature is a constant) but, like in the reference (the -100 is assigned
+ * under no_grad, Renderer.py:206-207), the gradient of their occupancy reaches the geometry decoder. */
 int glorie_render_train_bwd(const glorie_decoder_params* params, const glorie_decoder_grads* grads, const float* pts,
                             const float* views, const float* cloud_pos, const float* geo_feats,
                             const float* col_feats, const int64_t* I, const float* w, const uint8_t* has, long Q,
