@@ -63,13 +63,18 @@ struct MmArgs {
 };
 
 constexpr int kMaxJT = 13;
+constexpr int kWsLd = 212;            // floats per staged W row: 4 * 212 = 16 (mod 32) -> conflict-free operand reads
 
+// Workgroup = 4 waves = 64 rows x all J columns.  Per chunk of 16 reduction indices the W slice [16][J] is staged
+// ONCE in LDS for the four waves (two buffers: one barrier per chunk); a wave reads its B operands from there
+// (ds_read_b32, conflict-free) and its A operands as one float4 per lane (reduction index 4 g + s of the chunk
+// goes to MFMA k-step s on both operands: the order of a sum is free).
 template <bool TRANS>
 __global__ __launch_bounds__(256) void mm_rows_kernel(MmArgs a) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  __shared__ float Ws[2][16 * kWsLd];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int i = lane & 15, g = lane >> 4;
   const long q0 = ((long)blockIdx.x * 4 + wv) * 16;
-  if (q0 >= a.Q) return;
   const int njt = (a.J + 15) >> 4;
   f32x4 acc[kMaxJT];
 #pragma unroll
@@ -77,29 +82,51 @@ __global__ __launch_bounds__(256) void mm_rows_kernel(MmArgs a) {
   const long qa = q0 + i;
   const bool qok = qa < a.Q;
   const float* xrow = a.in + (qok ? qa : 0) * (long)a.ldi;
-  for (int r0 = 0; r0 < a.R; r0 += 16) {
-    float av[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int r = r0 + 4 * s + g;
-      av[s] = (qok && r < a.R) ? xrow[r] : 0.0f;
+  const bool vec = ((a.ldi & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.in) & 15) == 0);
+  const int nchunk = (a.R + 15) >> 4;
+  auto stage = [&](int c, int buf) {
+    // Ws[buf][rr][j] = W(r0 + rr, j), rr = 4 g' + s' in the chunk's own order (plain row order: the A side permutes)
+    const int r0 = c * 16;
+    for (int e = tid; e < 16 * a.J; e += 256) {
+      int rr, j;
+      if (TRANS) { j = e >> 4; rr = e & 15; }          // W[j][r0 + rr]: 16 consecutive floats per row j
+      else { rr = e / a.J; j = e - rr * a.J; }          // W[r0 + rr][j]: whole rows
+      const int r = r0 + rr;
+      const float v = r < a.R ? (TRANS ? a.W[(long)j * a.ldw + r] : a.W[(long)r * a.ldw + j]) : 0.0f;
+      Ws[buf][rr * kWsLd + j] = v;
     }
+  };
+  stage(0, 0);
+  __syncthreads();
+  for (int c = 0; c < nchunk; ++c) {
+    const int buf = c & 1;
+    if (c + 1 < nchunk) stage(c + 1, buf ^ 1);
+    const int r0 = c * 16;
+    float av[4];
+    if (vec && r0 + 16 <= a.R) {
+      const float4 v = *reinterpret_cast<const float4*>(xrow + r0 + 4 * g);
+      av[0] = qok ? v.x : 0.f; av[1] = qok ? v.y : 0.f; av[2] = qok ? v.z : 0.f; av[3] = qok ? v.w : 0.f;
+    } else {
 #pragma unroll
-    for (int t = 0; t < kMaxJT; ++t) {
-      if (t < njt) {
-        const int j = t * 16 + i;
-        float bv[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const int r = r0 + 4 * s + g;
-          const bool ok = r < a.R && j < a.J;
-          bv[s] = ok ? (TRANS ? a.W[(long)j * a.ldw + r] : a.W[(long)r * a.ldw + j]) : 0.0f;
-        }
-#pragma unroll
-        for (int s = 0; s < 4; ++s) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s], acc[t], 0, 0, 0);
+      for (int s_ = 0; s_ < 4; ++s_) {
+        const int r = r0 + 4 * g + s_;
+        av[s_] = (qok && r < a.R) ? xrow[r] : 0.0f;
       }
     }
+    if (q0 < a.Q) {
+#pragma unroll
+      for (int t = 0; t < kMaxJT; ++t) {
+        if (t < njt) {
+          const float* wp = &Ws[buf][(4 * g) * kWsLd + t * 16 + i];
+#pragma unroll
+          for (int s_ = 0; s_ < 4; ++s_)
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s_], wp[s_ * kWsLd], acc[t], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
   }
+  if (q0 >= a.Q) return;
   // lane: rows q0 + 4 g + rr, column t * 16 + i
 #pragma unroll
   for (int t = 0; t < kMaxJT; ++t) {
@@ -123,53 +150,74 @@ __global__ __launch_bounds__(256) void mm_rows_kernel(MmArgs a) {
 
 // ---------------------------------------------------------------------------------------------------------
 // dW[n][k] += sum_q dY[q][n] X[q][k]   (k < K),   db[n] += sum_q dY[q][n]   (the "k == K" column of ones)
-// grid (ceil(N/16), q-splits); a wave owns 16 rows n of dW and a contiguous q range, 4 rows q per MFMA
+// A workgroup owns a contiguous range of rows q and walks it in chunks of 32 rows: dY[32][N] and X[32][K (+1)] are
+// staged in LDS with whole-row (coalesced) loads - every element leaves HBM once - and the (n-tile, k-tile)
+// pairs of the [N][K+1] result are dealt round-robin to the four waves (<= 28 accumulator tiles per wave).
+// The partial result of the range is added to dW with fp32 atomics (one per element and workgroup).
 // ---------------------------------------------------------------------------------------------------------
 struct WgArgs {
   const float* dY; int ldy;
   const float* X; int ldx;
   float* dW; int ldw;
   float* db;
-  long Q; int N, K; long rows_per_wave;
+  long Q; int N, K; long rows_per_wg;
+  int Ns, Ks;                 // LDS row strides (== 16 mod 32: conflict-free operand reads)
 };
 
-constexpr int kMaxKT = 14;            // 208 columns + the bias column
+constexpr int kWgTiles = 28;
+constexpr int kWgRows = 32;
 
 __global__ __launch_bounds__(256) void mm_wgrad_kernel(WgArgs a) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  extern __shared__ __attribute__((aligned(16))) float wsm[];
+  float* Ys = wsm;                           // [32][Ns]
+  float* Xs = wsm + kWgRows * a.Ns;          // [32][Ks]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 15, g = lane >> 4;
-  const int n0 = blockIdx.x * 16;
-  const long qa = ((long)blockIdx.y * 4 + wv) * a.rows_per_wave;
-  if (qa >= a.Q) return;
-  const long qb = qa + a.rows_per_wave < a.Q ? qa + a.rows_per_wave : a.Q;
+  const long qa = (long)blockIdx.x * a.rows_per_wg;
+  const long qb = qa + a.rows_per_wg < a.Q ? qa + a.rows_per_wg : a.Q;
   const int KE = a.K + (a.db ? 1 : 0);
-  const int nkt = (KE + 15) >> 4;
-  f32x4 acc[kMaxKT];
+  const int nnt = (a.N + 15) >> 4, nkt = (KE + 15) >> 4;
+  const int ntiles = nnt * nkt;
+  f32x4 acc[kWgTiles];
 #pragma unroll
-  for (int t = 0; t < kMaxKT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const bool nok = n0 + i < a.N;
-  for (long q = qa; q < qb; q += 4) {
-    const long qq = q + g;
-    const bool ok = qq < qb;
-    const float av = (ok && nok) ? a.dY[qq * a.ldy + n0 + i] : 0.0f;
-    const float* xr = a.X + (ok ? qq : 0) * (long)a.ldx;
+  for (int t = 0; t < kWgTiles; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (long qc = qa; qc < qb; qc += kWgRows) {
+    // stage: rows qc .. qc + 31 (zero beyond the range), columns padded with zeros; X gets the column of ones.
+    // 8 threads per row walk its columns (no integer division in the loop, 32-byte segments per row and step)
+    {
+      const int r = tid >> 3, c0 = tid & 7;
+      const bool rok = qc + r < qb;
+      const float* yr = a.dY + (rok ? qc + r : 0) * (long)a.ldy;
+      const float* xr = a.X + (rok ? qc + r : 0) * (long)a.ldx;
+      for (int n = c0; n < a.Ns; n += 8) Ys[r * a.Ns + n] = (rok && n < a.N) ? yr[n] : 0.0f;
+      for (int k = c0; k < a.Ks; k += 8) Xs[r * a.Ks + k] = rok ? (k < a.K ? xr[k] : (k == a.K ? 1.0f : 0.0f)) : 0.0f;
+    }
+    __syncthreads();
 #pragma unroll
-    for (int t = 0; t < kMaxKT; ++t) {
-      if (t < nkt) {
-        const int k = t * 16 + i;
-        const float bv = ok ? (k < a.K ? xr[k] : (k == a.K ? 1.0f : 0.0f)) : 0.0f;
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[t], 0, 0, 0);
+    for (int t = 0; t < kWgTiles; ++t) {
+      const int tile = wv + 4 * t;
+      if (tile < ntiles) {
+        const int nt = tile / nkt, kt = tile - nt * nkt;
+        const float* yp = Ys + g * a.Ns + nt * 16 + i;
+        const float* xp = Xs + g * a.Ks + kt * 16 + i;
+#pragma unroll
+        for (int s_ = 0; s_ < kWgRows / 4; ++s_)
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(yp[4 * s_ * a.Ns], xp[4 * s_ * a.Ks], acc[t], 0, 0, 0);
       }
     }
+    __syncthreads();
   }
-  // lane: rows n0 + 4 g + rr of dW, column t * 16 + i
+  // lane: rows n = nt * 16 + 4 g + rr of dW, column kt * 16 + i
 #pragma unroll
-  for (int t = 0; t < kMaxKT; ++t) {
-    if (t >= nkt) continue;
-    const int k = t * 16 + i;
+  for (int t = 0; t < kWgTiles; ++t) {
+    const int tile = wv + 4 * t;
+    if (tile >= ntiles) continue;
+    const int nt = tile / nkt, kt = tile - nt * nkt;
+    const int k = kt * 16 + i;
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
-      const int n = n0 + 4 * g + rr;
+      const int n = nt * 16 + 4 * g + rr;
       if (n >= a.N) continue;
       const float v = acc[t][rr];
       if (k < a.K) atomicAdd(a.dW + (long)n * a.ldw + k, v);
@@ -312,25 +360,26 @@ __global__ __launch_bounds__(256) void nb_rows_fwd_kernel(const float* __restric
   X[row * ldx + col] = v;
 }
 
-// dX [8Q,52] -> dcol_feats[I] (columns 20..51, atomics) and dB_rel (columns 0..19)
+// dX [8Q,52] -> dcol_feats[I] (columns 20..51, atomics) and dB_rel (columns 0..19).  A workgroup walks many rows
+// (4 per step) and adds its 30 partial sums of dB_rel ONCE: one atomic per 4 rows on the same 30 addresses
+// serialised the whole launch (1.2 ms for 400k rows).
 __global__ __launch_bounds__(256) void nb_rows_bwd_kernel(const float* __restrict__ dX, int ldx, const float* __restrict__ pts,
                                                           const float* __restrict__ cloud, const int64_t* __restrict__ I,
                                                           const float* __restrict__ Brel, long Q,
-                                                          float* __restrict__ dfeats, float* __restrict__ dBrel) {
-  __shared__ float red[30];
-  if (threadIdx.x < 30) red[threadIdx.x] = 0.0f;
-  __syncthreads();
-  const long t = (long)blockIdx.x * 256 + threadIdx.x;
-  const long row = t >> 6;
-  const int col = (int)(t & 63);
-  if (row < Q * 8 && col < 52) {
+                                                          float* __restrict__ dfeats, float* __restrict__ dBrel,
+                                                          long rows_per_block) {
+  __shared__ float red[4][30];
+  const int col = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const long ra = (long)blockIdx.x * rows_per_block;
+  const long rb = ra + rows_per_block < Q * 8 ? ra + rows_per_block : Q * 8;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  const float tp = 6.283185307179586f;
+  for (long row = ra + rl; row < rb; row += 4) {
+    if (col >= 52) continue;
     const long q = row >> 3;
     long ik = I[row];
-    const bool neg = ik < 0;
-    if (neg) ik = 0;
+    if (ik < 0) ik = 0;       // feats[I.clamp(min=0)]: the weight of a missing neighbour is zero, so is its gradient row
     if (col >= 20) {
-      // feats[I.clamp(min=0)]: a missing neighbour (I = -1) reads row 0 and its gradient flows there too; the
-      // weight of such a row is zero, so its gradient row is exactly zero
       const float g = dX[row * ldx + col];
       if (g != 0.0f) atomicAdd(dfeats + ik * 32 + (col - 20), g);
     } else if (col < 10) {
@@ -339,13 +388,15 @@ __global__ __launch_bounds__(256) void nb_rows_bwd_kernel(const float* __restric
       for (int d = 0; d < 3; ++d) rel[d] = cloud[ik * 3 + d] - pts[q * 3 + d];
       const float ph = fourier_phase(rel, Brel, 10, col);
       const float gv = dX[row * ldx + col] * cosf(ph) - dX[row * ldx + 10 + col] * sinf(ph);
-      const float tp = 6.283185307179586f;
-#pragma unroll
-      for (int d = 0; d < 3; ++d) atomicAdd(&red[d * 10 + col], tp * rel[d] * gv);
+      s0 += tp * rel[0] * gv; s1 += tp * rel[1] * gv; s2 += tp * rel[2] * gv;
     }
   }
+  if (col < 10) { red[rl][col] = s0; red[rl][10 + col] = s1; red[rl][20 + col] = s2; }
   __syncthreads();
-  if (threadIdx.x < 30 && red[threadIdx.x] != 0.0f) atomicAdd(dBrel + threadIdx.x, red[threadIdx.x]);
+  if (threadIdx.x < 30) {
+    const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (v != 0.0f) atomicAdd(dBrel + threadIdx.x, v);
+  }
 }
 
 // c[q][ch] = has ? sum_k w[q][k] F[(q,k)][ch] : 0        and        dF[(q,k)][ch] = has ? w[q][k] dc[q][ch] : 0
@@ -486,17 +537,19 @@ static int mm(hipStream_t st, bool trans, const float* in, int ldi, const float*
   else hipLaunchKernelGGL(mm_rows_kernel<false>, grid, dim3(256), 0, st, a);
   return check_launch();
 }
+static int pad16mod32(int v) { int p = (v + 15) / 16 * 16; if ((p & 31) != 16) p += 16; return p; }
 static int wgrad(hipStream_t st, const float* dY, int ldy, const float* X, int ldx, long Q, int N, int K, float* dW, int ldw,
                  float* db) {
   if (Q == 0 || !dW) return GLORIE_OK;
-  if (K + 1 > kMaxKT * 16) return GLORIE_EUNSUPPORTED;
-  // ~256 waves per 16-row slab of dW are plenty; at least 256 rows per wave keep the atomics rare
-  long rpw = (Q + 255) / 256;
-  if (rpw < 256) rpw = 256;
-  rpw = (rpw + 3) / 4 * 4;
-  const long waves = (Q + rpw - 1) / rpw;
-  WgArgs a{dY, ldy, X, ldx, dW, ldw, db, Q, N, K, rpw};
-  hipLaunchKernelGGL(mm_wgrad_kernel, dim3((N + 15) / 16, (unsigned)((waves + 3) / 4)), dim3(256), 0, st, a);
+  const int KE = K + (db ? 1 : 0);
+  if (((N + 15) / 16) * ((KE + 15) / 16) > 4 * kWgTiles) return GLORIE_EUNSUPPORTED;
+  // ~1024 workgroups at most, at least 256 rows each (keeps the atomics rare), multiples of the 32-row chunk
+  long rows = (Q + 1023) / 1024;
+  if (rows < 256) rows = 256;
+  rows = (rows + kWgRows - 1) / kWgRows * kWgRows;
+  WgArgs a{dY, ldy, X, ldx, dW, ldw, db, Q, N, K, rows, pad16mod32(N), pad16mod32(KE)};
+  const size_t lds = sizeof(float) * (size_t)kWgRows * (a.Ns + a.Ks);
+  hipLaunchKernelGGL(mm_wgrad_kernel, dim3((unsigned)((Q + rows - 1) / rows)), dim3(256), lds, st, a);
   return check_launch();
 }
 
@@ -687,7 +740,7 @@ extern "C" int glorie_render_train_bwd(const glorie_decoder_params* P, const glo
     GLORIE_TRY(trunk_bwd(st, Q, G_HID, G_EMB, TACT_RELU, W.g_emb, W.g_c, P->g_W, P->g_U, G->g_W, G->g_b, G->g_U, G->g_u,
                          W.g_A, gH, W.g_cat, dH4, p0, p1, dz, W.t_cat, W.t_c32, G->g_B ? W.t_emb : nullptr));
     if (G->g_B) {
-      const int rpb = 2048;
+      const int rpb = 256;
       hipLaunchKernelGGL(fourier_bwd_kernel, dim3((unsigned)((Q + rpb - 1) / rpb)), dim3(256), 0, st, pts, 3, P->g_B, G_EMB, 0, Q,
                          W.t_emb, G_EMB, G->g_B, rpb);
     }
@@ -719,8 +772,9 @@ extern "C" int glorie_render_train_bwd(const glorie_decoder_params* P, const glo
       // one launch serves both; a NULL target is replaced by a scratch sink
       float* sinkB = G->n_B ? G->n_B : W.t_q4;          // 30 floats
       if (!d_col_feats) return GLORIE_EINVAL;
-      hipLaunchKernelGGL(nb_rows_bwd_kernel, dim3(blocks(Q * 8 * 64)), dim3(256), 0, st, W.t_n52, NB_IN, pts, cloud_pos, I,
-                         P->n_B, Q, d_col_feats, sinkB);
+      const long rpb = 1024;
+      hipLaunchKernelGGL(nb_rows_bwd_kernel, dim3((unsigned)((Q * 8 + rpb - 1) / rpb)), dim3(256), 0, st, W.t_n52, NB_IN, pts,
+                         cloud_pos, I, P->n_B, Q, d_col_feats, sinkB, rpb);
       GLORIE_TRY(check_launch());
     }
   }
