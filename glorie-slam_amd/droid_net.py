@@ -121,6 +121,80 @@ class UpdateModule(nn.Module):
         return net, delta, weight
 
 
+class ResidualBlock(nn.Module):
+    """extractor.py:4-57 (norm_fn 'instance' | 'none': the two the reference instantiates)"""
+
+    def __init__(self, in_planes, planes, norm_fn='group', stride=1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_planes, planes, kernel_size=3, padding=1, stride=stride)
+        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, padding=1)
+        self.relu = nn.ReLU(inplace=True)
+        mk = {'group': lambda: nn.GroupNorm(num_groups=planes // 8, num_channels=planes),
+              'batch': lambda: nn.BatchNorm2d(planes), 'instance': lambda: nn.InstanceNorm2d(planes),
+              'none': lambda: nn.Sequential()}[norm_fn]
+        self.norm1, self.norm2 = mk(), mk()
+        if stride > 1:
+            self.norm3 = mk()
+        self.downsample = None if stride == 1 else nn.Sequential(
+            nn.Conv2d(in_planes, planes, kernel_size=1, stride=stride, padding=0), self.norm3)
+
+    def forward(self, x):
+        y = self.relu(self.norm1(self.conv1(x)))
+        y = self.relu(self.norm2(self.conv2(y)))
+        if self.downsample is not None:
+            x = self.downsample(x)
+        return self.relu(x + y)
+
+
+class BasicEncoder(nn.Module):
+    """extractor.py:63-129: 7x7/2 stem, three pairs of residual blocks (32, 64/2, 128/2), 1x1 head -> 1/8 resolution.
+    Runs once per incoming frame (not on the BA-update path): plain torch convolutions."""
+
+    def __init__(self, out_dim, norm_fn='batch'):
+        super().__init__()
+        DIM = 32
+        self.out_dim, self.norm_fn = out_dim, norm_fn
+        self.norm1 = {'group': lambda: nn.GroupNorm(num_groups=8, num_channels=DIM), 'batch': lambda: nn.BatchNorm2d(DIM),
+                      'instance': lambda: nn.InstanceNorm2d(DIM), 'none': lambda: nn.Sequential()}[norm_fn]()
+        self.conv1 = nn.Conv2d(3, DIM, 7, 2, 3)
+        self.relu1 = nn.ReLU(inplace=True)
+        self.in_planes = DIM
+        self.layer1 = self._make_layer(DIM, stride=1)
+        self.layer2 = self._make_layer(2 * DIM, stride=2)
+        self.layer3 = self._make_layer(4 * DIM, stride=2)
+        self.conv2 = nn.Conv2d(4 * DIM, out_dim, kernel_size=(1, 1))
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+            elif isinstance(m, (nn.BatchNorm2d, nn.InstanceNorm2d, nn.GroupNorm)):
+                if m.weight is not None:
+                    nn.init.constant_(m.weight, 1)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+
+    def _make_layer(self, dim, stride=1):
+        layers = [ResidualBlock(self.in_planes, dim, self.norm_fn, stride=stride),
+                  ResidualBlock(dim, dim, self.norm_fn, stride=1)]
+        self.in_planes = dim
+        return nn.Sequential(*layers)
+
+    def forward(self, x):
+        b, n, c1, h1, w1 = x.shape
+        x = self.relu1(self.norm1(self.conv1(x.view(b * n, c1, h1, w1))))
+        x = self.conv2(self.layer3(self.layer2(self.layer1(x))))
+        return x.view(b, n, x.shape[1], x.shape[2], x.shape[3])
+
+
+class DroidNet(nn.Module):
+    """droid_net.py:142-147: `.fnet`, `.cnet`, `.update` - what src/slam.py:66-81 constructs and loads droid.pth into"""
+
+    def __init__(self):
+        super().__init__()
+        self.fnet = BasicEncoder(out_dim=128, norm_fn='instance')
+        self.cnet = BasicEncoder(out_dim=256, norm_fn='none')
+        self.update = UpdateModule()
+
+
 class HalfUpdate:
     """Inference copy of an UpdateModule in fp16 + channels_last.
 

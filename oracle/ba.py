@@ -177,14 +177,21 @@ def ba(poses, disps, intr, targets, weights, eta, ii, jj, t0, t1, iterations, lm
             j = jj_exp[r]
             if t0 <= j < t1:
                 rows_of_pose[j - t0].append(r)
-        for pi in range(P):
-            for pj in range(P):
-                for ra in rows_of_pose[pi]:
-                    for rb in rows_of_pose[pj]:
-                        if kk_exp[ra] == kk_exp[rb]:
-                            k = kk_exp[ra]
-                            blk = ((E[ra] * Q[k][None]).astype(np.float64) @ E[rb].astype(np.float64).T).astype(F)
-                            S[6 * pi:6 * pi + 6, 6 * pj:6 * pj + 6] += blk.astype(np.float64)
+        # droid_kernels.cu:1257-1272 enumerates (pose row, pose column, rows sharing a depth frame); the same triplets are
+        # visited here grouped by depth frame first (the fp64 sum of the fp32-rounded blocks only changes its order):
+        # the literal four nested loops are O(P^2 deg^2) Python iterations - minutes at 128 keyframes
+        rows_of_frame = [[] for _ in range(M)]
+        for r in range(len(ii_exp)):
+            if t0 <= jj_exp[r] < t1:
+                rows_of_frame[kk_exp[r]].append(r)
+        for k in range(M):
+            for ra in rows_of_frame[k]:
+                Ea = (E[ra] * Q[k][None]).astype(np.float64)
+                pi = jj_exp[ra] - t0
+                for rb in rows_of_frame[k]:
+                    pj = jj_exp[rb] - t0
+                    blk = (Ea @ E[rb].astype(np.float64).T).astype(F)
+                    S[6 * pi:6 * pi + 6, 6 * pj:6 * pj + 6] += blk.astype(np.float64)
         for r in range(len(ii_exp)):
             i = jj_exp[r] - t0
             if 0 <= i < P:

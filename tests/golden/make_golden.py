@@ -228,11 +228,33 @@ def make_render_grad():
           "| rows with a gradient", int((geo.grad.abs().sum(1) > 0).sum()), int((col.grad.abs().sum(1) > 0).sum()))
 
 
+def make_droidnet():
+    """F13: DroidNet (droid_net.py:142-147, extractor.py) - state-dict names / shapes, default init under seed 43 and the
+    encoder outputs on a random image pair (fp32, CPU)"""
+    from src.modules.droid_net.droid_net import DroidNet
+    torch.manual_seed(43)
+    net = DroidNet().eval()
+    sd = net.state_dict()
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(1, 2, 3, 48, 64, generator=g)
+    with torch.no_grad():
+        f = net.fnet(x)
+        c = net.cnet(x)
+    np.savez_compressed(os.path.join(OUT, "droidnet.npz"), keys=np.array(list(sd.keys())),
+                        shapes=np.array([",".join(map(str, v.shape)) for v in sd.values()]),
+                        param_abs_sum=np.float64(sum(float(v.double().abs().sum()) for v in sd.values())),
+                        fmap=f.numpy(), cmap=c.numpy())
+    print("droidnet.npz:", len(sd), "tensors, fmap", tuple(f.shape), "cmap", tuple(c.shape))
+
+
 def main():
     install_stubs()
     torch.set_num_threads(4)
     if "--only-render" in sys.argv:
         make_render()
+        return
+    if "--only-droidnet" in sys.argv:
+        make_droidnet()
         return
     if "--only-render-grad" in sys.argv:
         make_render_grad()
@@ -356,6 +378,7 @@ def main():
                         **{"sd__" + k: v for k, v in sd.items()})
     make_render()
     make_render_grad()
+    make_droidnet()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KB")

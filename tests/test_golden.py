@@ -154,3 +154,43 @@ def test_schur_solve_oracle_matches_reference():
     dxb, dzb = odspo.schur_solve(-f["H"][0], f["E"][0], f["C"][0], f["v"][0], f["w"][0], 0.1, 1e-4)
     assert np.all(f["dx_bad"] == 0) and np.all(dxb == 0)      # non-PD -> zero update
     np.testing.assert_allclose(dzb, f["dz_bad"][0], rtol=2e-4, atol=1e-5)
+
+
+def test_droidnet_matches_reference():
+    """DroidNet mirror (droid.pth loading contract of slam.py:70-81): state-dict names and shapes, identical default
+    initialisation under the seed, encoder outputs == the reference's on the same image pair (fixture F13)"""
+    from glorie_slam_amd.droid_net import DroidNet
+    f = gold("droidnet.npz")
+    torch.manual_seed(43)
+    net = DroidNet().eval()
+    sd = net.state_dict()
+    assert list(sd.keys()) == [str(k) for k in f["keys"]]
+    assert [",".join(map(str, v.shape)) for v in sd.values()] == [str(v) for v in f["shapes"]]
+    psum = sum(float(v.double().abs().sum()) for v in sd.values())
+    assert abs(psum - float(f["param_abs_sum"])) < 1e-9 * psum
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(1, 2, 3, 48, 64, generator=g)
+    with torch.no_grad():
+        np.testing.assert_allclose(net.fnet(x).numpy(), f["fmap"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(net.cnet(x).numpy(), f["cmap"], rtol=1e-5, atol=1e-5)
+
+
+def test_se3_helper_matches_oracle_conventions():
+    """glorie_slam_amd.lie.SE3 (the lietorch subset of the drivers) against oracle/se3.py and the matrix group"""
+    from glorie_slam_amd.lie import SE3
+    from oracle import se3 as ose3
+    torch.manual_seed(0)
+    xi = torch.randn(64, 6) * torch.tensor([1, 1, 1, 0.8, 0.8, 0.8])
+    xi[:5, 3:] *= 1e-6                                  # the small-angle branches
+    G = SE3.exp(xi)
+    t, q = ose3.se3_exp(xi.numpy())
+    np.testing.assert_allclose(G.data.numpy(), np.concatenate([t, q], -1), atol=1e-6)
+    np.testing.assert_allclose(G.log().numpy(), xi.numpy(), atol=5e-6)
+    H = SE3.exp(torch.randn(64, 6) * 0.3)
+    np.testing.assert_allclose((G * H).matrix().numpy(), (G.matrix() @ H.matrix()).numpy(), atol=1e-6)
+    np.testing.assert_allclose((G * G.inv()).matrix().numpy(), np.broadcast_to(np.eye(4), (64, 4, 4)), atol=1e-6)
+    for k in range(4):
+        np.testing.assert_allclose(G.matrix()[k].numpy(), ose3.matrix(G.data[k].numpy()), atol=1e-6)
+    # left retraction of the BA kernels == exp(xi) * G
+    r = ose3.retract(xi[7].numpy(), H.data[7].numpy())
+    np.testing.assert_allclose((SE3.exp(xi[7:8]) * H[7:8]).data[0].numpy(), r, atol=1e-6)
