@@ -280,12 +280,14 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 __global__ __launch_bounds__(256) void corr_lookup_r3_tiled_kernel(
     CorrLevels lv, int num_levels, const float* __restrict__ coords, _Float16* __restrict__ out,
-    int HW, int out_channels) {
+    int HW, int out_channels, const int* __restrict__ slots) {
   typedef _Float16 T;
   constexpr int R = 3, RD = 7, WIN = 8, PG = 8;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int row = lane & 7, grp = lane >> 3;
   const int n = blockIdx.y;
+  // volume of edge n: its own position in the stack, or - for an arena (CorrArena) - the slot it was built into
+  const size_t vn = slots ? (size_t)slots[n] : (size_t)n;
   const int pb = (blockIdx.x * 4 + wv) * 64 + grp * PG;   // first pixel of this lane's group
   const bool live = pb < HW;                              // HW % 8 == 0: groups are all-or-nothing
   const int pc = live ? pb : HW - PG;
@@ -321,7 +323,7 @@ __global__ __launch_bounds__(256) void corr_lookup_r3_tiled_kernel(
       const bool va = yok && bx0 >= 0 && bx0 < nbx;
       const bool vb = yok && sh > 0 && bx0 + 1 >= 0 && bx0 + 1 < nbx;
       const int yc = yok ? y1 : 0;
-      const T* base = vol + ((size_t)n * HW + pc + q) * plane + ((size_t)(yc >> 2) * nbx) * 32 + (yc & 3) * 8;
+      const T* base = vol + (vn * HW + pc + q) * plane + ((size_t)(yc >> 2) * nbx) * 32 + (yc & 3) * 8;
       const T* pa = base + (va ? bx0 * 32 + sh : 0);
       const T* pbk = base + (vb ? (bx0 + 1) * 32 + sh - 8 : 0);
       __builtin_memcpy(&la[q], pa, 16);
@@ -465,9 +467,24 @@ extern "C" int glorie_corr_lookup_pyramid(const void* const* volumes, int num_le
   return GLORIE_EUNSUPPORTED;
 }
 
+static int lookup_tiled(const void* const* volumes, int num_levels, const float* coords, void* out, int N, int h1,
+                        int w1, int h2, int w2, const int* slots, void* stream);
+
 extern "C" int glorie_corr_lookup_pyramid_tiled(const void* const* volumes, int num_levels,
                                                 const float* coords, void* out, int N, int h1, int w1,
                                                 int h2, int w2, void* stream) {
+  return lookup_tiled(volumes, num_levels, coords, out, N, h1, w1, h2, w2, nullptr, stream);
+}
+
+extern "C" int glorie_corr_lookup_arena(const void* const* levels, int num_levels, const int* slots,
+                                        const float* coords, void* out, int N, int h1, int w1, int h2, int w2,
+                                        void* stream) {
+  if (N > 0 && !slots) return GLORIE_EINVAL;
+  return lookup_tiled(levels, num_levels, coords, out, N, h1, w1, h2, w2, slots, stream);
+}
+
+static int lookup_tiled(const void* const* volumes, int num_levels, const float* coords, void* out, int N, int h1,
+                        int w1, int h2, int w2, const int* slots, void* stream) {
   if (num_levels < 1 || num_levels > kMaxLevels || N < 0 || h1 < 0 || w1 < 0) return GLORIE_EINVAL;
   const int HW = h1 * w1;
   if (N == 0 || HW == 0) return GLORIE_OK;
@@ -483,6 +500,6 @@ extern "C" int glorie_corr_lookup_pyramid_tiled(const void* const* volumes, int 
   }
   dim3 grid((HW + 255) / 256, N);
   hipLaunchKernelGGL(corr_lookup_r3_tiled_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     lv, num_levels, coords, reinterpret_cast<_Float16*>(out), HW, num_levels * 49);
+                     lv, num_levels, coords, reinterpret_cast<_Float16*>(out), HW, num_levels * 49, slots);
   return check_launch();
 }

@@ -529,6 +529,107 @@ class CorrBlock:
         return self
 
 
+class CorrArena:
+    """The correlation pyramids of a FactorGraph's edges in ONE slot-indexed store (scope row A1).
+
+    The reference keeps a CorrBlock per graph whose `cat` / `__getitem__` copy every volume of every level through
+    torch.cat and boolean masks whenever an edge is added or removed (corr.py:55-65, factor_graph.py:126,161:
+    61 MB per edge at 60x80).  Here an edge is built ONCE (glorie_corr_build: all four levels in the lookup's
+    tiled layout) into a free slot and stays there; adding / removing edges edits the int32 slot list the lookup
+    kernel indirects through.  Capacity grows geometrically (the only copy that can ever happen)."""
+
+    def __init__(self, h, w, device, num_levels=4, radius=3, capacity=16):
+        assert radius == 3
+        self.h, self.w, self.num_levels, self.radius = h, w, num_levels, radius
+        self.device = torch.device(device)
+        self.planes = [(((h >> l) + 3) // 4) * (((w >> l) + 7) // 8) * 32 for l in range(num_levels)]
+        self.capacity = 0
+        self.levels = None
+        self.free = []
+        self.slots = torch.zeros(0, dtype=torch.int32, device=self.device)      # slot of edge n, in edge order
+        self._host_slots = []
+        self._grow(capacity)
+
+    @property
+    def tiled(self):
+        return True
+
+    def __len__(self):
+        return len(self._host_slots)
+
+    def _grow(self, capacity):
+        hw = self.h * self.w
+        new = []
+        for l, pl in enumerate(self.planes):
+            # one spare plane on either side: read slack of the unaligned block-row loads of the lookup
+            t = torch.zeros((capacity * hw + 2, pl), dtype=torch.float16, device=self.device)
+            if self.levels is not None:
+                t[1:self.capacity * hw + 1] = self.levels[l][1:self.capacity * hw + 1]
+            new.append(t)
+        self.free += list(range(capacity - 1, self.capacity - 1, -1))
+        self.levels, self.capacity = new, capacity
+
+    def views(self):
+        hw = self.h * self.w
+        return [t[1:self.capacity * hw + 1] for t in self.levels]
+
+    def add(self, fmaps_cl, fi, fj):
+        """build the pyramids of new edges (source frames fi, target frames fj: int64 device tensors indexing the
+        channels-last, 1/4-scaled maps fmaps_cl [F, h*w, 128]) and append them to the edge list"""
+        import ctypes
+        from . import _lib as L
+        n = int(fi.shape[0])
+        if n == 0:
+            return
+        while len(self.free) < n:
+            self._grow(max(self.capacity * 3 // 2, self.capacity + n, 16))
+        take = [self.free.pop() for _ in range(n)]
+        new_slots = torch.tensor(take, dtype=torch.int32, device=self.device)
+        v = self.views()
+        arr = (ctypes.c_void_p * self.num_levels)(*[t.data_ptr() for t in v])
+        L.check(L.load().glorie_corr_build(L.ptr(fmaps_cl), L.ptr(fi.contiguous()), L.ptr(fj.contiguous()), L.ptr(new_slots),
+                                           ctypes.cast(arr, ctypes.c_void_p), self.num_levels, n, self.h, self.w,
+                                           int(fmaps_cl.shape[-1]), L.stream_ptr()), "glorie_corr_build")
+        self._host_slots += take
+        self.slots = torch.cat([self.slots, new_slots])
+
+    def keep(self, mask_host):
+        """drop the edges whose mask entry is False: their slots return to the free list, nothing moves"""
+        kept = []
+        for s_, k in zip(self._host_slots, mask_host):
+            if k:
+                kept.append(s_)
+            else:
+                self.free.append(s_)
+        self._host_slots = kept
+        self.slots = torch.tensor(kept, dtype=torch.int32, device=self.device)
+
+    def __call__(self, coords):
+        import ctypes
+        from . import _lib as L
+        batch, num, ht, wd, _ = coords.shape
+        N = batch * num
+        if N != len(self._host_slots):
+            raise RuntimeError(f"CorrArena holds {len(self._host_slots)} edges, coords has {N}")
+        c = coords.permute(0, 1, 4, 2, 3).contiguous().view(N, 2, ht, wd).float()
+        out = torch.empty((N, self.num_levels * 49, ht, wd), dtype=torch.float16, device=c.device)
+        v = self.views()
+        arr = (ctypes.c_void_p * self.num_levels)(*[t.data_ptr() for t in v])
+        L.check(L.load().glorie_corr_lookup_arena(ctypes.cast(arr, ctypes.c_void_p), self.num_levels, L.ptr(self.slots),
+                                                  L.ptr(c), L.ptr(out), N, ht, wd, self.h, self.w, L.stream_ptr()),
+                "glorie_corr_lookup_arena")
+        return out.view(batch, num, -1, ht, wd)
+
+    def level(self, l):
+        """row-major volumes [N, h, w, h>>l, w>>l] of the current edges (tests / debugging: copies)"""
+        hw = self.h * self.w
+        hl, wl = self.h >> l, self.w >> l
+        nby, nbx = (hl + 3) // 4, (wl + 7) // 8
+        v = self.views()[l].view(self.capacity, hw, nby, nbx, 4, 8)[self.slots.long()]
+        v = v.permute(0, 1, 2, 4, 3, 5).reshape(len(self), hw, nby * 4, nbx * 8)[:, :, :hl, :wl]
+        return v.reshape(len(self), self.h, self.w, hl, wl)
+
+
 class AltCorrBlock:
     """Volume-free correlation for long graphs (corr.py:79-145)."""
 

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import droid_backends
-from .droid_net import CorrBlock, AltCorrBlock, FusedUpdate, FusedLookup, OtfCorrBlock
+from .droid_net import CorrArena, CorrBlock, AltCorrBlock, FusedUpdate, FusedLookup, OtfCorrBlock
 
 
 def coords_grid(ht, wd, device):
@@ -53,6 +53,11 @@ class FactorGraph:
         # fp16 channels-last form of the update operator with fused element-wise stages
         # (droid_net.FusedUpdate, csrc/gru.hip)
         self.fast_update = FusedUpdate(update_op, inplace=self.use_graphs) if str(device).startswith("cuda") else None
+
+    def _use_arena(self):
+        """the HIP pyramid builder + slot arena (widths that are multiples of 8, fp16 maps on the GPU)"""
+        return (str(self.device).startswith("cuda") and self.wd % 8 == 0 and self.video.fmaps.dtype == torch.float16
+                and getattr(self, "use_arena", True))
 
     def _otf_block(self):
         """volume-free correlation operator over the stored feature maps (corr_impl == 'otf'),
@@ -123,11 +128,20 @@ class FactorGraph:
         net = self.video.nets[ii].to(self.device).unsqueeze(0)
         if self.corr_impl == "volume":
             c = (ii == jj).long()
-            fmap1 = self.video.fmaps[ii, 0].to(self.device).unsqueeze(0)
-            fmap2 = self.video.fmaps[jj, c].to(self.device).unsqueeze(0)
-            with torch.autocast("cuda", enabled=True):
-                corr = CorrBlock(fmap1, fmap2)
-            self.corr = corr if self.corr is None else self.corr.cat(corr)
+            if self._use_arena():
+                # slot-indexed store: the new edges are built into free slots (one launch), nothing else moves
+                blk = self._otf_block()             # channels-last, 1/4-scaled copies of the stored feature maps
+                rig = self._otf_rig
+                if self.corr is None:
+                    self.corr = CorrArena(self.ht, self.wd, self.device,
+                                          capacity=max(16, self.max_factors + 8 if self.max_factors > 0 else int(ii.shape[0])))
+                self.corr.add(blk.levels[0], rig * ii, rig * jj + c)
+            else:
+                fmap1 = self.video.fmaps[ii, 0].to(self.device).unsqueeze(0)
+                fmap2 = self.video.fmaps[jj, c].to(self.device).unsqueeze(0)
+                with torch.autocast("cuda", enabled=True):
+                    corr = CorrBlock(fmap1, fmap2)
+                self.corr = corr if self.corr is None else self.corr.cat(corr)
             inp = self.video.inps[ii].to(self.device).unsqueeze(0)
             self.inp = inp if self.inp is None else torch.cat([self.inp, inp], 1)
         elif self.corr_impl == "otf":
@@ -158,7 +172,10 @@ class FactorGraph:
         keep = ~mask
         self.ii, self.jj, self.age = self.ii[keep], self.jj[keep], self.age[keep]
         if self.corr_impl == "volume" and self.corr is not None:
-            self.corr = self.corr[keep]
+            if isinstance(self.corr, CorrArena):
+                self.corr.keep(keep.cpu().tolist())
+            else:
+                self.corr = self.corr[keep]
         if self.net is not None:
             self.net = self.net[:, keep]
         if self.inp is not None:

@@ -90,6 +90,21 @@ int glorie_corr_lookup_pyramid(const void* const* volumes, int num_levels,
 int glorie_corr_lookup_pyramid_tiled(const void* const* volumes, int num_levels, const float* coords,
                                      void* out, int N, int h1, int w1, int h2, int w2, void* stream);
 
+/* CorrBlock.__init__ for a batch of new edges (reference: src/modules/droid_net/corr.py:26-41,67-76 - all-pairs
+ * <f1/4, f2/4> as an fp16 GEMM with fp32 accumulation, then avg_pool2d level by level on the fp16 values), written
+ * directly in the tiled layout above into SLOTS of an arena: levels[l] is [capacity*h*w][plane_l] fp16 (plane_l =
+ * ceil((h>>l)/4)*ceil((w>>l)/8)*32 halfs, zero-initialised once: padding is never written), slots[e] the arena slot of
+ * new edge e.  fmaps_cl [F][h*w][128] fp16 channels-last, already scaled by 1/4 (the layout of glorie_corr_otf's
+ * level 0); ii / jj [n_new] select the source / target map.  C must be 128, w % 8 == 0.
+ * Edges keep their slot for life: add_factors / rm_factors / cat / __getitem__ of the reference (factor_graph.py:126,
+ * 161 re-copy every volume through a mask) become updates of the slot list. */
+int glorie_corr_build(const void* fmaps_cl, const int64_t* ii, const int64_t* jj, const int* slots,
+                      void* const* levels, int num_levels, int n_new, int h, int w, int C, void* stream);
+
+/* glorie_corr_lookup_pyramid_tiled on an arena: edge n reads the volumes of slot slots[n] (int32 [N]) */
+int glorie_corr_lookup_arena(const void* const* levels, int num_levels, const int* slots, const float* coords,
+                             void* out, int N, int h1, int w1, int h2, int w2, void* stream);
+
 /* Volume-free form of CorrBlock.__call__ / AltCorrBlock.__call__
  *   reference: src/modules/droid_net/corr.py:43-53 (volume lookup), :79-145 (alt-corr),
  *   src/lib/altcorr_kernel.cu:27-149

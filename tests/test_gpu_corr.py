@@ -216,3 +216,76 @@ def test_corr_otf_fused_encoder(gpu, smooth, H, W):
     only = torch.zeros(N, 128, H, W, dtype=torch.float16, device=gpu).contiguous(memory_format=torch.channels_last)
     assert blk.lookup_encode(c5, it, jt, OtfCorrBlock.pack_encoder(wgt), bias, only) is None
     assert torch.equal(only, wide[:, 128:256])
+
+
+def _fp16_ulp_diff(a, b):
+    """distance in fp16 representable values between two fp16 tensors of the same sign pattern"""
+    ia = a.view(torch.int16).int()
+    ib = b.view(torch.int16).int()
+    ia = torch.where(ia < 0, -(ia & 0x7fff), ia)
+    ib = torch.where(ib < 0, -(ib & 0x7fff), ib)
+    return (ia - ib).abs()
+
+
+@pytest.mark.parametrize("h,w", [(30, 40), (60, 80), (12, 16), (21, 24)])
+def test_corr_arena_build_matches_oracle_pyramid(gpu, h, w):
+    """glorie_corr_build: level 0 = fp16 all-pairs correlation (one fp16 ulp of the oracle's: fp32 summation order),
+    levels 1..3 = exactly avg_pool2d of the level below on the fp16 values; a removed edge frees its slot and the next
+    edge is built into it without touching the others; growth keeps every volume"""
+    from glorie_slam_amd.droid_net import CorrArena
+    from oracle import update_step as ostep
+    rng = np.random.default_rng(4)
+    F_ = 5
+    fm = rng.standard_normal((F_, 128, h, w)).astype(np.float16)
+    fcl = (torch.from_numpy(fm).to(gpu) / 4.0).permute(0, 2, 3, 1).reshape(F_, h * w, 128).contiguous()
+    ii = np.array([0, 1, 2, 4, 3], np.int64)
+    jj = np.array([1, 0, 4, 2, 3], np.int64)
+    arena = CorrArena(h, w, gpu, capacity=4)                       # 5 edges: grows once
+    arena.add(fcl, torch.from_numpy(ii[:3]).to(gpu), torch.from_numpy(jj[:3]).to(gpu))
+    arena.add(fcl, torch.from_numpy(ii[3:]).to(gpu), torch.from_numpy(jj[3:]).to(gpu))
+    assert len(arena) == 5 and arena.capacity >= 5
+    ref = ostep.corr_pyramid_fp16(fm[ii], fm[jj])
+    lv = [arena.level(l) for l in range(4)]
+    for l in range(4):
+        assert tuple(lv[l].shape) == (5, h, w, h >> l, w >> l)
+    r0 = torch.from_numpy(ref[0]).to(gpu)
+    assert int(_fp16_ulp_diff(lv[0], r0).max()) <= 1 and float((lv[0] == r0).float().mean()) > 0.98
+    for l in range(1, 4):
+        pooled = torch.nn.functional.avg_pool2d(lv[l - 1].reshape(-1, 1, h >> (l - 1), w >> (l - 1)).float(), 2, 2)
+        assert torch.equal(lv[l].reshape(pooled.shape).float(), pooled.half().float()), f"level {l}"
+        assert int(_fp16_ulp_diff(lv[l], torch.from_numpy(ref[l]).to(gpu)).max()) <= 1
+    # lookups through the slot list == the lookup on the row-major volumes
+    from glorie_slam_amd import droid_backends as db
+    coords = torch.from_numpy(_coords(rng, 5, h, w, h, w, margin=4.0)).to(gpu)
+    got = arena(coords.permute(0, 2, 3, 1)[None].contiguous())[0]
+    want = db.corr_lookup_pyramid([v.contiguous() for v in lv], coords, 3)
+    assert torch.equal(got, want)
+    # remove edges 1 and 3: their slots are recycled by the next additions, survivors keep their data in place
+    before = {s_: arena.views()[0].view(arena.capacity, h * w, -1)[s_].clone() for s_ in arena._host_slots}
+    freed = [arena._host_slots[1], arena._host_slots[3]]
+    arena.keep([True, False, True, False, True])
+    assert len(arena) == 3
+    arena.add(fcl, torch.tensor([3, 0], device=gpu), torch.tensor([1, 2], device=gpu))
+    assert sorted(arena._host_slots[3:]) == sorted(freed)
+    for s_ in arena._host_slots[:3]:
+        assert torch.equal(arena.views()[0].view(arena.capacity, h * w, -1)[s_], before[s_])
+    ref2 = ostep.corr_pyramid_fp16(fm[[3, 0]], fm[[1, 2]])
+    assert int(_fp16_ulp_diff(arena.level(0)[3:], torch.from_numpy(ref2[0]).to(gpu)).max()) <= 1
+
+
+def test_corr_arena_against_reference_fixture(gpu):
+    """fixture F4 (the reference's CorrBlock pyramid in fp32 on CPU; 16 channels there, so the 128-channel builder is
+    fed the fixture's maps zero-extended to 128 channels): fp16 tolerance"""
+    import os
+    from glorie_slam_amd.droid_net import CorrArena
+    f = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "corr_pyramid.npz"))
+    f1, f2 = f["fmap1"][0], f["fmap2"][0]                  # [2,16,8,8]
+    N, C, h, w = f1.shape
+    pad = lambda x: np.concatenate([x, np.zeros((N, 128 - C, h, w), x.dtype)], 1)
+    maps = np.concatenate([pad(f1), pad(f2)], 0).astype(np.float16)          # frames 0,1 = fmap1; 2,3 = fmap2
+    fcl = (torch.from_numpy(maps).to(gpu) / 4.0).permute(0, 2, 3, 1).reshape(2 * N, h * w, 128).contiguous()
+    arena = CorrArena(h, w, gpu, num_levels=3)
+    arena.add(fcl, torch.tensor([0, 1], device=gpu), torch.tensor([2, 3], device=gpu))
+    for l in range(3):
+        got = arena.level(l).float().cpu().numpy()
+        np.testing.assert_allclose(got, f[f"level{l}"], rtol=4e-3, atol=4e-3)

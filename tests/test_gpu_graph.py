@@ -166,8 +166,8 @@ def test_rm_factors_and_rm_keyframe(gpu):
     mask = (graph.ii == 5) | (graph.jj == 5)
     graph.rm_factors(mask, store=True)
     assert graph.ii.shape[0] == n0 - int(mask.sum()) and graph.ii_inac.shape[0] == int(mask.sum())
-    rows_per_edge = graph.ht * graph.wd if graph.corr.tiled else 1
-    assert graph.corr.corr_pyramid[0].shape[0] == graph.ii.shape[0] * rows_per_edge
+    assert len(graph.corr) == graph.ii.shape[0]               # the arena lists exactly the live edges
+    assert len(set(graph.corr._host_slots)) == len(graph.corr)
     graph.rm_keyframe(3)
     assert int(graph.ii.max()) <= 3 and not ((graph.ii == 3) & (graph.jj == 3)).any()
     p0 = video.poses.clone()
