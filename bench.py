@@ -114,19 +114,25 @@ def build_renderer(device, rank=0, world=1):
     torch.manual_seed(43)
     dec = POINT(cfg, use_view_direction=True).eval().to(device)
     ren = Renderer(cfg, _Cam())
-    rays = dict(o=t(ro[lo:hi]), d=t(rd[lo:hi]), depth=t(depth[lo:hi]), radius=t(radius[lo:hi]))
+    assert lo % 640 == 0 and hi % 640 == 0, "ranks take whole image rows"
+    rays = dict(o=t(ro[lo:hi]), d=t(rd[lo:hi]), depth=t(depth[lo:hi]), radius=t(radius[lo:hi]), W=640)
     return npc, dec, ren, rays
 
 
 def render_pass(npc, dec, ren, rays, device):
+    # the batching of Renderer.render_img: whole 16-row strips, so the neighbour search can walk image patches
     bs = ren.ray_batch_size
+    W = rays["W"]
+    image_w = W if os.environ.get("GLORIE_BENCH_KNN_LAYOUT", "image") == "image" else None
+    if image_w:
+        bs -= bs % (16 * W)
     n = rays["o"].shape[0]
     with torch.no_grad():
         for i in range(0, n, bs):
             ren.render_batch_ray(npc, dec, rays["d"][i:i + bs], rays["o"][i:i + bs], device, "color",
                                  gt_depth=rays["depth"][i:i + bs], npc_geo_feats=npc.geo_feats,
                                  npc_col_feats=npc.col_feats, cloud_pos=npc.cloud_pos(),
-                                 dynamic_r_query=rays["radius"][i:i + bs])
+                                 dynamic_r_query=rays["radius"][i:i + bs], image_w=image_w)
     return n
 
 
@@ -529,16 +535,18 @@ def main():
     dec.eval()
     # KNN + feature gather alone (HIP events), 2156 B per sample
     S = ren.N_surface
-    nq = min(rays["o"].shape[0], 65536)
+    nq = min(rays["o"].shape[0], 61440)            # 96 image rows: the batch render_img evaluates
     z = rays["depth"][:nq, None] * torch.linspace(0.95, 1.05, S, device=device)[None]
     pq = (rays["o"][:nq, None] + rays["d"][:nq, None] * z[..., None]).reshape(-1, 3).contiguous()
     rq = rays["radius"][:nq].repeat_interleave(S)
     from glorie_slam_amd import point_ops
 
+    img_w = int(rays["W"]) if "W" in rays else None
+    layout = (S, img_w) if (img_w and os.environ.get("GLORIE_BENCH_KNN_LAYOUT", "image") == "image") else None
+
     def knn_gather():
-        D, I, nn = npc.index.search(pq, 8, radius_per_query=rq)
-        point_ops.idw_gather(D, I, nn, npc.geo_feats, radius_per_query=rq)
-        point_ops.idw_gather(D, I, nn, npc.col_feats, radius_per_query=rq)
+        D, I, nn = npc.index.search(pq, 8, radius_per_query=rq, image_layout=layout)
+        point_ops.idw_gather2(D, I, nn, npc.geo_feats, npc.col_feats, radius_per_query=rq)
 
     knn_gather()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

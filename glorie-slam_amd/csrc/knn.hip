@@ -211,30 +211,31 @@ __global__ __launch_bounds__(256) void knn_scatter_kernel(const float* __restric
 // ------------------------------------------------------------------------------------
 // query
 // ------------------------------------------------------------------------------------
+// The k best (distance, index) pairs of a lane, ascending.  A pair is one 64-bit key (distance bits << 32 | index):
+// squared distances are >= +0, so the fp32 bit pattern orders like the value and ONE unsigned 64-bit compare is the
+// (distance, index) order - ties on distance fall to the smaller index, empty slots (FLT_MAX, -1) sort last.
+// push() is what the search spends its VALU time in (it runs whenever ANY lane of the wave improves its list): with
+// packed keys an insertion is k compares + 4k selects, no bubble pass and no separate tie logic.
 template <int K>
 struct TopK {
-  float d[K];
-  int i[K];
+  unsigned long long key[K];
   __device__ __forceinline__ void init() {
 #pragma unroll
-    for (int s = 0; s < K; ++s) { d[s] = FLT_MAX; i[s] = -1; }
+    for (int s = 0; s < K; ++s) key[s] = ((unsigned long long)__float_as_uint(FLT_MAX) << 32) | 0xffffffffull;
   }
-  __device__ __forceinline__ static bool less(float da, int ia, float db, int ib) {
-    // (distance, index) order; empty slots (i = -1, d = FLT_MAX) sort last
-    return da < db || (da == db && (unsigned)ia < (unsigned)ib);
-  }
+  __device__ __forceinline__ float dist(int s) const { return __uint_as_float((unsigned)(key[s] >> 32)); }
+  __device__ __forceinline__ int index(int s) const { return (int)(unsigned)key[s]; }
   __device__ __forceinline__ void push(float dd, int ii) {
-    if (!less(dd, ii, d[K - 1], i[K - 1])) return;
-    d[K - 1] = dd; i[K - 1] = ii;
+    const unsigned long long x = ((unsigned long long)__float_as_uint(dd) << 32) | (unsigned)ii;
+    bool c = x < key[K - 1];
+    if (!c) return;
 #pragma unroll
-    for (int s = K - 1; s > 0; --s) {
-      const bool sw = less(d[s], i[s], d[s - 1], i[s - 1]);
-      const float td = sw ? d[s - 1] : d[s];
-      const int ti = sw ? i[s - 1] : i[s];
-      d[s - 1] = sw ? d[s] : d[s - 1];
-      i[s - 1] = sw ? i[s] : i[s - 1];
-      d[s] = td; i[s] = ti;
+    for (int s = K - 1; s > 0; --s) {            // new[s] = x < old[s-1] ? old[s-1] : (x < old[s] ? x : old[s])
+      const bool cm = x < key[s - 1];
+      key[s] = cm ? key[s - 1] : (c ? x : key[s]);
+      c = cm;
     }
+    key[0] = c ? x : key[0];
   }
 };
 
@@ -267,31 +268,63 @@ __device__ __forceinline__ void knn_search(const float4* __restrict__ sorted,
     // face row of the shell is ONE contiguous point range (2 dependent index loads per row instead
     // of 2 per cell), and the range is walked 4 points at a time with independent 16-byte loads
     // (a lane's search is a chain of dependent loads: this is what bounds the kernel).
+    // ONE scan site (the insertion is ~60 VALU instructions, inlined once per load slot): ranges are walked 4 points
+    // at a time, the tail re-reads the last point with the insertion masked off.
     auto scan = [&](int b, int e) {
-      int t = b;
-      for (; t + 3 < e; t += 4) {
-        const float4 p0 = sorted[t], p1 = sorted[t + 1], p2 = sorted[t + 2], p3 = sorted[t + 3];
+      for (int t = b; t < e; t += 4) {
+        const int l = e - 1;
+        const float4 p0 = sorted[t], p1 = sorted[min(t + 1, l)], p2 = sorted[min(t + 2, l)], p3 = sorted[min(t + 3, l)];
         top.push(dist2_exact(qx, qy, qz, p0), __float_as_int(p0.w));
-        top.push(dist2_exact(qx, qy, qz, p1), __float_as_int(p1.w));
-        top.push(dist2_exact(qx, qy, qz, p2), __float_as_int(p2.w));
-        top.push(dist2_exact(qx, qy, qz, p3), __float_as_int(p3.w));
-      }
-      for (; t < e; ++t) {
-        const float4 p = sorted[t];
-        top.push(dist2_exact(qx, qy, qz, p), __float_as_int(p.w));
+        if (t + 1 < e) top.push(dist2_exact(qx, qy, qz, p1), __float_as_int(p1.w));
+        if (t + 2 < e) top.push(dist2_exact(qx, qy, qz, p2), __float_as_int(p2.w));
+        if (t + 3 < e) top.push(dist2_exact(qx, qy, qz, p3), __float_as_int(p3.w));
       }
     };
-    for (int z = z0; z <= z1; ++z)
+    // Once the list is full, cells whose box lies farther from q than the current k-th best cannot contribute
+    // (push() would reject every point in them): rows are skipped on their (y, z) slab distance and face rows are
+    // clipped in x to the ball.  A sample 10 cm off the surface otherwise reads ~400 points of a 5^3 shell to find
+    // the handful inside its ball.  Bounds are shrunk by 1e-3 cell and 0.1 % so that the fp32 rounding of the cell
+    // assignment can never exclude a point that would have been taken.
+    const float slack = 1e-3f * g.cs;
+#pragma unroll 1
+    for (int z = z0; z <= z1; ++z) {
+      const float zlo = g.oz + z * g.cs;
+      const float bz = fmaxf(fmaxf(zlo - qz, qz - (zlo + g.cs)) - slack, 0.0f);
+#pragma unroll 1
       for (int y = y0; y <= y1; ++y) {
         const bool face = (abs(z - cz) == m) || (abs(y - cy) == m);
         const int row = (z * g.ny + y) * g.nx;
-        if (face) {                                   // every x of the row belongs to the shell
-          scan(starts[row + x0], starts[row + x1 + 1]);
-        } else {                                      // only the two end cells (if they are on the shell)
-          if (abs(x0 - cx) == m) scan(starts[row + x0], starts[row + x0 + 1]);
-          if (x1 != x0 && abs(x1 - cx) == m) scan(starts[row + x1], starts[row + x1 + 1]);
+        const float ylo = g.oy + y * g.cs;
+        const float by = fmaxf(fmaxf(ylo - qy, qy - (ylo + g.cs)) - slack, 0.0f);
+        const float byz2 = by * by + bz * bz;
+        const float kth = top.dist(K - 1);
+        const bool full = kth < FLT_MAX;
+        if (full && byz2 > 1.001f * kth) continue;
+        // up to two cell ranges of this row: the whole (clipped) row on a face, else the end cells that lie on the shell
+        int sa = 0, sb = -1, ta = 0, tb = -1;
+        if (face) {
+          sa = x0; sb = x1;
+          if (full) {
+            const float rx = sqrtf(fmaxf(1.001f * kth - byz2, 0.0f)) + slack;
+            sa = max(x0, cell_coord(qx - rx, g.ox, g.inv_cs, g.nx));
+            sb = min(x1, cell_coord(qx + rx, g.ox, g.inv_cs, g.nx));
+          }
+        } else {
+          auto far_cell = [&](int x) {
+            const float xlo = g.ox + x * g.cs;
+            const float bx = fmaxf(fmaxf(xlo - qx, qx - (xlo + g.cs)) - slack, 0.0f);
+            return full && byz2 + bx * bx > 1.001f * kth;
+          };
+          if (abs(x0 - cx) == m && !far_cell(x0)) { sa = x0; sb = x0; }
+          if (x1 != x0 && abs(x1 - cx) == m && !far_cell(x1)) { ta = x1; tb = x1; }
+        }
+#pragma unroll 1
+        for (int seg = 0; seg < 2; ++seg) {
+          const int ca = seg ? ta : sa, cb = seg ? tb : sb;
+          if (ca <= cb) scan(starts[row + ca], starts[row + cb + 1]);
         }
       }
+    }
     // distance from q to the faces of the scanned cube that still have cells behind them
     float rho = FLT_MAX;
     if (cx - m > 0) rho = fminf(rho, qx - (g.ox + (cx - m) * g.cs));
@@ -301,7 +334,7 @@ __device__ __forceinline__ void knn_search(const float4* __restrict__ sorted,
     if (cz - m > 0) rho = fminf(rho, qz - (g.oz + (cz - m) * g.cs));
     if (cz + m < g.nz - 1) rho = fminf(rho, (g.oz + (cz + m + 1) * g.cs) - qz);
     if (rho == FLT_MAX) break;                       // the cube covers the whole grid
-    if (rho > 0.0f && top.d[K - 1] <= 0.998f * rho * rho) break;  // k-th best is inside
+    if (rho > 0.0f && top.dist(K - 1) <= 0.998f * rho * rho) break;  // k-th best is inside
   }
 }
 
@@ -310,26 +343,42 @@ __global__ __launch_bounds__(256) void knn_query_kernel(
     const float4* __restrict__ sorted, const int* __restrict__ starts,
     const KnnGrid* __restrict__ gp, const float* __restrict__ q, int Q, float radius,
     const float* __restrict__ radius_ptr, float* __restrict__ D, int64_t* __restrict__ I,
-    int* __restrict__ nn) {
+    int* __restrict__ nn, int S, int image_w) {
   // The 256 queries of a workgroup are processed in the order of their grid cells: lanes that sit in the same
   // cell walk the same shells over the same point ranges - identical trip counts and identical addresses
   // (one L1 transaction per wave instead of one per lane) - where in ray order a wave straddles ~5 cells
   // along its rays and every loop runs for the longest lane.  Each query is still searched by one lane and
   // written to its own row, so the result does not depend on the order.  Sort key = (cell id, local index)
   // in 30 bits (the build caps the grid at 2^22 cells), bitonic in LDS.
+  //
+  // image_w > 0: the queries are the S samples of the rays of an image strip (ray = y * image_w + x, query = ray * S + s,
+  // what render_img hands over).  The workgroup then takes the s-th sample of a 16 x 16 pixel patch instead of 256
+  // consecutive queries: ~25 rays x 10 depths straddle a 20 cm stretch of 6 cm cells, the patch at one depth is a
+  // ~6 cm square - one or two cells, the coherence of a global sort by cell without the sort.
   __shared__ unsigned skey[256];
   const int tid = threadIdx.x;
-  const int base = blockIdx.x * 256;
   const KnnGrid g = *gp;
+  auto query_of = [&](int l) -> int {
+    if (image_w <= 0) {
+      const int t = blockIdx.x * 256 + l;
+      return t < Q ? t : -1;
+    }
+    const int R = Q / S;
+    const int tiles_x = (image_w + 15) >> 4;
+    const int s = blockIdx.x % S, tile = blockIdx.x / S;
+    const int x = (tile % tiles_x) * 16 + (l & 15), y = (tile / tiles_x) * 16 + (l >> 4);
+    const int r = y * image_w + x;
+    return (x < image_w && r < R) ? r * S + s : -1;
+  };
   {
-    const int t = base + tid;
+    const int t = query_of(tid);
     unsigned key = 0xffffffffu;
-    if (t < Q && g.npoints > 0) {
+    if (t >= 0 && g.npoints > 0) {
       const int cx = cell_coord(q[(size_t)t * 3 + 0], g.ox, g.inv_cs, g.nx);
       const int cy = cell_coord(q[(size_t)t * 3 + 1], g.oy, g.inv_cs, g.ny);
       const int cz = cell_coord(q[(size_t)t * 3 + 2], g.oz, g.inv_cs, g.nz);
       key = ((unsigned)((cz * g.ny + cy) * g.nx + cx) << 8) | (unsigned)tid;
-    } else if (t < Q) {
+    } else if (t >= 0) {
       key = 0xffffff00u | (unsigned)tid;
     }
     skey[tid] = key;
@@ -347,7 +396,7 @@ __global__ __launch_bounds__(256) void knn_query_kernel(
     }
   const unsigned mine = skey[tid];
   if (mine == 0xffffffffu) return;           // past the end of the query array
-  const int t = base + (int)(mine & 255u);
+  const int t = query_of((int)(mine & 255u));
   TopK<K> top;
   knn_search<K>(sorted, starts, g, q[(size_t)t * 3 + 0], q[(size_t)t * 3 + 1], q[(size_t)t * 3 + 2], top);
   const float r = radius_ptr ? radius_ptr[t] : radius;
@@ -355,9 +404,9 @@ __global__ __launch_bounds__(256) void knn_query_kernel(
   int cnt = 0;
 #pragma unroll
   for (int s = 0; s < K; ++s) {
-    D[(size_t)t * K + s] = top.d[s];
-    I[(size_t)t * K + s] = (int64_t)top.i[s];
-    cnt += (top.d[s] < r2) ? 1 : 0;
+    D[(size_t)t * K + s] = top.dist(s);
+    I[(size_t)t * K + s] = (int64_t)top.index(s);
+    cnt += (top.dist(s) < r2) ? 1 : 0;
   }
   if (nn) nn[t] = cnt;
 }
@@ -407,19 +456,24 @@ extern "C" int glorie_knn_build(glorie_ctx* ctx, const float* points, int np, fl
   return check_launch();
 }
 
-extern "C" int glorie_knn_query(const float* sorted_pos, const int* cell_start, const void* grid,
-                                const float* queries, int Q, int k, float radius,
-                                const float* radius_ptr, float* D, int64_t* I, int* nn,
-                                void* stream) {
+static int knn_query_launch(const float* sorted_pos, const int* cell_start, const void* grid,
+                            const float* queries, int Q, int k, float radius,
+                            const float* radius_ptr, float* D, int64_t* I, int* nn, int S, int image_w,
+                            void* stream) {
   if (Q < 0 || k < 1) return GLORIE_EINVAL;
   if (Q == 0) return GLORIE_OK;
   if (!sorted_pos || !cell_start || !grid || !queries || !D || !I) return GLORIE_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   dim3 gridDim((Q + 255) / 256);
+  if (image_w > 0) {
+    if (S < 1 || Q % S != 0) return GLORIE_EINVAL;
+    const int R = Q / S, rows = (R + image_w - 1) / image_w;
+    gridDim = dim3((unsigned)(((image_w + 15) / 16) * ((rows + 15) / 16) * S));
+  }
 #define LAUNCH_K(KK)                                                                              \
   hipLaunchKernelGGL(knn_query_kernel<KK>, gridDim, dim3(256), 0, st,                             \
                      reinterpret_cast<const float4*>(sorted_pos), cell_start,                     \
-                     reinterpret_cast<const KnnGrid*>(grid), queries, Q, radius, radius_ptr, D, I, nn)
+                     reinterpret_cast<const KnnGrid*>(grid), queries, Q, radius, radius_ptr, D, I, nn, S, image_w)
   switch (k) {
     case 1: LAUNCH_K(1); break;
     case 4: LAUNCH_K(4); break;
@@ -429,4 +483,20 @@ extern "C" int glorie_knn_query(const float* sorted_pos, const int* cell_start, 
   }
 #undef LAUNCH_K
   return check_launch();
+}
+
+extern "C" int glorie_knn_query(const float* sorted_pos, const int* cell_start, const void* grid,
+                                const float* queries, int Q, int k, float radius,
+                                const float* radius_ptr, float* D, int64_t* I, int* nn,
+                                void* stream) {
+  return knn_query_launch(sorted_pos, cell_start, grid, queries, Q, k, radius, radius_ptr, D, I, nn, 1, 0, stream);
+}
+
+extern "C" int glorie_knn_query_image(const float* sorted_pos, const int* cell_start, const void* grid,
+                                      const float* queries, int Q, int k, float radius,
+                                      const float* radius_ptr, float* D, int64_t* I, int* nn,
+                                      int samples_per_ray, int image_w, void* stream) {
+  if (image_w < 1) return GLORIE_EINVAL;
+  return knn_query_launch(sorted_pos, cell_start, grid, queries, Q, k, radius, radius_ptr, D, I, nn,
+                          samples_per_ray, image_w, stream);
 }

@@ -58,8 +58,10 @@ class KnnIndex:
                                               L.ptr(self.cell_start), L.ptr(self.grid),
                                               L.stream_ptr()), "glorie_knn_build")
 
-    def search(self, q, k=8, radius=0.0, radius_per_query=None):
-        """-> D [Q,k] f32, I [Q,k] int64, neighbor_num [Q] int32 (count of D < r^2)"""
+    def search(self, q, k=8, radius=0.0, radius_per_query=None, image_layout=None):
+        """-> D [Q,k] f32, I [Q,k] int64, neighbor_num [Q] int32 (count of D < r^2).
+        image_layout = (samples_per_ray, image_w) when q holds the samples of row-major image rays (render_img): the same
+        result from a search that walks the image in 16 x 16 pixel patches (glorie_knn_query_image)."""
         q = q.detach().to(self.device, torch.float32).reshape(-1, 3).contiguous()
         Q = q.shape[0]
         D = torch.empty(Q, k, dtype=torch.float32, device=self.device)
@@ -71,10 +73,17 @@ class KnnIndex:
             if rp.shape[0] != Q:
                 raise RuntimeError("shape mis-match for input points and dynamic radius")
         with torch.cuda.device(self.device):
-            L.check(L.load().glorie_knn_query(L.ptr(self.sorted_pos), L.ptr(self.cell_start),
-                                              L.ptr(self.grid), L.ptr(q), Q, k, float(radius), L.ptr(rp),
-                                              L.ptr(D), L.ptr(I), L.ptr(nn), L.stream_ptr()),
-                    "glorie_knn_query")
+            if image_layout is not None:
+                S, image_w = int(image_layout[0]), int(image_layout[1])
+                L.check(L.load().glorie_knn_query_image(L.ptr(self.sorted_pos), L.ptr(self.cell_start),
+                                                        L.ptr(self.grid), L.ptr(q), Q, k, float(radius), L.ptr(rp),
+                                                        L.ptr(D), L.ptr(I), L.ptr(nn), S, image_w, L.stream_ptr()),
+                        "glorie_knn_query_image")
+            else:
+                L.check(L.load().glorie_knn_query(L.ptr(self.sorted_pos), L.ptr(self.cell_start),
+                                                  L.ptr(self.grid), L.ptr(q), Q, k, float(radius), L.ptr(rp),
+                                                  L.ptr(D), L.ptr(I), L.ptr(nn), L.stream_ptr()),
+                        "glorie_knn_query")
         return D, I, nn
 
 
@@ -96,6 +105,22 @@ def idw_gather(D, I, nn, feats, radius=0.0, radius_per_query=None, min_nn=2, exp
     if not raw_mask:
         has = has.bool()
     return (c, has, w) if return_weights else (c, has)
+
+
+def idw_gather2(D, I, nn, feats_a, feats_b, radius=0.0, radius_per_query=None, min_nn=2, expo=False):
+    """idw_gather on the geometry and the colour table in one launch -> c_a [Q,32], c_b [Q,32], has [Q] bool, w [Q,8]"""
+    L.need_cuda(D, I, nn, feats_a, feats_b)
+    Q, k = D.shape
+    ca = torch.empty(Q, 32, dtype=torch.float32, device=D.device)
+    cb = torch.empty(Q, 32, dtype=torch.float32, device=D.device)
+    has = torch.empty(Q, dtype=torch.uint8, device=D.device)
+    w = torch.empty(Q, k, dtype=torch.float32, device=D.device)
+    rp = radius_per_query.reshape(-1).contiguous().float() if radius_per_query is not None else None
+    L.check(L.load().glorie_idw_gather2(L.ptr(D.contiguous()), L.ptr(I.contiguous()), L.ptr(nn.contiguous()),
+                                        L.ptr(feats_a.contiguous()), L.ptr(feats_b.contiguous()), Q, k, feats_a.shape[1],
+                                        float(radius), L.ptr(rp), int(min_nn), int(bool(expo)), L.ptr(ca), L.ptr(cb),
+                                        L.ptr(w), L.ptr(has), L.stream_ptr()), "glorie_idw_gather2")
+    return ca, cb, has.bool(), w
 
 
 _T_LIN = {}

@@ -75,7 +75,7 @@ class Renderer(object):
         return z, near_mask, nz
 
     def _render_fast(self, npc, decoders, rays_d, rays_o, stage, gt_depth, npc_geo_feats, npc_col_feats,
-                     cloud_pos, dynamic_r_query):
+                     cloud_pos, dynamic_r_query, image_w=None):
         """Inference path of render_batch_ray for batches in which every ray has a depth prior: seven HIP
         launches (samples, KNN, IDW gather, three decoders, per-ray counts, compositing) and no torch glue.
         Returns None when a ray has no depth (sample_near_pcl is needed: general path)."""
@@ -91,7 +91,8 @@ class Renderer(object):
         flag.copy_(n_zero, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        D, I, nn_num = npc.find_neighbors_faiss(pts, step='query', dynamic_radius=rq)
+        D, I, nn_num = npc.find_neighbors_faiss(pts, step='query', dynamic_radius=rq,
+                                                image_layout=(S, image_w) if image_w else None)
         radius = 0.0 if g.use_dynamic_radius else npc.get_radius_query()
         # weights and mask only: the geometry kernel interpolates its feature itself (no [Q,32] round trip)
         _, has, w = point_ops.idw_gather(D, I, nn_num, None, radius=radius,
@@ -115,8 +116,10 @@ class Renderer(object):
 
     def render_batch_ray(self, npc, decoders, rays_d, rays_o, device, stage, gt_depth=None,
                          npc_geo_feats=None, npc_col_feats=None, is_tracker=False, cloud_pos=None,
-                         dynamic_r_query=None):
-        """Renderer.py:80-219 -> depth, uncertainty, color, valid_ray_mask, valid_ray_counts"""
+                         dynamic_r_query=None, image_w=None):
+        """Renderer.py:80-219 -> depth, uncertainty, color, valid_ray_mask, valid_ray_counts
+        image_w (not in the reference): the rays are consecutive row-major pixels of an image of that width, starting
+        at a row start - lets the neighbour search walk the image in patches; the result does not depend on it."""
         S = self.N_surface
         R = rays_o.shape[0]
         if (gt_depth is not None and R > 0 and torch.numel(gt_depth) == R and stage in ('geometry', 'color')
@@ -125,7 +128,7 @@ class Renderer(object):
                 and decoders._fused_ok(rays_o, npc_geo_feats, npc_col_feats, is_tracker, stage)
                 and decoders.geo_decoder.use_dynamic_radius == self.use_dynamic_radius):
             out = self._render_fast(npc, decoders, rays_d, rays_o, stage, gt_depth, npc_geo_feats,
-                                    npc_col_feats, cloud_pos, dynamic_r_query)
+                                    npc_col_feats, cloud_pos, dynamic_r_query, image_w=image_w)
             if out is not None:
                 return out
         if (torch.is_grad_enabled() and gt_depth is not None and R > 0 and torch.numel(gt_depth) == R and not is_tracker
@@ -172,12 +175,15 @@ class Renderer(object):
         gt = gt_depth.reshape(-1) if gt_depth is not None else None
         outs = [[], [], [], [], []]
         bs = self.ray_batch_size
+        if bs >= 16 * W:
+            bs -= bs % (16 * W)          # whole 16-row strips: every batch starts at a row start (image_w hint below)
+        image_w = W if bs % W == 0 else None
         for i in range(0, rays_d.shape[0], bs):
             ret = self.render_batch_ray(
                 npc, decoders, rays_d[i:i + bs], rays_o[i:i + bs], device, stage,
                 gt_depth=gt[i:i + bs] if gt is not None else None, npc_geo_feats=npc_geo_feats,
                 npc_col_feats=npc_col_feats, cloud_pos=cloud_pos,
-                dynamic_r_query=dynamic_r_query[i:i + bs] if self.use_dynamic_radius else None)
+                dynamic_r_query=dynamic_r_query[i:i + bs] if self.use_dynamic_radius else None, image_w=image_w)
             for o, v in zip(outs, ret):
                 o.append(v)
         depth = torch.cat(outs[0]).double().reshape(H, W)

@@ -390,6 +390,15 @@ int glorie_knn_query(const float* sorted_pos, const int* cell_start, const void*
                      const float* queries, int Q, int k, float radius, const float* radius_ptr,
                      float* D, int64_t* I, int* nn, void* stream);
 
+/* glorie_knn_query for the samples of an image strip: queries = the samples_per_ray samples of rays laid out row-major
+ * with image_w rays per row (query = (y * image_w + x) * samples_per_ray + s; what Renderer.render_img,
+ * src/utils/Renderer.py:221-306, evaluates).  Same outputs in the same rows, bit for bit; a workgroup searches one
+ * depth of a 16 x 16 pixel patch instead of 256 consecutive queries, so its lanes share cells and point ranges.
+ * The last row may be partial (Q / samples_per_ray need not be a multiple of image_w). */
+int glorie_knn_query_image(const float* sorted_pos, const int* cell_start, const void* grid,
+                           const float* queries, int Q, int k, float radius, const float* radius_ptr,
+                           float* D, int64_t* I, int* nn, int samples_per_ray, int image_w, void* stream);
+
 /* Feature interpolation of MLP_geometry/MLP_color.get_feature_at_pos
  *   reference: src/modules/conv_onet/models/decoder.py:130-173 (geometry), :340-389 (colour)
  * w = L1-normalise( [D <= r^2] / (D + 1e-10) )  (or exp(-20 sqrt(D)) when expo_weighting),
@@ -400,6 +409,13 @@ int glorie_idw_gather(const float* D, const int64_t* I, const int* nn, const flo
                       int Q, int k, int c_dim, float radius, const float* radius_ptr,
                       int min_nn, int expo_weighting, float* c_out, float* w_out,
                       uint8_t* has_out, void* stream);
+
+/* glorie_idw_gather on the geometry and the colour table in one pass (decoder.py:130-173 and :340-389 share the
+ * neighbours and the weights): c_out_a = sum_k w_k feats_a[I_k], c_out_b likewise.  Same bits as two calls. */
+int glorie_idw_gather2(const float* D, const int64_t* I, const int* nn, const float* feats_a,
+                       const float* feats_b, int Q, int k, int c_dim, float radius,
+                       const float* radius_ptr, int min_nn, int expo_weighting, float* c_out_a,
+                       float* c_out_b, float* w_out, uint8_t* has_out, void* stream);
 
 /* Fused decoders: POINT.forward(p, npc, stage, ...) minus the neighbour search
  *   reference: src/modules/conv_onet/models/decoder.py:175-225 (MLP_geometry.forward),

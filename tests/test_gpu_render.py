@@ -97,6 +97,31 @@ def test_knn_ray_ordered_queries_cooperative_path(gpu):
     _check_knn(gpu, pts, mixed, cell=0.08)
 
 
+@pytest.mark.parametrize("rows,W,S", [(48, 64, 10), (37, 50, 10), (5, 19, 3), (16, 16, 1)])
+def test_knn_image_layout_is_only_an_ordering(gpu, rows, W, S):
+    """glorie_knn_query_image: the patch-wise walk over an image strip (ragged widths, a partial last row) writes
+    the same (D, I, nn) into the same rows as the plain query, and both equal the brute-force oracle."""
+    import glorie_slam_amd.synth as synth
+    pts, _, _ = synth.box_cloud(n_hits=30000)
+    ro, rd, depth, _, _ = synth.box_rays(H=48, W=64, fx=32.0, fy=32.0, cx=31.5, cy=23.5)
+    yy, xx = np.meshgrid(np.arange(rows), np.arange(W), indexing="ij")
+    sel = (yy * 64 + xx % 64).reshape(-1)
+    sel = sel[:len(sel) - 7] if rows == 37 else sel               # partial last row
+    z = depth[sel, None] * np.linspace(0.95, 1.05, S, dtype=np.float32)[None]
+    q = (ro[sel, None] + rd[sel, None] * z[..., None]).reshape(-1, 3).astype(np.float32)
+    idx = _index(gpu, pts)
+    qd = torch.from_numpy(q).to(gpu)
+    rad = torch.from_numpy(np.random.default_rng(2).uniform(0.03, 0.2, len(q)).astype(np.float32)).to(gpu)
+    D0, I0, n0 = idx.search(qd, 8, radius_per_query=rad)
+    D1, I1, n1 = idx.search(qd, 8, radius_per_query=rad, image_layout=(S, W))
+    assert torch.equal(D0, D1) and torch.equal(I0, I1) and torch.equal(n0, n1)
+    if len(q) <= 20000:
+        rD, rI = oknn.knn_bruteforce(pts, q, 8)
+        assert np.array_equal(I1.cpu().numpy(), rI) and np.array_equal(D1.cpu().numpy(), rD)
+    with pytest.raises(RuntimeError):
+        idx.search(qd[:(S + 1) * 3 + 1], 8, radius=0.1, image_layout=(S + 1, W))     # Q is not a multiple of S
+
+
 def test_knn_point_permutation_invariance(gpu):
     rng = np.random.default_rng(4)
     pts = rng.uniform(0, 1, (2000, 3)).astype(np.float32)
@@ -123,6 +148,12 @@ def test_idw_gather(gpu):
     assert np.array_equal(has.cpu().numpy(), rhas) and 0 < rhas.sum() < len(rhas)
     np.testing.assert_allclose(w.cpu().numpy(), rw, rtol=1e-5, atol=1e-7)
     np.testing.assert_allclose(c.cpu().numpy(), rc, rtol=1e-4, atol=1e-6)
+    # both tables in one pass: the bits of two separate calls
+    feats_b = rng.normal(0, 0.1, (3000, 32)).astype(np.float32)
+    cb, _ = point_ops.idw_gather(D, I, nn, torch.from_numpy(feats_b).to(gpu), radius_per_query=torch.from_numpy(rad).to(gpu))
+    c2a, c2b, has2, w2 = point_ops.idw_gather2(D, I, nn, torch.from_numpy(feats).to(gpu), torch.from_numpy(feats_b).to(gpu),
+                                               radius_per_query=torch.from_numpy(rad).to(gpu))
+    assert torch.equal(c2a, c) and torch.equal(c2b, cb) and torch.equal(has2, has) and torch.equal(w2, w)
 
 
 def test_composite_matches_reference_fixture(gpu):
