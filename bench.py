@@ -480,7 +480,7 @@ def main():
     # M2 on the 5000-ray training batch (mapper.py:390-515 samples 5000 pixels per iteration), forward
     gsel = torch.Generator(device="cpu").manual_seed(5)
     pick = torch.randperm(rays["o"].shape[0], generator=gsel)[:5000].to(device)
-    b5 = {k: v[pick].contiguous() for k, v in rays.items()}
+    b5 = {k: v[pick].contiguous() for k, v in rays.items() if torch.is_tensor(v)}
 
     def batch5000():
         with torch.no_grad():
@@ -546,7 +546,7 @@ def main():
 
     def knn_gather():
         D, I, nn = npc.index.search(pq, 8, radius_per_query=rq, image_layout=layout)
-        point_ops.idw_gather2(D, I, nn, npc.geo_feats, npc.col_feats, radius_per_query=rq)
+        point_ops.idw_gather2(D, I, nn, npc.geo_feats, npc.col_feats, radius_per_query=rq, image_layout=layout)
 
     knn_gather()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -621,7 +621,7 @@ def main():
         "train_batch5000": train,
         "render": {"rays_local": int(n_r // render_reps), "samples_per_ray": int(S), "cloud_points": int(npc.pts_num()),
                    "ms_per_frame_shard": 1e3 * t_r / render_reps},
-        "roofline_knn": {"bound": "hbm", "kernel": "knn_query_kernel<8> + 2x idw_gather_kernel",
+        "roofline_knn": {"bound": "hbm", "kernel": "knn_query_kernel<8> (image-patch order) + idw_gather2_kernel (both feature tables)",
                          "achieved": knn_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": knn_gbs / HBM_PEAK_GBS, "traffic": knn_traffic if world == 1 else None,
                          "alg_bytes_per_launch": knn_bytes, "ms_per_launch": knn_ms,
