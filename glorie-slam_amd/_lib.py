@@ -39,7 +39,7 @@ SIGNATURES = {
     "glorie_segment_mean": (_c_int, [_vp, _c_int, _vp, _c_int, _vp, _c_int, _vp, _c_int, _c_int, _c_int, _vp]),
     "glorie_conv3x3_small": (_c_int, [_vp, _c_int, _vp, _c_int, _vp, _vp, _c_int, _c_int, _c_int, ctypes.c_float, _vp, _vp, _c_int, _c_int, _c_int, _vp]),
     "glorie_conv_igemm": (_c_int, [_vp, _c_int, _c_int, _vp, _c_int, _c_int, _vp, _c_int, _c_int, _c_int, _vp,
-                                   _c_int, _c_int, _vp, _c_int, _vp, _c_int, _vp, _c_int, _vp, _c_int, _vp, _c_int,
+                                   _c_int, _c_int, _vp, _c_int, _vp, _c_int, _vp, _c_int, _vp, _c_int, _vp, _c_int, _vp,
                                    _c_int, _c_int, _c_int, _vp]),
     "glorie_flow_conv7": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp]),
     "glorie_motion": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, ctypes.c_float, _vp]),

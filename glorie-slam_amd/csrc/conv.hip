@@ -32,6 +32,9 @@
 //   pixel tiles: the 9 taps, the halo rows and the output-channel tiles of a pixel range hit L2.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <type_traits>
 #include "common.hiph"
 
 namespace glorie {
@@ -55,6 +58,9 @@ struct ConvArgs {
   const _Float16* net; int net_stride;
   const _Float16* z; int z_stride;
   const _Float16* pre; int pre_stride;          // per-pixel term added before the gate non-linearity (or null)
+  const int* pre_map;                           // map (edge) -> map of `pre` it reads (null: its own)
+  int dbg;                                      // ablation bits of conv8_kernel (GLORIE_CONV8_DBG; timing experiments only)
+  unsigned long long* stamps;                   // dbg & 128: s_memtime checkpoints of workgroup 0, tiles 10-12, [8 waves][128]
 };
 
 constexpr int kTileN = 128;       // output channels per workgroup
@@ -68,6 +74,132 @@ __device__ __forceinline__ float ctanh(float x) {
 __device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// pixel of `pre` that output pixel p reads: maps that share their context features share one map of the term
+__device__ __forceinline__ long pre_pixel(const ConvArgs& a, long p) {
+  if (!a.pre_map) return p;
+  const int e = (int)(p / a.HW);
+  return (long)a.pre_map[e] * a.HW + (p - (long)e * a.HW);
+}
+
+// fused epilogue for the 4 consecutive output channels n..n+3 of pixel p (map e): bias + activation, the GRU gates
+// (z = sigmoid, r * net) or the GRU blend
+template <int EPI>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x4 v, long p, int e, int n) {
+  f16x4 o;
+  if (EPI == EPI_BIAS_ACT) {
+    float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.terms) b = *reinterpret_cast<const float4*>(a.terms + n);
+    float f[4] = {v[0] + b.x, v[1] + b.y, v[2] + b.z, v[3] + b.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (a.act == CACT_RELU) f[k] = fmaxf(f[k], 0.0f);
+      else if (a.act == CACT_SIGMOID) f[k] = csigmoid(f[k]);
+      o[k] = (_Float16)f[k];
+    }
+    *reinterpret_cast<f16x4*>(a.out + p * a.out_stride + n) = o;
+  } else if (EPI == EPI_GRU_ZR) {
+    // channels 0..127: z = sigmoid(.) ; 128..255: r -> r * net          (gru.py:28-30)
+    const float4 g = *reinterpret_cast<const float4*>(a.terms + (size_t)e * a.terms_stride + n);
+    const float s[4] = {csigmoid(v[0] + g.x), csigmoid(v[1] + g.y), csigmoid(v[2] + g.z),
+                        csigmoid(v[3] + g.w)};
+    if (n < 128) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = (_Float16)s[k];
+      *reinterpret_cast<f16x4*>(a.out + p * a.out_stride + n) = o;
+    } else {
+      const f16x4 nv = *reinterpret_cast<const f16x4*>(a.net + p * a.net_stride + (n - 128));
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = (_Float16)(s[k] * (float)nv[k]);
+      *reinterpret_cast<f16x4*>(a.out2 + p * a.out2_stride + (n - 128)) = o;
+    }
+  } else {
+    // net' = (1 - z) * net + z * tanh(.)                                (gru.py:31-33)
+    const float4 g = *reinterpret_cast<const float4*>(a.terms + (size_t)e * a.terms_stride + n);
+    const f16x4 nv = *reinterpret_cast<const f16x4*>(a.net + p * a.net_stride + n);
+    const f16x4 zv = *reinterpret_cast<const f16x4*>(a.z + p * a.z_stride + n);
+    const float qv[4] = {ctanh(v[0] + g.x), ctanh(v[1] + g.y), ctanh(v[2] + g.z), ctanh(v[3] + g.w)};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float zz = (float)zv[k];
+      o[k] = (_Float16)((1.0f - zz) * (float)nv[k] + zz * qv[k]);
+    }
+    *reinterpret_cast<f16x4*>(a.out + p * a.out_stride + n) = o;
+  }
+}
+
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+
+// Epilogue of a wave's MB x NB accumulator blocks without a branch: the lane owns channels nbase + 16*mi .. +3 of pixels
+// pbase + 16*ni.  Every load is issued with a clamped (always valid) address and every store goes through a buffer
+// descriptor with bit 31 of its offset set for pixels / channels past the end (the range check drops it) - a guarded
+// load + store per block is a chain of MB * NB dependent memory round trips at the tail of every workgroup.
+template <int EPI, int MB, int NB>
+__device__ __forceinline__ void conv_epilogue_tile(const ConvArgs& a, f32x4 (&acc)[MB][NB], long pbase, int nbase) {
+  const __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rO2 = __builtin_amdgcn_make_buffer_rsrc((void*)(EPI == EPI_GRU_ZR ? a.out2 : a.out), 0,
+                                                                      0x7fffffff, 0x00020000);
+  const bool upper = EPI == EPI_GRU_ZR && nbase >= 128;          // wave-uniform: this wave holds r (channels 128..255)
+#pragma unroll
+  for (int ni = 0; ni < NB; ++ni) {
+    const long p = pbase + ni * 16;
+    const bool okp = p < a.P;
+    const long pc = okp ? p : a.P - 1;
+    const int e = (int)(pc / a.HW);
+    float4 g[MB];
+    f16x4 nv[MB], zv[MB];
+#pragma unroll
+    for (int mi = 0; mi < MB; ++mi) {
+      const int nc = min(nbase + mi * 16, a.nout - 4);
+      if (EPI == EPI_BIAS_ACT) {
+        g[mi] = a.terms ? *reinterpret_cast<const float4*>(a.terms + nc) : make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        g[mi] = *reinterpret_cast<const float4*>(a.terms + (size_t)e * a.terms_stride + nc);
+        if (EPI == EPI_GRU_Q) {
+          nv[mi] = *reinterpret_cast<const f16x4*>(a.net + pc * a.net_stride + nc);
+          zv[mi] = *reinterpret_cast<const f16x4*>(a.z + pc * a.z_stride + nc);
+        } else if (upper) {
+          nv[mi] = *reinterpret_cast<const f16x4*>(a.net + pc * a.net_stride + (nc - 128));
+        }
+      }
+    }
+#pragma unroll
+    for (int mi = 0; mi < MB; ++mi) {
+      const int n = nbase + mi * 16;
+      const f32x4 v = acc[mi][ni];
+      const float f[4] = {v[0] + g[mi].x, v[1] + g[mi].y, v[2] + g[mi].z, v[3] + g[mi].w};
+      f16x4 o;
+      if (EPI == EPI_BIAS_ACT) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float t = f[k];
+          if (a.act == CACT_RELU) t = fmaxf(t, 0.0f);
+          else if (a.act == CACT_SIGMOID) t = csigmoid(t);
+          o[k] = (_Float16)t;
+        }
+      } else if (EPI == EPI_GRU_ZR) {
+        // channels 0..127: z = sigmoid(.) ; 128..255: r -> r * net          (gru.py:28-30)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = (_Float16)(upper ? csigmoid(f[k]) * (float)nv[mi][k] : csigmoid(f[k]));
+      } else {
+        // net' = (1 - z) * net + z * tanh(.)                                (gru.py:31-33)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float zz = (float)zv[mi][k];
+          o[k] = (_Float16)((1.0f - zz) * (float)nv[mi][k] + zz * ctanh(f[k]));
+        }
+      }
+      const bool ok = okp && n < a.nout;
+      if (upper) {
+        const unsigned vo = ok ? (unsigned)((pc * a.out2_stride + (n - 128)) * 2) : 0x80000000u;
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rO2, vo, 0, 0);
+      } else {
+        const unsigned vo = ok ? (unsigned)((pc * a.out_stride + n) * 2) : 0x80000000u;
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rO, vo, 0, 0);
+      }
+    }
+  }
 }
 
 // NB = 16-pixel blocks per wave, BK = channels per K step (32 | 64), NW = waves (2 channel halves x
@@ -193,23 +325,56 @@ __global__ __launch_bounds__(64 * NW, ST == 1 ? 3 : 2) void conv_igemm_kernel(Co
   for (int kk = 0; kk < KK; ++kk) foff[kk] = col * RB + (((kk * 4 + kg) ^ key(col)) << 4);
   const int wbase = XBYTES + wm * (16 * MB) * RB, xbase_l = wn * (16 * NB) * RB;
 
-  stage(0, 0);
   if (EPI != EPI_BIAS_ACT && a.pre) {
-    // the hoisted per-pixel term seeds the accumulators: its loads travel together with the first tile
-    // (an add in the epilogue would be an exposed round trip at the tail of every workgroup)
+    // The hoisted per-pixel term seeds the accumulators (an add in the epilogue would be an exposed round trip at the tail
+    // of every workgroup).  A lane owns 4 channels of 16 pixels per block: fetched directly that is 8-byte pieces of 16
+    // different rows per instruction, every 128-byte line requested by 8 instructions - measured +47 us on the 36-edge z|r
+    // launch.  With a 128 x 128 tile the [pixel][channel] fp16 tile is exactly the 32 KB LDS stage: it comes in as 32
+    // row-contiguous DMA pieces (16-byte slot XOR-swizzled with the row on the source side) and is read back per lane.
+    if constexpr (PT == 128 && TN == 128 && ST == 1 && BK == 64) {
+      const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void*)a.pre, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-    for (int ni = 0; ni < NB; ++ni) {
-      const long p = p0 + wn * (16 * NB) + ni * 16 + col;
+      for (int i = 0; i < 32 / NW; ++i) {
+        const int piece = i * NW + wv;
+        const int row = piece * 4 + (lane >> 4), sl = lane & 15;
+        const long p = pre_pixel(a, min(p0 + row, a.P - 1));
+        const unsigned vo = (unsigned)((p * a.pre_stride + n0) * 2 + ((sl ^ (row & 15)) << 4));
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rP, (__attribute__((address_space(3))) void*)(smem + piece * 1024), 16, vo,
+                                                 0, 0, 0);
+      }
+      __syncthreads();
 #pragma unroll
-      for (int mi = 0; mi < MB; ++mi) {
-        const int n = n0 + wm * (16 * MB) + mi * 16 + kg * 4;
-        if (p < a.P && n < a.nout) {
-          const f16x4 pv = *reinterpret_cast<const f16x4*>(a.pre + p * a.pre_stride + n);
-          acc[mi][ni] = f32x4{(float)pv[0], (float)pv[1], (float)pv[2], (float)pv[3]};
+      for (int ni = 0; ni < NB; ++ni) {
+        const int row = wn * (16 * NB) + ni * 16 + col;
+#pragma unroll
+        for (int mi = 0; mi < MB; ++mi) {
+          const int b = (wm * (16 * MB) + mi * 16 + kg * 4) * 2;
+          const f16x4 h = *reinterpret_cast<const f16x4*>(smem + row * 256 + ((((b >> 4) ^ (row & 15))) << 4) + (b & 15));
+          acc[mi][ni] = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
         }
       }
+      __syncthreads();                         // the stage is free for the first K tile
+    } else {
+      f16x4 pv[MB][NB];
+#pragma unroll
+      for (int ni = 0; ni < NB; ++ni) {
+        const long p = pre_pixel(a, min(p0 + wn * (16 * NB) + ni * 16 + col, a.P - 1));
+#pragma unroll
+        for (int mi = 0; mi < MB; ++mi) {
+          const int n = min(n0 + wm * (16 * MB) + mi * 16 + kg * 4, a.nout - 4);
+          pv[mi][ni] = *reinterpret_cast<const f16x4*>(a.pre + p * a.pre_stride + n);
+        }
+      }
+#pragma unroll
+      for (int ni = 0; ni < NB; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MB; ++mi) {
+          const f16x4 h = pv[mi][ni];
+          acc[mi][ni] = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+        }
     }
   }
+  stage(0, 0);
   int cur = 0;                                 // LDS stage holding tile t
   for (int t = 0; t < T; ++t) {
     __syncthreads();                           // tile t landed (vmcnt(0) + barrier); ST = 2: the other stage is free
@@ -245,60 +410,443 @@ __global__ __launch_bounds__(64 * NW, ST == 1 ? 3 : 2) void conv_igemm_kernel(Co
     if (ST == 2) cur ^= 1;
   }
 
-  // ---- epilogue: lane owns channels n0 + wm*64 + mi*16 + kg*4 .. +3 of pixel p0 + wn*16*NB + ni*16 + col ----
+  // ---- epilogue: lane owns channels n0 + wm*16*MB + mi*16 + kg*4 .. +3 of pixel p0 + wn*16*NB + ni*16 + col ----
+  conv_epilogue_tile<EPI, MB, NB>(a, acc, p0 + wn * (16 * NB) + col, n0 + wm * (16 * MB) + kg * 4);
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// 256 output channels x 256 pixels per workgroup, 8 waves (2 channel halves x 4 pixel quarters, wave tile 128 x 64 =
+// 8 x 4 accumulator blocks), 128 KB of LDS (two K-tile buffers), one workgroup per CU = two waves per SIMD.
+//
+// A K-tile (one tap of one 64-channel chunk: 256 + 256 rows of 128 B) is staged as FOUR 16 KB units, the row sets one
+// phase of the wave tile reads:   U0 = weights of the waves' channel blocks 0-3,  U1 = pixels of their blocks 0-1,
+//                                 U2 = pixel blocks 2-3,                          U3 = channel blocks 4-7.
+// Per K-tile four phases, each {fragment reads, DMA of ONE unit of a later tile, counted vmcnt, barrier,
+// 16 MFMAs = one quadrant of the wave tile x 64 channels, barrier}:
+//      p1 reads U0 U1, computes (c0-3, p0-1), stages U0(t+1)        p3 reads U3,  computes (c4-7, p2-3), stages U3(t+1)
+//      p2 reads U2,    computes (c0-3, p2-3), stages U2(t+1)        p4 reads -,   computes (c4-7, p0-1), stages U1(t+2)
+// Units are issued 4-5 phases before they are read and never waited for with vmcnt(0): after its issue each phase
+// waits until the unit issued three phases earlier has landed (6 loads may stay in flight across the barriers); the
+// barrier that follows publishes it, it is read from the next phase on.  A region is re-staged no earlier than two
+// phases after its last read (the pixel fragments of blocks 0-1 stay in registers for p4).
+// The two channel halves (waves 0-3 / 4-7 = the two waves of every SIMD) run half a phase apart (waves 4-7 take one
+// extra barrier before the loop, waves 0-3 one after it): while one wave of a SIMD is in its MFMA cluster the other
+// reads fragments and issues DMA.  Fragment reads are inline `ds_read_b128` + explicit lgkmcnt: a compiler-visible LDS
+// load would be preceded by a wait for EVERY outstanding LDS-DMA (the waitcnt pass cannot tell the buffers apart).
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ f16x8 lds_read16(unsigned addr) {
+  f16x8 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+template <int OFF>
+__device__ __forceinline__ f16x8 lds_read16_off(unsigned addr) {
+  f16x8 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+__device__ __forceinline__ void wait_vm_units(int n) {      // at most n units (2 loads each) still in flight
+  if (n >= 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if (n == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if (n == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int EPI, int SCHED, bool DBG>
+__global__ __launch_bounds__(512) void conv8_kernel(ConvArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int RB = 128;                     // bytes per staged row (64 halfs)
+  const int dbg = DBG ? a.dbg : 0;            // ablation / timing bits: a second instantiation, never the product kernel
+  constexpr int UNIT = 128 * RB;              // 16 KB
+  constexpr int BUF = 4 * UNIT;               // one K-tile: [U0 | U1 | U2 | U3]
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: LDS-DMA destinations stay in SGPRs
+  const int col = lane & 15, kg = lane >> 4;
+  const int wr = wv >> 2, wc = wv & 3;
+
+  const int nwg = gridDim.x, ntn = a.nout >> 8;
+  const int xcd = blockIdx.x & 7, q = nwg >> 3, r = nwg & 7;
+  const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+  const int pt = lid / ntn, nt = lid - pt * ntn;
+  const long p0 = (long)pt * 256;
+  const int n0 = nt * 256;
+
+  const int nch = a.cha + a.chb;
+  const int C = nch * 64;
+  const int T = a.taps * nch;                 // K-tiles
+  const int G = 4 * T;                        // units, in issue order U1(0) U0(0) U2(0) U3(0) U1(1) U0(1) ...
+
+  const int back = a.taps == 9 ? a.W + 1 : 0;
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(a.xa - (long)back * a.xa_stride), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(a.xb - (long)back * a.xb_stride), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, 0x7fffffff, 0x00020000);
+
+  // staging roles: a unit is 16 one-KB pieces (8 rows of 128 B, lane -> row lane/8, 16-byte slot lane%8, the slot
+  // XOR-swizzled with the row on the SOURCE side); wave wv moves pieces wv and wv + 8
+  const int srow = lane >> 3, slot = lane & 7;
+  unsigned woff[2][2];                        // [channel unit 0: U0 / 1: U3][piece]
+  unsigned xoffA[2][2], xoffB[2][2];          // [pixel unit 0: U1 / 1: U2][piece]
+  int xmask[2][2];
 #pragma unroll
-  for (int ni = 0; ni < NB; ++ni) {
-    const long p = p0 + wn * (16 * NB) + ni * 16 + col;
-    if (p >= a.P) continue;
-    const int e = (int)(p / a.HW);
+  for (int i = 0; i < 2; ++i) {
+    const int r0 = (wv + 8 * i) * 8 + srow;   // row of the unit
+    const int sw = (slot ^ (r0 & 7)) << 3;    // halfs
 #pragma unroll
-    for (int mi = 0; mi < MB; ++mi) {
-      const int n = n0 + wm * (16 * MB) + mi * 16 + kg * 4;
-      if (n >= a.nout) continue;
-      const f32x4 v = acc[mi][ni];
-      f16x4 o;
-      if (EPI == EPI_BIAS_ACT) {
-        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a.terms) b = *reinterpret_cast<const float4*>(a.terms + n);
-        float f[4] = {v[0] + b.x, v[1] + b.y, v[2] + b.z, v[3] + b.w};
+    for (int u = 0; u < 2; ++u) {
+      const int chn = n0 + (r0 >> 6) * 128 + u * 64 + (r0 & 63);
+      woff[u][i] = (unsigned)(((size_t)chn * C + sw) * 2);
+      const long pp = p0 + (r0 >> 5) * 64 + u * 32 + (r0 & 31);
+      int m = 0;
+      if (pp < a.P) {
+        const int xw = (int)(pp % a.W), yh = (int)((pp / a.W) % a.H);
+        if (a.taps == 9) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          if (a.act == CACT_RELU) f[k] = fmaxf(f[k], 0.0f);
-          else if (a.act == CACT_SIGMOID) f[k] = csigmoid(f[k]);
-          o[k] = (_Float16)f[k];
-        }
-        *reinterpret_cast<f16x4*>(a.out + p * a.out_stride + n) = o;
-      } else if (EPI == EPI_GRU_ZR) {
-        // channels 0..127: z = sigmoid(.) ; 128..255: r -> r * net          (gru.py:28-30)
-        const float4 g = *reinterpret_cast<const float4*>(a.terms + (size_t)e * a.terms_stride + n);
-        const float s[4] = {csigmoid(v[0] + g.x), csigmoid(v[1] + g.y), csigmoid(v[2] + g.z),
-                            csigmoid(v[3] + g.w)};
-        if (n < 128) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) o[k] = (_Float16)s[k];
-          *reinterpret_cast<f16x4*>(a.out + p * a.out_stride + n) = o;
+          for (int d = 0; d < 9; ++d) {
+            const int dy = d / 3 - 1, dx = d % 3 - 1;
+            if ((unsigned)(yh + dy) < (unsigned)a.H && (unsigned)(xw + dx) < (unsigned)a.W) m |= 1 << d;
+          }
         } else {
-          const f16x4 nv = *reinterpret_cast<const f16x4*>(a.net + p * a.net_stride + (n - 128));
-#pragma unroll
-          for (int k = 0; k < 4; ++k) o[k] = (_Float16)(s[k] * (float)nv[k]);
-          *reinterpret_cast<f16x4*>(a.out2 + p * a.out2_stride + (n - 128)) = o;
+          m = 1;
         }
-      } else {
-        // net' = (1 - z) * net + z * tanh(.)                                (gru.py:31-33)
-        const float4 g = *reinterpret_cast<const float4*>(a.terms + (size_t)e * a.terms_stride + n);
-        const f16x4 nv = *reinterpret_cast<const f16x4*>(a.net + p * a.net_stride + n);
-        const f16x4 zv = *reinterpret_cast<const f16x4*>(a.z + p * a.z_stride + n);
-        const float qv[4] = {ctanh(v[0] + g.x), ctanh(v[1] + g.y), ctanh(v[2] + g.z), ctanh(v[3] + g.w)};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float zz = (float)zv[k];
-          o[k] = (_Float16)((1.0f - zz) * (float)nv[k] + zz * qv[k]);
-        }
-        *reinterpret_cast<f16x4*>(a.out + p * a.out_stride + n) = o;
       }
+      xmask[u][i] = m;
+      const long pc = pp < a.P ? pp : 0;
+      xoffA[u][i] = (unsigned)((pc * a.xa_stride + sw) * 2);
+      xoffB[u][i] = (unsigned)((pc * a.xb_stride + sw) * 2);
     }
   }
+
+  // K-tile cursor: chunk-major, the taps of a chunk back to back (the 9 shifted reads of a chunk hit L2); advanced
+  // incrementally - no division in the loop
+  struct Cursor { int tile, ch, d, dy, dx; };
+  const bool taps9 = a.taps == 9;
+  auto advance = [&](Cursor& c) {
+    ++c.tile; ++c.d; ++c.dx;
+    const bool wx = c.dx > 1;
+    c.dx = wx ? -1 : c.dx; c.dy += wx ? 1 : 0;
+    const bool wc_ = c.d == a.taps;
+    c.d = wc_ ? 0 : c.d; c.ch += wc_ ? 1 : 0; c.dy = wc_ ? -1 : c.dy; c.dx = wc_ ? -1 : c.dx;
+  };
+  // what a unit's two DMA instructions need: computed ahead of the issue, beside the MFMAs (an LDS-DMA issue stalls its
+  // wave for 60-200 cycles; ~60 scalar instructions of address arithmetic in front of it doubled that).  The values are
+  // wave-uniform; readfirstlane keeps the loop-carried ones in SGPRs (a VGPR copy would turn every DMA into a waterfall loop)
+  auto sgpr = [](unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
+  struct UnitW { unsigned soff; bool on; };
+  struct UnitX { unsigned soff, vo0, vo1; bool segA, on; };
+  auto prep_w = [&](const Cursor& c) {
+    UnitW u;
+    u.on = c.tile < T && !((dbg & 1) && c.tile > 1) && !(dbg & 64);
+    u.soff = sgpr((unsigned)((((size_t)c.d * a.npad) * C + c.ch * 64) * 2));
+    return u;
+  };
+  auto prep_x = [&](const Cursor& c, int which) {            // which: 0 = U1, 1 = U2
+    UnitX u;
+    u.on = c.tile < T && !((dbg & 1) && c.tile > 1) && !(dbg & 32);
+    const int shift = (taps9 ? c.dy * a.W + c.dx : 0) + back;
+    u.segA = c.ch < a.cha;
+    const int xs = u.segA ? a.xa_stride : a.xb_stride;
+    u.soff = sgpr((unsigned)((shift * xs + (u.segA ? c.ch : c.ch - a.cha) * 64) * 2));
+    const unsigned i0 = ~((unsigned)xmask[which][0] >> c.d), i1 = ~((unsigned)xmask[which][1] >> c.d);
+    u.vo0 = (i0 << 31) | (u.segA ? xoffA[which][0] : xoffB[which][0]);
+    u.vo1 = (i1 << 31) | (u.segA ? xoffA[which][1] : xoffB[which][1]);
+    return u;
+  };
+  // region: position of the unit in its K-tile buffer (U0 | U1 | U2 | U3)
+  auto issue_w = [&](const UnitW& u, int tile, int region, int which) {
+    if (!u.on) return;
+    char* dst = smem + (tile & 1) * BUF + region * UNIT + wv * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (__attribute__((address_space(3))) void*)dst, 16, woff[which][0], u.soff, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (__attribute__((address_space(3))) void*)(dst + 8192), 16, woff[which][1],
+                                             u.soff, 0, 0);
+  };
+  auto issue_x = [&](const UnitX& u, int tile, int region) {
+    if (!u.on) return;
+    char* dst = smem + (tile & 1) * BUF + region * UNIT + wv * 1024;
+    if (u.segA) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)dst, 16, u.vo0, u.soff, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(dst + 8192), 16, u.vo1, u.soff, 0, 0);
+    } else {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (__attribute__((address_space(3))) void*)dst, 16, u.vo0, u.soff, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (__attribute__((address_space(3))) void*)(dst + 8192), 16, u.vo1, u.soff, 0, 0);
+    }
+  };
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+
+  f32x4 acc[8][4];                            // [channel block 4*quadrant + i][pixel block 2*quadrant + i]
+  const bool seeded = EPI != EPI_BIAS_ACT && a.pre;
+  f16x4 pv[2][4][2][2];
+  if (seeded) {
+    // the hoisted per-pixel term seeds the accumulators: 32 independent 8-byte loads (rows past the end re-read the
+    // last pixel; they are never stored), issued ahead of the first units and consumed behind them
+#pragma unroll
+    for (int nq = 0; nq < 2; ++nq)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const long p = pre_pixel(a, min(p0 + wc * 64 + nq * 32 + ni * 16 + col, a.P - 1));
+#pragma unroll
+        for (int mq = 0; mq < 2; ++mq)
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi)
+            pv[mq][mi][nq][ni] = *reinterpret_cast<const f16x4*>(a.pre + p * a.pre_stride + n0 + wr * 128 + mq * 64 +
+                                                                 mi * 16 + kg * 4);
+      }
+  }
+
+  // prologue: the first five units; U1(0) and U0(0) must have landed before the first reads
+  if ((dbg & 256) && a.stamps && lane == 0 && wv == 0 && lid < 64) a.stamps[1024 + lid * 2] = __builtin_readcyclecounter();
+  Cursor c1{0, 0, 0, -1, -1}, c2{0, 0, 0, -1, -1};   // c1: the tile whose U0/U2/U3 the coming phases stage, c2: the one after it
+  {
+    const UnitW w0 = prep_w(c1);
+    issue_x(prep_x(c1, 0), 0, 1); issue_w(w0, 0, 0, 0); issue_x(prep_x(c1, 1), 0, 2); issue_w(w0, 0, 3, 1);
+    advance(c1);
+    if (SCHED == 0) issue_x(prep_x(c1, 0), 1, 1);
+    c2 = c1; advance(c2);
+  }
+  UnitW pw = prep_w(c1);                      // weights of tile t+1
+  UnitX px, px2;                              // the pixel unit(s) the next load half issues
+  if (SCHED == 1) { px = prep_x(c1, 0); px2 = prep_x(c1, 1); }
+#pragma unroll
+  for (int mq = 0; mq < 2; ++mq)
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int nq = 0; nq < 2; ++nq)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const f16x4 h = pv[mq][mi][nq][ni];
+          acc[mq * 4 + mi][nq * 2 + ni] = seeded ? f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]}
+                                       : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+  wait_vm_units(SCHED == 1 ? 0 : min(G, 5) - 2);
+  __builtin_amdgcn_s_barrier();
+  if (SCHED == 0 && wr == 1) __builtin_amdgcn_s_barrier();  // the second channel half runs half a phase behind
+
+  // fragment addresses (LDS byte offsets): row = 16*blk + col, logical 16-byte slot kk*4 + kg, swizzle key col & 7
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
+  unsigned fa[2], fb[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    const unsigned f = (unsigned)(col * RB + (((kk * 4 + kg) ^ (col & 7)) << 4));
+    fa[kk] = lds0 + wr * 64 * RB + f;         // + region * UNIT + mi * 16 * RB as the instruction offset
+    fb[kk] = lds0 + wc * 32 * RB + f;
+  }
+
+  f16x8 wf[4][2] = {}, x0[2][2] = {}, x1[2][2] = {};
+  auto mfma_quadrant = [&](auto MQ, auto NQ, f16x8 (&wf)[4][2], f16x8 (&xf)[2][2]) {
+    constexpr int mq = decltype(MQ)::value, nq = decltype(NQ)::value;
+    if ((dbg & 4) || ((dbg & 512) && wr == 1)) return;
+    if (SCHED == 0) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[mq * 4 + mi][nq * 2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[mi][kk], xf[ni][kk], acc[mq * 4 + mi][nq * 2 + ni], 0, 0, 0);
+    if (SCHED == 0) __builtin_amdgcn_s_setprio(0);
+  };
+#define C8_READ_W(REGION)                                                                              \
+  if (!(dbg & 2)) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                                   \
+    wf[0][kk] = lds_read16_off<(REGION) * UNIT + 0 * 16 * RB>(fa[kk] + bufo);                          \
+    wf[1][kk] = lds_read16_off<(REGION) * UNIT + 1 * 16 * RB>(fa[kk] + bufo);                          \
+    wf[2][kk] = lds_read16_off<(REGION) * UNIT + 2 * 16 * RB>(fa[kk] + bufo);                          \
+    wf[3][kk] = lds_read16_off<(REGION) * UNIT + 3 * 16 * RB>(fa[kk] + bufo);                          \
+  }
+#define C8_READ_X(XF, REGION)                                                                          \
+  if (!(dbg & 2)) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                                   \
+    XF[0][kk] = lds_read16_off<(REGION) * UNIT + 0 * 16 * RB>(fb[kk] + bufo);                          \
+    XF[1][kk] = lds_read16_off<(REGION) * UNIT + 1 * 16 * RB>(fb[kk] + bufo);                          \
+  }
+  // the fragments become valid at the lgkmcnt(0): tying them to the wait keeps the MFMAs behind it
+#define C8_WAIT_W() asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wf[0][0]), "+v"(wf[0][1]), "+v"(wf[1][0]), "+v"(wf[1][1]), \
+                                 "+v"(wf[2][0]), "+v"(wf[2][1]), "+v"(wf[3][0]), "+v"(wf[3][1]) :: "memory")
+#define C8_WAIT_X(XF) asm volatile("" : "+v"(XF[0][0]), "+v"(XF[0][1]), "+v"(XF[1][0]), "+v"(XF[1][1]) :: "memory")
+#define C8_PHASE_SYNC(PH)                         \
+  __builtin_amdgcn_sched_barrier(0);              \
+  __builtin_amdgcn_s_barrier();                   \
+  __builtin_amdgcn_sched_barrier(0)
+#define C8_PHASE_END()                            \
+  __builtin_amdgcn_sched_barrier(0);              \
+  __builtin_amdgcn_s_barrier();                   \
+  __builtin_amdgcn_sched_barrier(0)
+
+  if constexpr (SCHED == 1) {
+    // ONE barrier per K-tile.  After barrier t every wave's pieces of tile t have landed and nobody reads the other buffer
+    // any more, so tile t+1 streams into it while tile t is computed; a wave waits for its own pieces (issued 1-2 k cycles
+    // earlier) only at the end of the tile.  An LDS-DMA issue blocks its wave for 60-200 cycles per piece: the two waves of a
+    // SIMD (channel halves 0 / 1) issue their 8 pieces at different points of the tile - at its start / between the second
+    // and the third quadrant - so one of them is in an MFMA cluster while the other is stuck in the texture queue.  Within the
+    // tile a wave is free-running: all 24 fragment reads go out ahead of the quadrant that needs them (counted lgkmcnt).
+    f16x8 wg[4][2] = {};                       // second weight set: channels 4-7 are read while 0-3 are still in use
+    auto issue_tile = [&](int tile) {
+      issue_x(px, tile, 1); issue_w(pw, tile, 0, 0); issue_x(px2, tile, 2); issue_w(pw, tile, 3, 1);
+    };
+    for (int t = 0; t < T; ++t) {
+      const unsigned bufo = (unsigned)((t & 1) * BUF);
+      if (wr == 0) issue_tile(t + 1);
+      C8_READ_X(x0, 1)
+      C8_READ_W(0)
+      C8_READ_X(x1, 2)
+      asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(wf[0][0]), "+v"(wf[0][1]), "+v"(wf[1][0]), "+v"(wf[1][1]), "+v"(wf[2][0]),
+                   "+v"(wf[2][1]), "+v"(wf[3][0]), "+v"(wf[3][1]), "+v"(x0[0][0]), "+v"(x0[0][1]), "+v"(x0[1][0]),
+                   "+v"(x0[1][1]) :: "memory");
+      mfma_quadrant(I0{}, I0{}, wf, x0);
+      if (!(dbg & 2)) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          wg[0][kk] = lds_read16_off<3 * UNIT + 0 * 16 * RB>(fa[kk] + bufo);
+          wg[1][kk] = lds_read16_off<3 * UNIT + 1 * 16 * RB>(fa[kk] + bufo);
+          wg[2][kk] = lds_read16_off<3 * UNIT + 2 * 16 * RB>(fa[kk] + bufo);
+          wg[3][kk] = lds_read16_off<3 * UNIT + 3 * 16 * RB>(fa[kk] + bufo);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(x1[0][0]), "+v"(x1[0][1]), "+v"(x1[1][0]), "+v"(x1[1][1]) :: "memory");
+      mfma_quadrant(I0{}, I1{}, wf, x1);
+      if (wr == 1) issue_tile(t + 1);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wg[0][0]), "+v"(wg[0][1]), "+v"(wg[1][0]), "+v"(wg[1][1]), "+v"(wg[2][0]),
+                   "+v"(wg[2][1]), "+v"(wg[3][0]), "+v"(wg[3][1]) :: "memory");
+      // operands of the tile after next: scalar work that hides in the MFMA gaps
+      advance(c1);
+      pw = prep_w(c1); px = prep_x(c1, 0); px2 = prep_x(c1, 1);
+      mfma_quadrant(I1{}, I1{}, wg, x1);
+      mfma_quadrant(I1{}, I0{}, wg, x0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
+#ifdef GLORIE_CONV8_TIMELINE        // per-phase checkpoints (tools/conv8_timeline.py); they cost ~100 cycles each: off in the product
+#define C8_STAMP(k) do { if ((dbg & 128) && lid == 0 && lane == 0 && t >= 10 && t < 13)                  \
+    a.stamps[wv * 128 + (t - 10) * 32 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define C8_STAMP(k) do { } while (0)
 #endif
+  for (int t = 0; t < T; ++t) {
+    const unsigned bufo = (unsigned)((t & 1) * BUF);
+    const int ph = 4 * t;
+    C8_STAMP(0);
+    // ---- p1: (channels 0-3, pixels 0-1)
+    C8_READ_X(x0, 1)
+    C8_READ_W(0)
+    C8_STAMP(1);
+    issue_w(pw, t + 1, 0, 0);
+    C8_STAMP(2);
+    wait_vm_units((dbg & 8) ? 0 : min(3, G - 3 - ph));
+    C8_STAMP(3);
+    C8_PHASE_SYNC(ph);
+    C8_STAMP(4);
+    C8_WAIT_W(); C8_WAIT_X(x0);
+    C8_STAMP(5);
+    px = prep_x(c1, 1);
+    mfma_quadrant(I0{}, I0{}, wf, x0);
+    C8_STAMP(6);
+    C8_PHASE_END();
+    C8_STAMP(7);
+    // ---- p2: (channels 0-3, pixels 2-3)
+    C8_READ_X(x1, 2)
+    C8_STAMP(8 + 1);
+    issue_x(px, t + 1, 2);
+    C8_STAMP(8 + 2);
+    wait_vm_units((dbg & 8) ? 0 : min(3, G - 3 - (ph + 1)));
+    C8_STAMP(8 + 3);
+    C8_PHASE_SYNC(ph + 1);
+    C8_STAMP(8 + 4);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); C8_WAIT_X(x1);
+    C8_STAMP(8 + 5);
+    mfma_quadrant(I0{}, I1{}, wf, x1);
+    C8_STAMP(8 + 6);
+    C8_PHASE_END();
+    C8_STAMP(8 + 7);
+    // ---- p3: (channels 4-7, pixels 2-3)
+    C8_READ_W(3)
+    C8_STAMP(16 + 1);
+    issue_w(pw, t + 1, 3, 1);
+    C8_STAMP(16 + 2);
+    wait_vm_units((dbg & 8) ? 0 : min(3, G - 3 - (ph + 2)));
+    C8_STAMP(16 + 3);
+    C8_PHASE_SYNC(ph + 2);
+    C8_STAMP(16 + 4);
+    C8_WAIT_W();
+    C8_STAMP(16 + 5);
+    px = prep_x(c2, 0);
+    mfma_quadrant(I1{}, I1{}, wf, x1);
+    C8_STAMP(16 + 6);
+    C8_PHASE_END();
+    C8_STAMP(16 + 7);
+    // ---- p4: (channels 4-7, pixels 0-1), fragments already in registers
+    C8_STAMP(24 + 1);
+    issue_x(px, t + 2, 1);
+    C8_STAMP(24 + 2);
+    wait_vm_units((dbg & 8) ? 0 : min(3, G - 3 - (ph + 3)));
+    C8_STAMP(24 + 3);
+    C8_PHASE_SYNC(ph + 3);
+    C8_STAMP(24 + 4);
+    C8_STAMP(24 + 5);
+    c1 = c2; advance(c2);
+    pw = prep_w(c1);
+    mfma_quadrant(I1{}, I0{}, wf, x0);
+    C8_STAMP(24 + 6);
+    C8_PHASE_END();
+    C8_STAMP(24 + 7);
+  }
+#undef C8_STAMP
+  if (wr == 0) __builtin_amdgcn_s_barrier();
+  }
+  if ((dbg & 256) && a.stamps && lane == 0 && wv == 0 && lid < 64) a.stamps[1024 + lid * 2 + 1] = __builtin_readcyclecounter();
+#undef C8_READ_W
+#undef C8_READ_X
+#undef C8_WAIT_W
+#undef C8_WAIT_X
+#undef C8_PHASE_SYNC
+#undef C8_PHASE_END
+
+  // ---- epilogue: lane owns channels n0 + wr*128 + 16*mi + kg*4 .. +3 of pixels p0 + wc*64 + 16*ni + col
+  conv_epilogue_tile<EPI, 8, 4>(a, acc, p0 + wc * 64 + col, n0 + wr * 128 + kg * 4);
+#endif
+}
+
+template <int EPI>
+static void launch_conv8_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
+  constexpr size_t lds = 2 * 4 * 128 * 128;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv8_kernel<EPI, 0, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv8_kernel<EPI, 1, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv8_kernel<EPI, 0, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv8_kernel<EPI, 1, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  const char* sc = getenv("GLORIE_CONV8_SCHED");
+  const bool phases8 = sc && sc[0] == '0';
+  if (a.dbg) {
+    if (phases8) hipLaunchKernelGGL((conv8_kernel<EPI, 0, true>), grid, dim3(512), lds, st, a);
+    else hipLaunchKernelGGL((conv8_kernel<EPI, 1, true>), grid, dim3(512), lds, st, a);
+  } else {
+    if (phases8) hipLaunchKernelGGL((conv8_kernel<EPI, 0, false>), grid, dim3(512), lds, st, a);
+    else hipLaunchKernelGGL((conv8_kernel<EPI, 1, false>), grid, dim3(512), lds, st, a);
+  }
+}
+
+static int launch_conv8(const ConvArgs& a, int epilogue, hipStream_t st) {
+  const long nwg = ((a.P + 255) / 256) * (a.nout / 256);
+  if (nwg > 0x7fffffffL) return GLORIE_EINVAL;
+  const dim3 grid((unsigned)nwg);
+  switch (epilogue) {
+    case EPI_BIAS_ACT: launch_conv8_one<EPI_BIAS_ACT>(a, grid, st); break;
+    case EPI_GRU_ZR: launch_conv8_one<EPI_GRU_ZR>(a, grid, st); break;
+    default: launch_conv8_one<EPI_GRU_Q>(a, grid, st); break;
+  }
+  return check_launch();
 }
 
 template <int EPI, int NB, int BK, int NW, int ST, int MB>
@@ -337,8 +885,8 @@ extern "C" int glorie_conv_igemm(const void* xa, int xa_stride, int ca, const vo
                                  int cb, const void* w_packed, int taps, int nout, int epilogue,
                                  const float* terms, int terms_stride, int act, const void* net,
                                  int net_stride, const void* z, int z_stride, void* out, int out_stride,
-                                 void* out2, int out2_stride, const void* pre, int pre_stride, int N, int H,
-                                 int W, void* stream) {
+                                 void* out2, int out2_stride, const void* pre, int pre_stride, const int* pre_map,
+                                 int N, int H, int W, void* stream) {
   if (N < 0 || H <= 0 || W <= 0 || (taps != 1 && taps != 9) || nout <= 0 || (nout & 3)) return GLORIE_EINVAL;
   if (ca < 0 || cb < 0 || (ca % 64) || (cb % 64) || ca + cb == 0) return GLORIE_EINVAL;
   if (epilogue < 0 || epilogue > 2) return GLORIE_EINVAL;
@@ -359,11 +907,15 @@ extern "C" int glorie_conv_igemm(const void* xa, int xa_stride, int ca, const vo
   a.terms = terms; a.terms_stride = terms_stride; a.act = act;
   a.net = reinterpret_cast<const _Float16*>(net); a.net_stride = net_stride;
   a.z = reinterpret_cast<const _Float16*>(z); a.z_stride = z_stride;
-  a.pre = reinterpret_cast<const _Float16*>(pre); a.pre_stride = pre_stride;
+  a.pre = reinterpret_cast<const _Float16*>(pre); a.pre_stride = pre_stride; a.pre_map = pre ? pre_map : nullptr;
+  { const char* d = getenv("GLORIE_CONV8_DBG"); a.dbg = d ? atoi(d) : 0; }
+  a.stamps = getenv("GLORIE_CONV8_STAMPS") ? (unsigned long long*)strtoull(getenv("GLORIE_CONV8_STAMPS"), nullptr, 0) : nullptr;
+  if (!a.stamps) a.dbg &= ~(128 | 256);
   // buffer-descriptor addressing: 31-bit byte offsets per input segment and for the weights
   const long lim = 0x7fffffffL;
   if (((a.P + W + 2) * (long)xa_stride + 64) * 2 > lim || ((a.P + W + 2) * (long)xb_stride + 64) * 2 > lim ||
-      ((long)taps * a.npad * (ca + cb) + 64) * 2 > lim)
+      ((long)taps * a.npad * (ca + cb) + 64) * 2 > lim || (pre && (a.P * (long)pre_stride + 512) * 2 > lim) ||
+      (a.P * (long)out_stride + nout) * 2 > lim || (out2 && (a.P * (long)out2_stride + 128) * 2 > lim))
     return GLORIE_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   // Measured on the update operator's layers at 36x60x80 (tools/bench_conv.py): the single-stage
@@ -372,6 +924,13 @@ extern "C" int glorie_conv_igemm(const void* xa, int xa_stride, int ca, const vo
   // (loads two steps ahead, ST = 4) 915, 8 waves with a 3-stage ring and counted vmcnt 830, 256-pixel
   // tiles 850, 32-channel steps at 4 workgroups per CU 824; the same wave tile on v_mfma_f32_32x32x16_f16
   // (16 instead of 32 MFMAs per step) 945.
+  // 256-channel multiples (the z|r gates) can run on 256 x 256 tiles (conv8_kernel, GLORIE_CONV8=1).  Measured on the
+  // 36-edge gate launch it needs 3107 cycles per 256 x 256 x 64 block against 4 x 807 = 3230 for the 128 x 128 kernel,
+  // but its 675 workgroups fill 2.64 rounds of 256 CUs (one workgroup per CU) where 2700 fill 3.52 rounds of 768 slots:
+  // 385 vs 345 us.  It stays opt-in; tests/test_gpu_update_op.py pins it bit for bit against the 128 x 128 kernel.
+  const char* c8 = getenv("GLORIE_CONV8");
+  const bool conv8_on = c8 && c8[0] == '1';
+  if (conv8_on && (nout & 255) == 0 && a.P >= 256) return launch_conv8(a, epilogue, st);
   // layers with <= 64 output channels (flow_encoder[2]) use a 64-channel tile instead of padding to 128
   if (nout <= 64 && epilogue == EPI_BIAS_ACT) return launch_conv<4, 64, 4, 1, 2>(a, epilogue, st);
   return launch_conv<4, 64, 4, 1>(a, epilogue, st);

@@ -216,22 +216,6 @@ class HalfUpdate:
             self._net = copy.deepcopy(self.src).eval().half().to(memory_format=torch.channels_last)
             self._ver = ver
 
-    @torch.no_grad()
-    def precompute_context(self):
-        """conv_z|r|q over the context features of every edge (hx[:, 0:128]) -> self._pre [N,384,h,w] fp16.
-        A convolution is linear in its input channels and `inp` never changes while an edge lives, so this
-        part of the three gate convolutions (128 of 448 input channels) is evaluated when the edges change
-        instead of in every iteration; the gate kernels add it in their epilogue."""
-        from . import update_ops as U
-        hx = self._hx
-        n, _, ht, wd = hx.shape
-        if self._pre is None or self._pre.shape[0] != n or self._pre.shape[2:] != hx.shape[2:] \
-                or self._pre.device != hx.device:
-            self._pre = torch.empty((n, 384, ht, wd), dtype=torch.float16, device=hx.device,
-                                    memory_format=torch.channels_last)
-        U.conv_igemm(hx[:, 0:128], None, self.W["pre"], 9, 384, self._pre)
-        return self._pre
-
     @staticmethod
     def _cl(t):
         b, n, c, h, w = t.shape
@@ -285,6 +269,7 @@ class FusedUpdate:
         self._ver = None
         self._hx = None
         self._inp_key = None      # (tensor kept alive, version) whose values sit in the inp slice of hx
+        self._pre_kf, self._pre_map, self._ctx_key = None, None, None   # context term shared per keyframe
 
     # -- weight packing ----------------------------------------------------------------
     def _sync(self):
@@ -355,9 +340,41 @@ class FusedUpdate:
         return self._streams
 
     @torch.no_grad()
-    def __call__(self, net, inp, corr, flow=None, ii=None, jj=None, groups=None):
+    def precompute_shared_context(self, context):
+        """context = (table [F,128,h,w] of per-keyframe context features, frames LongTensor [G] (sorted, distinct),
+        index [N] -> position in `frames`): the edges of one source keyframe share `inp = table[ii]`
+        (factor_graph.py:125-130), so conv_z|r|q over it is evaluated per KEYFRAME (G maps, not N) and the gate
+        kernels read it through `pre_map` - 36 edges over 8 keyframes read 29 MB instead of 133 MB per iteration."""
+        from . import update_ops as U
+        table, frames, index = context
+        g = int(frames.shape[0])
+        ht, wd = table.shape[-2:]
+        x = table[frames].half().contiguous(memory_format=torch.channels_last)
+        if self._pre_kf is None or self._pre_kf.shape[0] < g or tuple(self._pre_kf.shape[2:]) != (ht, wd) \
+                or self._pre_kf.device != x.device:
+            self._pre_kf = torch.empty((max(g, 8), 384, ht, wd), dtype=torch.float16, device=x.device,
+                                       memory_format=torch.channels_last)
+        U.conv_igemm(x, None, self.W["pre"], 9, 384, self._pre_kf[:g])
+        n = int(index.shape[0])
+        if self._pre_map is None or self._pre_map.shape[0] < n or self._pre_map.device != x.device:
+            self._pre_map = torch.zeros(max(n, 64), dtype=torch.int32, device=x.device)
+        self._pre_map[:n].copy_(index)
+        return self._pre_kf[:g], self._pre_map[:n]
+
+    def _shared_context(self, context):
+        table, frames, index = context
+        key = (table.data_ptr(), table._version, frames.data_ptr(), frames._version, index.data_ptr(), index._version,
+               int(frames.shape[0]), int(index.shape[0]), self._ver)
+        if self._ctx_key != key:
+            self.precompute_shared_context(context)
+            self._ctx_key = key
+        return self._pre_kf[:int(frames.shape[0])], self._pre_map[:int(index.shape[0])]
+
+    @torch.no_grad()
+    def __call__(self, net, inp, corr, flow=None, ii=None, jj=None, groups=None, context=None):
         """corr: the looked-up correlation features [1,N,196,h,w], or a callable returning them (it is
-        invoked on the caller's stream after the independent branches were forked)"""
+        invoked on the caller's stream after the independent branches were forked).
+        context (not in the reference): see precompute_shared_context; `inp` is then not read."""
         from . import update_ops as U
         self._sync()
         W = self.W
@@ -386,8 +403,11 @@ class FusedUpdate:
             fl = flow.reshape(n, 4, ht, wd).permute(0, 2, 3, 1).float().contiguous()   # no copy for a [.., h, w, 4] motion map
             f1 = U.flow_conv7(fl, W["fe1"], W["fe1_b"], cl_map(128))
             U.conv_igemm(f1, None, W["fe2"], 9, 64, hx[:, 256:320], terms=W["fe2_b"], act=U.ACT_RELU)
+        shared = context is not None and self.hoist_inp
         with torch.cuda.stream(side[1]):
-            if self._inp_key is None or self._inp_key[0] is not inp or self._inp_key[1] != inp._version:
+            if shared:
+                pre_kf, pre_map = self._shared_context(context)
+            elif self._inp_key is None or self._inp_key[0] is not inp or self._inp_key[1] != inp._version:
                 U.bias_act(self._cl(inp), None, U.ACT_NONE, out=hx[:, 0:128])
                 self._inp_key = (inp, inp._version)
                 if self.hoist_inp:
@@ -416,11 +436,12 @@ class FusedUpdate:
         aliased = net0.data_ptr() == net.data_ptr() and net.dtype == torch.float16
         new = net0 if (self.inplace and aliased) else cl_map(128)
         if self.hoist_inp:
-            dynx, pre = hx[:, 128:320], self._pre
+            dynx = hx[:, 128:320]
+            pre, pmap = (pre_kf, pre_map) if shared else (self._pre, None)
             U.conv_igemm(net0, dynx, W["zr_dyn"], 9, 256, z, epilogue=U.EPI_GRU_ZR, terms=g[:, 0:256], net=net0,
-                         out2=rnet, pre=pre[:, 0:256])
+                         out2=rnet, pre=pre[:, 0:256], pre_map=pmap)
             U.conv_igemm(rnet, dynx, W["q_dyn"], 9, 128, new, epilogue=U.EPI_GRU_Q, terms=g[:, 256:384], net=net0,
-                         z=z, pre=pre[:, 256:384])
+                         z=z, pre=pre[:, 256:384], pre_map=pmap)
         else:
             U.conv_igemm(net0, hx, W["zr"], 9, 256, z, epilogue=U.EPI_GRU_ZR, terms=g[:, 0:256], net=net0, out2=rnet)
             U.conv_igemm(rnet, hx, W["q"], 9, 128, new, epilogue=U.EPI_GRU_Q, terms=g[:, 256:384], net=net0, z=z)

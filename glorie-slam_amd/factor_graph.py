@@ -11,6 +11,8 @@ arguments.  What changed underneath:
     decisions, same edge order.
 """
 import numpy as np
+import os
+
 import torch
 
 from . import droid_backends
@@ -53,6 +55,8 @@ class FactorGraph:
         # fp16 channels-last form of the update operator with fused element-wise stages
         # (droid_net.FusedUpdate, csrc/gru.hip)
         self.fast_update = FusedUpdate(update_op, inplace=self.use_graphs) if str(device).startswith("cuda") else None
+        # gate term of the context features per keyframe instead of per edge (GLORIE_SHARE_CONTEXT=0: per edge, for A/B runs)
+        self.share_context = os.environ.get("GLORIE_SHARE_CONTEXT", "1") != "0"
 
     def _use_arena(self):
         """the HIP pyramid builder + slot arena (widths that are multiples of 8, fp16 maps on the GPU)"""
@@ -353,8 +357,12 @@ class FactorGraph:
         if self.fast_update is not None:
             # the lookup is handed over as a callable: FusedUpdate issues it behind the fork of its
             # independent branches (flow encoder, global context), which then overlap with it
+            # the edges of one source keyframe share their context features (inp = video.inps[ii], add_factors):
+            # the hoisted gate term is kept per keyframe and shared through the GraphAgg grouping
+            ix, _ = self._groups()
             self.net, delta, weight, damping, upmask = \
-                self.fast_update(self.net, self.inp, lookup, motn, self.ii, self.jj, self._groups())
+                self.fast_update(self.net, self.inp, lookup, motn, self.ii, self.jj, self._groups(),
+                                 context=(self.video.inps, uniq, ix) if self.share_context else None)
         else:
             corr = lookup()
             with torch.autocast("cuda", enabled=True):

@@ -162,11 +162,12 @@ def pack_conv_igemm(weight):
 
 
 def conv_igemm(xa, xb, w_packed, taps, nout, out, epilogue=EPI_BIAS_ACT, terms=None, act=ACT_NONE,
-               net=None, z=None, out2=None, pre=None):
+               net=None, z=None, out2=None, pre=None, pre_map=None):
     """Implicit-GEMM convolution with fused epilogue (csrc/conv.hip, include/glorie_hip.h).
     xa / xb: channels-last fp16 maps [N,Ca,h,w] / [N,Cb,h,w] (either may be None); writes `out`
     (and `out2` for the GRU gates) and returns `out`.  pre: fp16 channels-last [N,nout,h,w] added before the
-    gate non-linearity (the hoisted convolution over the context features)."""
+    gate non-linearity (the hoisted convolution over the context features); with pre_map (int32 [N]) map e reads map
+    pre_map[e] of `pre`, which then holds one map per distinct context (source keyframe) instead of one per edge."""
     ref = xa if xa is not None else xb
     L.need_cuda(ref, w_packed, out)
     n, _, h, w = ref.shape
@@ -187,13 +188,17 @@ def conv_igemm(xa, xb, w_packed, taps, nout, out, epilogue=EPI_BIAS_ACT, terms=N
     (pa, sa), (pb, sb) = opt(xa, "xa"), opt(xb, "xb")
     (pn, sn), (pz, sz), (po2, so2) = opt(net, "net"), opt(z, "z"), opt(out2, "out2")
     pp, sp = opt(pre, "pre")
-    if pre is not None and (epilogue == EPI_BIAS_ACT or pre.shape[0] != n or pre.shape[1] != nout):
+    if pre is not None and (epilogue == EPI_BIAS_ACT or (pre_map is None and pre.shape[0] != n) or pre.shape[1] != nout
+                            or tuple(pre.shape[2:]) != (h, w)):
         raise RuntimeError("conv_igemm: pre needs a gate epilogue and the shape [N,nout,h,w]")
+    if pre_map is not None and (pre is None or pre_map.dtype != torch.int32 or pre_map.numel() != n or
+                                not pre_map.is_contiguous() or pre_map.device != ref.device):
+        raise RuntimeError("conv_igemm: pre_map must be a contiguous int32 [N] on the device, next to pre")
     if out.shape[1] != (128 if epilogue != EPI_BIAS_ACT else nout) or out.shape[0] != n:
         raise RuntimeError("conv_igemm: bad output shape")
     L.check(L.load().glorie_conv_igemm(pa, sa, ca, pb, sb, cb, L.ptr(w_packed), taps, nout, epilogue,
                                        L.ptr(terms), ts, act, pn, sn, pz, sz, L.ptr(out), _rows(out, "out"),
-                                       po2, so2, pp, sp, n, h, w, L.stream_ptr()), "glorie_conv_igemm")
+                                       po2, so2, pp, sp, L.ptr(pre_map), n, h, w, L.stream_ptr()), "glorie_conv_igemm")
     return out
 
 

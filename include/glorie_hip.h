@@ -205,12 +205,14 @@ int glorie_conv3x3_small(const void* x, int x_stride, const float* in_bias, int 
  * non-linearity, like terms but per pixel -- the convolution over the context features `inp` of an edge,
  * which never change while the edge lives (factor_graph.py:125-130: inp = video.inps[ii] at add_factors) and
  * is therefore evaluated once per edge instead of once per iteration (a convolution is linear in its input
- * channels: conv([net|inp|corr|flow]) = conv_dyn([net|corr|flow]) + conv_inp(inp)). */
+ * channels: conv([net|inp|corr|flow]) = conv_dyn([net|corr|flow]) + conv_inp(inp)).
+ * pre_map (may be NULL): int32 [N], map e reads the rows of map pre_map[e] of `pre` - edges with the same source
+ * keyframe have the same context features (inp = video.inps[ii]), so the term is stored once per keyframe. */
 int glorie_conv_igemm(const void* xa, int xa_stride, int ca, const void* xb, int xb_stride, int cb,
                       const void* w_packed, int taps, int nout, int epilogue, const float* terms,
                       int terms_stride, int act, const void* net, int net_stride, const void* z,
                       int z_stride, void* out, int out_stride, void* out2, int out2_stride,
-                      const void* pre, int pre_stride, int N, int H, int W, void* stream);
+                      const void* pre, int pre_stride, const int* pre_map, int N, int H, int W, void* stream);
 
 /* flow_encoder[0] (droid_net.py:79-81): 7x7 convolution, zero padding 3, 4 -> 128 channels, + bias
  * + ReLU.  flow: float32 channels-last motion map [N*H*W][4]; out: fp16 rows of 128 channels,

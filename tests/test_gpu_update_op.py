@@ -211,6 +211,39 @@ def test_fused_update_without_graph_aggregation_and_repack(gpu):
     assert torch.isfinite(out3[0].float()).all()
 
 
+def test_shared_context_term_equals_per_edge_term(gpu):
+    """Edges with the same source keyframe have the same context features: the hoisted gate term kept once per
+    keyframe and read through pre_map gives the bits of the per-edge term."""
+    from glorie_slam_amd.droid_net import FusedUpdate, UpdateModule
+    torch.manual_seed(5)
+    mod = UpdateModule().to(gpu).eval()
+    n, h, w = 7, 12, 16
+    ii = torch.tensor([0, 0, 1, 3, 3, 3, 4], device=gpu)
+    jj = torch.tensor([1, 2, 0, 1, 2, 4, 3], device=gpu)
+    table = torch.randn(6, 128, h, w, device=gpu).half()
+    inp = table[ii][None]
+    net = torch.randn(1, n, 128, h, w, device=gpu).half()
+    corr = torch.randn(1, n, 196, h, w, device=gpu).half()
+    flow = torch.randn(1, n, 4, h, w, device=gpu)
+    frames, ix = torch.unique(ii, sorted=True, return_inverse=True)
+    a, b = FusedUpdate(mod), FusedUpdate(mod)
+    ra = a(net, inp, corr, flow, ii, jj)
+    rb = b(net, inp, corr, flow, ii, jj, context=(table, frames, ix))
+    assert b._pre is None and b._pre_kf is not None and tuple(b._pre_kf[:4].shape) == (4, 384, h, w)
+    for x, y in zip(ra, rb):
+        assert torch.equal(x, y)
+    # a changed table row is picked up (version key), an unchanged call does not recompute
+    key = b._ctx_key
+    b(net, inp, corr, flow, ii, jj, context=(table, frames, ix))
+    assert b._ctx_key == key
+    table[3] += 1.0
+    rc = b(net, table[ii][None], corr, flow, ii, jj, context=(table, frames, ix))
+    rd = a(net, table[ii][None].clone(), corr, flow, ii, jj)
+    assert b._ctx_key != key
+    for x, y in zip(rc, rd):
+        assert torch.equal(x, y)
+
+
 # ---- implicit-GEMM convolution (csrc/conv.hip) -------------------------------------------------
 def _conv_ref(xs, weight, bias=None):
     x = torch.cat([t.float() for t in xs if t is not None], 1)
@@ -262,6 +295,44 @@ def test_conv_igemm_gru_epilogues(gpu):
     q = torch.tanh(_conv_ref([rnet, hx], wq) + terms[:, 256:].reshape(n, 128, 1, 1))
     ref = (1 - z.float()) * net.float() + z.float() * q
     torch.testing.assert_close(new.float(), ref, atol=4e-3, rtol=4e-3)
+
+
+@pytest.mark.parametrize("n,h,w,ca,cb,nout,k,epi", [(36, 60, 80, 128, 192, 256, 3, "zr"),   # the G8 gate launch
+                                                     (3, 19, 23, 128, 192, 256, 3, "zr"),     # ragged last tile
+                                                     (2, 16, 24, 64, 0, 512, 3, "bias"),      # two channel tiles
+                                                     (5, 9, 11, 128, 128, 256, 1, "bias"),    # 1x1: two K-tiles only
+                                                     (1, 16, 16, 0, 64, 256, 3, "bias")])     # a single pixel tile
+def test_conv8_equals_the_128_tile_kernel_bit_for_bit(gpu, n, h, w, ca, cb, nout, k, epi, monkeypatch):
+    """The 256 x 256 8-phase kernel accumulates the same K-tiles in the same order as the 128 x 128 kernel, so any
+    difference at all is a staging race or a wrong tile - run several times, compared exactly."""
+    from glorie_slam_amd import update_ops as U
+    xa = _cl_half(n, ca, h, w, gpu, 41) if ca else None
+    wide = _cl_half(n, cb + 64, h, w, gpu, 42) if cb else None
+    xb = wide[:, 64:64 + cb] if cb else None
+    g = torch.Generator(device="cpu").manual_seed(43)
+    weight = (torch.randn(nout, ca + cb, k, k, generator=g) / (3.0 * (ca + cb) ** 0.5)).to(gpu)
+    wp = U.pack_conv_igemm(weight)
+    cl = lambda c: torch.empty((n, c, h, w), dtype=torch.float16, device=gpu, memory_format=torch.channels_last)
+
+    def run():
+        if epi == "zr":
+            net = _cl_half(n, 128, h, w, gpu, 44)
+            pre = _cl_half(n, 256, h, w, gpu, 45)
+            terms = torch.randn(n, 256, generator=g).to(gpu) if False else torch.linspace(-1, 1, n * 256, device=gpu).view(n, 256)
+            z, rnet = cl(128), cl(128)
+            U.conv_igemm(xa, xb, wp, k * k, nout, z, epilogue=U.EPI_GRU_ZR, terms=terms, net=net, out2=rnet, pre=pre)
+            return torch.cat([z, rnet], 1).clone()
+        out = cl(nout)
+        U.conv_igemm(xa, xb, wp, k * k, nout, out)
+        return out.clone()
+
+    monkeypatch.setenv("GLORIE_CONV8", "0")
+    ref = run()
+    monkeypatch.setenv("GLORIE_CONV8", "1")
+    for _ in range(5):
+        assert torch.equal(run(), ref)
+    if epi == "bias":
+        torch.testing.assert_close(ref.float(), _conv_ref([xa, xb], weight), atol=4e-3, rtol=4e-3)
 
 
 def test_flow_conv7_matches_conv2d(gpu):

@@ -45,3 +45,32 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def gate_case():
+    """the z|r gate launch of the update operator as the bench runs it: [net | corr, flow] 128 + 192 channels, hoisted
+    context term, sigmoid / r * net epilogue - against the plain 320 -> 256 convolution of the same size"""
+    dev = torch.device("cuda:0")
+    n, h, w = 36, 60, 80
+    torch.manual_seed(1)
+    cl = lambda c: torch.randn(n, c, h, w, device=dev).half().contiguous(memory_format=torch.channels_last)
+    net, wide, pre = cl(128), cl(320), cl(384)
+    dynx = wide[:, 128:320]
+    wp = U.pack_conv_igemm(torch.randn(256, 320, 3, 3, device=dev) / (320 * 9) ** 0.5)
+    terms = torch.randn(n, 384, device=dev)
+    z, rnet, out = cl(128), cl(128), cl(256)
+    fl = 2.0 * n * h * w * 320 * 9 * 256
+    t_gate = timed(lambda: U.conv_igemm(net, dynx, wp, 9, 256, z, epilogue=U.EPI_GRU_ZR, terms=terms[:, 0:256], net=net,
+                                        out2=rnet, pre=pre[:, 0:256]))
+    t_plain = timed(lambda: U.conv_igemm(net, dynx, wp, 9, 256, out))
+    t_nopre = timed(lambda: U.conv_igemm(net, dynx, wp, 9, 256, z, epilogue=U.EPI_GRU_ZR, terms=terms[:, 0:256], net=net,
+                                         out2=rnet))
+    bias = torch.randn(256, device=dev)
+    t_sig = timed(lambda: U.conv_igemm(net, dynx, wp, 9, 256, out, terms=bias, act=U.ACT_SIGMOID))
+    print(f"   gate without the context term {t_nopre:7.1f} us; plain + bias + sigmoid {t_sig:7.1f} us")
+    print(f"gate 320->256: fused gate {t_gate:7.1f} us ({fl / t_gate / 1e6:6.0f} TF/s)   plain {t_plain:7.1f} us "
+          f"({fl / t_plain / 1e6:6.0f} TF/s)", flush=True)
+
+
+if __name__ == "__main__" and os.environ.get("BENCH_CONV_GATE", "1") == "1":
+    gate_case()
