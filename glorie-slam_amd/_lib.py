@@ -66,7 +66,7 @@ SIGNATURES = {
     "glorie_knn_query_image": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_f, _vp, _vp, _vp, _vp, _c_int, _c_int,
                                         _vp]),
     "glorie_idw_gather2": (_c_int, [_vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_f, _vp, _c_int,
-                                    _c_int, _vp, _vp, _vp, _vp, _c_int, _c_int, _vp]),
+                                    _c_int, _vp, _vp, _vp, _vp, _vp]),
     "glorie_decoder_pack_floats": (_sz, []),
     "glorie_render_mlp": (_c_int, [_vp] * 10 + [_c_int, _vp, _vp, _c_int, _vp]),
     "glorie_composite": (_c_int, [_vp, _vp, _c_int, _c_int, _c_f, _vp, _vp, _vp, _vp, _vp]),

@@ -72,24 +72,11 @@ __global__ __launch_bounds__(256) void idw_gather2_kernel(
     const float* __restrict__ D, const int64_t* __restrict__ I, const int* __restrict__ nn,
     const float* __restrict__ feats_a, const float* __restrict__ feats_b, int Q, float radius,
     const float* __restrict__ radius_ptr, int min_nn, int expo_weighting, float* __restrict__ cout_a,
-    float* __restrict__ cout_b, float* __restrict__ wout, uint8_t* __restrict__ has_out, int S, int image_w) {
+    float* __restrict__ cout_b, float* __restrict__ wout, uint8_t* __restrict__ has_out) {
   const int lane = threadIdx.x & 63;
   const int j = lane & 7, grp = lane & ~7;
-  int q = (blockIdx.x * 256 + threadIdx.x) >> 3;
-  bool live = q < Q;
-  if (image_w > 0) {
-    // samples of an image strip (query = (y * image_w + x) * S + s): the 32 samples of a workgroup are one depth of
-    // an 8 x 4 pixel patch - neighbouring pixels at the same depth share most of their 8 neighbours, so the rows
-    // come out of the CU's L1 instead of 8 x 128 B per sample from L2
-    const int R = Q / S;
-    const int tiles_x = (image_w + 7) >> 3;
-    const int s = blockIdx.x % S, tile = blockIdx.x / S;
-    const int l = threadIdx.x >> 3;
-    const int x = (tile % tiles_x) * 8 + (l & 7), y = (tile / tiles_x) * 4 + (l >> 3);
-    const int r = y * image_w + x;
-    live = x < image_w && r < R;
-    q = r * S + s;
-  }
+  const int q = (blockIdx.x * 256 + threadIdx.x) >> 3;
+  const bool live = q < Q;
   const int qc = live ? q : Q - 1;
   const float d = D[(size_t)qc * 8 + j];
   const int idx = (int)I[(size_t)qc * 8 + j];
@@ -326,28 +313,22 @@ extern "C" int glorie_idw_gather(const float* D, const int64_t* I, const int* nn
   const long threads = (long)Q * 8;
   dim3 grid((unsigned)((threads + 255) / 256));
   hipLaunchKernelGGL(idw_gather2_kernel, grid, dim3(256), 0, (hipStream_t)stream, D, I, nn, feats, (const float*)nullptr,
-                     Q, radius, radius_ptr, min_nn, expo_weighting, c_out, (float*)nullptr, w_out, has_out, 1, 0);
+                     Q, radius, radius_ptr, min_nn, expo_weighting, c_out, (float*)nullptr, w_out, has_out);
   return check_launch();
 }
 
 extern "C" int glorie_idw_gather2(const float* D, const int64_t* I, const int* nn, const float* feats_a,
                                   const float* feats_b, int Q, int k, int c_dim, float radius,
                                   const float* radius_ptr, int min_nn, int expo_weighting, float* c_out_a,
-                                  float* c_out_b, float* w_out, uint8_t* has_out, int samples_per_ray,
-                                  int image_w, void* stream) {
+                                  float* c_out_b, float* w_out, uint8_t* has_out, void* stream) {
   if (Q < 0) return GLORIE_EINVAL;
   if (Q == 0) return GLORIE_OK;
   if (!D || !I || !nn || !feats_a || !feats_b || !c_out_a || !c_out_b) return GLORIE_EINVAL;
   if (k != 8 || c_dim != 32) return GLORIE_EUNSUPPORTED;
   const long threads = (long)Q * 8;
   dim3 grid((unsigned)((threads + 255) / 256));
-  if (image_w > 0) {
-    if (samples_per_ray < 1 || Q % samples_per_ray != 0) return GLORIE_EINVAL;
-    const int R = Q / samples_per_ray, rows = (R + image_w - 1) / image_w;
-    grid = dim3((unsigned)(((image_w + 7) / 8) * ((rows + 3) / 4) * samples_per_ray));
-  }
   hipLaunchKernelGGL(idw_gather2_kernel, grid, dim3(256), 0, (hipStream_t)stream, D, I, nn, feats_a, feats_b, Q, radius,
-                     radius_ptr, min_nn, expo_weighting, c_out_a, c_out_b, w_out, has_out, samples_per_ray, image_w);
+                     radius_ptr, min_nn, expo_weighting, c_out_a, c_out_b, w_out, has_out);
   return check_launch();
 }
 

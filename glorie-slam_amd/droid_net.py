@@ -270,6 +270,7 @@ class FusedUpdate:
         self._hx = None
         self._inp_key = None      # (tensor kept alive, version) whose values sit in the inp slice of hx
         self._pre_kf, self._pre_map, self._ctx_key = None, None, None   # context term shared per keyframe
+        self.gate_events = None   # a list: (start, end) events of every z|r gate launch are appended (eager steps only)
 
     # -- weight packing ----------------------------------------------------------------
     def _sync(self):
@@ -438,8 +439,15 @@ class FusedUpdate:
         if self.hoist_inp:
             dynx = hx[:, 128:320]
             pre, pmap = (pre_kf, pre_map) if shared else (self._pre, None)
+            ev = self.gate_events                         # bench.py: HIP events around the z|r launch inside real steps
+            if ev is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             U.conv_igemm(net0, dynx, W["zr_dyn"], 9, 256, z, epilogue=U.EPI_GRU_ZR, terms=g[:, 0:256], net=net0,
                          out2=rnet, pre=pre[:, 0:256], pre_map=pmap)
+            if ev is not None:
+                e1.record()
+                ev.append((e0, e1))
             U.conv_igemm(rnet, dynx, W["q_dyn"], 9, 128, new, epilogue=U.EPI_GRU_Q, terms=g[:, 256:384], net=net0,
                          z=z, pre=pre[:, 256:384], pre_map=pmap)
         else:

@@ -107,7 +107,7 @@ def idw_gather(D, I, nn, feats, radius=0.0, radius_per_query=None, min_nn=2, exp
     return (c, has, w) if return_weights else (c, has)
 
 
-def idw_gather2(D, I, nn, feats_a, feats_b, radius=0.0, radius_per_query=None, min_nn=2, expo=False, image_layout=None):
+def idw_gather2(D, I, nn, feats_a, feats_b, radius=0.0, radius_per_query=None, min_nn=2, expo=False):
     """idw_gather on the geometry and the colour table in one launch -> c_a [Q,32], c_b [Q,32], has [Q] bool, w [Q,8]"""
     L.need_cuda(D, I, nn, feats_a, feats_b)
     Q, k = D.shape
@@ -119,8 +119,7 @@ def idw_gather2(D, I, nn, feats_a, feats_b, radius=0.0, radius_per_query=None, m
     L.check(L.load().glorie_idw_gather2(L.ptr(D.contiguous()), L.ptr(I.contiguous()), L.ptr(nn.contiguous()),
                                         L.ptr(feats_a.contiguous()), L.ptr(feats_b.contiguous()), Q, k, feats_a.shape[1],
                                         float(radius), L.ptr(rp), int(min_nn), int(bool(expo)), L.ptr(ca), L.ptr(cb),
-                                        L.ptr(w), L.ptr(has), int(image_layout[0]) if image_layout else 1,
-                                        int(image_layout[1]) if image_layout else 0, L.stream_ptr()), "glorie_idw_gather2")
+                                        L.ptr(w), L.ptr(has), L.stream_ptr()), "glorie_idw_gather2")
     return ca, cb, has.bool(), w
 
 

@@ -413,14 +413,11 @@ int glorie_idw_gather(const float* D, const int64_t* I, const int* nn, const flo
                       uint8_t* has_out, void* stream);
 
 /* glorie_idw_gather on the geometry and the colour table in one pass (decoder.py:130-173 and :340-389 share the
- * neighbours and the weights): c_out_a = sum_k w_k feats_a[I_k], c_out_b likewise.  Same bits as two calls.
- * image_w > 0: the samples are those of an image strip (layout of glorie_knn_query_image) and are walked patch-wise;
- * image_w = 0: in order (samples_per_ray ignored). */
+ * neighbours and the weights): c_out_a = sum_k w_k feats_a[I_k], c_out_b likewise.  Same bits as two calls. */
 int glorie_idw_gather2(const float* D, const int64_t* I, const int* nn, const float* feats_a,
                        const float* feats_b, int Q, int k, int c_dim, float radius,
                        const float* radius_ptr, int min_nn, int expo_weighting, float* c_out_a,
-                       float* c_out_b, float* w_out, uint8_t* has_out, int samples_per_ray, int image_w,
-                       void* stream);
+                       float* c_out_b, float* w_out, uint8_t* has_out, void* stream);
 
 /* Fused decoders: POINT.forward(p, npc, stage, ...) minus the neighbour search
  *   reference: src/modules/conv_onet/models/decoder.py:175-225 (MLP_geometry.forward),

@@ -19,20 +19,20 @@ g, video, graph = bench.build_graph(dev)
 coords1, _ = video.reproject(graph.ii, graph.jj)
 for _ in range(3):
     graph.corr(coords1)
-conv_launch, _ = bench.gru_gate_conv_workload(dev, graph.ii.shape[0], graph.ht, graph.wd)
+conv_launch, _ = bench.gru_gate_conv_workload(dev, graph.ii.shape[0], graph.ht, graph.wd,
+                                              graph.ii if graph.share_context else None)
 for _ in range(3):
     conv_launch()
 npc, dec, ren, rays = bench.build_renderer(dev)
 S = ren.N_surface
-nq = 65536
+nq = 61440                                   # 96 image rows: the batch render_img evaluates
 z = rays["depth"][:nq, None] * torch.linspace(0.95, 1.05, S, device=dev)[None]
 pq = (rays["o"][:nq, None] + rays["d"][:nq, None] * z[..., None]).reshape(-1, 3).contiguous()
 rq = rays["radius"][:nq].repeat_interleave(S)
 from glorie_slam_amd import point_ops  # noqa: E402
 for _ in range(3):
-    D, I, nn = npc.index.search(pq, 8, radius_per_query=rq)
-    point_ops.idw_gather(D, I, nn, npc.geo_feats, radius_per_query=rq)
-    point_ops.idw_gather(D, I, nn, npc.col_feats, radius_per_query=rq)
+    D, I, nn = npc.index.search(pq, 8, radius_per_query=rq, image_layout=(S, rays["W"]))
+    point_ops.idw_gather2(D, I, nn, npc.geo_feats, npc.col_feats, radius_per_query=rq)
 # calibration: a 1 GiB float4 streaming copy (reads 1 GiB, writes 1 GiB)
 src = torch.empty(1 << 28, dtype=torch.float32, device=dev).normal_()
 for _ in range(3):

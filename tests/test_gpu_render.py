@@ -154,10 +154,6 @@ def test_idw_gather(gpu):
     c2a, c2b, has2, w2 = point_ops.idw_gather2(D, I, nn, torch.from_numpy(feats).to(gpu), torch.from_numpy(feats_b).to(gpu),
                                                radius_per_query=torch.from_numpy(rad).to(gpu))
     assert torch.equal(c2a, c) and torch.equal(c2b, cb) and torch.equal(has2, has) and torch.equal(w2, w)
-    # ... and walked as the samples of a 37-ray-wide image strip (1000 = 100 rays x 10 samples, partial last row)
-    c3a, c3b, has3, w3 = point_ops.idw_gather2(D, I, nn, torch.from_numpy(feats).to(gpu), torch.from_numpy(feats_b).to(gpu),
-                                               radius_per_query=torch.from_numpy(rad).to(gpu), image_layout=(10, 37))
-    assert torch.equal(c3a, c) and torch.equal(c3b, cb) and torch.equal(has3, has) and torch.equal(w3, w)
 
 
 def test_composite_matches_reference_fixture(gpu):

@@ -39,10 +39,7 @@ def main():
         D, I, nn = npc.index.search(pq, 8, radius_per_query=rq)
         g1 = timed(lambda: point_ops.idw_gather(D, I, nn, npc.geo_feats, radius_per_query=rq))
         g2 = timed(lambda: point_ops.idw_gather2(D, I, nn, npc.geo_feats, npc.col_feats, radius_per_query=rq))
-        g3 = timed(lambda: point_ops.idw_gather2(D, I, nn, npc.geo_feats, npc.col_feats, radius_per_query=rq,
-                                                 image_layout=(S, 640)))
-        print(f"two tables, patch order {g3:.3f} ms")
-        tot = t1 + min(g2, g3)
+        tot = t1 + g2
         print(f"rays {nq}: search plain {t0:.3f} ms, image {t1:.3f} ms; gather one table {g1:.3f} ms, two tables {g2:.3f} ms; "
               f"search+gather {tot:.3f} ms = {2156.0 * pq.shape[0] / tot / 1e6:.0f} GB/s ({2156.0 * pq.shape[0] / tot / 8e9 * 1e3:.3f} of 8 TB/s)",
               flush=True)
