@@ -3,8 +3,10 @@
 
 Module / parameter names match the reference so that `droid.pth` loads with
 `load_state_dict` unchanged (src/slam.py:70-81): update.{corr_encoder,flow_encoder,weight,
-delta,gru,agg}.* .  The convolutions go through PyTorch-ROCm (MIOpen); the correlation
-lookup, the segment mean of GraphAgg and the convex upsampling are libglorie_hip kernels.
+delta,gru,agg}.* .  `UpdateModule` / `DroidNet` are plain nn.Modules (the definition the checkpoint loads into and
+the fp32 reference of the parity tests); the product path is `FusedUpdate`, which evaluates the same operator entirely
+on libglorie_hip kernels (csrc/conv.hip, gru.hip, flowenc.hip: implicit-GEMM MFMA convolutions with fused gate
+epilogues), and the correlation blocks (`CorrBlock`, `CorrArena`, `OtfCorrBlock`, `AltCorrBlock`) on csrc/corr*.hip.
 """
 import torch
 import torch.nn as nn
