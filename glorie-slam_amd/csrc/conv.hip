@@ -59,6 +59,7 @@ struct ConvArgs {
   const _Float16* z; int z_stride;
   const _Float16* pre; int pre_stride;          // per-pixel term added before the gate non-linearity (or null)
   const int* pre_map;                           // map (edge) -> map of `pre` it reads (null: its own)
+  long pbeg;                                    // first pixel of this launch (a layer may be split into two launches)
   int dbg;                                      // ablation bits of conv8_kernel (GLORIE_CONV8_DBG; timing experiments only)
   unsigned long long* stamps;                   // dbg & 128: s_memtime checkpoints of workgroup 0, tiles 10-12, [8 waves][128]
 };
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(64 * NW, ST == 1 ? 3 : 2) void conv_igemm_kernel(Co
   const int xcd = blockIdx.x & 7, q = nwg >> 3, r = nwg & 7;
   const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
   const int pt = lid / ntn, nt = lid - pt * ntn;
-  const long p0 = (long)pt * PT;
+  const long p0 = a.pbeg + (long)pt * PT;
   const int n0 = nt * TN;
 
   const int cpc = 64 / BK;                    // K steps per 64-channel chunk
@@ -331,10 +332,10 @@ __global__ __launch_bounds__(64 * NW, ST == 1 ? 3 : 2) void conv_igemm_kernel(Co
     // different rows per instruction, every 128-byte line requested by 8 instructions - measured +47 us on the 36-edge z|r
     // launch.  With a 128 x 128 tile the [pixel][channel] fp16 tile is exactly the 32 KB LDS stage: it comes in as 32
     // row-contiguous DMA pieces (16-byte slot XOR-swizzled with the row on the source side) and is read back per lane.
-    if constexpr (PT == 128 && TN == 128 && ST == 1 && BK == 64) {
+    if constexpr ((PT == 128 || PT == 64) && TN == 128 && ST == 1 && BK == 64) {
       const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void*)a.pre, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-      for (int i = 0; i < 32 / NW; ++i) {
+      for (int i = 0; i < PT / 4 / NW; ++i) {
         const int piece = i * NW + wv;
         const int row = piece * 4 + (lane >> 4), sl = lane & 15;
         const long p = pre_pixel(a, min(p0 + row, a.P - 1));
@@ -470,7 +471,7 @@ __global__ __launch_bounds__(512) void conv8_kernel(ConvArgs a) {
   const int xcd = blockIdx.x & 7, q = nwg >> 3, r = nwg & 7;
   const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
   const int pt = lid / ntn, nt = lid - pt * ntn;
-  const long p0 = (long)pt * 256;
+  const long p0 = a.pbeg + (long)pt * 256;
   const int n0 = nt * 256;
 
   const int nch = a.cha + a.chb;
@@ -838,7 +839,7 @@ static void launch_conv8_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
 }
 
 static int launch_conv8(const ConvArgs& a, int epilogue, hipStream_t st) {
-  const long nwg = ((a.P + 255) / 256) * (a.nout / 256);
+  const long nwg = ((a.P - a.pbeg + 255) / 256) * (a.nout / 256);
   if (nwg > 0x7fffffffL) return GLORIE_EINVAL;
   const dim3 grid((unsigned)nwg);
   switch (epilogue) {
@@ -863,9 +864,11 @@ static void launch_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
 }
 
 template <int NB, int BK, int NW, int ST, int MB = 4>
-static int launch_conv(const ConvArgs& a, int epilogue, hipStream_t st) {
+static int launch_conv(const ConvArgs& a, int epilogue, hipStream_t st, long max_ptiles = -1) {
   constexpr int PT = (NW / 2) * 16 * NB;
-  const long ptiles = (a.P + PT - 1) / PT;
+  long ptiles = (a.P - a.pbeg + PT - 1) / PT;
+  if (max_ptiles >= 0) ptiles = ptiles < max_ptiles ? ptiles : max_ptiles;
+  if (ptiles <= 0) return GLORIE_OK;
   const long nwg = ptiles * ((a.nout + 32 * MB - 1) / (32 * MB));
   if (nwg > 0x7fffffffL) return GLORIE_EINVAL;
   const dim3 grid((unsigned)nwg);
@@ -908,6 +911,7 @@ extern "C" int glorie_conv_igemm(const void* xa, int xa_stride, int ca, const vo
   a.net = reinterpret_cast<const _Float16*>(net); a.net_stride = net_stride;
   a.z = reinterpret_cast<const _Float16*>(z); a.z_stride = z_stride;
   a.pre = reinterpret_cast<const _Float16*>(pre); a.pre_stride = pre_stride; a.pre_map = pre ? pre_map : nullptr;
+  a.pbeg = 0;
   { const char* d = getenv("GLORIE_CONV8_DBG"); a.dbg = d ? atoi(d) : 0; }
   a.stamps = getenv("GLORIE_CONV8_STAMPS") ? (unsigned long long*)strtoull(getenv("GLORIE_CONV8_STAMPS"), nullptr, 0) : nullptr;
   if (!a.stamps) a.dbg &= ~(128 | 256);
@@ -933,5 +937,23 @@ extern "C" int glorie_conv_igemm(const void* xa, int xa_stride, int ca, const vo
   if (conv8_on && (nout & 255) == 0 && a.P >= 256) return launch_conv8(a, epilogue, st);
   // layers with <= 64 output channels (flow_encoder[2]) use a 64-channel tile instead of padding to 128
   if (nout <= 64 && epilogue == EPI_BIAS_ACT) return launch_conv<4, 64, 4, 1, 2>(a, epilogue, st);
+  // Tail of the last round.  The 36-edge z|r launch is 2700 workgroups on 768 slots = 3.52 rounds; running the whole rounds
+  // on 128-pixel tiles and the remainder as a second launch of 64-pixel tiles (4 per CU) was measured: 292 us against 275 us
+  // (all 64-pixel tiles: 329 us; q gate 171 / 190 / 182 us; 128 -> 384 heads 153 / 168 / 181 us) - a 64-pixel workgroup costs
+  // 0.8 of a 128-pixel one, and workgroups do not run in lockstep rounds, so the tail is cheaper than a round model says.
+  // GLORIE_CONV_TILE=64|split keeps both variants reachable for measurements (tools/bench_conv.py).
+  const int ntn = (nout + 127) / 128;
+  const long slots128 = 3L * 256;
+  const long full_rounds = ((a.P + 127) / 128 * ntn) / slots128;
+  const long pt_a = full_rounds * slots128 / ntn;               // pixel tiles of the whole rounds
+  int mode = 0;                                                 // 0: 128, 1: 64, 2: split
+  if (const char* tm = getenv("GLORIE_CONV_TILE")) mode = tm[0] == '6' ? 1 : (tm[0] == 's' ? 2 : 0);
+  if (mode == 1) return launch_conv<2, 64, 4, 1>(a, epilogue, st);
+  if (mode == 2 && full_rounds >= 1) {
+    const int rc_a = launch_conv<4, 64, 4, 1>(a, epilogue, st, pt_a);
+    if (rc_a != GLORIE_OK) return rc_a;
+    a.pbeg = pt_a * 128;
+    return a.pbeg < a.P ? launch_conv<2, 64, 4, 1>(a, epilogue, st) : GLORIE_OK;
+  }
   return launch_conv<4, 64, 4, 1>(a, epilogue, st);
 }

@@ -72,5 +72,37 @@ def gate_case():
           f"({fl / t_plain / 1e6:6.0f} TF/s)", flush=True)
 
 
+def tile_modes():
+    """the z|r and q gate launches and the 128 -> 384 head convolution under the three tile policies of glorie_conv_igemm"""
+    dev = torch.device("cuda:0")
+    n, h, w = 36, 60, 80
+    torch.manual_seed(2)
+    cl = lambda c: torch.randn(n, c, h, w, device=dev).half().contiguous(memory_format=torch.channels_last)
+    net, wide, pre = cl(128), cl(320), cl(384)
+    dynx = wide[:, 128:320]
+    wzr = U.pack_conv_igemm(torch.randn(256, 320, 3, 3, device=dev) / 54)
+    wq = U.pack_conv_igemm(torch.randn(128, 320, 3, 3, device=dev) / 54)
+    wh = U.pack_conv_igemm(torch.randn(384, 128, 3, 3, device=dev) / 34)
+    terms = torch.randn(n, 384, device=dev)
+    z, rnet, new, h1 = cl(128), cl(128), cl(128), cl(384)
+    cases = {
+        "z|r gate 320->256": lambda: U.conv_igemm(net, dynx, wzr, 9, 256, z, epilogue=U.EPI_GRU_ZR, terms=terms[:, 0:256],
+                                                  net=net, out2=rnet, pre=pre[:, 0:256]),
+        "q gate 320->128": lambda: U.conv_igemm(rnet, dynx, wq, 9, 128, new, epilogue=U.EPI_GRU_Q, terms=terms[:, 256:384],
+                                                net=net, z=z, pre=pre[:, 256:384]),
+        "heads 128->384": lambda: U.conv_igemm(net, None, wh, 9, 384, h1),
+    }
+    for name, fn in cases.items():
+        res = []
+        for mode in ("128", "64", "split", None):
+            if mode is None:
+                os.environ.pop("GLORIE_CONV_TILE", None)
+            else:
+                os.environ["GLORIE_CONV_TILE"] = mode
+            res.append(f"{mode or 'auto'} {timed(fn):6.1f} us")
+        print(f"{name:20s} " + "   ".join(res), flush=True)
+
+
 if __name__ == "__main__" and os.environ.get("BENCH_CONV_GATE", "1") == "1":
     gate_case()
+    tile_modes()
