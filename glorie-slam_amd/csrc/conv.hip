@@ -207,7 +207,7 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvArgs& a, f32x4 (&ac
 // NW/2 pixel groups: pixel tile = NW/2 * 16*NB), ST = LDS stages (1: single stage + register-resident
 // fragments, the shipped form; 2: classic double buffering with one __syncthreads per step)
 template <int EPI, int NB, int BK, int NW, int ST, int MB = 4>
-__global__ __launch_bounds__(64 * NW, ST == 1 ? 3 : 2) void conv_igemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__(64 * NW, (ST == 1 && MB * NB <= 16) ? 3 : 2) void conv_igemm_kernel(ConvArgs a) {
   constexpr int TN = 32 * MB;               // output channels per workgroup (MB 16-channel blocks per wave)
   static_assert(ST == 1 || ST == 2, "LDS stages");
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (buffer-resource types are device-only)
@@ -256,13 +256,17 @@ __global__ __launch_bounds__(64 * NW, ST == 1 ? 3 : 2) void conv_igemm_kernel(Co
 
   // staging roles: DMA instruction i of wave wv fills rows (i*4 + wv)*RPI .. +RPI-1; lane -> (row, slot)
   const int srow = lane / SL, slot = lane % SL;
-  unsigned voffA[XI], voffB[XI], woff[WI];
-  int vmask[XI];
+  // rows of consecutive instructions are NW * RPI apart and share the swizzle key (it depends on the row modulo RPI
+  // only), so one VGPR offset per operand serves all of them: instruction i adds i * NW * RPI rows to the SGPR offset
+  const int row0 = wv * RPI + srow;
+  const int sw0 = (slot ^ key(row0)) << 3;           // swizzled 16-byte slot, in halfs
+  const unsigned voffA0 = (unsigned)(((p0 + row0) * a.xa_stride + sw0) * 2);
+  const unsigned voffB0 = (unsigned)(((p0 + row0) * a.xb_stride + sw0) * 2);
+  const unsigned woff0 = (unsigned)(((size_t)row0 * C + sw0) * 2);
+  int vmask[XI];                                     // rows past the end have no valid tap: their loads are dropped
 #pragma unroll
   for (int i = 0; i < XI; ++i) {
-    const int row = (i * NW + wv) * RPI + srow;
-    const int sw = (slot ^ key(row)) << 3;          // swizzled 16-byte slot, in halfs
-    const long p = p0 + row;
+    const long p = p0 + (i * NW + wv) * RPI + srow;
     int m = 0;
     if (p < a.P) {
       const int xw = (int)(p % a.W), yh = (int)((p / a.W) % a.H);
@@ -277,14 +281,6 @@ __global__ __launch_bounds__(64 * NW, ST == 1 ? 3 : 2) void conv_igemm_kernel(Co
       }
     }
     vmask[i] = m;
-    const long pc = p < a.P ? p : 0;
-    voffA[i] = (unsigned)((pc * a.xa_stride + sw) * 2);
-    voffB[i] = (unsigned)((pc * a.xb_stride + sw) * 2);
-  }
-#pragma unroll
-  for (int i = 0; i < WI; ++i) {
-    const int row = (i * NW + wv) * RPI + srow;
-    woff[i] = (unsigned)(((size_t)row * C + ((slot ^ key(row)) << 3)) * 2);
   }
 
   auto stage = [&](int t, int buf) {
@@ -301,17 +297,18 @@ __global__ __launch_bounds__(64 * NW, ST == 1 ? 3 : 2) void conv_igemm_kernel(Co
     const unsigned wsoff = (unsigned)((((size_t)d * a.npad + n0) * C + ch * 64 + sub * BK) * 2);
     char* lx = smem + buf * (XBYTES + WBYTES);
     char* lw = lx + XBYTES;
+    const unsigned xstep = (unsigned)(NW * RPI * xs * 2), wstep = (unsigned)(NW * RPI * C * 2);
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
       const unsigned inv = ~((unsigned)vmask[i] >> d);
-      const unsigned vo = (inv << 31) | (segA ? voffA[i] : voffB[i]);
+      const unsigned vo = (inv << 31) | (segA ? voffA0 : voffB0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(segA ? rA : rB,
-          (__attribute__((address_space(3))) void*)(lx + (i * NW + wv) * RPI * RB), 16, vo, xsoff, 0, 0);
+          (__attribute__((address_space(3))) void*)(lx + (i * NW + wv) * RPI * RB), 16, vo, xsoff + i * xstep, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < WI; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rW,
-          (__attribute__((address_space(3))) void*)(lw + (i * NW + wv) * RPI * RB), 16, woff[i], wsoff, 0, 0);
+          (__attribute__((address_space(3))) void*)(lw + (i * NW + wv) * RPI * RB), 16, woff0, wsoff + i * wstep, 0, 0);
   };
 
   f32x4 acc[MB][NB];
@@ -332,12 +329,14 @@ __global__ __launch_bounds__(64 * NW, ST == 1 ? 3 : 2) void conv_igemm_kernel(Co
     // different rows per instruction, every 128-byte line requested by 8 instructions - measured +47 us on the 36-edge z|r
     // launch.  With a 128 x 128 tile the [pixel][channel] fp16 tile is exactly the 32 KB LDS stage: it comes in as 32
     // row-contiguous DMA pieces (16-byte slot XOR-swizzled with the row on the source side) and is read back per lane.
-    if constexpr ((PT == 128 || PT == 64) && TN == 128 && ST == 1 && BK == 64) {
+    if constexpr ((PT == 128 || PT == 64) && (TN == 128 || TN == 256) && ST == 1 && BK == 64) {
+      // (the launch reserves max(stage, PT * TN * 2) bytes of LDS: 64 KB for the 256-channel tile)
+      constexpr int ROWB = TN * 2, SLOTS = ROWB / 16, RPP = 64 / SLOTS;      // bytes / 16-byte slots per row, rows per piece
       const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void*)a.pre, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-      for (int i = 0; i < PT / 4 / NW; ++i) {
+      for (int i = 0; i < PT / RPP / NW; ++i) {
         const int piece = i * NW + wv;
-        const int row = piece * 4 + (lane >> 4), sl = lane & 15;
+        const int row = piece * RPP + lane / SLOTS, sl = lane % SLOTS;
         const long p = pre_pixel(a, min(p0 + row, a.P - 1));
         const unsigned vo = (unsigned)((p * a.pre_stride + n0) * 2 + ((sl ^ (row & 15)) << 4));
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rP, (__attribute__((address_space(3))) void*)(smem + piece * 1024), 16, vo,
@@ -350,7 +349,7 @@ __global__ __launch_bounds__(64 * NW, ST == 1 ? 3 : 2) void conv_igemm_kernel(Co
 #pragma unroll
         for (int mi = 0; mi < MB; ++mi) {
           const int b = (wm * (16 * MB) + mi * 16 + kg * 4) * 2;
-          const f16x4 h = *reinterpret_cast<const f16x4*>(smem + row * 256 + ((((b >> 4) ^ (row & 15))) << 4) + (b & 15));
+          const f16x4 h = *reinterpret_cast<const f16x4*>(smem + row * ROWB + ((((b >> 4) ^ (row & 15))) << 4) + (b & 15));
           acc[mi][ni] = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
         }
       }
@@ -853,7 +852,11 @@ static int launch_conv8(const ConvArgs& a, int epilogue, hipStream_t st) {
 template <int EPI, int NB, int BK, int NW, int ST, int MB>
 static void launch_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
   constexpr int RB = BK * 2, PT = (NW / 2) * 16 * NB;
-  constexpr size_t lds = (size_t)ST * (PT * RB + 32 * MB * RB);
+  constexpr size_t stage_bytes = (size_t)ST * (PT * RB + 32 * MB * RB);
+  // gate epilogues seed their accumulators through LDS: the [pixel][channel] fp16 tile of the context term must fit
+  constexpr size_t seed_bytes = (EPI != EPI_BIAS_ACT && ST == 1 && BK == 64 && (PT == 128 || PT == 64) && MB * 32 <= 256)
+                                    ? (size_t)PT * 32 * MB * 2 : 0;
+  constexpr size_t lds = stage_bytes > seed_bytes ? stage_bytes : seed_bytes;
   static bool attr = false;            // > 64 KB of dynamic LDS needs the opt-in once per kernel
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<EPI, NB, BK, NW, ST, MB>),
@@ -937,19 +940,24 @@ extern "C" int glorie_conv_igemm(const void* xa, int xa_stride, int ca, const vo
   if (conv8_on && (nout & 255) == 0 && a.P >= 256) return launch_conv8(a, epilogue, st);
   // layers with <= 64 output channels (flow_encoder[2]) use a 64-channel tile instead of padding to 128
   if (nout <= 64 && epilogue == EPI_BIAS_ACT) return launch_conv<4, 64, 4, 1, 2>(a, epilogue, st);
-  // Tail of the last round.  The 36-edge z|r launch is 2700 workgroups on 768 slots = 3.52 rounds; running the whole rounds
-  // on 128-pixel tiles and the remainder as a second launch of 64-pixel tiles (4 per CU) was measured: 292 us against 275 us
-  // (all 64-pixel tiles: 329 us; q gate 171 / 190 / 182 us; 128 -> 384 heads 153 / 168 / 181 us) - a 64-pixel workgroup costs
-  // 0.8 of a 128-pixel one, and workgroups do not run in lockstep rounds, so the tail is cheaper than a round model says.
-  // GLORIE_CONV_TILE=64|split keeps both variants reachable for measurements (tools/bench_conv.py).
+  // Tile choice.  Default: 128 x 128 (3 workgroups per CU); layers whose output channels are a multiple of 256 (the z|r
+  // gates) take 256 channels x 128 pixels - 4 waves of 128 x 64, 2 workgroups per CU, 25 % fewer staged bytes per MFMA:
+  // 448 -> 256 at 36x60x80 345 -> 315 us, the fused gate launch 277 -> 265 us stand-alone.
+  // Measured and NOT used: 128 channels x 256 pixels for the 128-channel layers (q gate 174 -> 176 us); 64-pixel tiles
+  // (4 per CU; z|r 329 us); whole rounds on 128-pixel tiles + the remainder as a second launch of 64-pixel tiles
+  // (292 us: a 64-pixel workgroup costs 0.8 of a 128-pixel one and workgroups do not run in lockstep rounds, so the
+  // partly filled last round is cheaper than a round model says).  GLORIE_CONV_TILE = 128 | 64 | split | wide keeps the
+  // variants reachable for tools/bench_conv.py.
   const int ntn = (nout + 127) / 128;
   const long slots128 = 3L * 256;
   const long full_rounds = ((a.P + 127) / 128 * ntn) / slots128;
   const long pt_a = full_rounds * slots128 / ntn;               // pixel tiles of the whole rounds
-  int mode = 0;                                                 // 0: 128, 1: 64, 2: split
-  if (const char* tm = getenv("GLORIE_CONV_TILE")) mode = tm[0] == '6' ? 1 : (tm[0] == 's' ? 2 : 0);
-  if (mode == 1) return launch_conv<2, 64, 4, 1>(a, epilogue, st);
-  if (mode == 2 && full_rounds >= 1) {
+  const char* tm = getenv("GLORIE_CONV_TILE");
+  const char t0c = tm ? tm[0] : 0;
+  if (t0c == 0 && (nout & 255) == 0) return launch_conv<4, 64, 4, 1, 8>(a, epilogue, st);
+  if (t0c == 'w') return launch_conv<8, 64, 4, 1, 4>(a, epilogue, st);
+  if (t0c == '6') return launch_conv<2, 64, 4, 1>(a, epilogue, st);
+  if (t0c == 's' && full_rounds >= 1) {
     const int rc_a = launch_conv<4, 64, 4, 1>(a, epilogue, st, pt_a);
     if (rc_a != GLORIE_OK) return rc_a;
     a.pbeg = pt_a * 128;

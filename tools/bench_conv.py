@@ -94,7 +94,7 @@ def tile_modes():
     }
     for name, fn in cases.items():
         res = []
-        for mode in ("128", "64", "split", None):
+        for mode in ("128", "wide", "64", "split", None):
             if mode is None:
                 os.environ.pop("GLORIE_CONV_TILE", None)
             else:
