@@ -195,8 +195,13 @@ __global__ __launch_bounds__(256) void composite_kernel(
 //   separately like the chain of torch ops), pts = o + dir * z, and the per-ray view direction / query
 //   radius repeated per sample.  Rays with d <= 0 get z = 0 and are counted in *n_zero: the host sends such a
 //   batch through the general path (they need the 25-probe search of sample_near_pcl).
+// CAMERA: the rays are those of consecutive row-major pixels of a pinhole view (get_rays, common.py:302-322: OpenGL convention,
+// dirs = ((i - cx) / fx, -(j - cy) / fy, -1), rays_d = sum(dirs * c2w[:3,:3], -1), rays_o = c2w[:3,3]) and are formed here
+// instead of being read - scope row R7 fused into R4; `cam` = c2w rows 0..2 (12 floats), 1/fx, 1/fy, cx, cy.
+template <bool CAMERA>
 __global__ __launch_bounds__(256) void ray_samples_kernel(
-    const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ depth,
+    const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ cam, int img_w,
+    long first_pixel, const float* __restrict__ depth,
     const float* __restrict__ radius, const float* __restrict__ t_lin, int R, int S, float near_s, float far_s,
     float* __restrict__ z_vals, float* __restrict__ pts, float* __restrict__ views,
     float* __restrict__ radius_s, int* __restrict__ n_zero) {
@@ -211,12 +216,31 @@ __global__ __launch_bounds__(256) void ray_samples_kernel(
   const float z = d > 0.0f ? p1 + p2 : 0.0f;
   if (sidx == 0 && !(d > 0.0f)) atomicAdd(n_zero, 1);
   z_vals[idx] = z;
+  float o[3], dir[3];
+  if (CAMERA) {
+    const long px = first_pixel + r;
+    const float fi = (float)(px % img_w), fj = (float)(px / img_w);
+    // torch divides by a Python scalar as a multiplication with its fp32 reciprocal, and its 3-element row sum adds
+    // element 2 before element 1 (vectorised partial accumulators): reproduced, so the rays are the bits of get_rays
+    const float x = (fi - cam[14]) * cam[12];
+    const float y = -((fj - cam[15]) * cam[13]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float q0 = x * cam[k * 4 + 0], q1 = y * cam[k * 4 + 1], q2 = -1.0f * cam[k * 4 + 2];
+      float sum = q0 + q2;
+      sum = sum + q1;
+      dir[k] = sum;
+      o[k] = cam[k * 4 + 3];
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { dir[k] = rays_d[(size_t)r * 3 + k]; o[k] = rays_o[(size_t)r * 3 + k]; }
+  }
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    const float dir = rays_d[(size_t)r * 3 + k];
-    const float m = dir * z;
-    pts[idx * 3 + k] = rays_o[(size_t)r * 3 + k] + m;
-    views[idx * 3 + k] = dir;
+    const float m = dir[k] * z;
+    pts[idx * 3 + k] = o[k] + m;
+    views[idx * 3 + k] = dir[k];
   }
   if (radius_s) radius_s[idx] = radius[r];
 }
@@ -271,9 +295,24 @@ extern "C" int glorie_ray_samples(const float* rays_o, const float* rays_d, cons
   if (!rays_o || !rays_d || !depth || !t_lin || !z_vals || !pts || !views || !n_zero) return GLORIE_EINVAL;
   if ((radius == nullptr) != (radius_s == nullptr)) return GLORIE_EINVAL;
   const long total = (long)R * S;
-  hipLaunchKernelGGL(ray_samples_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     rays_o, rays_d, depth, radius, t_lin, R, S, near_s, far_s, z_vals, pts, views, radius_s,
-                     n_zero);
+  hipLaunchKernelGGL(ray_samples_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     rays_o, rays_d, (const float*)nullptr, 1, 0L, depth, radius, t_lin, R, S, near_s, far_s, z_vals, pts,
+                     views, radius_s, n_zero);
+  return check_launch();
+}
+
+extern "C" int glorie_ray_samples_camera(const float* cam, int image_w, long first_pixel, const float* depth,
+                                         const float* radius, const float* t_lin, int R, int S, float near_s,
+                                         float far_s, float* z_vals, float* pts, float* views, float* radius_s,
+                                         int* n_zero, void* stream) {
+  if (R < 0 || S < 1 || image_w < 1 || first_pixel < 0) return GLORIE_EINVAL;
+  if (R == 0) return GLORIE_OK;
+  if (!cam || !depth || !t_lin || !z_vals || !pts || !views || !n_zero) return GLORIE_EINVAL;
+  if ((radius == nullptr) != (radius_s == nullptr)) return GLORIE_EINVAL;
+  const long total = (long)R * S;
+  hipLaunchKernelGGL(ray_samples_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)nullptr, (const float*)nullptr, cam, image_w, first_pixel, depth, radius, t_lin, R, S,
+                     near_s, far_s, z_vals, pts, views, radius_s, n_zero);
   return check_launch();
 }
 

@@ -35,9 +35,6 @@ class DepthVideo:
         dev = self.device
         f32 = dict(device=dev, dtype=torch.float)
 
-        def shared(t):
-            return t.share_memory_() if t.device.type == 'cpu' or True else t
-
         self.timestamp = torch.zeros(buffer, **f32)
         store_images = cfg['tracking'].get('store_images', True)
         self.images = torch.zeros(buffer if store_images else 0, 3, ht, wd, device=dev, dtype=torch.uint8)

@@ -152,6 +152,41 @@ def ray_samples(rays_o, rays_d, depth, radius, S, near_s, far_s):
     return z, pts, views, rs, nz
 
 
+def camera_block(c2w, fx, fy, cx, cy, device):
+    """the 16 floats glorie_ray_samples_camera reads: c2w rows 0..2, 1/fx, 1/fy (fp32 reciprocals), cx, cy"""
+    import numpy as np
+    c = torch.as_tensor(c2w, dtype=torch.float32).to(device)[:3, :4].reshape(-1)
+    # torch evaluates `tensor / python_scalar` as tensor * float32(1.0 / scalar), the reciprocal taken in double
+    k = np.array([np.float32(1.0 / float(fx)), np.float32(1.0 / float(fy)), cx, cy], dtype=np.float32)
+    return torch.cat([c, torch.from_numpy(k).to(device)]).contiguous()
+
+
+def ray_samples_camera(cam, image_w, first_pixel, depth, radius, S, near_s, far_s):
+    """ray_samples for R = len(depth) consecutive row-major pixels of the view `cam` (camera_block) starting at
+    first_pixel: get_rays (common.py:302-322) happens inside the kernel"""
+    L.need_cuda(cam, depth)
+    dev = depth.device
+    f = lambda t: t.detach().reshape(-1).contiguous().float()
+    g = f(depth)
+    R = g.shape[0]
+    key = (str(dev), int(S))
+    if key not in _T_LIN:
+        _T_LIN[key] = torch.linspace(0.0, 1.0, steps=S, device=dev)
+    z = torch.empty(R, S, device=dev)
+    pts = torch.empty(R * S, 3, device=dev)
+    views = torch.empty(R * S, 3, device=dev)
+    rs = torch.empty(R * S, device=dev) if radius is not None else None
+    nz = torch.zeros(1, dtype=torch.int32, device=dev)
+    r = f(radius) if radius is not None else None
+    if r is not None and r.shape[0] != R:
+        raise RuntimeError("ray_samples_camera: radius must have one entry per ray")
+    L.check(L.load().glorie_ray_samples_camera(L.ptr(cam), int(image_w), int(first_pixel), L.ptr(g), L.ptr(r),
+                                               L.ptr(_T_LIN[key]), R, int(S), float(near_s), float(far_s), L.ptr(z),
+                                               L.ptr(pts), L.ptr(views), L.ptr(rs), L.ptr(nz), L.stream_ptr()),
+            "glorie_ray_samples_camera")
+    return z, pts, views, rs, nz
+
+
 def ray_counts(has, S, min_samples=3):
     """decoder.py:202-204: has [R*S] (bool / uint8) -> counts [R] int64, valid [R] bool"""
     L.need_cuda(has)

@@ -75,16 +75,22 @@ class Renderer(object):
         return z, near_mask, nz
 
     def _render_fast(self, npc, decoders, rays_d, rays_o, stage, gt_depth, npc_geo_feats, npc_col_feats,
-                     cloud_pos, dynamic_r_query, image_w=None):
+                     cloud_pos, dynamic_r_query, image_w=None, camera=None):
         """Inference path of render_batch_ray for batches in which every ray has a depth prior: seven HIP
         launches (samples, KNN, IDW gather, three decoders, per-ray counts, compositing) and no torch glue.
         Returns None when a ray has no depth (sample_near_pcl is needed: general path)."""
         S = self.N_surface
-        R = rays_o.shape[0]
+        R = gt_depth.shape[0]
         g = decoders.geo_decoder
         rad = dynamic_r_query if self.use_dynamic_radius else None
-        z_vals, pts, views, rq, n_zero = point_ops.ray_samples(rays_o, rays_d, gt_depth, rad, S,
-                                                               self.near_end_surface, self.far_end_surface)
+        if camera is not None:
+            # render_img: the rays of this strip are formed inside the sampling kernel (get_rays fused, row R7)
+            cam, first_pixel = camera
+            z_vals, pts, views, rq, n_zero = point_ops.ray_samples_camera(cam, image_w, first_pixel, gt_depth, rad, S,
+                                                                          self.near_end_surface, self.far_end_surface)
+        else:
+            z_vals, pts, views, rq, n_zero = point_ops.ray_samples(rays_o, rays_d, gt_depth, rad, S,
+                                                                   self.near_end_surface, self.far_end_surface)
         # the zero-depth count travels to pinned host memory behind the sampling kernel; it is looked at after
         # the rest of the batch has been enqueued, so the device never waits for the host
         flag = self._pinned_flag()
@@ -114,6 +120,14 @@ class Renderer(object):
             self._flag = torch.zeros(1, dtype=torch.int32).pin_memory()
         return self._flag
 
+    def _fast_ok(self, decoders, probe, R, gt_depth, stage, npc_geo_feats, npc_col_feats, is_tracker, dynamic_r_query):
+        """the batch can take the all-HIP inference path (every ray must also have a depth prior: checked on the device)"""
+        return (gt_depth is not None and R > 0 and torch.numel(gt_depth) == R and stage in ('geometry', 'color')
+                and getattr(self, "use_fast_path", True)
+                and (dynamic_r_query is not None or not self.use_dynamic_radius)
+                and decoders._fused_ok(probe, npc_geo_feats, npc_col_feats, is_tracker, stage)
+                and decoders.geo_decoder.use_dynamic_radius == self.use_dynamic_radius)
+
     def render_batch_ray(self, npc, decoders, rays_d, rays_o, device, stage, gt_depth=None,
                          npc_geo_feats=None, npc_col_feats=None, is_tracker=False, cloud_pos=None,
                          dynamic_r_query=None, image_w=None):
@@ -122,11 +136,7 @@ class Renderer(object):
         at a row start - lets the neighbour search walk the image in patches; the result does not depend on it."""
         S = self.N_surface
         R = rays_o.shape[0]
-        if (gt_depth is not None and R > 0 and torch.numel(gt_depth) == R and stage in ('geometry', 'color')
-                and getattr(self, "use_fast_path", True)
-                and (dynamic_r_query is not None or not self.use_dynamic_radius)
-                and decoders._fused_ok(rays_o, npc_geo_feats, npc_col_feats, is_tracker, stage)
-                and decoders.geo_decoder.use_dynamic_radius == self.use_dynamic_radius):
+        if self._fast_ok(decoders, rays_o, R, gt_depth, stage, npc_geo_feats, npc_col_feats, is_tracker, dynamic_r_query):
             out = self._render_fast(npc, decoders, rays_d, rays_o, stage, gt_depth, npc_geo_feats,
                                     npc_col_feats, cloud_pos, dynamic_r_query, image_w=image_w)
             if out is not None:
@@ -168,8 +178,7 @@ class Renderer(object):
                    npc_col_feats=None, dynamic_r_query=None, cloud_pos=None):
         """Renderer.py:221-306"""
         H, W = self.H, self.W
-        rays_o, rays_d = get_rays(H, W, self.fx, self.fy, self.cx, self.cy, c2w, device)
-        rays_o, rays_d = rays_o.reshape(-1, 3), rays_d.reshape(-1, 3)
+        n_rays = H * W
         if self.use_dynamic_radius:
             dynamic_r_query = dynamic_r_query.reshape(-1, 1)
         gt = gt_depth.reshape(-1) if gt_depth is not None else None
@@ -178,12 +187,28 @@ class Renderer(object):
         if bs >= 16 * W:
             bs -= bs % (16 * W)          # whole 16-row strips: every batch starts at a row start (image_w hint below)
         image_w = W if bs % W == 0 else None
-        for i in range(0, rays_d.shape[0], bs):
-            ret = self.render_batch_ray(
-                npc, decoders, rays_d[i:i + bs], rays_o[i:i + bs], device, stage,
-                gt_depth=gt[i:i + bs] if gt is not None else None, npc_geo_feats=npc_geo_feats,
-                npc_col_feats=npc_col_feats, cloud_pos=cloud_pos,
-                dynamic_r_query=dynamic_r_query[i:i + bs] if self.use_dynamic_radius else None, image_w=image_w)
+        # strips in which every pixel has a depth prior never materialise their rays: get_rays (common.py:302-322) is
+        # evaluated inside the sampling kernel (row R7 fused into R4); the ray tensors are only built if a strip needs
+        # the general path
+        cam = point_ops.camera_block(c2w, self.fx, self.fy, self.cx, self.cy, device) \
+            if (image_w and gt is not None and gt.is_cuda and getattr(self, "fuse_get_rays", True)) else None
+        rays = None
+        for i in range(0, n_rays, bs):
+            g_i = gt[i:i + bs] if gt is not None else None
+            r_i = dynamic_r_query[i:i + bs] if self.use_dynamic_radius else None
+            ret = None
+            if cam is not None and self._fast_ok(decoders, g_i, g_i.shape[0], g_i, stage, npc_geo_feats, npc_col_feats,
+                                                 False, r_i):
+                ret = self._render_fast(npc, decoders, None, None, stage, g_i, npc_geo_feats, npc_col_feats, cloud_pos,
+                                        r_i, image_w=image_w, camera=(cam, i))
+            if ret is None:
+                if rays is None:
+                    rays_o, rays_d = get_rays(H, W, self.fx, self.fy, self.cx, self.cy, c2w, device)
+                    rays = (rays_o.reshape(-1, 3), rays_d.reshape(-1, 3))
+                ret = self.render_batch_ray(
+                    npc, decoders, rays[1][i:i + bs], rays[0][i:i + bs], device, stage, gt_depth=g_i,
+                    npc_geo_feats=npc_geo_feats, npc_col_feats=npc_col_feats, cloud_pos=cloud_pos,
+                    dynamic_r_query=r_i, image_w=image_w)
             for o, v in zip(outs, ret):
                 o.append(v)
         depth = torch.cat(outs[0]).double().reshape(H, W)

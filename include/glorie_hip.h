@@ -449,6 +449,15 @@ int glorie_ray_samples(const float* rays_o, const float* rays_d, const float* de
                        float* z_vals, float* pts, float* views, float* radius_s, int* n_zero,
                        void* stream);
 
+/* glorie_ray_samples for the rays of R consecutive row-major pixels of a pinhole view, starting at pixel first_pixel, formed
+ * in the kernel instead of read: get_rays (reference: src/utils/common.py:302-322, OpenGL convention) fused into the sample
+ * placement (scope rows R7 + R4; Renderer.render_img, src/utils/Renderer.py:221-306).
+ * cam: 16 device floats = c2w rows 0..2 (3 x 4, row-major), 1/fx, 1/fy (the double reciprocal rounded to fp32: how torch divides a
+ * tensor by a Python scalar), cx, cy.  Same bits as get_rays + glorie_ray_samples. */
+int glorie_ray_samples_camera(const float* cam, int image_w, long first_pixel, const float* depth, const float* radius,
+                              const float* t_lin, int R, int S, float near_s, float far_s, float* z_vals, float* pts,
+                              float* views, float* radius_s, int* n_zero, void* stream);
+
 /* proj_depth_map(c2w, npc, ...): z-buffer projection of a point set into a view
  *   reference: src/neural_point.py:446-506
  * points [n,3] world coordinates, mask [n] uint8 (NULL = all points), w2c = inverse of the camera-to-world

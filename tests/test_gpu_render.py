@@ -314,6 +314,32 @@ def test_render_img_matches_reference_renderer(gpu):
     _check_render(out, f, "img")
 
 
+def test_ray_samples_camera_equals_get_rays_plus_ray_samples(gpu):
+    """get_rays fused into the sample placement (row R7 + R4): the rays of a pixel strip formed in the kernel give the bits of
+    get_rays followed by ray_samples, for a rotated camera and a strip that starts and ends inside image rows"""
+    from glorie_slam_amd import point_ops
+    from glorie_slam_amd.common import get_rays
+    H, W, fx, fy, cx, cy = 48, 64, 51.3, 49.7, 31.2, 23.9
+    ang = np.array([0.3, -0.7, 1.1])
+    from scipy.spatial.transform import Rotation as Rot
+    c2w = np.eye(4, dtype=np.float32)
+    c2w[:3, :3] = Rot.from_rotvec(ang).as_matrix().astype(np.float32)
+    c2w[:3, 3] = [0.4, -1.3, 2.2]
+    ro, rd = get_rays(H, W, fx, fy, cx, cy, torch.from_numpy(c2w), gpu)
+    ro, rd = ro.reshape(-1, 3).contiguous(), rd.reshape(-1, 3).contiguous()
+    g = torch.Generator(device="cpu").manual_seed(3)
+    first, R = 64 * 5 + 17, 64 * 20 + 9
+    depth = (torch.rand(R, generator=g) * 3 + 0.5).to(gpu)
+    depth[5] = 0.0
+    radius = (torch.rand(R, generator=g) * 0.1 + 0.02).to(gpu)
+    a = point_ops.ray_samples(ro[first:first + R], rd[first:first + R], depth, radius, 10, 0.95, 1.05)
+    cam = point_ops.camera_block(c2w, fx, fy, cx, cy, gpu)
+    b = point_ops.ray_samples_camera(cam, W, first, depth, radius, 10, 0.95, 1.05)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    assert int(b[4]) == 1
+
+
 def test_render_fast_path_equals_general_path(gpu):
     """all rays with a depth prior: render_batch_ray takes the HIP-only path (ray_samples, KNN, gather,
     decoders, ray_counts, compositing); same numbers as the general path built from torch ops.  One ray
