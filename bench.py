@@ -646,6 +646,8 @@ def main():
                           "measured_hbm_frac": (corr_traffic / (corr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
                           if (full and corr_traffic) else None},
         "rays_per_sec": rays_per_s,
+        # the frame is a fixed ray budget split over the ranks (strong scaling); the BA-update graph grows with N (weak)
+        "rays_scaling": "strong",
         "rays_per_sec_batch5000": 5000.0 / (batch_ms * 1e-3), "ms_per_batch5000": batch_ms,
         "train_batch5000": train,
         "render": {"rays_local": int(n_r // render_reps), "samples_per_ray": int(S), "cloud_points": int(npc.pts_num()),
