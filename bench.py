@@ -464,7 +464,7 @@ def main():
         corr_fn = lambda: fl.encode_into(fu.W["ce1_p"], fu.W["ce1_b"], c1buf)
         corr_kernel = "corr_otf8_kernel<false,true> (volume-free MFMA lookup, 8x8 source tiles, + fused corr_encoder[0])"
     else:
-        corr_fn = lambda: graph.corr(coords1)
+        corr_fn = lambda: graph.corr(coords1, channels_last=True)    # as the step launches it (FactorGraph.update)
         corr_kernel = "corr_lookup_r3_tiled_kernel (fp16, 4x8-tiled pyramid)"
     for _ in range(3):
         corr_fn()

@@ -278,6 +278,12 @@ __global__ __launch_bounds__(256) void corr_lookup_r3_v2_kernel(
 // ------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
+// CL: the output is channels-last with the window padded to 8 x 8 per level - channel l * 64 + row * 8 + tap, rows / taps 7
+// zero - i.e. one 512-byte row of 256 halfs per pixel.  The lane that owns window row `row` of a pixel then writes ONE 16-byte
+// piece (its 7 taps + a zero), the 8 row lanes of a pixel group together one full 128-byte line per (pixel, level): the same
+// store efficiency as the planar layout, and corr_encoder[0] can consume the map as a 1x1 implicit-GEMM convolution with
+// permuted weight columns (no library GEMM over the planar layout, no separate bias / ReLU pass).
+template <bool CL>
 __global__ __launch_bounds__(256) void corr_lookup_r3_tiled_kernel(
     CorrLevels lv, int num_levels, const float* __restrict__ coords, _Float16* __restrict__ out,
     int HW, int out_channels, const int* __restrict__ slots) {
@@ -357,7 +363,19 @@ __global__ __launch_bounds__(256) void corr_lookup_r3_tiled_kernel(
       for (int i = 0; i < RD; ++i)
         o[i].v[q] = blend4(sq[i], nx[i], sq[i + 1], nx[i + 1], w00, w01, w10, w11);
     }
-    if (live && row < RD) {
+    if (CL) {
+      if (live) {
+        T* op = out + ((size_t)n * HW + pb) * out_channels + l * 64 + row * 8;
+#pragma unroll
+        for (int q = 0; q < PG; ++q) {
+          Out8<T> px;
+#pragma unroll
+          for (int i = 0; i < RD; ++i) px.v[i] = row < RD ? o[i].v[q] : (T)0.0f;
+          px.v[RD] = (T)0.0f;
+          *reinterpret_cast<Out8<T>*>(op + (size_t)q * out_channels) = px;
+        }
+      }
+    } else if (live && row < RD) {
       T* op = out + ((size_t)n * out_channels + (size_t)l * RD * RD + row) * HW + pb;
 #pragma unroll
       for (int i = 0; i < RD; ++i)
@@ -468,7 +486,7 @@ extern "C" int glorie_corr_lookup_pyramid(const void* const* volumes, int num_le
 }
 
 static int lookup_tiled(const void* const* volumes, int num_levels, const float* coords, void* out, int N, int h1,
-                        int w1, int h2, int w2, const int* slots, void* stream);
+                        int w1, int h2, int w2, const int* slots, void* stream, bool channels_last = false);
 
 extern "C" int glorie_corr_lookup_pyramid_tiled(const void* const* volumes, int num_levels,
                                                 const float* coords, void* out, int N, int h1, int w1,
@@ -483,8 +501,15 @@ extern "C" int glorie_corr_lookup_arena(const void* const* levels, int num_level
   return lookup_tiled(levels, num_levels, coords, out, N, h1, w1, h2, w2, slots, stream);
 }
 
+extern "C" int glorie_corr_lookup_tiled_cl(const void* const* levels, int num_levels, const int* slots,
+                                           const float* coords, void* out, int N, int h1, int w1, int h2, int w2,
+                                           void* stream) {
+  if (num_levels != 4) return GLORIE_EUNSUPPORTED;             // the 256-channel row holds 4 levels of 8 x 8
+  return lookup_tiled(levels, num_levels, coords, out, N, h1, w1, h2, w2, slots, stream, true);
+}
+
 static int lookup_tiled(const void* const* volumes, int num_levels, const float* coords, void* out, int N, int h1,
-                        int w1, int h2, int w2, const int* slots, void* stream) {
+                        int w1, int h2, int w2, const int* slots, void* stream, bool channels_last) {
   if (num_levels < 1 || num_levels > kMaxLevels || N < 0 || h1 < 0 || w1 < 0) return GLORIE_EINVAL;
   const int HW = h1 * w1;
   if (N == 0 || HW == 0) return GLORIE_OK;
@@ -499,7 +524,11 @@ static int lookup_tiled(const void* const* volumes, int num_levels, const float*
     lv.w2[l] = w2 >> l;
   }
   dim3 grid((HW + 255) / 256, N);
-  hipLaunchKernelGGL(corr_lookup_r3_tiled_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     lv, num_levels, coords, reinterpret_cast<_Float16*>(out), HW, num_levels * 49, slots);
+  if (channels_last)
+    hipLaunchKernelGGL(corr_lookup_r3_tiled_kernel<true>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       lv, num_levels, coords, reinterpret_cast<_Float16*>(out), HW, num_levels * 64, slots);
+  else
+    hipLaunchKernelGGL(corr_lookup_r3_tiled_kernel<false>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       lv, num_levels, coords, reinterpret_cast<_Float16*>(out), HW, num_levels * 49, slots);
   return check_launch();
 }

@@ -287,6 +287,7 @@ class FusedUpdate:
         W["ce1_t"] = m.corr_encoder[0].weight.detach().view(128, -1).t().half().contiguous()
         W["ce1_b"] = f32(m.corr_encoder[0].bias)
         W["ce1_p"] = OtfCorrBlock.pack_encoder(m.corr_encoder[0].weight)
+        W["ce1_cl"] = U.pack_corr_encoder(m.corr_encoder[0].weight)
         W["ce2"], W["ce2_b"] = U.pack_conv_igemm(m.corr_encoder[2].weight), f32(m.corr_encoder[2].bias)
         W["fe1"], W["fe1_b"] = U.pack_flow_conv7(m.flow_encoder[0].weight), f32(m.flow_encoder[0].bias)
         W["fe2"], W["fe2_b"] = U.pack_conv_igemm(m.flow_encoder[2].weight), f32(m.flow_encoder[2].bias)
@@ -427,9 +428,14 @@ class FusedUpdate:
         else:
             if callable(corr):
                 corr = corr()                          # the lookup itself, issued behind the forks
-            c1 = torch.matmul(corr.reshape(n, -1, hw).half().transpose(1, 2), W["ce1_t"])
-            c1 = c1.view(n, ht, wd, 128).permute(0, 3, 1, 2)
-            U.bias_act(c1, W["ce1_b"], U.ACT_RELU)
+            if corr.dim() == 4 and corr.shape[1] == 256 and corr.dtype == torch.float16:
+                # channels-last lookup (corr_lookup_tiled_cl): the 1x1 encoder is an implicit-GEMM launch with the
+                # bias and the ReLU in its epilogue - no library GEMM over the planar map, no separate bias pass
+                c1 = U.conv_igemm(corr, None, W["ce1_cl"], 1, 128, cl_map(128), terms=W["ce1_b"], act=U.ACT_RELU)
+            else:
+                c1 = torch.matmul(corr.reshape(n, -1, hw).half().transpose(1, 2), W["ce1_t"])
+                c1 = c1.view(n, ht, wd, 128).permute(0, 3, 1, 2)
+                U.bias_act(c1, W["ce1_b"], U.ACT_RELU)
         U.conv_igemm(c1, None, W["ce2"], 9, 128, hx[:, 128:256], terms=W["ce2_b"], act=U.ACT_RELU)
         for st in side:
             if st is not main:
@@ -520,9 +526,11 @@ class CorrBlock:
         b = fmap2.reshape(batch * num, dim, ht * wd) / 4.0
         return torch.matmul(a.transpose(1, 2), b).view(batch, num, ht, wd, ht, wd)
 
-    def __call__(self, coords):
+    def __call__(self, coords, channels_last=False):
         batch, num, ht, wd, _ = coords.shape
         c = coords.permute(0, 1, 4, 2, 3).contiguous().view(batch * num, 2, ht, wd).float()
+        if channels_last and self.tiled and self.num_levels == 4 and self.radius == 3:
+            return droid_backends.corr_lookup_tiled_cl(self.corr_pyramid, c, self.dims[2], self.dims[3])
         if self.tiled:
             out = droid_backends.corr_lookup_pyramid_tiled(self.corr_pyramid, c, self.dims[2], self.dims[3])
         else:
@@ -635,7 +643,9 @@ class CorrArena:
         self._host_slots = kept
         self.slots = torch.tensor(kept, dtype=torch.int32, device=self.device)
 
-    def __call__(self, coords):
+    def __call__(self, coords, channels_last=False):
+        """channels_last: the [N,256,h,w] fp16 map of droid_backends.corr_lookup_tiled_cl (what FusedUpdate consumes)
+        instead of the reference's [batch, num, 196, h, w]"""
         import ctypes
         from . import _lib as L
         batch, num, ht, wd, _ = coords.shape
@@ -643,6 +653,8 @@ class CorrArena:
         if N != len(self._host_slots):
             raise RuntimeError(f"CorrArena holds {len(self._host_slots)} edges, coords has {N}")
         c = coords.permute(0, 1, 4, 2, 3).contiguous().view(N, 2, ht, wd).float()
+        if channels_last and self.num_levels == 4:
+            return droid_backends.corr_lookup_tiled_cl(self.views(), c, self.h, self.w, slots=self.slots)
         out = torch.empty((N, self.num_levels * 49, ht, wd), dtype=torch.float16, device=c.device)
         v = self.views()
         arr = (ctypes.c_void_p * self.num_levels)(*[t.data_ptr() for t in v])

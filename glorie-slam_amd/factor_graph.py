@@ -351,6 +351,8 @@ class FactorGraph:
             oi, oj = self._graphs[ck]
             lookup = FusedLookup(blk, coords1, oi, oj) if (self.fast_update is not None and blk.num_levels == 4) \
                 else (lambda: blk(coords1, oi, oj))
+        elif self.fast_update is not None and isinstance(self.corr, (CorrArena, CorrBlock)):
+            lookup = lambda: self.corr(coords1, channels_last=True)      # what FusedUpdate's 1x1 encoder consumes
         else:
             lookup = lambda: self.corr(coords1)
         uniq = self._unique_ii()

@@ -161,6 +161,19 @@ def pack_conv_igemm(weight):
     return torch.cat([w.reshape(-1), torch.zeros(64, dtype=torch.float16, device=weight.device)])
 
 
+def pack_corr_encoder(weight):
+    """corr_encoder[0] weight [128, 196, 1, 1] (droid_net.py:73-75) -> the 1x1 operand of glorie_conv_igemm over the
+    channels-last lookup of glorie_corr_lookup_tiled_cl: column l*64 + dy*8 + dx takes the reference's column
+    l*49 + dx*7 + dy, the padding columns are zero"""
+    nout, C = weight.shape[0], weight.shape[1]
+    if C != 196 or tuple(weight.shape[2:]) != (1, 1):
+        raise RuntimeError("pack_corr_encoder: expected a [n, 196, 1, 1] weight")
+    w = weight.detach().reshape(nout, 4, 7, 7)                 # [n][level][dx][dy]
+    wp = torch.zeros(nout, 4, 8, 8, dtype=w.dtype, device=w.device)
+    wp[:, :, :7, :7] = w.permute(0, 1, 3, 2)                  # [n][level][dy][dx]
+    return pack_conv_igemm(wp.reshape(nout, 256, 1, 1))
+
+
 def conv_igemm(xa, xb, w_packed, taps, nout, out, epilogue=EPI_BIAS_ACT, terms=None, act=ACT_NONE,
                net=None, z=None, out2=None, pre=None, pre_map=None):
     """Implicit-GEMM convolution with fused epilogue (csrc/conv.hip, include/glorie_hip.h).

@@ -18,7 +18,7 @@ dev = torch.device("cuda:0")
 g, video, graph = bench.build_graph(dev)
 coords1, _ = video.reproject(graph.ii, graph.jj)
 for _ in range(3):
-    graph.corr(coords1)
+    graph.corr(coords1, channels_last=True)
 conv_launch, _ = bench.gru_gate_conv_workload(dev, graph.ii.shape[0], graph.ht, graph.wd,
                                               graph.ii if graph.share_context else None)
 for _ in range(3):

@@ -87,6 +87,15 @@ def test_corr_lookup_tiled_bit_exact(gpu, N, h, w, margin):
     assert torch.equal(got.view(torch.int16), plain.view(torch.int16))
     ref = ocorr.corr_lookup_pyramid(levels, coords, 3)          # every size, incl. the BASELINE 60x80 planes
     assert np.array_equal(got.cpu().numpy().view(np.uint16), ref.view(np.uint16))
+    # channels-last form for the fused update operator: the same values at channel l*64 + dy*8 + dx, padding zero
+    if (h * w) % 8 == 0:
+        cl = db.corr_lookup_tiled_cl(tiled, ct, h, w)
+        assert cl.shape == (N, 256, h, w) and cl.is_contiguous(memory_format=torch.channels_last)
+        v = cl.view(N, 4, 8, 8, h, w)                              # [n][level][dy][dx][y][x]
+        assert float(v[:, :, 7].abs().max()) == 0.0 and float(v[:, :, :, 7].abs().max()) == 0.0
+        planar = got.view(N, 4, 7, 7, h, w)                        # [n][level][dx][dy][y][x]
+        assert torch.equal(v[:, :, :7, :7].contiguous().view(torch.int16),
+                           planar.permute(0, 1, 3, 2, 4, 5).contiguous().view(torch.int16))
 
 
 def test_corrblock_tiled_cat_and_index(gpu):

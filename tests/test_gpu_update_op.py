@@ -211,6 +211,30 @@ def test_fused_update_without_graph_aggregation_and_repack(gpu):
     assert torch.isfinite(out3[0].float()).all()
 
 
+def test_fused_update_on_the_channels_last_lookup(gpu):
+    """corr_encoder[0] as a 1x1 implicit-GEMM convolution over the channels-last lookup (permuted weight columns, bias and
+    ReLU in the epilogue) against the library GEMM over the planar map: same operator, only the fp16 GEMM's summation order
+    differs"""
+    from glorie_slam_amd.droid_net import FusedUpdate, UpdateModule
+    torch.manual_seed(6)
+    mod = UpdateModule().to(gpu).eval()
+    n, h, w = 5, 12, 16
+    ii = torch.tensor([0, 0, 1, 2, 2], device=gpu)
+    jj = torch.tensor([1, 2, 0, 0, 1], device=gpu)
+    net = torch.randn(1, n, 128, h, w, device=gpu).half()
+    inp = torch.randn(1, n, 128, h, w, device=gpu).half()
+    corr = torch.randn(1, n, 196, h, w, device=gpu).half()
+    flow = torch.randn(1, n, 4, h, w, device=gpu)
+    cl = torch.zeros(n, 4, 8, 8, h, w, device=gpu, dtype=torch.float16)
+    cl[:, :, :7, :7] = corr.view(n, 4, 7, 7, h, w).permute(0, 1, 3, 2, 4, 5)
+    cl = cl.view(n, 256, h, w).contiguous(memory_format=torch.channels_last)
+    a, b = FusedUpdate(mod), FusedUpdate(mod)
+    ra = a(net, inp, corr, flow, ii, jj)
+    rb = b(net, inp, cl, flow, ii, jj)
+    for x, y in zip(ra, rb):
+        torch.testing.assert_close(x.float(), y.float(), atol=4e-3, rtol=4e-3)
+
+
 def test_shared_context_term_equals_per_edge_term(gpu):
     """Edges with the same source keyframe have the same context features: the hoisted gate term kept once per
     keyframe and read through pre_map gives the bits of the per-edge term."""
