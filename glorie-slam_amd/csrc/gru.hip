@@ -395,6 +395,41 @@ extern "C" int glorie_gru_gate_q(const void* qc, int q_stride, const float* gq, 
   return check_launch();
 }
 
+// Bookkeeping between the update operator and the BA (factor_graph.py:219-223,248): target = coords1 + delta,
+// damping[frames] = eta, the BA's damping input 0.2 * eta + EP, and the age of every edge - four element-wise torch
+// launches and a gather in the reference's formulation, one launch here.
+__global__ __launch_bounds__(256) void update_bookkeeping_kernel(
+    const float* __restrict__ coords1, const float* __restrict__ delta, float* __restrict__ target, long n_target,
+    const float* __restrict__ eta, const int64_t* __restrict__ frames, float* __restrict__ damping_table,
+    float* __restrict__ damping_ba, long n_eta, int HW, float ep, int64_t* __restrict__ age, int n_edges) {
+#pragma clang fp contract(off)
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n_target) target[i] = coords1[i] + delta[i];
+  if (i < n_eta) {
+    const float e = eta[i];
+    const long g = i / HW;
+    damping_table[(size_t)frames[g] * HW + (i - g * HW)] = e;
+    const float m = e * 0.2f;
+    damping_ba[i] = m + ep;
+  }
+  if (age && i < n_edges) age[i] += 1;
+}
+
+extern "C" int glorie_update_bookkeeping(const float* coords1, const float* delta, float* target, long n_target,
+                                         const float* eta, const int64_t* frames, float* damping_table,
+                                         float* damping_ba, int G, int HW, float ep, int64_t* age, int n_edges,
+                                         void* stream) {
+  if (n_target < 0 || G < 0 || HW <= 0 || n_edges < 0) return GLORIE_EINVAL;
+  const long n_eta = (long)G * HW;
+  const long n = n_target > n_eta ? n_target : n_eta;
+  if (n == 0) return GLORIE_OK;
+  if ((n_target && (!coords1 || !delta || !target)) || (n_eta && (!eta || !frames || !damping_table || !damping_ba)))
+    return GLORIE_EINVAL;
+  hipLaunchKernelGGL(update_bookkeeping_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     coords1, delta, target, n_target, eta, frames, damping_table, damping_ba, n_eta, HW, ep, age, n_edges);
+  return check_launch();
+}
+
 extern "C" int glorie_segment_mean(const void* x, int x_stride, const float* bias, int relu,
                                    const int64_t* ix, int N, void* out, int o_stride, int G, int HW,
                                    void* stream) {

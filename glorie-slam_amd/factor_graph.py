@@ -372,13 +372,32 @@ class FactorGraph:
                     self.update_op(self.net, self.inp, corr, motn, self.ii, self.jj)
         if t0 is None or t1 is None:
             t0, t1 = self._window(t0, t1, use_inactive)
-        if self.target.shape == coords1.shape and self.target.dtype == torch.float32 and self.target.is_contiguous():
+        sharded = getattr(self.video, "shard", None) is not None and self.video.shard["world"] > 1
+        # target = coords1 + delta, damping[uniq] = eta, the BA's damping 0.2 * eta + EP and age += 1 in ONE launch
+        # (glorie_update_bookkeeping) when the tensors are the plain fp32 ones of the fused operator
+        fused_book = (self.fast_update is not None and not use_inactive and not sharded and coords1.is_cuda
+                      and self.target.shape == coords1.shape and self.target.dtype == torch.float32
+                      and self.target.is_contiguous() and coords1.is_contiguous() and coords1.dtype == torch.float32
+                      and delta.dtype == torch.float32 and delta.is_contiguous() and delta.shape == coords1.shape
+                      and damping.dtype == torch.float32 and damping.is_contiguous()
+                      and self.damping.dtype == torch.float32 and self.damping.is_contiguous()
+                      and damping.numel() == uniq.shape[0] * self.ht * self.wd and self.age.is_contiguous())
+        damping_ba = None
+        if fused_book:
+            from . import _lib as L
+            damping_ba = torch.empty((uniq.shape[0], self.ht, self.wd), dtype=torch.float32, device=coords1.device)
+            L.check(L.load().glorie_update_bookkeeping(
+                L.ptr(coords1), L.ptr(delta), L.ptr(self.target), coords1.numel(), L.ptr(damping), L.ptr(uniq),
+                L.ptr(self.damping), L.ptr(damping_ba), int(uniq.shape[0]), self.ht * self.wd, float(EP), L.ptr(self.age),
+                int(self.age.shape[0]), L.stream_ptr()), "glorie_update_bookkeeping")
+            self._age_done = True
+        elif self.target.shape == coords1.shape and self.target.dtype == torch.float32 and self.target.is_contiguous():
             torch.add(coords1, delta.to(dtype=torch.float), out=self.target)   # no new tensor, no copy when captured
         else:
             self.target = coords1 + delta.to(dtype=torch.float)
         self.weight = weight.to(dtype=torch.float)
-        self.damping[uniq] = damping.to(self.damping.dtype)
-        sharded = getattr(self.video, "shard", None) is not None and self.video.shard["world"] > 1
+        if not fused_book:
+            self.damping[uniq] = damping.to(self.damping.dtype)
         if use_inactive:
             # the inactive factors that still touch the window (factor_graph.py:232-238) do not change while
             # the edge set stays the same: their indices, the frame list and one [inactive | active] buffer
@@ -407,7 +426,9 @@ class FactorGraph:
             if ck not in self._graphs:
                 self._graphs[ck] = torch.unique(torch.cat([torch.arange(t0, t1, device=ii.device), ii]))
             uq = self._graphs[ck]
-        if uq is uniq:
+        if uq is uniq and damping_ba is not None:
+            damping = damping_ba
+        elif uq is uniq:
             # same frames as just written: 0.2 * eta + EP straight from the operator's output (no gather)
             damping = damping.reshape(-1, self.ht, self.wd).to(self.damping.dtype).mul(0.2).add_(EP)
         else:
@@ -435,7 +456,10 @@ class FactorGraph:
         if getattr(self.video, "shard", None) is not None and self.video.shard["world"] > 1:
             self.video.sync_owned_state()
             self.video.mark_upsampled()
-        self.age += 1
+        if getattr(self, "_age_done", False):
+            self._age_done = False                  # incremented by the bookkeeping launch of this update
+        else:
+            self.age += 1
 
     @torch.no_grad()
     def update_lowmem(self, t0=None, t1=None, itrs=2, use_inactive=False, EP=1e-7, steps=8,

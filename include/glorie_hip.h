@@ -149,6 +149,16 @@ int glorie_altcorr_fwd(const float* fmap1, const float* fmap2, const float* coor
                        float* out, int B, int S, int H, int W, int H2, int W2, int C,
                        int radius, void* stream);
 
+/* Bookkeeping of FactorGraph.update between the update operator and the BA, in one launch
+ *   reference: src/factor_graph.py:219-223 (target = coords1 + delta, damping[unique(ii)] = damping), :248
+ *   (BA damping 0.2 * damping + EP), :256 (age += 1)
+ * coords1 / delta / target: n_target floats ([N,h,w,2]); eta [G,HW] = the operator's damping output for the G frames
+ * `frames` (int64 [G]); damping_table [B,HW] receives the rows, damping_ba [G,HW] = 0.2 * eta + ep (each op rounded
+ * separately, as the torch chain); age int64 [n_edges] is incremented (may be NULL). */
+int glorie_update_bookkeeping(const float* coords1, const float* delta, float* target, long n_target,
+                              const float* eta, const int64_t* frames, float* damping_table, float* damping_ba,
+                              int G, int HW, float ep, int64_t* age, int n_edges, void* stream);
+
 /* Fused stages of UpdateModule / ConvGRU / GraphAgg between the (MIOpen) convolutions
  *   reference: src/modules/droid_net/gru.py:20-34, src/modules/droid_net/droid_net.py:34-66,106-139
  * All activations are channels-last fp16: row p (= edge*HW + pixel) holds C contiguous halfs;

@@ -1,5 +1,6 @@
-"""Prints the kernels of the last BA-update step of a rocprofv3 kernel trace (csv), i.e. everything
-between two consecutive launches of a marker kernel (the fullest such window).  Usage: python tools/trace_step.py <kernel_trace.csv> [marker]"""
+"""Prints the kernels of one BA-update step of a rocprofv3 kernel trace (csv): everything between two consecutive launches
+of a marker kernel.  Usage: python tools/trace_step.py <kernel_trace.csv> [marker] [k]
+k omitted: the fullest window (latest wins); k given: the k-th window that holds 30..120 kernels (a regular step)."""
 import csv
 import sys
 
@@ -7,8 +8,11 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 marker = sys.argv[2] if len(sys.argv) > 2 else "corr_lookup"
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"]]
-# the window between consecutive markers with the most kernels in it, latest wins
-a, b = max(zip(idx[:-1], idx[1:]), key=lambda ab: (ab[1] - ab[0], ab[0]))
+pairs = list(zip(idx[:-1], idx[1:]))
+if len(sys.argv) > 3:
+    a, b = [ab for ab in pairs if 30 <= ab[1] - ab[0] <= 120][int(sys.argv[3])]
+else:
+    a, b = max(pairs, key=lambda ab: (ab[1] - ab[0], ab[0]))
 tot = 0.0
 t_first = int(rows[a]["Start_Timestamp"])
 for r in rows[a:b]:
