@@ -498,8 +498,12 @@ class FactorGraph:
                 continue
             v = slice(None) if bool(vh.all()) else torch.as_tensor(vh, device=self.device)
             iis, jjs = self.ii[v], self.jj[v]
-            chunks.append((v, iis, jjs, rig * iis, rig * jjs + (iis == jjs).long(), torch.unique(iis),
-                           self.video.inps[None, iis]))
+            uq_c, ix_c = torch.unique(iis, sorted=True, return_inverse=True)
+            # (the per-edge context tensor of the reference call is only gathered when the operator needs it: with the
+            # shared-context form the gate term is evaluated per source keyframe straight from video.inps)
+            share = self.fast_update is not None and self.share_context
+            chunks.append((v, iis, jjs, rig * iis, rig * jjs + (iis == jjs).long(), uq_c,
+                           None if share else self.video.inps[None, iis], (uq_c, ix_c) if share else None))
         if self.fast_update is not None and self._lowmem_update is None:
             self._lowmem_update = [FusedUpdate(self.update_op)]
         while self.fast_update is not None and len(self._lowmem_update) < min(len(chunks), 4):
@@ -507,7 +511,7 @@ class FactorGraph:
         for step in range(steps):
             coords1, mask = self.video.reproject(self.ii, self.jj)
             motn = self._motion(coords1)
-            for ci, (v, iis, jjs, ci1, cj1, uq, inp) in enumerate(chunks):
+            for ci, (v, iis, jjs, ci1, cj1, uq, inp, ctx) in enumerate(chunks):
                 whole = isinstance(v, slice)
                 corr1 = corr_op(coords1 if whole else coords1[:, v], ci1, cj1)
                 net_in = self.net if whole else self.net[:, v]
@@ -516,7 +520,9 @@ class FactorGraph:
                     # chunks differ in size: separate FusedUpdate objects (own buffers, never in place); the
                     # first four chunks keep their hoisted context term across the steps
                     fu = self._lowmem_update[min(ci, len(self._lowmem_update) - 1)]
-                    net, delta, weight, damping, upmask = fu(net_in, inp, corr1, mot_in, iis, jjs)
+                    net, delta, weight, damping, upmask = fu(
+                        net_in, inp, corr1, mot_in, iis, jjs,
+                        context=(self.video.inps, ctx[0], ctx[1]) if ctx is not None else None)
                     self.video.upsample(uq, upmask, softmax_f32=True)   # inside autocast in the reference: fp32 softmax
                 else:
                     with torch.autocast("cuda", enabled=True):
