@@ -943,7 +943,8 @@ extern "C" int glorie_conv_igemm(const void* xa, int xa_stride, int ca, const vo
   // Tile choice.  Default: 128 x 128 (3 workgroups per CU); layers whose output channels are a multiple of 256 (the z|r
   // gates) take 256 channels x 128 pixels - 4 waves of 128 x 64, 2 workgroups per CU, 25 % fewer staged bytes per MFMA:
   // 448 -> 256 at 36x60x80 345 -> 315 us, the fused gate launch 277 -> 265 us stand-alone.
-  // Measured and NOT used: 128 channels x 256 pixels for the 128-channel layers (q gate 174 -> 176 us); 64-pixel tiles
+  // Measured and NOT used: 192 channels x 128 pixels for the 384-channel head convolution (155 -> 167 us);
+  // 128 channels x 256 pixels for the 128-channel layers (q gate 174 -> 176 us); 64-pixel tiles
   // (4 per CU; z|r 329 us); whole rounds on 128-pixel tiles + the remainder as a second launch of 64-pixel tiles
   // (292 us: a 64-pixel workgroup costs 0.8 of a 128-pixel one and workgroups do not run in lockstep rounds, so the
   // partly filled last round is cheaper than a round model says).  GLORIE_CONV_TILE = 128 | 64 | split | wide keeps the
