@@ -162,15 +162,34 @@ __global__ __launch_bounds__(512, 4) void mlp_geo_v3_kernel(GeoParams P, const f
       c[0] = f32x4{0.f, 0.f, 0.f, 0.f};
       c[1] = f32x4{0.f, 0.f, 0.f, 0.f};
       const bool on = has[q] != 0;
+      // the rows of GEO_NB neighbours are requested together and unconditionally (index clamped, zero-weight rows dropped
+      // by a select - the same bits): a load under `if (wk != 0)` is one exposed L2 round trip per neighbour at the head
+      // of every workgroup
+#ifndef GLORIE_GEO_NB
+#define GLORIE_GEO_NB 2
+#endif
+      constexpr int GEO_NB = GLORIE_GEO_NB;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const float wk = wts[(size_t)q * 8 + k];
-        const long ik = I[(size_t)q * 8 + k];
-        if (on && wk != 0.0f) {
+      for (int k0 = 0; k0 < 8; k0 += GEO_NB) {
+        float wk[GEO_NB];
+        float4 v[GEO_NB][2];
+#pragma unroll
+        for (int k = 0; k < GEO_NB; ++k) {
+          wk[k] = wts[(size_t)q * 8 + k0 + k];
+          const long ik = max(I[(size_t)q * 8 + k0 + k], 0L);
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+            v[k][t] = *reinterpret_cast<const float4*>(geo_feats + (size_t)ik * 32 + 16 * t + 4 * g);
+        }
+#pragma unroll
+        for (int k = 0; k < GEO_NB; ++k) {
+          const bool use = on && wk[k] != 0.0f;
 #pragma unroll
           for (int t = 0; t < 2; ++t) {
-            const float4 v = *reinterpret_cast<const float4*>(geo_feats + (size_t)ik * 32 + 16 * t + 4 * g);
-            c[t][0] += wk * v.x; c[t][1] += wk * v.y; c[t][2] += wk * v.z; c[t][3] += wk * v.w;
+            c[t][0] = use ? c[t][0] + wk[k] * v[k][t].x : c[t][0];
+            c[t][1] = use ? c[t][1] + wk[k] * v[k][t].y : c[t][1];
+            c[t][2] = use ? c[t][2] + wk[k] * v[k][t].z : c[t][2];
+            c[t][3] = use ? c[t][3] + wk[k] * v[k][t].w : c[t][3];
           }
         }
       }
