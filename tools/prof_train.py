@@ -10,7 +10,7 @@ from glorie_slam_amd.render_train import FeatureAdam
 dev = torch.device("cuda", 0)
 npc, dec, ren, rays = bench.build_renderer(dev)
 pick = torch.randperm(rays["o"].shape[0], generator=torch.Generator().manual_seed(5))[:5000].to(dev)
-b5 = {k: v[pick].contiguous() for k, v in rays.items()}
+b5 = {k: v[pick].contiguous() for k, v in rays.items() if torch.is_tensor(v)}
 gt = torch.rand(5000, 3, device=dev)
 hip = os.environ.get("TRAIN_TORCH") is None
 geo = npc.geo_feats.detach().clone().requires_grad_(True)
