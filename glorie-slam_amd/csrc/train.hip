@@ -29,19 +29,22 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 enum { TACT_NONE = 0, TACT_RELU = 1, TACT_SOFTPLUS = 2, TACT_SIGMOID = 3 };
 constexpr float kBeta = 100.0f;       // nn.Softplus(beta=100), decoder.py:108,312
 
+// The transcendental parts run on the hardware's v_exp_f32 / v_log_f32 (base 2), like the inference kernels of
+// csrc/mlp.hip: libm's expf / log1pf are ~60 VALU instructions per element and the 128-wide softplus layers of the
+// per-neighbour network apply them to 51 M elements per pass.
 __device__ __forceinline__ float t_act(float v, int act) {
   if (act == TACT_RELU) return fmaxf(v, 0.0f);
-  if (act == TACT_SOFTPLUS) {         // torch: x if beta x > 20 else log1p(exp(beta x)) / beta
-    const float bx = kBeta * v;
-    return bx > 20.0f ? v : log1pf(expf(bx)) / kBeta;
+  if (act == TACT_SOFTPLUS) {         // softplus(beta = 100) = max(x, 0) + ln(1 + exp(-beta |x|)) / beta (exactly x beyond beta x = 20 in fp32)
+    const float e = __builtin_amdgcn_exp2f(-144.26950408889634f * __builtin_fabsf(v));
+    return fmaf(0.006931471805599453f, __builtin_amdgcn_logf(1.0f + e), fmaxf(v, 0.0f));
   }
-  if (act == TACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
+  if (act == TACT_SIGMOID) return 1.0f / (1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
   return v;
 }
 // derivative of the activation expressed through its OUTPUT y (only outputs are saved)
 __device__ __forceinline__ float t_dact(float y, int act) {
   if (act == TACT_RELU) return y > 0.0f ? 1.0f : 0.0f;
-  if (act == TACT_SOFTPLUS) return 1.0f - expf(-kBeta * y);        // sigmoid(beta z) = 1 - exp(-beta softplus(z))
+  if (act == TACT_SOFTPLUS) return 1.0f - __builtin_amdgcn_exp2f(-144.26950408889634f * y);   // sigmoid(beta z) = 1 - exp(-beta softplus(z))
   if (act == TACT_SIGMOID) return y * (1.0f - y);
   return 1.0f;
 }
@@ -96,22 +99,31 @@ __global__ __launch_bounds__(256) void mm_rows_kernel(MmArgs a) {
       Ws[buf][rr * kWsLd + j] = v;
     }
   };
-  stage(0, 0);
-  __syncthreads();
-  for (int c = 0; c < nchunk; ++c) {
-    const int buf = c & 1;
-    if (c + 1 < nchunk) stage(c + 1, buf ^ 1);
+  // the A operands of chunk c + 1 are requested before the MFMAs of chunk c (one exposed global round trip per 16
+  // reduction indices otherwise: as long as the 32-52 MFMAs of a chunk themselves)
+  auto load_a = [&](int c, float (&out)[4]) {
     const int r0 = c * 16;
-    float av[4];
     if (vec && r0 + 16 <= a.R) {
       const float4 v = *reinterpret_cast<const float4*>(xrow + r0 + 4 * g);
-      av[0] = qok ? v.x : 0.f; av[1] = qok ? v.y : 0.f; av[2] = qok ? v.z : 0.f; av[3] = qok ? v.w : 0.f;
+      out[0] = qok ? v.x : 0.f; out[1] = qok ? v.y : 0.f; out[2] = qok ? v.z : 0.f; out[3] = qok ? v.w : 0.f;
     } else {
 #pragma unroll
       for (int s_ = 0; s_ < 4; ++s_) {
         const int r = r0 + 4 * g + s_;
-        av[s_] = (qok && r < a.R) ? xrow[r] : 0.0f;
+        out[s_] = (qok && r < a.R) ? xrow[r] : 0.0f;
       }
+    }
+  };
+  float an[4];
+  load_a(0, an);
+  stage(0, 0);
+  __syncthreads();
+  for (int c = 0; c < nchunk; ++c) {
+    const int buf = c & 1;
+    float av[4] = {an[0], an[1], an[2], an[3]};
+    if (c + 1 < nchunk) {
+      load_a(c + 1, an);
+      stage(c + 1, buf ^ 1);
     }
     if (q0 < a.Q) {
 #pragma unroll
@@ -162,10 +174,11 @@ struct WgArgs {
   float* db;
   long Q; int N, K; long rows_per_wg;
   int Ns, Ks;                 // LDS row strides (== 16 mod 32: conflict-free operand reads)
+  int vec_y, vec_x;           // rows can be staged in 16-byte pieces (N resp. K, the leading dimension and the base 16-byte aligned)
 };
 
 constexpr int kWgTiles = 28;
-constexpr int kWgRows = 32;
+constexpr int kWgRows = 32;           // 64-row chunks measured slower (fewer resident workgroups)
 
 __global__ __launch_bounds__(256) void mm_wgrad_kernel(WgArgs a) {
   extern __shared__ __attribute__((aligned(16))) float wsm[];
@@ -186,12 +199,33 @@ __global__ __launch_bounds__(256) void mm_wgrad_kernel(WgArgs a) {
     // stage: rows qc .. qc + 31 (zero beyond the range), columns padded with zeros; X gets the column of ones.
     // 8 threads per row walk its columns (no integer division in the loop, 32-byte segments per row and step)
     {
-      const int r = tid >> 3, c0 = tid & 7;
+      const int c0 = tid & 7;
+      for (int r = tid >> 3; r < kWgRows; r += 32) {
       const bool rok = qc + r < qb;
       const float* yr = a.dY + (rok ? qc + r : 0) * (long)a.ldy;
       const float* xr = a.X + (rok ? qc + r : 0) * (long)a.ldx;
-      for (int n = c0; n < a.Ns; n += 8) Ys[r * a.Ns + n] = (rok && n < a.N) ? yr[n] : 0.0f;
-      for (int k = c0; k < a.Ks; k += 8) Xs[r * a.Ks + k] = rok ? (k < a.K ? xr[k] : (k == a.K ? 1.0f : 0.0f)) : 0.0f;
+      // 16-byte pieces where the row layout allows it (every layer but the 93-column embeddings): a wave then reads
+      // 8 rows x 128 B per instruction instead of 8 x 32 B, with a quarter of the instructions
+      if (a.vec_y) {
+        for (int n = c0 * 4; n < a.Ns; n += 32) {
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (rok && n < a.N) v = *reinterpret_cast<const float4*>(yr + n);
+          *reinterpret_cast<float4*>(Ys + r * a.Ns + n) = v;
+        }
+      } else {
+        for (int n = c0; n < a.Ns; n += 8) Ys[r * a.Ns + n] = (rok && n < a.N) ? yr[n] : 0.0f;
+      }
+      if (a.vec_x) {
+        for (int k = c0 * 4; k < a.Ks; k += 32) {
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (rok && k < a.K) v = *reinterpret_cast<const float4*>(xr + k);
+          if (rok && k == a.K) v.x = 1.0f;                       // the column of ones behind the last input column
+          *reinterpret_cast<float4*>(Xs + r * a.Ks + k) = v;
+        }
+      } else {
+        for (int k = c0; k < a.Ks; k += 8) Xs[r * a.Ks + k] = rok ? (k < a.K ? xr[k] : (k == a.K ? 1.0f : 0.0f)) : 0.0f;
+      }
+      }
     }
     __syncthreads();
 #pragma unroll
@@ -547,7 +581,9 @@ static int wgrad(hipStream_t st, const float* dY, int ldy, const float* X, int l
   long rows = (Q + 1023) / 1024;
   if (rows < 256) rows = 256;
   rows = (rows + kWgRows - 1) / kWgRows * kWgRows;
-  WgArgs a{dY, ldy, X, ldx, dW, ldw, db, Q, N, K, rows, pad16mod32(N), pad16mod32(KE)};
+  const int vec_y = ((N | ldy) & 3) == 0 && (reinterpret_cast<uintptr_t>(dY) & 15) == 0;
+  const int vec_x = ((K | ldx) & 3) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0;
+  WgArgs a{dY, ldy, X, ldx, dW, ldw, db, Q, N, K, rows, pad16mod32(N), pad16mod32(KE), vec_y, vec_x};
   const size_t lds = sizeof(float) * (size_t)kWgRows * (a.Ns + a.Ks);
   hipLaunchKernelGGL(mm_wgrad_kernel, dim3((unsigned)((Q + rows - 1) / rows)), dim3(256), lds, st, a);
   return check_launch();
