@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
+#include <stdlib.h>
 #include "common.hiph"
 
 namespace glorie {
@@ -177,13 +178,17 @@ struct WgArgs {
   int vec_y, vec_x;           // rows can be staged in 16-byte pieces (N resp. K, the leading dimension and the base 16-byte aligned)
 };
 
-constexpr int kWgTiles = 28;
-constexpr int kWgRows = 32;           // 64-row chunks measured slower (fewer resident workgroups)
-
+// The reduction runs over the SAMPLES (50 k - 400 k rows), the result is tiny: a workgroup owns a contiguous range of rows
+// and walks it four rows (= one MFMA k-step) at a time.  No LDS and no barrier: lane (i, g) takes its A operand
+// dY[q0 + g][16 nt + i] and its B operand X[q0 + g][16 kt + i] straight from global memory (64 contiguous bytes per row and
+// tile), every wave loads all NNT row tiles of dY and the column tiles kt = wave, wave + 4, ... (KT of them) of X, and the
+// operands of the next DEPTH steps are in flight while a step is multiplied (a register ring, refilled slot by slot).
+// (The first version staged 32-row chunks in LDS between two barriers: one exposed memory round trip per chunk, an order of
+// magnitude above the fp32-MFMA time of these layers.)  Instantiated per layer shape so that the small layers (32 x 32:
+// 8 accumulator registers) keep 8 steps in flight at full occupancy and the 128 x 209 layer (128 accumulator registers) two.
+// The partial result of the range is added to dW with fp32 atomics (one per element and workgroup).
+template <int NNT, int KT, int DEPTH>
 __global__ __launch_bounds__(256) void mm_wgrad_kernel(WgArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float wsm[];
-  float* Ys = wsm;                           // [32][Ns]
-  float* Xs = wsm + kWgRows * a.Ns;          // [32][Ks]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 15, g = lane >> 4;
@@ -191,71 +196,62 @@ __global__ __launch_bounds__(256) void mm_wgrad_kernel(WgArgs a) {
   const long qb = qa + a.rows_per_wg < a.Q ? qa + a.rows_per_wg : a.Q;
   const int KE = a.K + (a.db ? 1 : 0);
   const int nnt = (a.N + 15) >> 4, nkt = (KE + 15) >> 4;
-  const int ntiles = nnt * nkt;
-  f32x4 acc[kWgTiles];
+  f32x4 acc[KT][NNT];
 #pragma unroll
-  for (int t = 0; t < kWgTiles; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (long qc = qa; qc < qb; qc += kWgRows) {
-    // stage: rows qc .. qc + 31 (zero beyond the range), columns padded with zeros; X gets the column of ones.
-    // 8 threads per row walk its columns (no integer division in the loop, 32-byte segments per row and step)
-    {
-      const int c0 = tid & 7;
-      for (int r = tid >> 3; r < kWgRows; r += 32) {
-      const bool rok = qc + r < qb;
-      const float* yr = a.dY + (rok ? qc + r : 0) * (long)a.ldy;
-      const float* xr = a.X + (rok ? qc + r : 0) * (long)a.ldx;
-      // 16-byte pieces where the row layout allows it (every layer but the 93-column embeddings): a wave then reads
-      // 8 rows x 128 B per instruction instead of 8 x 32 B, with a quarter of the instructions
-      if (a.vec_y) {
-        for (int n = c0 * 4; n < a.Ns; n += 32) {
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (rok && n < a.N) v = *reinterpret_cast<const float4*>(yr + n);
-          *reinterpret_cast<float4*>(Ys + r * a.Ns + n) = v;
-        }
-      } else {
-        for (int n = c0; n < a.Ns; n += 8) Ys[r * a.Ns + n] = (rok && n < a.N) ? yr[n] : 0.0f;
-      }
-      if (a.vec_x) {
-        for (int k = c0 * 4; k < a.Ks; k += 32) {
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (rok && k < a.K) v = *reinterpret_cast<const float4*>(xr + k);
-          if (rok && k == a.K) v.x = 1.0f;                       // the column of ones behind the last input column
-          *reinterpret_cast<float4*>(Xs + r * a.Ks + k) = v;
-        }
-      } else {
-        for (int k = c0; k < a.Ks; k += 8) Xs[r * a.Ks + k] = rok ? (k < a.K ? xr[k] : (k == a.K ? 1.0f : 0.0f)) : 0.0f;
-      }
-      }
+  for (int j = 0; j < KT; ++j)
+#pragma unroll
+    for (int t = 0; t < NNT; ++t) acc[j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // per-lane column state: which columns exist, which one is the column of ones (the bias gradient)
+  bool yok[NNT], xok[KT], xone[KT];
+#pragma unroll
+  for (int t = 0; t < NNT; ++t) yok[t] = t < nnt && t * 16 + i < a.N;
+#pragma unroll
+  for (int j = 0; j < KT; ++j) {
+    const int col = (wv + 4 * j) * 16 + i;
+    xok[j] = wv + 4 * j < nkt && col < a.K;
+    xone[j] = wv + 4 * j < nkt && col == a.K && a.db;
+  }
+  auto load = [&](long q0, float (&yf)[NNT], float (&xf)[KT]) {
+    const long q = q0 + g;
+    const bool rok = q < qb;
+    const float* yr = a.dY + (rok ? q : qa) * (long)a.ldy + i;
+    const float* xr = a.X + (rok ? q : qa) * (long)a.ldx + wv * 16 + i;
+#pragma unroll
+    for (int t = 0; t < NNT; ++t) yf[t] = (rok && yok[t]) ? yr[t * 16] : 0.0f;
+#pragma unroll
+    for (int j = 0; j < KT; ++j) xf[j] = (rok && xok[j]) ? xr[j * 64] : ((rok && xone[j]) ? 1.0f : 0.0f);
+  };
+  float yf[DEPTH][NNT], xf[DEPTH][KT];
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) load(qa + 4 * d, yf[d], xf[d]);
+  for (long q0 = qa; q0 < qb; q0 += 4 * DEPTH) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+#pragma unroll
+      for (int j = 0; j < KT; ++j)
+#pragma unroll
+        for (int t = 0; t < NNT; ++t)
+          acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(yf[d][t], xf[d][j], acc[j][t], 0, 0, 0);
+      load(q0 + 4 * (DEPTH + d), yf[d], xf[d]);
     }
-    __syncthreads();
-#pragma unroll
-    for (int t = 0; t < kWgTiles; ++t) {
-      const int tile = wv + 4 * t;
-      if (tile < ntiles) {
-        const int nt = tile / nkt, kt = tile - nt * nkt;
-        const float* yp = Ys + g * a.Ns + nt * 16 + i;
-        const float* xp = Xs + g * a.Ks + kt * 16 + i;
-#pragma unroll
-        for (int s_ = 0; s_ < kWgRows / 4; ++s_)
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(yp[4 * s_ * a.Ns], xp[4 * s_ * a.Ks], acc[t], 0, 0, 0);
-      }
-    }
-    __syncthreads();
   }
   // lane: rows n = nt * 16 + 4 g + rr of dW, column kt * 16 + i
 #pragma unroll
-  for (int t = 0; t < kWgTiles; ++t) {
-    const int tile = wv + 4 * t;
-    if (tile >= ntiles) continue;
-    const int nt = tile / nkt, kt = tile - nt * nkt;
+  for (int j = 0; j < KT; ++j) {
+    const int kt = wv + 4 * j;
+    if (kt >= nkt) continue;
     const int k = kt * 16 + i;
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const int n = nt * 16 + 4 * g + rr;
-      if (n >= a.N) continue;
-      const float v = acc[t][rr];
-      if (k < a.K) atomicAdd(a.dW + (long)n * a.ldw + k, v);
-      else if (k == a.K && a.db) atomicAdd(a.db + n, v);
+    for (int t = 0; t < NNT; ++t) {
+      if (t >= nnt) continue;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int n = t * 16 + 4 * g + rr;
+        if (n >= a.N) continue;
+        const float v = acc[j][t][rr];
+        if (k < a.K) atomicAdd(a.dW + (long)n * a.ldw + k, v);
+        else if (k == a.K && a.db) atomicAdd(a.db + n, v);
+      }
     }
   }
 }
@@ -560,32 +556,39 @@ __global__ __launch_bounds__(256) void dact_kernel(const float* __restrict__ dy,
 // ---------------------------------------------------------------------------------------------------------
 // host side: launch helpers
 // ---------------------------------------------------------------------------------------------------------
+static int pad16mod32(int v) { int p = (v + 15) / 16 * 16; if ((p & 31) != 16) p += 16; return p; }
 static int mm(hipStream_t st, bool trans, const float* in, int ldi, const float* W, int ldw, const float* bias, int Q, int R,
               int J, int act, float* out, int ldo, const float* res = nullptr, int ldr = 0, const float* saved = nullptr,
               int lds = 0, int dact = 0, int accumulate = 0) {
   if (Q == 0) return GLORIE_OK;
   if (J > kMaxJT * 16) return GLORIE_EUNSUPPORTED;
   MmArgs a{in, ldi, W, ldw, bias, res, ldr, saved, lds, dact, out, ldo, Q, R, J, act, accumulate};
+  // (staging the whole weight matrix once per persistent workgroup - no barrier in the reduction loop - was measured
+  // slower: 5.39 vs 5.03 ms per mapping iteration; one workgroup per CU for the large layers)
   const dim3 grid((unsigned)((Q + 63) / 64));
   if (trans) hipLaunchKernelGGL(mm_rows_kernel<true>, grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL(mm_rows_kernel<false>, grid, dim3(256), 0, st, a);
   return check_launch();
 }
-static int pad16mod32(int v) { int p = (v + 15) / 16 * 16; if ((p & 31) != 16) p += 16; return p; }
 static int wgrad(hipStream_t st, const float* dY, int ldy, const float* X, int ldx, long Q, int N, int K, float* dW, int ldw,
                  float* db) {
   if (Q == 0 || !dW) return GLORIE_OK;
   const int KE = K + (db ? 1 : 0);
-  if (((N + 15) / 16) * ((KE + 15) / 16) > 4 * kWgTiles) return GLORIE_EUNSUPPORTED;
-  // ~1024 workgroups at most, at least 256 rows each (keeps the atomics rare), multiples of the 32-row chunk
+  if (N > 128 || KE > 256) return GLORIE_EUNSUPPORTED;
+  // ~1024 workgroups at most, at least 256 rows each (keeps the atomics rare)
   long rows = (Q + 1023) / 1024;
   if (rows < 256) rows = 256;
-  rows = (rows + kWgRows - 1) / kWgRows * kWgRows;
-  const int vec_y = ((N | ldy) & 3) == 0 && (reinterpret_cast<uintptr_t>(dY) & 15) == 0;
-  const int vec_x = ((K | ldx) & 3) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0;
-  WgArgs a{dY, ldy, X, ldx, dW, ldw, db, Q, N, K, rows, pad16mod32(N), pad16mod32(KE), vec_y, vec_x};
-  const size_t lds = sizeof(float) * (size_t)kWgRows * (a.Ns + a.Ks);
-  hipLaunchKernelGGL(mm_wgrad_kernel, dim3((unsigned)((Q + rows - 1) / rows)), dim3(256), lds, st, a);
+  rows = (rows + 31) / 32 * 32;
+  WgArgs a{dY, ldy, X, ldx, dW, ldw, db, Q, N, K, rows, 0, 0, 0, 0};
+  const dim3 grid((unsigned)((Q + rows - 1) / rows));
+  // columns of X per wave: KT tiles of 16, waves interleaved (kt = wave + 4 j)
+  const int nnt = (N + 15) / 16, kt = ((KE + 15) / 16 + 3) / 4;
+  if (nnt <= 2 && kt <= 1) hipLaunchKernelGGL((mm_wgrad_kernel<2, 1, 8>), grid, dim3(256), 0, st, a);
+  else if (nnt <= 2 && kt <= 2) hipLaunchKernelGGL((mm_wgrad_kernel<2, 2, 8>), grid, dim3(256), 0, st, a);
+  else if (nnt <= 2) hipLaunchKernelGGL((mm_wgrad_kernel<2, 4, 4>), grid, dim3(256), 0, st, a);
+  else if (kt <= 1) hipLaunchKernelGGL((mm_wgrad_kernel<8, 1, 4>), grid, dim3(256), 0, st, a);
+  else if (kt <= 2) hipLaunchKernelGGL((mm_wgrad_kernel<8, 2, 4>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((mm_wgrad_kernel<8, 4, 2>), grid, dim3(256), 0, st, a);
   return check_launch();
 }
 
