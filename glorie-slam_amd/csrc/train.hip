@@ -543,6 +543,30 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   p[i] -= (lr / bc1) * mi / denom;
 }
 
+// the same update for MANY small tensors in one launch (the 52 decoder tensors of a mapping iteration: 52 launches of a few
+// hundred elements each otherwise).  Table entry = 10 x 8 bytes: p, g, m, v, n, (lr, b1), (b2, eps), 3 x pad - nothing in it
+// changes from step to step, so the host re-sends it only when a pointer moved;
+// block (x, y) updates elements [1024 x, 1024 x + 1024) of tensor y.
+struct AdamEntry { float* p; const float* g; float* m; float* v; long n; float lr, b1, b2, eps; long pad[3]; };
+__global__ __launch_bounds__(256) void adam_multi_kernel(const AdamEntry* __restrict__ table, int step) {
+  const AdamEntry e = table[blockIdx.y];
+  const long base = (long)blockIdx.x * 1024;
+  if (base >= e.n) return;
+  const float bc1 = 1.0f - powf(e.b1, (float)step);          // as glorie_adam_step forms them on the host
+  const float bc2s = sqrtf(1.0f - powf(e.b2, (float)step));
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const long i = base + r * 256 + threadIdx.x;
+    if (i >= e.n) break;
+    const float gi = e.g[i];
+    const float mi = e.b1 * e.m[i] + (1.0f - e.b1) * gi;
+    const float vi = e.b2 * e.v[i] + (1.0f - e.b2) * gi * gi;
+    e.m[i] = mi; e.v[i] = vi;
+    const float denom = sqrtf(vi) / bc2s + e.eps;
+    e.p[i] -= (e.lr / bc1) * mi / denom;
+  }
+}
+
 // dz[q][j] = dy[q][j] * act'(through the saved output y[q][j])
 __global__ __launch_bounds__(256) void dact_kernel(const float* __restrict__ dy, int ldd, const float* __restrict__ y, int ldy,
                                                    int act, long Q, int J, float* __restrict__ dz, int ldz) {
@@ -840,5 +864,15 @@ extern "C" int glorie_adam_step(float* param, const float* grad, float* exp_avg,
   const float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
   hipLaunchKernelGGL(adam_kernel, dim3(blocks(n)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr,
                      beta1, beta2, eps, bc1, bc2s, row_mask, row_len > 0 ? row_len : 1);
+  return check_launch();
+}
+
+extern "C" int glorie_adam_multi(const void* table, int n_tensors, long max_numel, int step, void* stream) {
+  if (n_tensors < 0 || max_numel < 0 || step < 1) return GLORIE_EINVAL;
+  if (n_tensors == 0 || max_numel == 0) return GLORIE_OK;
+  if (!table) return GLORIE_EINVAL;
+  static_assert(sizeof(AdamEntry) == 80, "table layout");
+  const dim3 grid((unsigned)((max_numel + 1023) / 1024), (unsigned)n_tensors);
+  hipLaunchKernelGGL(adam_multi_kernel, grid, dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const AdamEntry*>(table), step);
   return check_launch();
 }

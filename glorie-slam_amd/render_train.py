@@ -103,7 +103,15 @@ class RenderTrain(torch.autograd.Function):
         d_geo = torch.zeros(ctx.shapes[0], dtype=torch.float32, device=dev) if need[1] else None
         # the colour table's gradient buffer is needed by the kernel whenever the colour stage runs
         d_col = torch.zeros(ctx.shapes[1], dtype=torch.float32, device=dev) if (need[2] or color) else None
-        grads = [torch.zeros_like(p) if (need[3 + i] and i not in (28, 29)) else None for i, p in enumerate(pcs)]
+        # one zero-filled buffer for all parameter gradients (views of it are returned): 1 fill instead of 50
+        wanted = [(need[3 + i] and i not in (28, 29)) for i in range(len(pcs))]
+        offs, total = [], 0
+        for i, p in enumerate(pcs):
+            offs.append(total)
+            if wanted[i]:
+                total += (p.numel() + 3) // 4 * 4                   # keep every view 16-byte aligned
+        flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        grads = [flat[offs[i]:offs[i] + p.numel()].view(p.shape) if wanted[i] else None for i, p in enumerate(pcs)]
         P, G = _ptr_struct(pcs), _ptr_struct(grads)
         L.check(lib.glorie_render_train_bwd(ctypes.byref(P), ctypes.byref(G), L.ptr(pts), L.ptr(views), L.ptr(cloud_pos),
                                             L.ptr(geo_feats_c), L.ptr(col_feats_c), L.ptr(I), L.ptr(w), L.ptr(has8), Q,
@@ -130,12 +138,20 @@ def render_rays(renderer, npc, decoders, rays_d, rays_o, stage, gt_depth, npc_ge
                                           radius_per_query=rq if g.use_dynamic_radius else None,
                                           min_nn=g.min_nn_num, return_weights=True, raw_mask=True)
         counts, valid = point_ops.ray_counts(has8, S, 3)
-        if int(n_zero) != 0:
-            return None
+        # the zero-depth count travels to pinned memory behind the sampling kernel and is looked at after the forward pass
+        # has been enqueued: `int(n_zero)` here would stall the host until the previous iteration's backward and Adam
+        # step have drained (the loop was host-bound on exactly that wait)
+        flag = renderer._pinned_flag()
+        flag.copy_(n_zero, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
     cp = (cloud_pos if cloud_pos is not None else npc.cloud_pos()).detach().contiguous().float()
     meta = (pts, views, cp, I.contiguous(), w.contiguous(), has8.contiguous(), z_vals, renderer.sigmoid_coefficient,
             stage == "color")
     depth, var, rgb = RenderTrain.apply(meta, npc_geo_feats, npc_col_feats, *decoder_tensors(decoders))
+    ev.synchronize()
+    if int(flag[0]) != 0:
+        return None                      # a ray without depth: the general path redoes the batch
     return depth, var, rgb, valid, counts
 
 
@@ -159,21 +175,49 @@ class FeatureAdam:
             for p in g["params"]:
                 p.grad = None
 
+    MULTI_MAX = 1 << 16           # tensors up to this many elements share one launch (the decoder's 52 tensors)
+
     @torch.no_grad()
     def step(self, row_masks=None):
+        import struct
         lib = L.load()
+        small = []
         for g in self.param_groups:
             for p in g["params"]:
                 if p.grad is None:
                     continue
-                st = self.state.setdefault(id(p), {"step": 0, "m": torch.zeros_like(p), "v": torch.zeros_like(p)})
+                st = self.state.get(id(p))
+                if st is None:               # (setdefault would build - and zero-fill - the default on every call)
+                    st = self.state[id(p)] = {"step": 0, "m": torch.zeros_like(p), "v": torch.zeros_like(p)}
                 st["step"] += 1
                 mask = row_masks.get(id(p)) if row_masks else None
                 if not (p.is_contiguous() and p.grad.is_contiguous() and p.dtype == torch.float32):
                     raise RuntimeError("FeatureAdam: contiguous float32 parameters expected")
+                if mask is None and p.numel() <= self.MULTI_MAX and p.is_cuda:
+                    small.append((p, st, g))
+                    continue
                 row_len = p.shape[-1] if mask is not None else 1
                 m8 = mask.to(torch.uint8).contiguous() if mask is not None else None
                 L.check(lib.glorie_adam_step(L.ptr(p), L.ptr(p.grad), L.ptr(st["m"]), L.ptr(st["v"]), p.numel(),
                                              float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
                                              int(st["step"]), L.ptr(m8), int(row_len), L.stream_ptr(p.device)),
                         "glorie_adam_step")
+        if small and len({st["step"] for _, st, _ in small}) > 1:
+            for p, st, g in small:                                  # tensors at different steps: one launch each
+                L.check(lib.glorie_adam_step(L.ptr(p), L.ptr(p.grad), L.ptr(st["m"]), L.ptr(st["v"]), p.numel(),
+                                             float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
+                                             int(st["step"]), None, 1, L.stream_ptr(p.device)), "glorie_adam_step")
+        elif small:
+            # glorie_adam_multi: one 80-byte table entry per tensor; re-packed and re-sent only when a pointer moved (the
+            # caching allocator hands the gradient buffer of the previous iteration back most of the time)
+            key = tuple(p.grad.data_ptr() for p, _, _ in small) + (len(small),)
+            dev = small[0][0].device
+            if getattr(self, "_table_key", None) != key:
+                buf = b"".join(struct.pack("<qqqqqffffqqq", p.data_ptr(), p.grad.data_ptr(), st["m"].data_ptr(),
+                                           st["v"].data_ptr(), p.numel(), float(g["lr"]), float(g["betas"][0]),
+                                           float(g["betas"][1]), float(g["eps"]), 0, 0, 0) for p, st, g in small)
+                self._table = torch.frombuffer(bytearray(buf), dtype=torch.uint8).to(dev)
+                self._table_key = key
+                self._table_max = max(p.numel() for p, _, _ in small)
+            L.check(lib.glorie_adam_multi(L.ptr(self._table), len(small), self._table_max, int(small[0][1]["step"]),
+                                          L.stream_ptr(dev)), "glorie_adam_multi")

@@ -570,6 +570,11 @@ int glorie_composite_bwd(const float* raw, const float* z_vals, int R, int S, fl
 int glorie_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr,
                      float beta1, float beta2, float eps, int step, const uint8_t* row_mask, int row_len, void* stream);
 
+/* glorie_adam_step for many small tensors that are at the same step, in one launch.  table: n_tensors entries of 80 bytes on
+ * the device - { float* param; const float* grad; float* exp_avg; float* exp_avg_sq; int64 numel; float lr, beta1, beta2, eps;
+ * 24 bytes padding } (nothing step-dependent: it is re-sent only when a pointer moved); max_numel = the largest numel. */
+int glorie_adam_multi(const void* table, int n_tensors, long max_numel, int step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

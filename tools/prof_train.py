@@ -35,3 +35,18 @@ for _ in range(10):
     it()
 torch.cuda.synchronize()
 print("ms per iteration", 1e3 * (time.perf_counter() - t) / 10)
+# host time of an iteration (enqueue only) and where it goes
+import cProfile, pstats
+torch.cuda.synchronize()
+t = time.perf_counter()
+for _ in range(10):
+    it()
+t_host = 1e3 * (time.perf_counter() - t) / 10
+torch.cuda.synchronize()
+print("host ms per iteration (enqueue only)", t_host)
+if os.environ.get("TRAIN_CPROFILE"):
+    pr = cProfile.Profile(); pr.enable()
+    for _ in range(10):
+        it()
+    pr.disable(); torch.cuda.synchronize()
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
