@@ -60,6 +60,23 @@ def supported(decoders):
     return all(tuple(t.shape) == s for t, s in zip(decoder_tensors(decoders), _SHAPES))
 
 
+_DEV_CACHE = {}
+
+
+def _on_device(t, dev):
+    """t on `dev`.  Tensors that live elsewhere - the fixed Fourier matrices of the colour decoder are plain attributes, not
+    buffers, and stay on the host when the module is moved - are copied once per version: a pageable host-to-device copy in
+    every forward pass stalls the host until the stream has drained (2.7 ms per mapping iteration)."""
+    if t.device == dev:
+        return t
+    key = (t.data_ptr(), tuple(t.shape), str(dev))
+    hit = _DEV_CACHE.get(key)
+    if hit is None or hit[0] != t._version:
+        hit = (t._version, t.to(dev))
+        _DEV_CACHE[key] = hit
+    return hit[1]
+
+
 class RenderTrain(torch.autograd.Function):
     """(geo_feats, col_feats, *decoder tensors) -> (depth, uncertainty, colour) for samples that are already placed"""
 
@@ -72,7 +89,7 @@ class RenderTrain(torch.autograd.Function):
         lib = L.load()
         f32c = lambda t: t.detach().contiguous().float()
         geo_feats_c, col_feats_c = f32c(geo_feats), f32c(col_feats)
-        pcs = [f32c(p).to(dev) for p in params]
+        pcs = [_on_device(f32c(p), dev) for p in params]
         ws = torch.empty(int(lib.glorie_render_train_workspace(Q)) // 4, dtype=torch.float32, device=dev)
         raw = torch.empty(Q, 4, dtype=torch.float32, device=dev)
         P = _ptr_struct(pcs)
