@@ -60,6 +60,7 @@ struct ConvArgs {
   const _Float16* pre; int pre_stride;          // per-pixel term added before the gate non-linearity (or null)
   const int* pre_map;                           // map (edge) -> map of `pre` it reads (null: its own)
   long pbeg;                                    // first pixel of this launch (a layer may be split into two launches)
+  int pre_late;                                 // add `pre` in the epilogue instead of seeding the accumulators with it
   int dbg;                                      // ablation bits of conv8_kernel (GLORIE_CONV8_DBG; timing experiments only)
   unsigned long long* stamps;                   // dbg & 128: s_memtime checkpoints of workgroup 0, tiles 10-12, [8 waves][128]
 };
@@ -149,10 +150,13 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvArgs& a, f32x4 (&ac
     const long pc = okp ? p : a.P - 1;
     const int e = (int)(pc / a.HW);
     float4 g[MB];
-    f16x4 nv[MB], zv[MB];
+    f16x4 nv[MB], zv[MB], pl[MB];
+    const bool late = EPI != EPI_BIAS_ACT && a.pre && a.pre_late;       // wave-uniform
+    const long pp = late ? pre_pixel(a, pc) : 0;
 #pragma unroll
     for (int mi = 0; mi < MB; ++mi) {
       const int nc = min(nbase + mi * 16, a.nout - 4);
+      if (late) pl[mi] = *reinterpret_cast<const f16x4*>(a.pre + pp * a.pre_stride + nc);
       if (EPI == EPI_BIAS_ACT) {
         g[mi] = a.terms ? *reinterpret_cast<const float4*>(a.terms + nc) : make_float4(0.f, 0.f, 0.f, 0.f);
       } else {
@@ -168,7 +172,8 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvArgs& a, f32x4 (&ac
 #pragma unroll
     for (int mi = 0; mi < MB; ++mi) {
       const int n = nbase + mi * 16;
-      const f32x4 v = acc[mi][ni];
+      f32x4 v = acc[mi][ni];
+      if (late) { v[0] += (float)pl[mi][0]; v[1] += (float)pl[mi][1]; v[2] += (float)pl[mi][2]; v[3] += (float)pl[mi][3]; }
       const float f[4] = {v[0] + g[mi].x, v[1] + g[mi].y, v[2] + g[mi].z, v[3] + g[mi].w};
       f16x4 o;
       if (EPI == EPI_BIAS_ACT) {
@@ -323,7 +328,7 @@ __global__ __launch_bounds__(64 * NW, (ST == 1 && MB * NB <= 16) ? 3 : 2) void c
   for (int kk = 0; kk < KK; ++kk) foff[kk] = col * RB + (((kk * 4 + kg) ^ key(col)) << 4);
   const int wbase = XBYTES + wm * (16 * MB) * RB, xbase_l = wn * (16 * NB) * RB;
 
-  if (EPI != EPI_BIAS_ACT && a.pre) {
+  if (EPI != EPI_BIAS_ACT && a.pre && !a.pre_late) {
     // The hoisted per-pixel term seeds the accumulators (an add in the epilogue would be an exposed round trip at the tail
     // of every workgroup).  A lane owns 4 channels of 16 pixels per block: fetched directly that is 8-byte pieces of 16
     // different rows per instruction, every 128-byte line requested by 8 instructions - measured +47 us on the 36-edge z|r
@@ -578,7 +583,7 @@ __global__ __launch_bounds__(512) void conv8_kernel(ConvArgs a) {
   using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
 
   f32x4 acc[8][4];                            // [channel block 4*quadrant + i][pixel block 2*quadrant + i]
-  const bool seeded = EPI != EPI_BIAS_ACT && a.pre;
+  const bool seeded = EPI != EPI_BIAS_ACT && a.pre && !a.pre_late;
   f16x4 pv[2][4][2][2];
   if (seeded) {
     // the hoisted per-pixel term seeds the accumulators: 32 independent 8-byte loads (rows past the end re-read the
@@ -915,6 +920,10 @@ extern "C" int glorie_conv_igemm(const void* xa, int xa_stride, int ca, const vo
   a.z = reinterpret_cast<const _Float16*>(z); a.z_stride = z_stride;
   a.pre = reinterpret_cast<const _Float16*>(pre); a.pre_stride = pre_stride; a.pre_map = pre ? pre_map : nullptr;
   a.pbeg = 0;
+  // the context term is added in the epilogue when it is the shared per-keyframe map (pre_map: 8 maps read by 36 edges in
+  // every iteration, L2 resident - its loads ride with the epilogue's other loads, 277 -> 274 us in the steps) and seeds the
+  // accumulators through LDS when it is a per-edge tensor streamed from HBM; GLORIE_CONV_PRE=e|s forces either
+  { const char* pl_ = getenv("GLORIE_CONV_PRE"); a.pre_late = pl_ ? (pl_[0] == 'e') : (a.pre_map != nullptr); }
   { const char* d = getenv("GLORIE_CONV8_DBG"); a.dbg = d ? atoi(d) : 0; }
   a.stamps = getenv("GLORIE_CONV8_STAMPS") ? (unsigned long long*)strtoull(getenv("GLORIE_CONV8_STAMPS"), nullptr, 0) : nullptr;
   if (!a.stamps) a.dbg &= ~(128 | 256);
