@@ -235,9 +235,11 @@ def test_fused_update_on_the_channels_last_lookup(gpu):
         torch.testing.assert_close(x.float(), y.float(), atol=4e-3, rtol=4e-3)
 
 
-def test_shared_context_term_equals_per_edge_term(gpu):
+def test_shared_context_term_equals_per_edge_term(gpu, monkeypatch):
     """Edges with the same source keyframe have the same context features: the hoisted gate term kept once per
-    keyframe and read through pre_map gives the bits of the per-edge term."""
+    keyframe and read through pre_map gives the bits of the per-edge term (with both forms seeding the accumulators;
+    by default the shared form is added in the epilogue instead - same sum, one fp32 rounding in a different place)."""
+    monkeypatch.setenv("GLORIE_CONV_PRE", "s")
     from glorie_slam_amd.droid_net import FusedUpdate, UpdateModule
     torch.manual_seed(5)
     mod = UpdateModule().to(gpu).eval()
@@ -266,6 +268,11 @@ def test_shared_context_term_equals_per_edge_term(gpu):
     assert b._ctx_key != key
     for x, y in zip(rc, rd):
         assert torch.equal(x, y)
+    # default placement of the shared term (epilogue): equal up to the rounding of one fp32 addition
+    monkeypatch.delenv("GLORIE_CONV_PRE")
+    re_ = b(net, table[ii][None], corr, flow, ii, jj, context=(table, frames, ix))
+    for x, y in zip(re_, rd):
+        torch.testing.assert_close(x.float(), y.float(), atol=2e-3, rtol=2e-3)
 
 
 # ---- implicit-GEMM convolution (csrc/conv.hip) -------------------------------------------------
