@@ -366,6 +366,36 @@ def test_conv8_equals_the_128_tile_kernel_bit_for_bit(gpu, n, h, w, ca, cb, nout
         torch.testing.assert_close(ref.float(), _conv_ref([xa, xb], weight), atol=4e-3, rtol=4e-3)
 
 
+@pytest.mark.parametrize("mode", ["128", "64", "split", "wide"])
+def test_conv_tile_variants_are_bit_identical(gpu, mode, monkeypatch):
+    """GLORIE_CONV_TILE only changes which pixels / channels a workgroup owns: every output element sums the same products in
+    the same order, so the 64-pixel, split-launch and 128 x 256 variants must reproduce the default kernel bit for bit
+    (13 maps of 24 x 32 = 9984 pixels: 78 tiles of 128, enough for one whole round + a remainder in the split form)"""
+    from glorie_slam_amd import update_ops as U
+    n, h, w = 13, 24, 32
+    net = _cl_half(n, 128, h, w, gpu, 51)
+    wide_t = _cl_half(n, 256, h, w, gpu, 52)
+    xb = wide_t[:, 64:256]
+    g = torch.Generator(device="cpu").manual_seed(53)
+    wq = U.pack_conv_igemm((torch.randn(128, 320, 3, 3, generator=g) / 54).to(gpu))
+    wzr = U.pack_conv_igemm((torch.randn(256, 320, 3, 3, generator=g) / 54).to(gpu))
+    terms = torch.randn(n, 384, generator=g).to(gpu)
+    pre = _cl_half(n, 384, h, w, gpu, 54)
+    z0 = _cl_half(n, 128, h, w, gpu, 55).abs().clamp(max=1.0)
+    cl = lambda c: torch.empty((n, c, h, w), dtype=torch.float16, device=gpu, memory_format=torch.channels_last)
+
+    def run():
+        new, z, rnet = cl(128), cl(128), cl(128)
+        U.conv_igemm(net, xb, wq, 9, 128, new, epilogue=U.EPI_GRU_Q, terms=terms[:, 256:], net=net, z=z0, pre=pre[:, 256:384])
+        U.conv_igemm(net, xb, wzr, 9, 256, z, epilogue=U.EPI_GRU_ZR, terms=terms[:, :256], net=net, out2=rnet, pre=pre[:, 0:256])
+        return torch.cat([new, z, rnet], 1).clone()
+
+    monkeypatch.delenv("GLORIE_CONV_TILE", raising=False)
+    ref = run()
+    monkeypatch.setenv("GLORIE_CONV_TILE", mode)
+    assert torch.equal(run(), ref)
+
+
 def test_flow_conv7_matches_conv2d(gpu):
     from glorie_slam_amd import update_ops as U
     n, h, w = 3, 9, 11                                              # 297 pixels: ragged last tile, maps < 7 wide halo
