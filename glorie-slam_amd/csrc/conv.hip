@@ -43,7 +43,7 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-enum { EPI_BIAS_ACT = 0, EPI_GRU_ZR = 1, EPI_GRU_Q = 2 };
+enum { EPI_BIAS_ACT = 0, EPI_GRU_ZR = 1, EPI_GRU_Q = 2, EPI_GLO = 3 };
 enum { CACT_NONE = 0, CACT_RELU = 1, CACT_SIGMOID = 2 };
 
 struct ConvArgs {
@@ -208,6 +208,59 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvArgs& a, f32x4 (&ac
   }
 }
 
+// EPI_GLO: the global-context reduction of the ConvGRU (gru.py:25-26) as the epilogue of its 1x1 convolution w: nothing
+// is stored per pixel; the workgroup reduces  sigmoid(acc + bias[n]) * net[p][n]  over the pixels of its tile that belong
+// to its map (tiles are laid per map, see the kernel) and writes one partial sum per channel to out = float
+// [map][tile of the map][128]; glorie_gru_glo_from_tiles sums the tiles of a map in a fixed order.  Replaces a 44 MB store +
+// two 44 MB reads of the intermediate map.
+template <int MB, int NB>
+__device__ __forceinline__ void conv_epilogue_glo(const ConvArgs& a, f32x4 (&acc)[MB][NB], long p0, long pbase, int wm,
+                                                  int wn, int kg, int col, char* smem, int tile) {
+  static_assert(MB == 4, "128-channel tile");
+  const long pend = (p0 / a.HW + 1) * a.HW;             // end of this tile's map
+  float s0[MB][4];
+#pragma unroll
+  for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s0[mi][k] = 0.0f;
+  const int nb = wm * 64 + kg * 4;
+#pragma unroll
+  for (int ni = 0; ni < NB; ++ni) {
+    const long p = pbase + ni * 16;
+    const bool okp = p < pend;
+    const long pc = okp ? p : pend - 1;
+#pragma unroll
+    for (int mi = 0; mi < MB; ++mi) {
+      const int n = nb + mi * 16;
+      const float4 b = *reinterpret_cast<const float4*>(a.terms + n);
+      const f16x4 nv = *reinterpret_cast<const f16x4*>(a.net + pc * a.net_stride + n);
+      const f32x4 v = acc[mi][ni];
+      s0[mi][0] += okp ? csigmoid(v[0] + b.x) * (float)nv[0] : 0.0f;
+      s0[mi][1] += okp ? csigmoid(v[1] + b.y) * (float)nv[1] : 0.0f;
+      s0[mi][2] += okp ? csigmoid(v[2] + b.z) * (float)nv[2] : 0.0f;
+      s0[mi][3] += okp ? csigmoid(v[3] + b.w) * (float)nv[3] : 0.0f;
+    }
+  }
+  // sum over the 16 pixel lanes of the block column (lanes that share kg), then over the two pixel waves through LDS
+#pragma unroll
+  for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) s0[mi][k] += __shfl_xor(s0[mi][k], off, 64);
+  float* red = reinterpret_cast<float*>(smem);          // [pixel wave][128]
+  __syncthreads();                                      // the stage is no longer read
+  if (col == 0) {
+#pragma unroll
+    for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) red[wn * 128 + nb + mi * 16 + k] = s0[mi][k];
+  }
+  __syncthreads();
+  const int tid = threadIdx.x;
+  if (tid < 128) reinterpret_cast<float*>(a.out)[(size_t)tile * 128 + tid] = red[tid] + red[128 + tid];
+}
+
 // NB = 16-pixel blocks per wave, BK = channels per K step (32 | 64), NW = waves (2 channel halves x
 // NW/2 pixel groups: pixel tile = NW/2 * 16*NB), ST = LDS stages (1: single stage + register-resident
 // fragments, the shipped form; 2: classic double buffering with one __syncthreads per step)
@@ -238,7 +291,10 @@ __global__ __launch_bounds__(64 * NW, (ST == 1 && MB * NB <= 16) ? 3 : 2) void c
   const int xcd = blockIdx.x & 7, q = nwg >> 3, r = nwg & 7;
   const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
   const int pt = lid / ntn, nt = lid - pt * ntn;
-  const long p0 = a.pbeg + (long)pt * PT;
+  // EPI_GLO tiles every map separately (ceil(HW / PT) tiles per map, the last one ragged): the grouping of a map's pixel
+  // sums then does not depend on where the map sits in the batch (the result is invariant under edge permutations)
+  const int tpm = (a.HW + PT - 1) / PT;
+  const long p0 = EPI == EPI_GLO ? (long)(pt / tpm) * a.HW + (long)(pt % tpm) * PT : a.pbeg + (long)pt * PT;
   const int n0 = nt * TN;
 
   const int cpc = 64 / BK;                    // K steps per 64-channel chunk
@@ -416,7 +472,12 @@ __global__ __launch_bounds__(64 * NW, (ST == 1 && MB * NB <= 16) ? 3 : 2) void c
   }
 
   // ---- epilogue: lane owns channels n0 + wm*16*MB + mi*16 + kg*4 .. +3 of pixel p0 + wn*16*NB + ni*16 + col ----
-  conv_epilogue_tile<EPI, MB, NB>(a, acc, p0 + wn * (16 * NB) + col, n0 + wm * (16 * MB) + kg * 4);
+  if constexpr (EPI == EPI_GLO) {
+    if constexpr (MB == 4 && NB == 4 && NW == 4 && ST == 1)
+      conv_epilogue_glo<MB, NB>(a, acc, p0, p0 + wn * (16 * NB) + col, wm, wn, kg, col, smem, pt);
+  } else {
+    conv_epilogue_tile<EPI, MB, NB>(a, acc, p0 + wn * (16 * NB) + col, n0 + wm * (16 * MB) + kg * 4);
+  }
 #endif
 }
 
@@ -875,6 +936,7 @@ template <int NB, int BK, int NW, int ST, int MB = 4>
 static int launch_conv(const ConvArgs& a, int epilogue, hipStream_t st, long max_ptiles = -1) {
   constexpr int PT = (NW / 2) * 16 * NB;
   long ptiles = (a.P - a.pbeg + PT - 1) / PT;
+  if (epilogue == EPI_GLO) ptiles = (a.P / a.HW) * ((a.HW + PT - 1) / PT);      // tiles laid per map
   if (max_ptiles >= 0) ptiles = ptiles < max_ptiles ? ptiles : max_ptiles;
   if (ptiles <= 0) return GLORIE_OK;
   const long nwg = ptiles * ((a.nout + 32 * MB - 1) / (32 * MB));
@@ -883,6 +945,10 @@ static int launch_conv(const ConvArgs& a, int epilogue, hipStream_t st, long max
   switch (epilogue) {
     case EPI_BIAS_ACT: launch_one<EPI_BIAS_ACT, NB, BK, NW, ST, MB>(a, grid, st); break;
     case EPI_GRU_ZR: launch_one<EPI_GRU_ZR, NB, BK, NW, ST, MB>(a, grid, st); break;
+    case EPI_GLO:
+      if constexpr (MB == 4 && NB == 4 && NW == 4 && ST == 1) launch_one<EPI_GLO, NB, BK, NW, ST, MB>(a, grid, st);
+      else return GLORIE_EUNSUPPORTED;
+      break;
     default: launch_one<EPI_GRU_Q, NB, BK, NW, ST, MB>(a, grid, st); break;
   }
   return check_launch();
@@ -900,13 +966,14 @@ extern "C" int glorie_conv_igemm(const void* xa, int xa_stride, int ca, const vo
                                  int N, int H, int W, void* stream) {
   if (N < 0 || H <= 0 || W <= 0 || (taps != 1 && taps != 9) || nout <= 0 || (nout & 3)) return GLORIE_EINVAL;
   if (ca < 0 || cb < 0 || (ca % 64) || (cb % 64) || ca + cb == 0) return GLORIE_EINVAL;
-  if (epilogue < 0 || epilogue > 2) return GLORIE_EINVAL;
+  if (epilogue < 0 || epilogue > 3) return GLORIE_EINVAL;
   if (N == 0) return GLORIE_OK;               // nothing to do: pointers of empty maps may be null
   if ((ca && (!xa || (xa_stride & 7))) || (cb && (!xb || (xb_stride & 7)))) return GLORIE_EINVAL;
   if (!w_packed || !out || (out_stride & 3)) return GLORIE_EINVAL;
   if (epilogue == EPI_GRU_ZR && (nout != 256 || !terms || !net || !out2 || (terms_stride & 3))) return GLORIE_EINVAL;
   if (epilogue == EPI_GRU_Q && (nout != 128 || !terms || !net || !z || (terms_stride & 3))) return GLORIE_EINVAL;
-  if (pre && (epilogue == EPI_BIAS_ACT || (pre_stride & 3))) return GLORIE_EINVAL;
+  if (pre && (epilogue == EPI_BIAS_ACT || epilogue == EPI_GLO || (pre_stride & 3))) return GLORIE_EINVAL;
+  if (epilogue == EPI_GLO && (nout != 128 || taps != 1 || !terms || !net)) return GLORIE_EINVAL;
   ConvArgs a;
   a.xa = reinterpret_cast<const _Float16*>(xa); a.xa_stride = xa_stride; a.cha = ca / 64;
   a.xb = reinterpret_cast<const _Float16*>(xb); a.xb_stride = xb_stride; a.chb = cb / 64;

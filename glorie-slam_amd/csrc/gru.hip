@@ -352,6 +352,42 @@ extern "C" int glorie_bias_act(const void* x, int x_stride, const float* bias, v
   return check_launch();
 }
 
+// The same terms from the per-tile partial sums of glorie_conv_igemm's epilogue 3 (tiles [N][ceil(HW / 128)][128]: every
+// map tiled on its own): map n sums its tiles in ascending order (deterministic), divides by HW and applies the [128 x M]
+// product.
+__global__ __launch_bounds__(128) void glo_from_tiles_kernel(const float* __restrict__ tiles, const float* __restrict__ G,
+                                                             const float* __restrict__ Gb, int M,
+                                                             float* __restrict__ g, int HW) {
+  __shared__ float glo[128];
+  const int n = blockIdx.x;
+  const int tpm = (HW + 127) >> 7;
+  float s = 0.0f;
+  for (int t = 0; t < tpm; ++t) s += tiles[((size_t)n * tpm + t) * 128 + threadIdx.x];
+  glo[threadIdx.x] = s / (float)HW;
+  __syncthreads();
+  const int o = blockIdx.y * 128 + threadIdx.x;
+  if (o >= M) return;
+  float acc0 = Gb[o], acc1 = 0.0f, acc2 = 0.0f, acc3 = 0.0f;
+#pragma unroll 8
+  for (int c = 0; c < 128; c += 4) {
+    acc0 = fmaf(glo[c], G[(size_t)c * M + o], acc0);
+    acc1 = fmaf(glo[c + 1], G[(size_t)(c + 1) * M + o], acc1);
+    acc2 = fmaf(glo[c + 2], G[(size_t)(c + 2) * M + o], acc2);
+    acc3 = fmaf(glo[c + 3], G[(size_t)(c + 3) * M + o], acc3);
+  }
+  g[(size_t)n * M + o] = (acc0 + acc1) + (acc2 + acc3);
+}
+
+extern "C" int glorie_gru_glo_from_tiles(const float* tiles, const float* G, const float* Gb, int M, float* g, int N,
+                                         int HW, void* stream) {
+  if (N < 0 || HW < 1 || M <= 0) return GLORIE_EINVAL;
+  if (N == 0) return GLORIE_OK;
+  if (!tiles || !G || !Gb || !g) return GLORIE_EINVAL;
+  hipLaunchKernelGGL(glo_from_tiles_kernel, dim3(N, (M + 127) / 128), dim3(128), 0, (hipStream_t)stream, tiles, G, Gb, M,
+                     g, HW);
+  return check_launch();
+}
+
 extern "C" int glorie_gru_glo_terms(const void* wn, int w_stride, const float* bw, const void* net,
                                     int n_stride, const float* G, const float* Gb, int M,
                                     float* partial, int parts, float* g, int N, int HW, void* stream) {

@@ -272,6 +272,7 @@ class FusedUpdate:
         self._hx = None
         self._inp_key = None      # (tensor kept alive, version) whose values sit in the inp slice of hx
         self._pre_kf, self._pre_map, self._ctx_key = None, None, None   # context term shared per keyframe
+        self.fuse_glo = True      # global-context reduction inside the epilogue of its 1x1 convolution
         self.gate_events = None   # a list: (start, end) events of every z|r gate launch are appended (eager steps only)
 
     # -- weight packing ----------------------------------------------------------------
@@ -417,8 +418,11 @@ class FusedUpdate:
                 if self.hoist_inp:
                     self.precompute_context()
             # global context of the ConvGRU (gru.py:25-31)
-            wn = U.conv_igemm(net0, None, W["w"], 1, 128, cl_map(128))
-            g = U.gru_glo_terms(wn, W["w_b"], net0, W["G"], W["G_b"])
+            if self.fuse_glo:
+                g = U.gru_glo_terms_fused(net0, W["w"], W["w_b"], W["G"], W["G_b"])
+            else:
+                wn = U.conv_igemm(net0, None, W["w"], 1, 128, cl_map(128))
+                g = U.gru_glo_terms(wn, W["w_b"], net0, W["G"], W["G_b"])
         # corr_encoder (droid_net.py:73-77): 1x1 as a transposed GEMM on the NCHW lookup output
         if hasattr(corr, "encode_into"):
             # volume-free lookup with corr_encoder[0] fused behind it (csrc/corr_otf.hip): the 196-channel map

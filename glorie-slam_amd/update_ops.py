@@ -66,6 +66,29 @@ def gru_glo_terms(wn, bw, net, G, Gb, parts=16):
     return g
 
 
+def gru_glo_terms_fused(net, w_packed, bw, G, Gb):
+    """gru_glo_terms with the 1x1 convolution w (gru.py:25) inside: conv_igemm's epilogue 3 reduces
+    sigmoid(w(net) + bw) * net over 128-pixel tiles, glorie_gru_glo_from_tiles finishes per map - the intermediate
+    [N,128,h,w] map never exists.  w_packed = pack_conv_igemm(gru.w.weight)."""
+    L.need_cuda(net, w_packed, G, Gb)
+    n, c, h, w = net.shape
+    if c != 128 or G.shape[0] != 128 or not G.is_contiguous() or G.dtype != torch.float32 \
+            or Gb.dtype != torch.float32 or Gb.numel() != G.shape[1]:
+        raise RuntimeError("gru_glo_terms_fused: bad shapes")
+    M = G.shape[1]
+    tiles = torch.empty((n, (h * w + 127) // 128, 128), dtype=torch.float32, device=net.device)
+    g = torch.empty((n, M), dtype=torch.float32, device=net.device)
+    if n == 0:
+        return g
+    lib = L.load()
+    L.check(lib.glorie_conv_igemm(L.ptr(net), _rows(net, "net"), 128, None, 0, 0, L.ptr(w_packed), 1, 128, EPI_GLO,
+                                  L.ptr(bw), 0, ACT_NONE, L.ptr(net), _rows(net, "net"), None, 0, L.ptr(tiles), 128,
+                                  None, 0, None, 0, None, n, h, w, L.stream_ptr()), "glorie_conv_igemm (epilogue 3)")
+    L.check(lib.glorie_gru_glo_from_tiles(L.ptr(tiles), L.ptr(G), L.ptr(Gb), M, L.ptr(g), n, h * w, L.stream_ptr()),
+            "glorie_gru_glo_from_tiles")
+    return g
+
+
 def gru_gate_zr(zr, g, net, z, rnet):
     """z = sigmoid(zr[:, :128] + g[n, :128]); rnet = sigmoid(zr[:, 128:] + g[n, 128:]) * net
     (gru.py:28-30).  zr: raw [N,256,h,w] output of the merged convz|convr; g float32 [N,256]"""
@@ -146,7 +169,7 @@ def conv3x3_small(x, w_packed, out_bias, K, acts, scale=1.0, in_bias=None, in_re
     return out
 
 
-EPI_BIAS_ACT, EPI_GRU_ZR, EPI_GRU_Q = 0, 1, 2
+EPI_BIAS_ACT, EPI_GRU_ZR, EPI_GRU_Q, EPI_GLO = 0, 1, 2, 3
 
 
 def pack_conv_igemm(weight):

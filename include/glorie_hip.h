@@ -190,6 +190,11 @@ int glorie_bias_act(const void* x, int x_stride, const float* bias, void* y, int
 int glorie_gru_glo_terms(const void* wn, int w_stride, const float* bw, const void* net, int n_stride,
                          const float* G, const float* Gb, int M, float* partial, int parts, float* g,
                          int N, int HW, void* stream);
+/* glorie_gru_glo_terms from the per-tile partial sums that glorie_conv_igemm's epilogue 3 leaves (the 1x1 convolution w of
+ * gru.py:25 with the sigmoid, the product with net and the pixel reduction in its epilogue): tiles = float
+ * [ceil(N*HW/128)][2][128]. */
+int glorie_gru_glo_from_tiles(const float* tiles, const float* G, const float* Gb, int M, float* g, int N, int HW,
+                              void* stream);
 int glorie_gru_gate_zr(const void* zr, int zr_stride, const float* g, int g_stride, const void* net,
                        int n_stride, void* z, int z_stride, void* rnet, int r_stride, int N, int HW,
                        void* stream);
@@ -217,6 +222,10 @@ int glorie_conv3x3_small(const void* x, int x_stride, const float* in_bias, int 
  *             out2[p][c] = sigmoid(acc[128+c] + terms[e][128+c]) * net[p][c]
  * epilogue 2: GRU blend, nout = 128 (gru.py:31-33):
  *             out[p][c] = (1 - z[p][c]) * net[p][c] + z[p][c] * tanh(acc[c] + terms[e][c])
+ * epilogue 3: global-context reduction (gru.py:25-26), nout = 128, taps = 1: nothing is stored per pixel; every map is
+ *             tiled on its own (ceil(H*W / 128) tiles of 128 pixels) and out = float [N][tiles per map][128] receives, per
+ *             tile and channel, the sum of sigmoid(acc[c] + terms[c]) * net[p][c] over the tile's pixels;
+ *             glorie_gru_glo_from_tiles turns them into the gate terms.
  * e = p / (H*W) is the map (edge) index; terms rows are terms_stride floats apart (gates) and come
  * from glorie_gru_glo_terms.  out / out2 / net / z are fp16 rows with their own strides (halfs).
  * pre (may be NULL; gate epilogues only): fp16 rows [p][nout] added to the accumulator before the

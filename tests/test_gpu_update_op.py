@@ -211,6 +211,28 @@ def test_fused_update_without_graph_aggregation_and_repack(gpu):
     assert torch.isfinite(out3[0].float()).all()
 
 
+@pytest.mark.parametrize("n,h,w", [(5, 12, 16), (3, 10, 13), (36, 60, 80)])
+def test_global_context_terms_fused_into_the_1x1_convolution(gpu, n, h, w):
+    """gate terms from the convolution epilogue's per-tile partial sums (tiles that straddle two maps, a ragged last tile)
+    against the two-launch form on the stored map and against fp32 torch"""
+    from glorie_slam_amd import update_ops as U
+    net = _cl_half(n, 128, h, w, gpu, 61)
+    g = torch.Generator(device="cpu").manual_seed(62)
+    ww = (torch.randn(128, 128, 1, 1, generator=g) / 11).to(gpu)
+    bw = torch.randn(128, generator=g).to(gpu)
+    G = (torch.randn(128, 384, generator=g) / 11).to(gpu).contiguous()
+    Gb = torch.randn(384, generator=g).to(gpu)
+    wp = U.pack_conv_igemm(ww)
+    fused = U.gru_glo_terms_fused(net, wp, bw, G, Gb)
+    wn = U.conv_igemm(net, None, wp, 1, 128, torch.empty_like(net))
+    two = U.gru_glo_terms(wn, bw, net, G, Gb)
+    torch.testing.assert_close(fused, two, atol=2e-3, rtol=2e-3)      # `two` rounds the map to fp16 in between
+    x = net.float()
+    wmap = F.conv2d(x, ww.half().float())
+    glo = (torch.sigmoid(wmap + bw.view(1, -1, 1, 1)) * x).mean((2, 3))
+    torch.testing.assert_close(fused, glo @ G + Gb, atol=1e-3, rtol=1e-3)
+
+
 def test_fused_update_on_the_channels_last_lookup(gpu):
     """corr_encoder[0] as a 1x1 implicit-GEMM convolution over the channels-last lookup (permuted weight columns, bias and
     ReLU in the epilogue) against the library GEMM over the planar map: same operator, only the fp16 GEMM's summation order
