@@ -41,6 +41,9 @@ SIGNATURES = {
     "glorie_gru_glo_from_tiles": (_c_int, [_vp, _vp, _vp, _c_int, _vp, _c_int, _c_int, _vp]),
     "glorie_update_bookkeeping": (_c_int, [_vp, _vp, _vp, ctypes.c_long, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_f, _vp, _c_int,
                                            _vp]),
+    "glorie_conv_igemm_heads": (_c_int, [_vp, _c_int, _c_int, _vp, _c_int, _c_int, _vp, _vp, _c_int, _c_int, _vp, _vp,
+                                         _c_int, _c_int, _c_int, _c_int, _vp]),
+    "glorie_conv_stencil": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, ctypes.c_float, _vp, _c_int, _c_int, _c_int, _vp]),
     "glorie_conv_igemm": (_c_int, [_vp, _c_int, _c_int, _vp, _c_int, _c_int, _vp, _c_int, _c_int, _c_int, _vp,
                                    _c_int, _c_int, _vp, _c_int, _vp, _c_int, _vp, _c_int, _vp, _c_int, _vp, _c_int, _vp,
                                    _c_int, _c_int, _c_int, _vp]),

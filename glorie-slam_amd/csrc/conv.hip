@@ -43,7 +43,7 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-enum { EPI_BIAS_ACT = 0, EPI_GRU_ZR = 1, EPI_GRU_Q = 2, EPI_GLO = 3 };
+enum { EPI_BIAS_ACT = 0, EPI_GRU_ZR = 1, EPI_GRU_Q = 2, EPI_GLO = 3, EPI_HEADS = 4 };
 enum { CACT_NONE = 0, CACT_RELU = 1, CACT_SIGMOID = 2 };
 
 struct ConvArgs {
@@ -63,6 +63,8 @@ struct ConvArgs {
   int pre_late;                                 // add `pre` in the epilogue instead of seeding the accumulators with it
   int dbg;                                      // ablation bits of conv8_kernel (GLORIE_CONV8_DBG; timing experiments only)
   unsigned long long* stamps;                   // dbg & 128: s_memtime checkpoints of workgroup 0, tiles 10-12, [8 waves][128]
+  // EPI_HEADS: the first tap_groups 128-channel tiles feed the tap GEMM of a 3x3 head instead of being stored
+  const f16x8* tap_w; float* tap_out; int tap_groups, tap_ncols, tap_stride;
 };
 
 constexpr int kTileN = 128;       // output channels per workgroup
@@ -138,7 +140,8 @@ typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 // descriptor with bit 31 of its offset set for pixels / channels past the end (the range check drops it) - a guarded
 // load + store per block is a chain of MB * NB dependent memory round trips at the tail of every workgroup.
 template <int EPI, int MB, int NB>
-__device__ __forceinline__ void conv_epilogue_tile(const ConvArgs& a, f32x4 (&acc)[MB][NB], long pbase, int nbase) {
+__device__ __forceinline__ void conv_epilogue_tile(const ConvArgs& a, f32x4 (&acc)[MB][NB], long pbase, int nbase,
+                                                   int out_ch0 = 0) {
   const __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rO2 = __builtin_amdgcn_make_buffer_rsrc((void*)(EPI == EPI_GRU_ZR ? a.out2 : a.out), 0,
                                                                       0x7fffffff, 0x00020000);
@@ -201,8 +204,81 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvArgs& a, f32x4 (&ac
         const unsigned vo = ok ? (unsigned)((pc * a.out2_stride + (n - 128)) * 2) : 0x80000000u;
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rO2, vo, 0, 0);
       } else {
-        const unsigned vo = ok ? (unsigned)((pc * a.out_stride + n) * 2) : 0x80000000u;
+        const unsigned vo = ok ? (unsigned)((pc * a.out_stride + (n - out_ch0)) * 2) : 0x80000000u;
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rO, vo, 0, 0);
+      }
+    }
+  }
+}
+
+// EPI_HEADS: the tile's 128 channels are the hidden layer of one 3x3 head (droid_net.py:85-93: conv3x3 -> ReLU -> conv3x3
+// 128 -> K).  The hidden activations are never stored: relu(acc + bias) as fp16 IS the MFMA B operand of the head's tap
+// GEMM  taps[d*K + j][pixel] = < w2[j][:, d], hidden[:, pixel] >  (the K order of a GEMM is free: k-slot (kg, s) of chunk c
+// is channel wm*64 + (2c + s/4)*16 + kg*4 + s%4, the weight fragments are packed to match, update_ops.
+// pack_head_taps).  Each channel half (wave pair) does 16 MFMAs, the halves are summed through LDS and the float tap rows
+// go where glorie_conv3x3_small would have written them; glorie_conv_stencil finishes the head.  Saves the store and
+// the re-read of 2 x 128 channels per pixel (88 + 88 MB per iteration at 36x60x80) and the tap kernel's launch.
+template <int MB, int NB>
+__device__ __forceinline__ void conv_epilogue_heads(const ConvArgs& a, f32x4 (&acc)[MB][NB], long p0, int n0, int wm,
+                                                    int wn, int kg, int col, int lane, char* smem) {
+  static_assert(MB == 4 && NB == 4, "128 x 128 tile");
+  const int grp = n0 >> 7;
+  const f16x8* wp = a.tap_w + (size_t)(grp * 2 + wm) * 4 * 64 + lane;          // [group][half][chunk*2 + row block][64]
+  f16x8 wf[2][2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) wf[c][rb] = wp[(c * 2 + rb) * 64];
+  float4 b[MB];
+#pragma unroll
+  for (int mi = 0; mi < MB; ++mi) b[mi] = *reinterpret_cast<const float4*>(a.terms + n0 + wm * 64 + mi * 16 + kg * 4);
+  f32x4 t[2][NB];
+#pragma unroll
+  for (int ni = 0; ni < NB; ++ni) {
+    f16x8 hf[2];
+#pragma unroll
+    for (int mi = 0; mi < MB; ++mi) {
+      const f32x4 v = acc[mi][ni];
+      const int h = (mi & 1) * 4;
+      hf[mi >> 1][h + 0] = (_Float16)fmaxf(v[0] + b[mi].x, 0.0f);
+      hf[mi >> 1][h + 1] = (_Float16)fmaxf(v[1] + b[mi].y, 0.0f);
+      hf[mi >> 1][h + 2] = (_Float16)fmaxf(v[2] + b[mi].z, 0.0f);
+      hf[mi >> 1][h + 3] = (_Float16)fmaxf(v[3] + b[mi].w, 0.0f);
+    }
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < 2; ++c) s = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[c][rb], hf[c], s, 0, 0, 0);
+      t[rb][ni] = s;
+    }
+  }
+  // t[rb][ni][r] = tap row rb*16 + kg*4 + r of pixel wn*64 + ni*16 + col, summed over this wave's 64 channels
+  float* red = reinterpret_cast<float*>(smem);          // [pixel wave][8 blocks][4][64 lanes]
+  __syncthreads();                                      // the stage is no longer read
+  if (wm == 1) {
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int ni = 0; ni < NB; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[((wn * 8 + rb * 4 + ni) * 4 + r) * 64 + lane] = t[rb][ni][r];
+  }
+  __syncthreads();
+  if (wm == 0) {
+#pragma unroll
+    for (int ni = 0; ni < NB; ++ni) {
+      const long p = p0 + wn * 64 + ni * 16 + col;
+      if (p >= a.P) continue;
+      float* dst = a.tap_out + p * a.tap_stride + grp * a.tap_ncols;
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        const int n = rb * 16 + kg * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = t[rb][ni][r] + red[((wn * 8 + rb * 4 + ni) * 4 + r) * 64 + lane];
+          if (n + r < a.tap_ncols) dst[n + r] = v;
+        }
       }
     }
   }
@@ -475,6 +551,14 @@ __global__ __launch_bounds__(64 * NW, (ST == 1 && MB * NB <= 16) ? 3 : 2) void c
   if constexpr (EPI == EPI_GLO) {
     if constexpr (MB == 4 && NB == 4 && NW == 4 && ST == 1)
       conv_epilogue_glo<MB, NB>(a, acc, p0, p0 + wn * (16 * NB) + col, wm, wn, kg, col, smem, pt);
+  } else if constexpr (EPI == EPI_HEADS) {
+    if constexpr (MB == 4 && NB == 4 && NW == 4 && ST == 1) {
+      if (nt < a.tap_groups)                                                    // workgroup-uniform
+        conv_epilogue_heads<MB, NB>(a, acc, p0, n0, wm, wn, kg, col, lane, smem);
+      else
+        conv_epilogue_tile<EPI_BIAS_ACT, MB, NB>(a, acc, p0 + wn * (16 * NB) + col, n0 + wm * (16 * MB) + kg * 4,
+                                                 a.tap_groups * 128);
+    }
   } else {
     conv_epilogue_tile<EPI, MB, NB>(a, acc, p0 + wn * (16 * NB) + col, n0 + wm * (16 * MB) + kg * 4);
   }
@@ -949,6 +1033,10 @@ static int launch_conv(const ConvArgs& a, int epilogue, hipStream_t st, long max
       if constexpr (MB == 4 && NB == 4 && NW == 4 && ST == 1) launch_one<EPI_GLO, NB, BK, NW, ST, MB>(a, grid, st);
       else return GLORIE_EUNSUPPORTED;
       break;
+    case EPI_HEADS:
+      if constexpr (MB == 4 && NB == 4 && NW == 4 && ST == 1) launch_one<EPI_HEADS, NB, BK, NW, ST, MB>(a, grid, st);
+      else return GLORIE_EUNSUPPORTED;
+      break;
     default: launch_one<EPI_GRU_Q, NB, BK, NW, ST, MB>(a, grid, st); break;
   }
   return check_launch();
@@ -958,15 +1046,19 @@ static int launch_conv(const ConvArgs& a, int epilogue, hipStream_t st, long max
 
 using namespace glorie;
 
-extern "C" int glorie_conv_igemm(const void* xa, int xa_stride, int ca, const void* xb, int xb_stride,
-                                 int cb, const void* w_packed, int taps, int nout, int epilogue,
-                                 const float* terms, int terms_stride, int act, const void* net,
-                                 int net_stride, const void* z, int z_stride, void* out, int out_stride,
-                                 void* out2, int out2_stride, const void* pre, int pre_stride, const int* pre_map,
-                                 int N, int H, int W, void* stream) {
+static int conv_igemm_impl(const void* xa, int xa_stride, int ca, const void* xb, int xb_stride,
+                           int cb, const void* w_packed, int taps, int nout, int epilogue,
+                           const float* terms, int terms_stride, int act, const void* net,
+                           int net_stride, const void* z, int z_stride, void* out, int out_stride,
+                           void* out2, int out2_stride, const void* pre, int pre_stride, const int* pre_map,
+                           int N, int H, int W, void* stream, const void* tap_w, float* tap_out, int tap_groups,
+                           int tap_ncols) {
   if (N < 0 || H <= 0 || W <= 0 || (taps != 1 && taps != 9) || nout <= 0 || (nout & 3)) return GLORIE_EINVAL;
   if (ca < 0 || cb < 0 || (ca % 64) || (cb % 64) || ca + cb == 0) return GLORIE_EINVAL;
-  if (epilogue < 0 || epilogue > 3) return GLORIE_EINVAL;
+  if (epilogue < 0 || epilogue > 4) return GLORIE_EINVAL;
+  if (epilogue == EPI_HEADS && (!tap_w || !tap_out || !terms || tap_groups < 1 || tap_ncols < 1 || tap_ncols > 32 ||
+                                nout < 128 * tap_groups || (nout & 127) || act != CACT_RELU || pre))
+    return GLORIE_EINVAL;
   if (N == 0) return GLORIE_OK;               // nothing to do: pointers of empty maps may be null
   if ((ca && (!xa || (xa_stride & 7))) || (cb && (!xb || (xb_stride & 7)))) return GLORIE_EINVAL;
   if (!w_packed || !out || (out_stride & 3)) return GLORIE_EINVAL;
@@ -987,6 +1079,8 @@ extern "C" int glorie_conv_igemm(const void* xa, int xa_stride, int ca, const vo
   a.z = reinterpret_cast<const _Float16*>(z); a.z_stride = z_stride;
   a.pre = reinterpret_cast<const _Float16*>(pre); a.pre_stride = pre_stride; a.pre_map = pre ? pre_map : nullptr;
   a.pbeg = 0;
+  a.tap_w = reinterpret_cast<const f16x8*>(tap_w); a.tap_out = tap_out; a.tap_groups = tap_groups;
+  a.tap_ncols = tap_ncols; a.tap_stride = tap_ncols * tap_groups;
   // the context term is added in the epilogue when it is the shared per-keyframe map (pre_map: 8 maps read by 36 edges in
   // every iteration, L2 resident - its loads ride with the epilogue's other loads, 277 -> 274 us in the steps) and seeds the
   // accumulators through LDS when it is a per-edge tensor streamed from HBM; GLORIE_CONV_PRE=e|s forces either
@@ -1013,6 +1107,7 @@ extern "C" int glorie_conv_igemm(const void* xa, int xa_stride, int ca, const vo
   // 385 vs 345 us.  It stays opt-in; tests/test_gpu_update_op.py pins it bit for bit against the 128 x 128 kernel.
   const char* c8 = getenv("GLORIE_CONV8");
   const bool conv8_on = c8 && c8[0] == '1';
+  if (epilogue == EPI_HEADS) return launch_conv<4, 64, 4, 1>(a, epilogue, st);
   if (conv8_on && (nout & 255) == 0 && a.P >= 256) return launch_conv8(a, epilogue, st);
   // layers with <= 64 output channels (flow_encoder[2]) use a 64-channel tile instead of padding to 128
   if (nout <= 64 && epilogue == EPI_BIAS_ACT) return launch_conv<4, 64, 4, 1, 2>(a, epilogue, st);
@@ -1041,4 +1136,28 @@ extern "C" int glorie_conv_igemm(const void* xa, int xa_stride, int ca, const vo
     return a.pbeg < a.P ? launch_conv<2, 64, 4, 1>(a, epilogue, st) : GLORIE_OK;
   }
   return launch_conv<4, 64, 4, 1>(a, epilogue, st);
+}
+
+extern "C" int glorie_conv_igemm(const void* xa, int xa_stride, int ca, const void* xb, int xb_stride,
+                                 int cb, const void* w_packed, int taps, int nout, int epilogue,
+                                 const float* terms, int terms_stride, int act, const void* net,
+                                 int net_stride, const void* z, int z_stride, void* out, int out_stride,
+                                 void* out2, int out2_stride, const void* pre, int pre_stride, const int* pre_map,
+                                 int N, int H, int W, void* stream) {
+  if (epilogue == EPI_HEADS) return GLORIE_EINVAL;          // has its own entry point
+  return conv_igemm_impl(xa, xa_stride, ca, xb, xb_stride, cb, w_packed, taps, nout, epilogue, terms, terms_stride, act,
+                         net, net_stride, z, z_stride, out, out_stride, out2, out2_stride, pre, pre_stride, pre_map, N, H,
+                         W, stream, nullptr, nullptr, 0, 0);
+}
+
+extern "C" int glorie_conv_igemm_heads(const void* x, int x_stride, int c, const void* w_packed, int taps, int nout,
+                                       const float* bias, const void* tap_w, int groups, int K, float* tap_out,
+                                       void* out, int out_stride, int N, int H, int W, void* stream) {
+  if (K < 1 || K > 3 || groups < 1 || groups > 4) return GLORIE_EINVAL;
+  if (nout > 128 * groups && !out) return GLORIE_EINVAL;
+  // `out` holds channels 128*groups .. nout-1 only; with no such channels any non-null pointer passes the checks
+  void* o = out ? out : (void*)tap_out;
+  return conv_igemm_impl(x, x_stride, c, nullptr, 0, 0, w_packed, taps, nout, EPI_HEADS, bias, 0, CACT_RELU, nullptr, 0,
+                         nullptr, 0, o, out ? out_stride : 4, nullptr, 0, nullptr, 0, nullptr, N, H, W, stream, tap_w,
+                         tap_out, groups, 9 * K);
 }

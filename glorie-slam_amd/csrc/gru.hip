@@ -504,3 +504,15 @@ extern "C" int glorie_conv3x3_small(const void* x, int x_stride, const float* in
                      ncols, tstride, out_bias, K, groups, act_packed, scale, out, P, H, W);
   return check_launch();
 }
+
+// second half of glorie_conv3x3_small alone: the tap rows were written by glorie_conv_igemm_heads
+extern "C" int glorie_conv_stencil(const float* taps, const float* out_bias, int groups, int K, int act_packed,
+                                   float scale, float* out, int N, int H, int W, void* stream) {
+  if (N < 0 || H <= 0 || W <= 0 || groups < 1 || groups > 4 || K < 1 || K > 3) return GLORIE_EINVAL;
+  if (N == 0) return GLORIE_OK;
+  if (!taps || !out) return GLORIE_EINVAL;
+  const long P = (long)N * H * W, total = P * K * groups;
+  hipLaunchKernelGGL(conv_stencil_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     taps, 9 * K, 9 * K * groups, out_bias, K, groups, act_packed, scale, out, P, H, W);
+  return check_launch();
+}

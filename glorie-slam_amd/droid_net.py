@@ -273,6 +273,7 @@ class FusedUpdate:
         self._inp_key = None      # (tensor kept alive, version) whose values sit in the inp slice of hx
         self._pre_kf, self._pre_map, self._ctx_key = None, None, None   # context term shared per keyframe
         self.fuse_glo = True      # global-context reduction inside the epilogue of its 1x1 convolution
+        self.fuse_heads = True    # tap GEMMs of the delta / weight heads inside the epilogue of their hidden convolution
         self.gate_events = None   # a list: (start, end) events of every z|r gate launch are appended (eager steps only)
 
     # -- weight packing ----------------------------------------------------------------
@@ -310,6 +311,7 @@ class FusedUpdate:
         W["h1"] = U.pack_conv_igemm(torch.cat([m.delta[0].weight, m.weight[0].weight, m.agg.conv1.weight], 0))
         W["h1_b"] = f32(torch.cat([m.delta[0].bias, m.weight[0].bias, m.agg.conv1.bias]))
         W["h2"] = U.pack_conv3x3_small([m.delta[2].weight, m.weight[2].weight])
+        W["h2_taps"] = U.pack_head_taps([m.delta[2].weight, m.weight[2].weight])
         W["h2_b"] = f32(torch.cat([m.delta[2].bias, m.weight[2].bias]))
         W["a2"], W["a2_b"] = U.pack_conv_igemm(m.agg.conv2.weight), f32(m.agg.conv2.bias)
         W["eta"], W["eta_b"] = U.pack_conv3x3_small([m.agg.eta[0].weight]), f32(m.agg.eta[0].bias)
@@ -467,8 +469,15 @@ class FusedUpdate:
             U.conv_igemm(rnet, hx, W["q"], 9, 128, new, epilogue=U.EPI_GRU_Q, terms=g[:, 256:384], net=net0, z=z)
         net_out = new.view(batch, num, 128, ht, wd)
         # heads (droid_net.py:85-93) + first conv of GraphAgg (droid_net.py:38,53)
-        h1 = U.conv_igemm(new, None, W["h1"], 9, 384, cl_map(384), terms=W["h1_b"], act=U.ACT_RELU)
-        dw = U.conv3x3_small(h1, W["h2"], W["h2_b"], 2, (U.ACT_NONE, U.ACT_SIGMOID))
+        if self.fuse_heads:
+            # the heads' hidden maps are consumed in the epilogue of their convolution (tap rows), only the GraphAgg third is stored
+            agg_in = cl_map(128)
+            rows = U.conv_igemm_heads(new, W["h1"], 9, 384, W["h1_b"], W["h2_taps"], 2, out=agg_in)
+            dw = U.conv_stencil(rows, W["h2_b"], n, ht, wd, 2, 2, (U.ACT_NONE, U.ACT_SIGMOID))
+        else:
+            h1 = U.conv_igemm(new, None, W["h1"], 9, 384, cl_map(384), terms=W["h1_b"], act=U.ACT_RELU)
+            dw = U.conv3x3_small(h1, W["h2"], W["h2_b"], 2, (U.ACT_NONE, U.ACT_SIGMOID))
+            agg_in = h1[:, 256:384]
         delta = dw[0].view(batch, num, ht, wd, 2)
         weight = dw[1].view(batch, num, ht, wd, 2)
         if ii is None:
@@ -479,7 +488,7 @@ class FusedUpdate:
             ngroups = uniq.shape[0]
         else:
             ix, ngroups = groups
-        agg = U.segment_mean(h1[:, 256:384], ix.contiguous(), ngroups)
+        agg = U.segment_mean(agg_in, ix.contiguous(), ngroups)
         a2 = torch.empty((ngroups, 128, ht, wd), dtype=torch.float16, device=dev,
                          memory_format=torch.channels_last)
         U.conv_igemm(agg, None, W["a2"], 9, 128, a2, terms=W["a2_b"], act=U.ACT_RELU)

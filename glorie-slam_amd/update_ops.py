@@ -238,6 +238,62 @@ def conv_igemm(xa, xb, w_packed, taps, nout, out, epilogue=EPI_BIAS_ACT, terms=N
     return out
 
 
+def pack_head_taps(weights):
+    """weights: list (one per head) of the heads' second conv weights [K,128,3,3] -> the fp16 MFMA A fragments of
+    glorie_conv_igemm_heads [groups][2][2][2][64][8] (layout in include/glorie_hip.h): tap row d*K + j of hidden channel
+    64*half + 16*(2*chunk + s//4) + 4*(lane>>4) + s%4"""
+    K = weights[0].shape[0]
+    ncols = 9 * K
+    packs = []
+    for wgt in weights:
+        if tuple(wgt.shape) != (K, 128, 3, 3):
+            raise RuntimeError("pack_head_taps: expected [K,128,3,3] weights")
+        rows = torch.zeros(32, 128, dtype=torch.float32, device=wgt.device)
+        rows[:ncols] = wgt.detach().float().reshape(K, 128, 9).permute(2, 0, 1).reshape(ncols, 128)
+        # channel = 64*half + 32*chunk + 16*blk + 4*kg + q, fragment slot s = 4*blk + q, lane = 16*kg + i, row = 16*rb + i
+        r = rows.view(2, 16, 2, 2, 2, 4, 4)                  # [rb][i][half][chunk][blk][kg][q]
+        packs.append(r.permute(2, 3, 0, 5, 1, 4, 6).reshape(2, 2, 2, 64, 8))   # [half][chunk][rb][kg*16+i][blk*4+q]
+    return torch.stack(packs).half().contiguous()
+
+
+def conv_igemm_heads(x, w_packed, taps, nout, bias, tap_w, K, out=None):
+    """glorie_conv_igemm_heads: the hidden layers of `groups` 3x3 heads (+ trailing channels stored to `out`) and the
+    heads' tap rows in one launch; returns the float32 tap rows [N*h*w, groups*9K] for conv_stencil"""
+    L.need_cuda(x, w_packed, tap_w)
+    n, c, h, w = x.shape
+    groups = tap_w.shape[0]
+    if w_packed.dtype != torch.float16 or w_packed.numel() != taps * nout * c + 64 or nout % 128:
+        raise RuntimeError("conv_igemm_heads: packed weights do not match (taps, nout, channels)")
+    if tap_w.dtype != torch.float16 or tuple(tap_w.shape[1:]) != (2, 2, 2, 64, 8) or not tap_w.is_contiguous():
+        raise RuntimeError("conv_igemm_heads: tap_w must come from pack_head_taps")
+    if bias.dtype != torch.float32 or bias.numel() != nout or not bias.is_contiguous():
+        raise RuntimeError("conv_igemm_heads: bias must be contiguous float32 [nout]")
+    rest = nout - 128 * groups
+    if rest < 0 or (rest > 0 and (out is None or out.shape[0] != n or out.shape[1] != rest)):
+        raise RuntimeError("conv_igemm_heads: `out` must hold the nout - 128*groups trailing channels")
+    rows = torch.empty((n * h * w, groups * 9 * K), dtype=torch.float32, device=x.device)
+    L.check(L.load().glorie_conv_igemm_heads(L.ptr(x), _rows(x, "x"), c, L.ptr(w_packed), taps, nout, L.ptr(bias),
+                                             L.ptr(tap_w), groups, K, L.ptr(rows), L.ptr(out) if rest else None,
+                                             _rows(out, "out") if rest else 0, n, h, w, L.stream_ptr()),
+            "glorie_conv_igemm_heads")
+    return rows
+
+
+def conv_stencil(rows, out_bias, n, h, w, groups, K, acts, scale=1.0):
+    """the 9-point stencil half of conv3x3_small on tap rows [n*h*w, groups*9K] -> float32 [groups, n, h, w, K]"""
+    L.need_cuda(rows)
+    if rows.dtype != torch.float32 or tuple(rows.shape) != (n * h * w, groups * 9 * K) or not rows.is_contiguous() \
+            or len(acts) != groups:
+        raise RuntimeError("conv_stencil: bad tap rows")
+    out = torch.empty((groups, n, h, w, K), dtype=torch.float32, device=rows.device)
+    packed = 0
+    for gidx, a in enumerate(acts):
+        packed |= int(a) << (4 * gidx)
+    L.check(L.load().glorie_conv_stencil(L.ptr(rows), L.ptr(out_bias), groups, K, packed, float(scale), L.ptr(out),
+                                         n, h, w, L.stream_ptr()), "glorie_conv_stencil")
+    return out
+
+
 def pack_flow_conv7(weight):
     """flow_encoder[0] weight [128,4,7,7] -> fp16 [128][224], column ky*32 + kx*4 + c (kx = 7 zero)"""
     if tuple(weight.shape) != (128, 4, 7, 7):

@@ -241,6 +241,24 @@ int glorie_conv_igemm(const void* xa, int xa_stride, int ca, const void* xb, int
                       int z_stride, void* out, int out_stride, void* out2, int out2_stride,
                       const void* pre, int pre_stride, const int* pre_map, int N, int H, int W, void* stream);
 
+/* The hidden layers of the update operator's heads and their tap GEMMs in one launch (droid_net.py:85-93 delta / weight
+ * heads: conv3x3 -> ReLU -> conv3x3 128 -> K; droid_net.py:38 the first convolution of GraphAgg shares the input).
+ * A 3x3 / 1x1 convolution x [N*H*W][c] -> nout channels (nout % 128 == 0) with bias + ReLU as glorie_conv_igemm's
+ * epilogue 0, except that the first `groups` 128-channel slices of its output are NOT stored: each is the input of a 3x3
+ * head with K (<= 3) output channels, whose tap rows  tap_out[p][grp*9K + d*K + j] = < w2[grp][j][:, d], hidden[p][grp] >
+ * (the `taps` workspace of glorie_conv3x3_small, float [N*H*W][groups*9K]) are formed from the accumulators;
+ * glorie_conv_stencil finishes the heads.  Channels 128*groups .. nout-1 are stored to out (fp16 rows of nout - 128*groups
+ * channels, out_stride halfs apart; may be NULL when there are none).
+ * tap_w: fp16 MFMA A fragments [groups][2][2][2][64][8]: element [grp][half][chunk][rb][lane][s] = w2[grp][j][ch][d] for
+ * tap row 16rb + (lane&15) = d*K + j (zero beyond 9K) and hidden channel ch = 64half + 16(2chunk + s/4) + 4(lane>>4) + s%4
+ * - the order in which the convolution's accumulator registers hold the hidden channels. */
+int glorie_conv_igemm_heads(const void* x, int x_stride, int c, const void* w_packed, int taps, int nout,
+                            const float* bias, const void* tap_w, int groups, int K, float* tap_out, void* out,
+                            int out_stride, int N, int H, int W, void* stream);
+/* second half of glorie_conv3x3_small on tap rows already in memory: out float [groups][N*H*W][K] */
+int glorie_conv_stencil(const float* taps, const float* out_bias, int groups, int K, int act_packed, float scale,
+                        float* out, int N, int H, int W, void* stream);
+
 /* flow_encoder[0] (droid_net.py:79-81): 7x7 convolution, zero padding 3, 4 -> 128 channels, + bias
  * + ReLU.  flow: float32 channels-last motion map [N*H*W][4]; out: fp16 rows of 128 channels,
  * out_stride halfs apart.  w_packed: fp16 [128][224], column ky*32 + kx*4 + c = weight[n][c][ky][kx],

@@ -233,6 +233,35 @@ def test_global_context_terms_fused_into_the_1x1_convolution(gpu, n, h, w):
     torch.testing.assert_close(fused, glo @ G + Gb, atol=1e-3, rtol=1e-3)
 
 
+@pytest.mark.parametrize("n,h,w", [(5, 12, 16), (3, 10, 13), (36, 60, 80)])
+def test_head_taps_fused_into_the_hidden_convolution(gpu, n, h, w):
+    """delta / weight heads (droid_net.py:85-93) with their hidden maps consumed in the convolution's epilogue against the
+    stored-map form (conv_igemm + conv3x3_small) and against fp32 torch; the trailing (GraphAgg) channels are bit-identical"""
+    from glorie_slam_amd import update_ops as U
+    x = _cl_half(n, 128, h, w, gpu, 71)
+    g = torch.Generator(device="cpu").manual_seed(72)
+    w1 = (torch.randn(384, 128, 3, 3, generator=g) / 30).to(gpu)
+    b1 = (torch.randn(384, generator=g) / 4).to(gpu).contiguous()
+    w2 = [(torch.randn(2, 128, 3, 3, generator=g) / 30).to(gpu) for _ in range(2)]
+    b2 = torch.randn(4, generator=g).to(gpu)
+    wp = U.pack_conv_igemm(w1)
+    acts = (U.ACT_NONE, U.ACT_SIGMOID)
+    rest = torch.empty((n, 128, h, w), dtype=torch.float16, device=gpu).contiguous(memory_format=torch.channels_last)
+    rows = U.conv_igemm_heads(x, wp, 9, 384, b1, U.pack_head_taps(w2), 2, out=rest)
+    fused = U.conv_stencil(rows, b2, n, h, w, 2, 2, acts)
+    h1 = torch.empty((n, 384, h, w), dtype=torch.float16, device=gpu).contiguous(memory_format=torch.channels_last)
+    U.conv_igemm(x, None, wp, 9, 384, h1, terms=b1, act=U.ACT_RELU)
+    two = U.conv3x3_small(h1, U.pack_conv3x3_small(w2), b2, 2, acts)
+    assert torch.equal(rest, h1[:, 256:384])
+    torch.testing.assert_close(fused, two, atol=2e-4, rtol=2e-4)        # same fp16 operands, another summation order
+    hid = torch.relu(F.conv2d(x.float(), w1.half().float(), b1, padding=1)).half().float()
+    for k in range(2):
+        ref = F.conv2d(hid[:, 128 * k:128 * k + 128], w2[k].half().float(), b2[2 * k:2 * k + 2], padding=1)
+        if k == 1:
+            ref = torch.sigmoid(ref)
+        torch.testing.assert_close(fused[k], ref.permute(0, 2, 3, 1), atol=3e-3, rtol=3e-3)
+
+
 def test_fused_update_on_the_channels_last_lookup(gpu):
     """corr_encoder[0] as a 1x1 implicit-GEMM convolution over the channels-last lookup (permuted weight columns, bias and
     ReLU in the epilogue) against the library GEMM over the planar map: same operator, only the fp16 GEMM's summation order
