@@ -64,7 +64,7 @@ struct ConvArgs {
   int dbg;                                      // ablation bits of conv8_kernel (GLORIE_CONV8_DBG; timing experiments only)
   unsigned long long* stamps;                   // dbg & 128: s_memtime checkpoints of workgroup 0, tiles 10-12, [8 waves][128]
   // EPI_HEADS: the first tap_groups 128-channel tiles feed the tap GEMM of a 3x3 head instead of being stored
-  const f16x8* tap_w; float* tap_out; int tap_groups, tap_ncols, tap_stride;
+  const f16x8* tap_w; float* tap_out; int tap_groups, tap_ncols;
 };
 
 constexpr int kTileN = 128;       // output channels per workgroup
@@ -216,7 +216,7 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvArgs& a, f32x4 (&ac
 // GEMM  taps[d*K + j][pixel] = < w2[j][:, d], hidden[:, pixel] >  (the K order of a GEMM is free: k-slot (kg, s) of chunk c
 // is channel wm*64 + (2c + s/4)*16 + kg*4 + s%4, the weight fragments are packed to match, update_ops.
 // pack_head_taps).  Each channel half (wave pair) does 16 MFMAs, the halves are summed through LDS and the float tap rows
-// go where glorie_conv3x3_small would have written them; glorie_conv_stencil finishes the head.  Saves the store and
+// are written as planes [group*9K + row][pixel]; glorie_conv_stencil finishes the head.  Saves the store and
 // the re-read of 2 x 128 channels per pixel (88 + 88 MB per iteration at 36x60x80) and the tap kernel's launch.
 template <int MB, int NB>
 __device__ __forceinline__ void conv_epilogue_heads(const ConvArgs& a, f32x4 (&acc)[MB][NB], long p0, int n0, int wm,
@@ -270,14 +270,14 @@ __device__ __forceinline__ void conv_epilogue_heads(const ConvArgs& a, f32x4 (&a
     for (int ni = 0; ni < NB; ++ni) {
       const long p = p0 + wn * 64 + ni * 16 + col;
       if (p >= a.P) continue;
-      float* dst = a.tap_out + p * a.tap_stride + grp * a.tap_ncols;
+      float* dst = a.tap_out + (size_t)(grp * a.tap_ncols) * a.P + p;          // tap planes [groups * ncols][P]
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb) {
         const int n = rb * 16 + kg * 4;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float v = t[rb][ni][r] + red[((wn * 8 + rb * 4 + ni) * 4 + r) * 64 + lane];
-          if (n + r < a.tap_ncols) dst[n + r] = v;
+          if (n + r < a.tap_ncols) dst[(size_t)(n + r) * a.P] = v;
         }
       }
     }
@@ -1080,7 +1080,7 @@ static int conv_igemm_impl(const void* xa, int xa_stride, int ca, const void* xb
   a.pre = reinterpret_cast<const _Float16*>(pre); a.pre_stride = pre_stride; a.pre_map = pre ? pre_map : nullptr;
   a.pbeg = 0;
   a.tap_w = reinterpret_cast<const f16x8*>(tap_w); a.tap_out = tap_out; a.tap_groups = tap_groups;
-  a.tap_ncols = tap_ncols; a.tap_stride = tap_ncols * tap_groups;
+  a.tap_ncols = tap_ncols;
   // the context term is added in the epilogue when it is the shared per-keyframe map (pre_map: 8 maps read by 36 edges in
   // every iteration, L2 resident - its loads ride with the epilogue's other loads, 277 -> 274 us in the steps) and seeds the
   // accumulators through LDS when it is a per-edge tensor streamed from HBM; GLORIE_CONV_PRE=e|s forces either

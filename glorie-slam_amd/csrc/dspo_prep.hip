@@ -169,6 +169,16 @@ __global__ __launch_bounds__(256) void prep_edges_kernel(const uint8_t* __restri
   if (on) atomicOr(any_on, 1);
 }
 
+// The one host decision of a depth_scale stage recorded into a hipGraph (`any edge enabled`, depth_video.py:290-294)
+// without a stream synchronisation: the word (launch count << 1 | flag) is stored straight into pinned host memory; the
+// host knows how many launches it has enqueued and polls the word until the count matches - 300 us before the replay
+// ends, so the next replay is enqueued while this one still runs (a stream sync here left the GPU idle for 40 us per step).
+__global__ void publish_flag_kernel(const int* __restrict__ flag, int* __restrict__ counter, int* host_word) {
+  const int c = *counter + 1;
+  *counter = c;
+  __hip_atomic_store(host_word, (c << 1) | (*flag != 0 ? 1 : 0), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Two-view validity mask for an arbitrary frame list and map size (scope row N4:
 // DepthVideo.update_valid_depth_mask(up=True) at full resolution, depth_video.py:326-361): the
@@ -288,6 +298,12 @@ extern "C" int glorie_dspo_prepare(const float* poses, const float* disps, const
   if (N > 0)
     hipLaunchKernelGGL(prep_edges_kernel, dim3((N + 255) / 256), dim3(256), 0, st, bad, ii, jj, N, n, edge_on,
                        any_on);
+  return check_launch();
+}
+
+extern "C" int glorie_publish_flag(const int* flag, int* counter, int* host_word, void* stream) {
+  if (!flag || !counter || !host_word) return GLORIE_EINVAL;
+  hipLaunchKernelGGL(publish_flag_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, flag, counter, host_word);
   return check_launch();
 }
 

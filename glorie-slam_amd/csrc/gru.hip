@@ -303,14 +303,17 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const _Float16* __restri
 
 __device__ __forceinline__ float softplusf_(float x) { return x > 20.0f ? x : log1pf(__expf(x)); }
 
+// PLANAR: taps = [groups*ncols][P] (written by glorie_conv_igemm_heads; a wave reads 64 consecutive pixels of one tap
+// plane), else rows [P][groups*ncols] (conv_taps_kernel)
+template <bool PLANAR>
 __global__ __launch_bounds__(256) void conv_stencil_kernel(const float* __restrict__ taps, int ncols,
                                                            int tstride, const float* __restrict__ bias,
                                                            int K, int groups, int act_packed, float scale,
                                                            float* __restrict__ out, long P, int H, int W) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= P * K * groups) return;
-  const int gk = (int)(idx % (K * groups));
-  const long p = idx / (K * groups);
+  const int gk = PLANAR ? (int)(idx / P) : (int)(idx % (K * groups));
+  const long p = PLANAR ? idx - (long)gk * P : idx / (K * groups);
   const int grp = gk / K, j = gk - grp * K;
   const int xw = (int)(p % W), yh = (int)((p / W) % H);
   float acc = bias ? bias[grp * K + j] : 0.0f;
@@ -318,7 +321,8 @@ __global__ __launch_bounds__(256) void conv_stencil_kernel(const float* __restri
   for (int d = 0; d < 9; ++d) {
     const int dy = d / 3 - 1, dx = d % 3 - 1;
     if ((unsigned)(yh + dy) < (unsigned)H && (unsigned)(xw + dx) < (unsigned)W)
-      acc += taps[(p + dy * W + dx) * tstride + grp * ncols + d * K + j];
+      acc += PLANAR ? taps[(size_t)(grp * ncols + d * K + j) * P + (p + dy * W + dx)]
+                    : taps[(p + dy * W + dx) * tstride + grp * ncols + d * K + j];
   }
   const int act = (act_packed >> (4 * grp)) & 15;
   if (act == ACT_RELU) acc = fmaxf(acc, 0.0f);
@@ -500,19 +504,19 @@ extern "C" int glorie_conv3x3_small(const void* x, int x_stride, const float* in
                        reinterpret_cast<const _Float16*>(x), x_stride, in_bias, in_relu,
                        reinterpret_cast<const f16x8*>(w_packed), taps, ncols, tstride, P);
   const long total = P * K * groups;
-  hipLaunchKernelGGL(conv_stencil_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, taps,
+  hipLaunchKernelGGL(conv_stencil_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, taps,
                      ncols, tstride, out_bias, K, groups, act_packed, scale, out, P, H, W);
   return check_launch();
 }
 
-// second half of glorie_conv3x3_small alone: the tap rows were written by glorie_conv_igemm_heads
+// second half of glorie_conv3x3_small alone, on the tap PLANES written by glorie_conv_igemm_heads
 extern "C" int glorie_conv_stencil(const float* taps, const float* out_bias, int groups, int K, int act_packed,
                                    float scale, float* out, int N, int H, int W, void* stream) {
   if (N < 0 || H <= 0 || W <= 0 || groups < 1 || groups > 4 || K < 1 || K > 3) return GLORIE_EINVAL;
   if (N == 0) return GLORIE_OK;
   if (!taps || !out) return GLORIE_EINVAL;
   const long P = (long)N * H * W, total = P * K * groups;
-  hipLaunchKernelGGL(conv_stencil_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(conv_stencil_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      taps, 9 * K, 9 * K * groups, out_bias, K, groups, act_packed, scale, out, P, H, W);
   return check_launch();
 }

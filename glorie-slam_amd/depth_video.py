@@ -205,11 +205,40 @@ class DepthVideo:
         return d.reshape(N, N) if return_matrix else d
 
     # ---- bundle adjustment -----------------------------------------------------------
-    def deferred_any_on(self):
-        """pinned int32[1]: `any edge enabled` of the last depth_scale stage recorded into a hipGraph"""
-        if getattr(self, "_any_on_host", None) is None:
-            self._any_on_host = torch.ones(1, dtype=torch.int32).pin_memory()
-        return self._any_on_host
+    def deferred_flag_init(self):
+        """buffers of the deferred stage-1 decision (allocated outside any hipGraph capture): a pinned host word the device
+        stores (launch count << 1 | any edge enabled) into, the device-side launch counter, the host's own count"""
+        if getattr(self, "_flag_host", None) is None:
+            self._flag_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self._flag_np = self._flag_host.numpy()
+            self._flag_count = torch.zeros(1, dtype=torch.int32, device=self.device)
+            self._flag_expected = 0
+
+    def publish_any_on(self, any_on):
+        """record the store of a depth_scale stage's `any edge enabled` into the pinned word (csrc/dspo_prep.hip)"""
+        from . import _lib as L
+        self.deferred_flag_init()
+        L.check(L.load().glorie_publish_flag(L.ptr(any_on), L.ptr(self._flag_count), self._flag_host.data_ptr(),
+                                             L.stream_ptr()), "glorie_publish_flag")
+
+    def await_any_on(self, timeout=0.05):
+        """the flag of the deferred stage replayed last.  Polls the pinned word for this replay's launch count: the host
+        learns the decision when the preparation kernels are through (the rest of the replay is still running) and can
+        enqueue the next step behind it; a stream synchronisation is only the fallback."""
+        import time
+        self._flag_expected += 1
+        want = self._flag_expected
+        t_end = time.perf_counter() + timeout
+        while True:
+            word = int(self._flag_np[0])
+            if (word >> 1) == want:
+                return word & 1
+            if time.perf_counter() > t_end:
+                torch.cuda.current_stream().synchronize()
+                word = int(self._flag_np[0])
+                if (word >> 1) != want:
+                    raise RuntimeError("deferred depth_scale decision: launch count %d, expected %d" % (word >> 1, want))
+                return word & 1
 
     def dspo(self, target, weight, eta, ii, jj, t0=1, t1=None, itrs=2, lm=1e-4, ep=0.1,
              motion_only=False, opt_type="pose_depth"):

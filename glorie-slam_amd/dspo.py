@@ -73,9 +73,9 @@ def depth_scale_stage(video, target, weight, eta, ii, jj, itrs, lm, ep, fused=Tr
         if any_on.is_cuda and torch.cuda.is_current_stream_capturing():
             # hipGraph capture: no host decision is possible here.  With every edge off the stage-2
             # launch below leaves all frames untouched, so it is recorded unconditionally; the flag
-            # goes to pinned memory and the owner of the graph (FactorGraph.update) runs the stage-1
-            # fallback after the replay if it reads 0.
-            video.deferred_any_on().copy_(any_on, non_blocking=True)
+            # goes to pinned memory (tagged with a launch count, DepthVideo.publish_any_on) and the owner
+            # of the graph (FactorGraph.update) runs the stage-1 fallback after the replay if it reads 0.
+            video.publish_any_on(any_on)
             video.deferred_fallback = True
         elif not bool(any_on.item()):   # the one scalar sync: decides the stage-1 fallback
             return False

@@ -289,9 +289,9 @@ class FactorGraph:
             return self._update_finish(itrs, motion_only, opt_type)
         if deferred:
             # the recorded depth_scale stage could not take its stage-1 fallback decision on the host
-            # (dspo.depth_scale_stage): read the flag it left in pinned memory and redo it here
-            torch.cuda.current_stream().synchronize()
-            if int(self.video.deferred_any_on()[0]) == 0:
+            # (dspo.depth_scale_stage): read the flag it leaves in pinned memory (no stream synchronisation:
+            # DepthVideo.await_any_on polls for this replay's launch count) and redo it here
+            if self.video.await_any_on() == 0:
                 self.video.stage2_fallbacks += 1
                 target, weight, damping, ii, jj, uniq, upmask, t0_, t1_ = ba_args
                 self.video.dspo(target, weight, damping, ii, jj, t0_, t1_, itrs, 1e-4, 0.1, motion_only,
@@ -312,6 +312,7 @@ class FactorGraph:
             if src is not dst:
                 dst.copy_(src)
         keep = (self.net, self.target, self.weight)
+        self.video.deferred_flag_init()          # persistent buffers: not from the graph's private pool
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         self.net, self.target, self.weight = s_net, s_target, s_weight

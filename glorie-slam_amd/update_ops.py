@@ -258,7 +258,7 @@ def pack_head_taps(weights):
 
 def conv_igemm_heads(x, w_packed, taps, nout, bias, tap_w, K, out=None):
     """glorie_conv_igemm_heads: the hidden layers of `groups` 3x3 heads (+ trailing channels stored to `out`) and the
-    heads' tap rows in one launch; returns the float32 tap rows [N*h*w, groups*9K] for conv_stencil"""
+    heads' tap planes in one launch; returns the float32 planes [groups*9K, N*h*w] for conv_stencil"""
     L.need_cuda(x, w_packed, tap_w)
     n, c, h, w = x.shape
     groups = tap_w.shape[0]
@@ -271,7 +271,7 @@ def conv_igemm_heads(x, w_packed, taps, nout, bias, tap_w, K, out=None):
     rest = nout - 128 * groups
     if rest < 0 or (rest > 0 and (out is None or out.shape[0] != n or out.shape[1] != rest)):
         raise RuntimeError("conv_igemm_heads: `out` must hold the nout - 128*groups trailing channels")
-    rows = torch.empty((n * h * w, groups * 9 * K), dtype=torch.float32, device=x.device)
+    rows = torch.empty((groups * 9 * K, n * h * w), dtype=torch.float32, device=x.device)
     L.check(L.load().glorie_conv_igemm_heads(L.ptr(x), _rows(x, "x"), c, L.ptr(w_packed), taps, nout, L.ptr(bias),
                                              L.ptr(tap_w), groups, K, L.ptr(rows), L.ptr(out) if rest else None,
                                              _rows(out, "out") if rest else 0, n, h, w, L.stream_ptr()),
@@ -280,11 +280,11 @@ def conv_igemm_heads(x, w_packed, taps, nout, bias, tap_w, K, out=None):
 
 
 def conv_stencil(rows, out_bias, n, h, w, groups, K, acts, scale=1.0):
-    """the 9-point stencil half of conv3x3_small on tap rows [n*h*w, groups*9K] -> float32 [groups, n, h, w, K]"""
+    """the 9-point stencil half of conv3x3_small on tap planes [groups*9K, n*h*w] -> float32 [groups, n, h, w, K]"""
     L.need_cuda(rows)
-    if rows.dtype != torch.float32 or tuple(rows.shape) != (n * h * w, groups * 9 * K) or not rows.is_contiguous() \
+    if rows.dtype != torch.float32 or tuple(rows.shape) != (groups * 9 * K, n * h * w) or not rows.is_contiguous() \
             or len(acts) != groups:
-        raise RuntimeError("conv_stencil: bad tap rows")
+        raise RuntimeError("conv_stencil: bad tap planes")
     out = torch.empty((groups, n, h, w, K), dtype=torch.float32, device=rows.device)
     packed = 0
     for gidx, a in enumerate(acts):

@@ -245,8 +245,8 @@ int glorie_conv_igemm(const void* xa, int xa_stride, int ca, const void* xb, int
  * heads: conv3x3 -> ReLU -> conv3x3 128 -> K; droid_net.py:38 the first convolution of GraphAgg shares the input).
  * A 3x3 / 1x1 convolution x [N*H*W][c] -> nout channels (nout % 128 == 0) with bias + ReLU as glorie_conv_igemm's
  * epilogue 0, except that the first `groups` 128-channel slices of its output are NOT stored: each is the input of a 3x3
- * head with K (<= 3) output channels, whose tap rows  tap_out[p][grp*9K + d*K + j] = < w2[grp][j][:, d], hidden[p][grp] >
- * (the `taps` workspace of glorie_conv3x3_small, float [N*H*W][groups*9K]) are formed from the accumulators;
+ * head with K (<= 3) output channels, whose tap planes  tap_out[grp*9K + d*K + j][p] = < w2[grp][j][:, d], hidden[p][grp] >
+ * (the `taps` workspace of glorie_conv3x3_small transposed: float [groups*9K][N*H*W]) are formed from the accumulators;
  * glorie_conv_stencil finishes the heads.  Channels 128*groups .. nout-1 are stored to out (fp16 rows of nout - 128*groups
  * channels, out_stride halfs apart; may be NULL when there are none).
  * tap_w: fp16 MFMA A fragments [groups][2][2][2][64][8]: element [grp][half][chunk][rb][lane][s] = w2[grp][j][ch][d] for
@@ -255,7 +255,7 @@ int glorie_conv_igemm(const void* xa, int xa_stride, int ca, const void* xb, int
 int glorie_conv_igemm_heads(const void* x, int x_stride, int c, const void* w_packed, int taps, int nout,
                             const float* bias, const void* tap_w, int groups, int K, float* tap_out, void* out,
                             int out_stride, int N, int H, int W, void* stream);
-/* second half of glorie_conv3x3_small on tap rows already in memory: out float [groups][N*H*W][K] */
+/* second half of glorie_conv3x3_small on the tap planes of glorie_conv_igemm_heads: out float [groups][N*H*W][K] */
 int glorie_conv_stencil(const float* taps, const float* out_bias, int groups, int K, int act_packed, float scale,
                         float* out, int N, int H, int W, void* stream);
 
@@ -401,6 +401,11 @@ int glorie_dspo_prepare(const float* poses, const float* disps, const float* int
                         int visible_num, float mono_thres, const int64_t* ii, const int64_t* jj, int N,
                         uint8_t* valid_mask, float* scales, float* shifts, uint8_t* edge_on,
                         int* any_on, void* scratch, void* stream);
+
+/* *host_word = (++*counter << 1) | (*flag != 0), stored by the device into pinned (device-mapped) host memory: a host
+ * that counts its launches can poll the word for the flag of a given launch instead of synchronising the stream
+ * (the stage-1 fallback decision of a depth_scale stage replayed from a hipGraph, depth_video.py:290-294). */
+int glorie_publish_flag(const int* flag, int* counter, int* host_word, void* stream);
 
 /* Two-view validity mask of the frames ix[0..num) of a depth video at any resolution
  * (DepthVideo.update_valid_depth_mask, depth_video.py:326-361):

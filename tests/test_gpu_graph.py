@@ -191,12 +191,16 @@ def test_normalize_and_valid_mask(gpu):
     assert video.valid_depth_mask_small[:7].any()
 
 
-def test_graph_replay_matches_eager(gpu):
-    """use_graphs=True (hipGraph replay of update()) walks the same states as eager launches"""
-    outs = []
+@pytest.mark.parametrize("stage2", [True, False])
+def test_graph_replay_matches_eager(gpu, stage2):
+    """use_graphs=True (hipGraph replay of update()) walks the same states as eager launches - also when every
+    depth_scale stage falls back to pose_depth (depth_video.py:290-294): the replay defers that host decision to a
+    flag the device stores into pinned memory"""
+    outs, fallbacks = [], []
     for use_graphs in (False, True):
         g, video = make_video(gpu, 6, 24, 32)
-        video.cfg["tracking"]["multiview_filter"]["thresh"] = 0.25     # let stage 2 run (random-init operator)
+        if stage2:
+            video.cfg["tracking"]["multiview_filter"]["thresh"] = 0.25     # let stage 2 run (random-init operator)
         from glorie_slam_amd.factor_graph import FactorGraph
         from glorie_slam_amd.droid_net import UpdateModule
         torch.manual_seed(43)
@@ -212,6 +216,8 @@ def test_graph_replay_matches_eager(gpu):
             assert captured[0][1] is captured[1][1]                                # ... on shared static state
         outs.append([t.float().clone() for t in (video.poses, video.disps, video.disps_up, video.depth_scale,
                                                   graph.net, graph.target, graph.weight, graph.damping)])
+        fallbacks.append(video.stage2_fallbacks)
+    assert fallbacks[0] == fallbacks[1] == (0 if stage2 else 4)
     names = ["poses", "disps", "disps_up", "depth_scale", "net", "target", "weight", "damping"]
     for name, a, b in zip(names, *outs):
         assert torch.isfinite(a).all(), name
