@@ -286,7 +286,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 template <bool CL>
 __global__ __launch_bounds__(256) void corr_lookup_r3_tiled_kernel(
     CorrLevels lv, int num_levels, const float* __restrict__ coords, _Float16* __restrict__ out,
-    int HW, int out_channels, const int* __restrict__ slots) {
+    int HW, int out_channels, const int* __restrict__ slots, int coords_xy) {
   typedef _Float16 T;
   constexpr int R = 3, RD = 7, WIN = 8, PG = 8;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -299,7 +299,13 @@ __global__ __launch_bounds__(256) void corr_lookup_r3_tiled_kernel(
   const int pc = live ? pb : HW - PG;
 
   float x0[PG], y0[PG];
-  {
+  if (coords_xy) {
+    // [N][HW][2] as the reprojection writes it (no permute + copy in front of the lookup): 8 pixels = 64 contiguous bytes
+    const float4* cp = reinterpret_cast<const float4*>(coords + ((size_t)n * HW + pc) * 2);
+    const float4 a = cp[0], b = cp[1], c = cp[2], d = cp[3];
+    x0[0] = a.x; y0[0] = a.y; x0[1] = a.z; y0[1] = a.w; x0[2] = b.x; y0[2] = b.y; x0[3] = b.z; y0[3] = b.w;
+    x0[4] = c.x; y0[4] = c.y; x0[5] = c.z; y0[5] = c.w; x0[6] = d.x; y0[6] = d.y; x0[7] = d.z; y0[7] = d.w;
+  } else {
     const float4* cx = reinterpret_cast<const float4*>(coords + ((size_t)n * 2 + 0) * HW + pc);
     const float4* cy = reinterpret_cast<const float4*>(coords + ((size_t)n * 2 + 1) * HW + pc);
     const float4 a = cx[0], b = cx[1], c = cy[0], d = cy[1];
@@ -486,7 +492,7 @@ extern "C" int glorie_corr_lookup_pyramid(const void* const* volumes, int num_le
 }
 
 static int lookup_tiled(const void* const* volumes, int num_levels, const float* coords, void* out, int N, int h1,
-                        int w1, int h2, int w2, const int* slots, void* stream, bool channels_last = false);
+                        int w1, int h2, int w2, const int* slots, void* stream, bool channels_last = false, int coords_xy = 0);
 
 extern "C" int glorie_corr_lookup_pyramid_tiled(const void* const* volumes, int num_levels,
                                                 const float* coords, void* out, int N, int h1, int w1,
@@ -502,14 +508,14 @@ extern "C" int glorie_corr_lookup_arena(const void* const* levels, int num_level
 }
 
 extern "C" int glorie_corr_lookup_tiled_cl(const void* const* levels, int num_levels, const int* slots,
-                                           const float* coords, void* out, int N, int h1, int w1, int h2, int w2,
-                                           void* stream) {
+                                           const float* coords, int coords_xy, void* out, int N, int h1, int w1,
+                                           int h2, int w2, void* stream) {
   if (num_levels != 4) return GLORIE_EUNSUPPORTED;             // the 256-channel row holds 4 levels of 8 x 8
-  return lookup_tiled(levels, num_levels, coords, out, N, h1, w1, h2, w2, slots, stream, true);
+  return lookup_tiled(levels, num_levels, coords, out, N, h1, w1, h2, w2, slots, stream, true, coords_xy != 0);
 }
 
 static int lookup_tiled(const void* const* volumes, int num_levels, const float* coords, void* out, int N, int h1,
-                        int w1, int h2, int w2, const int* slots, void* stream, bool channels_last) {
+                        int w1, int h2, int w2, const int* slots, void* stream, bool channels_last, int coords_xy) {
   if (num_levels < 1 || num_levels > kMaxLevels || N < 0 || h1 < 0 || w1 < 0) return GLORIE_EINVAL;
   const int HW = h1 * w1;
   if (N == 0 || HW == 0) return GLORIE_OK;
@@ -526,9 +532,9 @@ static int lookup_tiled(const void* const* volumes, int num_levels, const float*
   dim3 grid((HW + 255) / 256, N);
   if (channels_last)
     hipLaunchKernelGGL(corr_lookup_r3_tiled_kernel<true>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       lv, num_levels, coords, reinterpret_cast<_Float16*>(out), HW, num_levels * 64, slots);
+                       lv, num_levels, coords, reinterpret_cast<_Float16*>(out), HW, num_levels * 64, slots, coords_xy);
   else
     hipLaunchKernelGGL(corr_lookup_r3_tiled_kernel<false>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       lv, num_levels, coords, reinterpret_cast<_Float16*>(out), HW, num_levels * 49, slots);
+                       lv, num_levels, coords, reinterpret_cast<_Float16*>(out), HW, num_levels * 49, slots, coords_xy);
   return check_launch();
 }

@@ -36,9 +36,10 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
 __global__ __launch_bounds__(1024) void prep_stats_kernel(const float* __restrict__ disps, int HW,
                                                           float mv_thresh, float* __restrict__ thresh,
                                                           float* __restrict__ avg_disp,
-                                                          int64_t* __restrict__ ix) {
+                                                          int64_t* __restrict__ ix, int* __restrict__ any_on) {
   __shared__ double red[16];
   const int f = blockIdx.x;
+  if (f == 0 && threadIdx.x == 0) *any_on = 0;      // prep_edges_kernel ORs into it three launches later (no memset node)
   const float* d = disps + (size_t)f * HW;
   double sd = 0.0, sz = 0.0;
   for (int k = threadIdx.x; k < HW; k += blockDim.x) {
@@ -273,8 +274,7 @@ extern "C" int glorie_dspo_prepare(const float* poses, const float* disps, const
   if ((size_t)HW * 4 > 150 * 1024) return GLORIE_EUNSUPPORTED;
   if (!any_on) return GLORIE_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  GLORIE_TRY(check_hip(hipMemsetAsync(any_on, 0, sizeof(int), st)));
-  if (n == 0) return GLORIE_OK;
+  if (n == 0) return check_hip(hipMemsetAsync(any_on, 0, sizeof(int), st));
   if (!poses || !disps || !intrinsics || !mono_disps || !valid_mask || !scales || !shifts || !scratch ||
       (N > 0 && (!ii || !jj || !edge_on)))
     return GLORIE_EINVAL;
@@ -285,7 +285,7 @@ extern "C" int glorie_dspo_prepare(const float* poses, const float* disps, const
   float* avg = thresh + n;
   int64_t* ix = reinterpret_cast<int64_t*>(sp + ((((size_t)n * HW + 2 * n) * 4 + 7) / 8) * 8);
   uint8_t* bad = reinterpret_cast<uint8_t*>(ix + n);
-  hipLaunchKernelGGL(prep_stats_kernel, dim3(n), dim3(1024), 0, st, disps, HW, mv_thresh, thresh, avg, ix);
+  hipLaunchKernelGGL(prep_stats_kernel, dim3(n), dim3(1024), 0, st, disps, HW, mv_thresh, thresh, avg, ix, any_on);
   GLORIE_TRY(glorie_depth_filter(poses, disps, intrinsics, ix, thresh, count, B, n, h, w, stream));
   static bool attr = false;
   if (!attr) {

@@ -365,19 +365,45 @@ __global__ __launch_bounds__(128) void glo_from_tiles_kernel(const float* __rest
   __shared__ float glo[128];
   const int n = blockIdx.x;
   const int tpm = (HW + 127) >> 7;
+  // latency-bound (one small block per map and 128 outputs): loads are issued 8 / 16 at a time, the sums keep their order
+  const float* tp = tiles + (size_t)n * tpm * 128 + threadIdx.x;
   float s = 0.0f;
-  for (int t = 0; t < tpm; ++t) s += tiles[((size_t)n * tpm + t) * 128 + threadIdx.x];
+  int t = 0;
+  for (; t + 8 <= tpm; t += 8) {
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = tp[(size_t)(t + k) * 128];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += v[k];
+  }
+  for (; t < tpm; ++t) s += tp[(size_t)t * 128];
+  const int o = blockIdx.y * 128 + threadIdx.x;
+  const int oc = min(o, M - 1);
+  float gv[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) gv[k] = G[(size_t)k * M + oc];          // first batch of G in flight across the barrier
   glo[threadIdx.x] = s / (float)HW;
   __syncthreads();
-  const int o = blockIdx.y * 128 + threadIdx.x;
   if (o >= M) return;
   float acc0 = Gb[o], acc1 = 0.0f, acc2 = 0.0f, acc3 = 0.0f;
-#pragma unroll 8
-  for (int c = 0; c < 128; c += 4) {
-    acc0 = fmaf(glo[c], G[(size_t)c * M + o], acc0);
-    acc1 = fmaf(glo[c + 1], G[(size_t)(c + 1) * M + o], acc1);
-    acc2 = fmaf(glo[c + 2], G[(size_t)(c + 2) * M + o], acc2);
-    acc3 = fmaf(glo[c + 3], G[(size_t)(c + 3) * M + o], acc3);
+#pragma unroll
+  for (int c0 = 0; c0 < 128; c0 += 16) {
+    float nx[16];
+    if (c0 + 16 < 128) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) nx[k] = G[(size_t)(c0 + 16 + k) * M + o];
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k += 4) {
+      acc0 = fmaf(glo[c0 + k], gv[k], acc0);
+      acc1 = fmaf(glo[c0 + k + 1], gv[k + 1], acc1);
+      acc2 = fmaf(glo[c0 + k + 2], gv[k + 2], acc2);
+      acc3 = fmaf(glo[c0 + k + 3], gv[k + 3], acc3);
+    }
+    if (c0 + 16 < 128) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) gv[k] = nx[k];
+    }
   }
   g[(size_t)n * M + o] = (acc0 + acc1) + (acc2 + acc3);
 }

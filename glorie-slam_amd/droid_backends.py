@@ -101,12 +101,18 @@ def corr_lookup_pyramid_tiled(pyramid, coords, h2, w2):
     return out
 
 
-def corr_lookup_tiled_cl(pyramid, coords, h2, w2, slots=None):
+def corr_lookup_tiled_cl(pyramid, coords, h2, w2, slots=None, interleaved=False):
     """the tiled lookup with a channels-last result (glorie_corr_lookup_tiled_cl): pyramid = 4 tiled levels (stacked in
-    edge order, or arena tensors with `slots` int32 [N]), coords [N,2,h1,w1] f32 UNscaled -> fp16 [N,256,h1,w1] in
-    channels_last memory format, channel l*64 + dy*8 + dx = the reference's channel l*49 + dx*7 + dy, padding zero"""
+    edge order, or arena tensors with `slots` int32 [N]), coords f32 UNscaled, planar [N,2,h1,w1] or - interleaved=True -
+    [N,h1,w1,2] (the reprojection's layout: no permute + copy) -> fp16 [N,256,h1,w1] in channels_last memory format,
+    channel l*64 + dy*8 + dx = the reference's channel l*49 + dx*7 + dy, padding zero"""
     L.need_cuda(coords, *pyramid)
-    N, _, h1, w1 = coords.shape
+    if coords.dim() != 4 or coords.shape[3 if interleaved else 1] != 2:
+        raise RuntimeError("coords must be [N,2,h1,w1] (planar) or [N,h1,w1,2] (interleaved)")
+    if interleaved:
+        N, h1, w1, _ = coords.shape
+    else:
+        N, _, h1, w1 = coords.shape
     if len(pyramid) != 4:
         raise RuntimeError("corr_lookup_tiled_cl: 4 levels expected")
     if not coords.is_contiguous() or coords.dtype != torch.float32:
@@ -114,7 +120,7 @@ def corr_lookup_tiled_cl(pyramid, coords, h2, w2, slots=None):
     out = torch.empty((N, 256, h1, w1), dtype=torch.float16, device=coords.device, memory_format=torch.channels_last)
     arr = (ctypes.c_void_p * 4)(*[v.data_ptr() for v in pyramid])
     L.check(L.load().glorie_corr_lookup_tiled_cl(ctypes.cast(arr, ctypes.c_void_p), 4, L.ptr(slots), L.ptr(coords),
-                                                 L.ptr(out), N, h1, w1, h2, w2, L.stream_ptr()),
+                                                 int(bool(interleaved)), L.ptr(out), N, h1, w1, h2, w2, L.stream_ptr()),
             "glorie_corr_lookup_tiled_cl")
     return out
 

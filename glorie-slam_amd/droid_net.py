@@ -541,9 +541,10 @@ class CorrBlock:
 
     def __call__(self, coords, channels_last=False):
         batch, num, ht, wd, _ = coords.shape
-        c = coords.permute(0, 1, 4, 2, 3).contiguous().view(batch * num, 2, ht, wd).float()
         if channels_last and self.tiled and self.num_levels == 4 and self.radius == 3:
-            return droid_backends.corr_lookup_tiled_cl(self.corr_pyramid, c, self.dims[2], self.dims[3])
+            return droid_backends.corr_lookup_tiled_cl(self.corr_pyramid, coords.reshape(batch * num, ht, wd, 2).float()
+                                                       .contiguous(), self.dims[2], self.dims[3], interleaved=True)
+        c = coords.permute(0, 1, 4, 2, 3).contiguous().view(batch * num, 2, ht, wd).float()
         if self.tiled:
             out = droid_backends.corr_lookup_pyramid_tiled(self.corr_pyramid, c, self.dims[2], self.dims[3])
         else:
@@ -665,9 +666,10 @@ class CorrArena:
         N = batch * num
         if N != len(self._host_slots):
             raise RuntimeError(f"CorrArena holds {len(self._host_slots)} edges, coords has {N}")
-        c = coords.permute(0, 1, 4, 2, 3).contiguous().view(N, 2, ht, wd).float()
         if channels_last and self.num_levels == 4:
-            return droid_backends.corr_lookup_tiled_cl(self.views(), c, self.h, self.w, slots=self.slots)
+            return droid_backends.corr_lookup_tiled_cl(self.views(), coords.reshape(N, ht, wd, 2).float().contiguous(),
+                                                       self.h, self.w, slots=self.slots, interleaved=True)
+        c = coords.permute(0, 1, 4, 2, 3).contiguous().view(N, 2, ht, wd).float()
         out = torch.empty((N, self.num_levels * 49, ht, wd), dtype=torch.float16, device=c.device)
         v = self.views()
         arr = (ctypes.c_void_p * self.num_levels)(*[t.data_ptr() for t in v])

@@ -109,9 +109,11 @@ int glorie_corr_lookup_arena(const void* const* levels, int num_levels, const in
  * l * 64 + dy * 8 + dx holds the reference's channel l * 49 + dx * 7 + dy (corr.py:43-53: CorrSampler output
  * [.., 2r+1 (x), 2r+1 (y), h, w], levels concatenated), the 8th row / tap of every level is zero.  corr_encoder[0]
  * (droid_net.py:73-75, 1x1, 196 -> 128) then runs as glorie_conv_igemm with taps = 1 on weight columns permuted the same way
- * (update_ops.pack_corr_encoder).  slots may be NULL (volumes stacked in edge order); 4 levels, radius 3 only. */
+ * (update_ops.pack_corr_encoder).  slots may be NULL (volumes stacked in edge order); 4 levels, radius 3 only.
+ * coords_xy != 0: coords are [N][h1*w1][2] (x, y interleaved, the layout the reprojection produces, factor_graph.py:205-215)
+ * instead of the planar [N][2][h1*w1]. */
 int glorie_corr_lookup_tiled_cl(const void* const* levels, int num_levels, const int* slots, const float* coords,
-                                void* out, int N, int h1, int w1, int h2, int w2, void* stream);
+                                int coords_xy, void* out, int N, int h1, int w1, int h2, int w2, void* stream);
 
 /* Volume-free form of CorrBlock.__call__ / AltCorrBlock.__call__
  *   reference: src/modules/droid_net/corr.py:43-53 (volume lookup), :79-145 (alt-corr),

@@ -96,6 +96,9 @@ def test_corr_lookup_tiled_bit_exact(gpu, N, h, w, margin):
         planar = got.view(N, 4, 7, 7, h, w)                        # [n][level][dx][dy][y][x]
         assert torch.equal(v[:, :, :7, :7].contiguous().view(torch.int16),
                            planar.permute(0, 1, 3, 2, 4, 5).contiguous().view(torch.int16))
+        # coordinates in the reprojection's interleaved [N,h,w,2] layout: same bits, no permute + copy in front
+        xy = db.corr_lookup_tiled_cl(tiled, ct.permute(0, 2, 3, 1).contiguous(), h, w, interleaved=True)
+        assert torch.equal(xy.view(torch.int16), cl.view(torch.int16))
 
 
 def test_corrblock_tiled_cat_and_index(gpu):
