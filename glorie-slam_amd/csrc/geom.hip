@@ -318,6 +318,28 @@ __global__ __launch_bounds__(256) void motion_kernel(const float2* __restrict__ 
   out[i] = o;
 }
 
+// the same features as the zero-padded fp16 map glorie_flow_conv7_padded reads ([N][h+6][w+8][4] halfs, interior at row 3,
+// pixel 3; the borders are never written and must be zero): the flow encoder rounds its input to fp16 anyway
+typedef __attribute__((ext_vector_type(4))) _Float16 mot4;
+__global__ __launch_bounds__(256) void motion_padded_kernel(const float2* __restrict__ coords1,
+                                                            const float2* __restrict__ coords0,
+                                                            const float2* __restrict__ target,
+                                                            _Float16* __restrict__ out, long total, int h, int w, float lim) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int HW = h * w;
+  const long n = i / HW;
+  const int q = (int)(i - n * HW);
+  const int y = q / w, x = q - y * w;
+  const float2 c1 = coords1[i], c0 = coords0[q], t = target[i];
+  mot4 o;
+  o[0] = (_Float16)fminf(fmaxf(c1.x - c0.x, -lim), lim);
+  o[1] = (_Float16)fminf(fmaxf(c1.y - c0.y, -lim), lim);
+  o[2] = (_Float16)fminf(fmaxf(t.x - c1.x, -lim), lim);
+  o[3] = (_Float16)fminf(fmaxf(t.y - c1.y, -lim), lim);
+  *reinterpret_cast<mot4*>(out + (((n * (h + 6) + y + 3) * (w + 8)) + x + 3) * 4) = o;
+}
+
 // Same operator on a CHANNELS-LAST fp16 mask ([pixel][576], what the 1x1 upmask convolution of
 // GraphAgg writes): lane = (sub-row a, pixel q of a group of 8).  For tap k the 8 sub-column
 // weights of (a) are 16 contiguous bytes, a wave reads 8 pixels x 128 contiguous bytes per tap and
@@ -460,5 +482,17 @@ extern "C" int glorie_motion(const float* coords1, const float* coords0, const f
                      reinterpret_cast<const float2*>(coords1), reinterpret_cast<const float2*>(coords0),
                      reinterpret_cast<const float2*>(target), reinterpret_cast<float4*>(out), total, h * w,
                      limit);
+  return check_launch();
+}
+
+extern "C" int glorie_motion_padded(const float* coords1, const float* coords0, const float* target, void* padded,
+                                    int N, int h, int w, float limit, void* stream) {
+  if (N < 0 || h < 0 || w < 0) return GLORIE_EINVAL;
+  const long total = (long)N * h * w;
+  if (total == 0) return GLORIE_OK;
+  if (!coords1 || !coords0 || !target || !padded) return GLORIE_EINVAL;
+  hipLaunchKernelGGL(motion_padded_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const float2*>(coords1), reinterpret_cast<const float2*>(coords0),
+                     reinterpret_cast<const float2*>(target), reinterpret_cast<_Float16*>(padded), total, h, w, limit);
   return check_launch();
 }

@@ -230,6 +230,20 @@ def motion(coords1, coords0, target, limit=64.0):
     return out
 
 
+def motion_padded(coords1, coords0, target, padded, limit=64.0):
+    """motion() written as the zero-padded fp16 map the flow encoder's first convolution reads
+    (update_ops.PaddedFlow, glorie_flow_conv7_padded): no fp32 map, no conversion in the convolution"""
+    L.need_cuda(coords1, coords0, target, padded.buf)
+    L.need_contiguous(coords1=coords1, coords0=coords0, target=target)
+    h, w = coords0.shape[-3], coords0.shape[-2]
+    n = coords1.numel() // (h * w * 2)
+    if target.numel() != coords1.numel() or coords0.numel() != h * w * 2 or not padded.fits(n, h, w, coords1.device):
+        raise RuntimeError("motion_padded: shape mismatch")
+    L.check(L.load().glorie_motion_padded(L.ptr(coords1), L.ptr(coords0), L.ptr(target), L.ptr(padded.buf), n, h, w,
+                                          float(limit), L.stream_ptr()), "glorie_motion_padded")
+    return padded
+
+
 def valid_depth_mask(poses, disps, intrinsics, ix, mv_thresh, visible_num):
     """two-view validity mask of frames `ix` on the map stack `disps` [B,h,w]
     (DepthVideo.update_valid_depth_mask, depth_video.py:326-361) -> bool [len(ix), h, w]"""

@@ -272,6 +272,7 @@ class FusedUpdate:
         self._hx = None
         self._inp_key = None      # (tensor kept alive, version) whose values sit in the inp slice of hx
         self._pre_kf, self._pre_map, self._ctx_key = None, None, None   # context term shared per keyframe
+        self._flow_pad = None     # zero-padded fp16 motion map (update_ops.PaddedFlow) for callers that pass fp32 flow
         self.fuse_glo = True      # global-context reduction inside the epilogue of its 1x1 convolution
         self.fuse_heads = True    # tap GEMMs of the delta / weight heads inside the epilogue of their hidden convolution
         self.gate_events = None   # a list: (start, end) events of every z|r gate launch are appended (eager steps only)
@@ -405,10 +406,16 @@ class FusedUpdate:
                 st.wait_stream(main)
         with torch.cuda.stream(side[0]):
             # flow_encoder (droid_net.py:79-83)
-            if flow is None:
-                flow = torch.zeros(batch, num, 4, ht, wd, device=dev)
-            fl = flow.reshape(n, 4, ht, wd).permute(0, 2, 3, 1).float().contiguous()   # no copy for a [.., h, w, 4] motion map
-            f1 = U.flow_conv7(fl, W["fe1"], W["fe1_b"], cl_map(128))
+            if isinstance(flow, U.PaddedFlow):
+                pf = flow                                  # FactorGraph._motion wrote the padded fp16 map directly
+            else:
+                if flow is None:
+                    flow = torch.zeros(batch, num, 4, ht, wd, device=dev)
+                fl = flow.reshape(n, 4, ht, wd).permute(0, 2, 3, 1).float().contiguous()   # no copy for a [.., h, w, 4] motion map
+                if self._flow_pad is None or not self._flow_pad.fits(n, ht, wd, dev):
+                    self._flow_pad = U.PaddedFlow(n, ht, wd, dev)
+                pf = U.flow_pad(fl, self._flow_pad)
+            f1 = U.flow_conv7_padded(pf, W["fe1"], W["fe1_b"], cl_map(128))
             U.conv_igemm(f1, None, W["fe2"], 9, 64, hx[:, 256:320], terms=W["fe2_b"], act=U.ACT_RELU)
         shared = context is not None and self.hoist_inp
         with torch.cuda.stream(side[1]):

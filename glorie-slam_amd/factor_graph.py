@@ -208,8 +208,16 @@ class FactorGraph:
         self.rm_factors(m, store=False)
 
     # ---- one BA-update iteration -----------------------------------------------------
-    def _motion(self, coords1):
-        """[1, N, 4, h, w] view of the channels-last motion map (factor_graph.py:219-221)"""
+    def _motion(self, coords1, padded=False):
+        """[1, N, 4, h, w] view of the channels-last motion map (factor_graph.py:219-221); padded=True: the zero-padded
+        fp16 form FusedUpdate's flow encoder reads (update_ops.PaddedFlow), written directly"""
+        if coords1.is_cuda and padded:
+            from .update_ops import PaddedFlow
+            n = coords1.numel() // (self.ht * self.wd * 2)
+            pf = self._graphs.get("flow_pad")
+            if pf is None or not pf.fits(n, self.ht, self.wd, coords1.device):
+                pf = self._graphs["flow_pad"] = PaddedFlow(n, self.ht, self.wd, coords1.device)
+            return droid_backends.motion_padded(coords1.contiguous(), self.coords0.contiguous(), self.target.contiguous(), pf)
         if coords1.is_cuda:
             m = droid_backends.motion(coords1.contiguous(), self.coords0.contiguous(), self.target.contiguous())
             return m.permute(0, 3, 1, 2).unsqueeze(0)
@@ -342,7 +350,7 @@ class FactorGraph:
     def _update_eager(self, t0=None, t1=None, itrs=2, use_inactive=False, EP=1e-7, motion_only=False,
                       opt_type="pose_depth", run_ba=True):
         coords1, mask = self.video.reproject(self.ii, self.jj)
-        motn = self._motion(coords1)
+        motn = self._motion(coords1, padded=self.fast_update is not None)
         if self.corr_impl == "otf":
             blk = self._otf_block()
             rig = self._otf_rig

@@ -303,6 +303,43 @@ def pack_flow_conv7(weight):
     return w.reshape(128, 224).contiguous()
 
 
+class PaddedFlow:
+    """the motion map of N edges as zero-padded fp16 [N, h+6, w+8, 4] (include/glorie_hip.h: glorie_flow_conv7_padded);
+    the borders are zeroed once here and never written again"""
+
+    def __init__(self, n, h, w, device):
+        self.n, self.h, self.w = n, h, w
+        self.buf = torch.zeros((n, h + 6, w + 8, 4), dtype=torch.float16, device=device)
+
+    def fits(self, n, h, w, device):
+        return (self.n, self.h, self.w) == (n, h, w) and self.buf.device == torch.device(device)
+
+    def interior(self):
+        """[N, h, w, 4] view of the map itself (tests)"""
+        return self.buf[:, 3:3 + self.h, 3:3 + self.w]
+
+
+def flow_pad(flow, padded):
+    """fp32 channels-last motion map [N,h,w,4] -> the interior of `padded` (PaddedFlow)"""
+    L.need_cuda(flow, padded.buf)
+    n, h, w, c = flow.shape
+    if c != 4 or flow.dtype != torch.float32 or not flow.is_contiguous() or not padded.fits(n, h, w, flow.device):
+        raise RuntimeError("flow_pad: flow must be contiguous float32 [N,h,w,4] matching the padded map")
+    L.check(L.load().glorie_flow_pad(L.ptr(flow), L.ptr(padded.buf), n, h, w, L.stream_ptr()), "glorie_flow_pad")
+    return padded
+
+
+def flow_conv7_padded(padded, w_packed, bias, out):
+    """flow_conv7 on a PaddedFlow (droid_net.py:79-81): out channels-last fp16 [N,128,h,w] (slice allowed)"""
+    L.need_cuda(padded.buf, w_packed, bias, out)
+    if out.shape[1] != 128 or out.shape[0] != padded.n or tuple(out.shape[2:]) != (padded.h, padded.w):
+        raise RuntimeError("flow_conv7_padded: bad output shape")
+    L.check(L.load().glorie_flow_conv7_padded(L.ptr(padded.buf), L.ptr(w_packed), L.ptr(bias), L.ptr(out),
+                                              _rows(out, "out"), padded.n, padded.h, padded.w, L.stream_ptr()),
+            "glorie_flow_conv7_padded")
+    return out
+
+
 def flow_conv7(flow, w_packed, bias, out):
     """out = relu(conv7x7(flow) + bias); flow float32 [N,h,w,4] contiguous (channels-last motion
     map), out channels-last fp16 [N,128,h,w] (slice allowed)   (droid_net.py:79-81)"""

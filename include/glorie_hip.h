@@ -268,6 +268,16 @@ int glorie_conv_stencil(const float* taps, const float* out_bias, int groups, in
 int glorie_flow_conv7(const float* flow, const void* w_packed, const float* bias, void* out,
                       int out_stride, int N, int H, int W, void* stream);
 
+/* The same layer on the motion map as ZERO-PADDED fp16: padded = halfs [N][H+6][W+8][4], map pixel (y, x) at row y + 3,
+ * pixel x + 3, every other element zero (3 rows above / below each map, 3 pixels left, 5 right).  A stencil row's taps are
+ * then the MFMA fragment as loaded (no conversion, no boundary selects): 43 -> ~20 us at 36x60x80.  The flow encoder rounds its
+ * input to fp16 in both forms: same results.  glorie_flow_pad fills the interior from the fp32 map [N][H][W][4] (the
+ * borders are never written: zero them once), glorie_motion_padded (below) writes the motion features there directly.
+ * out_stride % 8 == 0. */
+int glorie_flow_pad(const float* flow, void* padded, int N, int H, int W, void* stream);
+int glorie_flow_conv7_padded(const void* padded, const void* w_packed, const float* bias, void* out, int out_stride,
+                             int N, int H, int W, void* stream);
+
 /* ------------------------------------------------------------------------------------ */
 /* A/B. projective geometry                                                              */
 /* ------------------------------------------------------------------------------------ */
@@ -314,6 +324,9 @@ int glorie_cvx_upsample(const float* disps, const int64_t* ix, const void* mask,
  * (coords1, target [N,h,w,2]; coords0 [h,w,2]; out [N,h,w,4] = a channels-last 4-channel map) */
 int glorie_motion(const float* coords1, const float* coords0, const float* target, float* out, int N,
                   int h, int w, float limit, void* stream);
+/* glorie_motion with the zero-padded fp16 map of glorie_flow_conv7_padded as its output (interior only) */
+int glorie_motion_padded(const float* coords1, const float* coords0, const float* target, void* padded, int N, int h,
+                         int w, float limit, void* stream);
 
 /* same operator, mask given channels-last in fp16: row (m*h*w + pixel) holds the 576 logits,
  * rows `mask_stride` halfs apart -- the layout the 1x1 upmask convolution produces */

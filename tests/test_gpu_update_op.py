@@ -462,6 +462,33 @@ def test_flow_conv7_matches_conv2d(gpu):
     assert float(wide[:, :64].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("n,h,w", [(3, 9, 11), (1, 7, 7), (5, 12, 16), (36, 60, 80)])
+def test_flow_conv7_on_the_padded_fp16_map_is_bit_identical(gpu, n, h, w):
+    """flow_encoder[0] on the zero-padded fp16 motion map (one 16-byte load per stencil row is the MFMA fragment) against
+    the fp32-map kernel: same fp16 operands, same K order -> same bits; glorie_motion_padded writes what glorie_motion
+    + the fp16 rounding give"""
+    from glorie_slam_amd import update_ops as U, droid_backends as db
+    g = torch.Generator(device="cpu").manual_seed(33)
+    flow = (8.0 * torch.randn(n, h, w, 4, generator=g)).to(gpu)
+    weight = (torch.randn(128, 4, 7, 7, generator=g) / 14).to(gpu)
+    bias = torch.randn(128, generator=g).to(gpu)
+    wp = U.pack_flow_conv7(weight)
+    a = torch.zeros((n, 128, h, w), dtype=torch.float16, device=gpu).contiguous(memory_format=torch.channels_last)
+    wide = torch.zeros((n, 192, h, w), dtype=torch.float16, device=gpu).contiguous(memory_format=torch.channels_last)
+    U.flow_conv7(flow, wp, bias, a)
+    pf = U.flow_pad(flow, U.PaddedFlow(n, h, w, gpu))
+    assert torch.equal(pf.interior(), flow.half())
+    assert float(pf.buf.float().abs().sum()) == float(flow.half().float().abs().sum())       # borders stay zero
+    U.flow_conv7_padded(pf, wp, bias, wide[:, 64:192])
+    assert torch.equal(wide[:, 64:192], a)
+    assert float(wide[:, :64].abs().max()) == 0.0
+    coords0 = torch.randn(h, w, 2, generator=g).to(gpu) * 5
+    coords1 = (coords0 + 40.0 * torch.randn(1, n, h, w, 2, generator=g).to(gpu)).contiguous()
+    target = (coords1 + 40.0 * torch.randn(1, n, h, w, 2, generator=g).to(gpu)).contiguous()
+    pm = db.motion_padded(coords1, coords0, target, U.PaddedFlow(n, h, w, gpu))
+    assert torch.equal(pm.interior(), db.motion(coords1, coords0, target).half())
+
+
 def test_empty_inputs_are_no_ops(gpu):
     """zero edges / zero frames: every new entry point returns without touching its outputs"""
     from glorie_slam_amd import update_ops as U, droid_backends as db
