@@ -60,13 +60,57 @@ __device__ __forceinline__ bool frame_enabled(const BaWork& wk, const uint8_t* e
   return false;
 }
 
+// one workgroup (the LAST accumulation block to finish): per-frame 2x2 solve -> wk.dx [M][2]; all-or-nothing failure.
+// The partial sums of the other workgroups are read with agent-scope atomic loads (they were written under another XCD's L2).
+__device__ __forceinline__ void dspo2_solve(const BaWork& wk, const Dspo2Args& a, int M, int nchunks, float lm, float ep,
+                                            int* fail) {
+  const int tid = threadIdx.x;
+  for (int s = tid; s < M; s += kBaThreads) {
+    const bool on = frame_enabled(wk, a.edge_on, s);
+    double x1 = 0.0, x2 = 0.0;
+    if (on) {
+      double v[10];
+      for (int q = 0; q < 10; ++q) v[q] = 0.0;
+      for (int c = 0; c < nchunks; ++c)
+        for (int q = 0; q < 10; ++q)
+          v[q] += (double)__hip_atomic_load(&wk.Hpart[((size_t)s * nchunks + c) * 10 + q], __ATOMIC_RELAXED,
+                                            __HIP_MEMORY_SCOPE_AGENT);
+      // damping BEFORE the Schur complement (chol.py:68-69)
+      const double H11 = v[0] + ep + lm * v[0], H22 = v[2] + ep + lm * v[2];
+      const double S11 = H11 - v[3], S12 = v[1] - v[4], S22 = H22 - v[5];
+      const double b1 = v[6] - v[8], b2 = v[7] - v[9];
+      const double l21 = (S11 > 0.0) ? S12 / sqrt(S11) : 0.0;
+      const double l22sq = S22 - l21 * l21;
+      if (!(S11 > 0.0) || !(l22sq > 0.0)) {
+        atomicOr(fail, 1);
+      } else {
+        const double det = S11 * S22 - S12 * S12;
+        x1 = (S22 * b1 - S12 * b2) / det;
+        x2 = (S11 * b2 - S12 * b1) / det;
+      }
+    }
+    wk.dx[2 * s + 0] = (float)x1;
+    wk.dx[2 * s + 1] = (float)x2;
+  }
+  __syncthreads();
+  if (*fail) {
+    for (int s = tid; s < 2 * M; s += kBaThreads) wk.dx[s] = 0.0f;
+    if (tid == 0) {
+      atomicOr(&wk.status[0], BA_ST_CHOL_FAILED);
+      atomicAdd(&wk.status[2], 1);
+    }
+  }
+}
+
 // per-frame pixel sums: H11 H12 H22 | G11 G12 G22 | u1 u2 | g1 g2   (grid: chunks x M)
+// + the reduced solve by the last workgroup to finish (one launch instead of two: these kernels are launch-bound)
 __global__ __launch_bounds__(kBaThreads) void dspo2_accum_kernel(BaWork wk, Dspo2Args a, int HW,
-                                                                 int w, int nchunks) {
+                                                                 int w, int nchunks, int M, float lm, float ep) {
   __shared__ float red[4][10];
+  __shared__ int last, fail;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int chunk = blockIdx.x, s = blockIdx.y;
-  if (wk.status[0] & BA_ST_M_MISMATCH) return;
+  if (wk.status[0] & BA_ST_M_MISMATCH) return;          // uniform over the grid: nobody counts, nobody solves
   const int k = wk.kx[s];
   const int e0 = wk.csr_ptr[s], e1 = wk.csr_ptr[s + 1];
   const int px = chunk * kBaThreads + tid;
@@ -107,78 +151,50 @@ __global__ __launch_bounds__(kBaThreads) void dspo2_accum_kernel(BaWork wk, Dspo
     Cp += wu * Jzu * Jzu + wvv * Jzv * Jzv;
     Wp += wu * ru * Jzu + wvv * rv * Jzv;
   }
-  if (n_on == 0) return;  // frame without enabled edges is not in kx of the reference
-  float sums[10];
+  if (n_on != 0) {          // a frame without enabled edges is not in kx of the reference: no sums, its block only counts
+    float sums[10];
 #pragma unroll
-  for (int q = 0; q < 10; ++q) sums[q] = 0.0f;
-  if (live) {
-    const float mono = a.mono[(size_t)k * HW + px];
-    const PriorJ J = prior_jacobians(mono, a.vmask[(size_t)k * HW + px] != 0, a.alpha);
-    const float rd = sqrtf(a.alpha) * (dsp - (a.scales[k] * mono + a.shifts[k]));
-    const float C = Cp + J.Jd * J.Jd + a.eta[(size_t)s * HW + px];
-    const float Wv = Wp - J.Jd * rd;
-    const float Q = 1.0f / C;
-    wk.Q[(size_t)s * HW + px] = Q;
-    wk.W[(size_t)s * HW + px] = Wv;
-    const float e1v = J.Js * J.Jd, e2v = J.Jq * J.Jd;
-    sums[0] = J.Js * J.Js; sums[1] = J.Js * J.Jq; sums[2] = J.Jq * J.Jq;
-    sums[3] = e1v * Q * e1v; sums[4] = e1v * Q * e2v; sums[5] = e2v * Q * e2v;
-    sums[6] = -J.Js * rd; sums[7] = -J.Jq * rd;
-    sums[8] = e1v * Q * Wv; sums[9] = e2v * Q * Wv;
-  }
-#pragma unroll
-  for (int q = 0; q < 10; ++q) sums[q] = wave_sum(sums[q]);
-  if (lane == 0) {
-#pragma unroll
-    for (int q = 0; q < 10; ++q) red[wv][q] = sums[q];
-  }
-  __syncthreads();
-  if (tid < 10)
-    wk.Hpart[((size_t)s * nchunks + chunk) * 10 + tid] =
-        (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
-}
-
-// one workgroup: per-frame 2x2 solve -> wk.dx [M][2]; all-or-nothing failure
-__global__ __launch_bounds__(256) void dspo2_solve_kernel(BaWork wk, Dspo2Args a, int M, int nchunks,
-                                                          float lm, float ep) {
-  __shared__ int fail;
-  const int tid = threadIdx.x;
-  if (tid == 0) fail = 0;
-  __syncthreads();
-  if (wk.status[0] & BA_ST_M_MISMATCH) return;
-  for (int s = tid; s < M; s += 256) {
-    const bool on = frame_enabled(wk, a.edge_on, s);
-    double x1 = 0.0, x2 = 0.0;
-    if (on) {
-      double v[10];
-      for (int q = 0; q < 10; ++q) v[q] = 0.0;
-      for (int c = 0; c < nchunks; ++c)
-        for (int q = 0; q < 10; ++q) v[q] += (double)wk.Hpart[((size_t)s * nchunks + c) * 10 + q];
-      // damping BEFORE the Schur complement (chol.py:68-69)
-      const double H11 = v[0] + ep + lm * v[0], H22 = v[2] + ep + lm * v[2];
-      const double S11 = H11 - v[3], S12 = v[1] - v[4], S22 = H22 - v[5];
-      const double b1 = v[6] - v[8], b2 = v[7] - v[9];
-      const double l21 = (S11 > 0.0) ? S12 / sqrt(S11) : 0.0;
-      const double l22sq = S22 - l21 * l21;
-      if (!(S11 > 0.0) || !(l22sq > 0.0)) {
-        atomicOr(&fail, 1);
-      } else {
-        const double det = S11 * S22 - S12 * S12;
-        x1 = (S22 * b1 - S12 * b2) / det;
-        x2 = (S11 * b2 - S12 * b1) / det;
-      }
+    for (int q = 0; q < 10; ++q) sums[q] = 0.0f;
+    if (live) {
+      const float mono = a.mono[(size_t)k * HW + px];
+      const PriorJ J = prior_jacobians(mono, a.vmask[(size_t)k * HW + px] != 0, a.alpha);
+      const float rd = sqrtf(a.alpha) * (dsp - (a.scales[k] * mono + a.shifts[k]));
+      const float C = Cp + J.Jd * J.Jd + a.eta[(size_t)s * HW + px];
+      const float Wv = Wp - J.Jd * rd;
+      const float Q = 1.0f / C;
+      wk.Q[(size_t)s * HW + px] = Q;
+      wk.W[(size_t)s * HW + px] = Wv;
+      const float e1v = J.Js * J.Jd, e2v = J.Jq * J.Jd;
+      sums[0] = J.Js * J.Js; sums[1] = J.Js * J.Jq; sums[2] = J.Jq * J.Jq;
+      sums[3] = e1v * Q * e1v; sums[4] = e1v * Q * e2v; sums[5] = e2v * Q * e2v;
+      sums[6] = -J.Js * rd; sums[7] = -J.Jq * rd;
+      sums[8] = e1v * Q * Wv; sums[9] = e2v * Q * Wv;
     }
-    wk.dx[2 * s + 0] = (float)x1;
-    wk.dx[2 * s + 1] = (float)x2;
+#pragma unroll
+    for (int q = 0; q < 10; ++q) sums[q] = wave_sum(sums[q]);
+    if (lane == 0) {
+#pragma unroll
+      for (int q = 0; q < 10; ++q) red[wv][q] = sums[q];
+    }
+    __syncthreads();
+    if (tid < 10)
+      wk.Hpart[((size_t)s * nchunks + chunk) * 10 + tid] =
+          (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+  }
+  // the last workgroup to get here solves the reduced systems (status[3] counts arrivals and is left at 0)
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) {
+    const int total = (int)(gridDim.x * gridDim.y);
+    const int seen = atomicAdd(&wk.status[3], 1);
+    last = seen == total - 1;
+    fail = 0;
+    if (last) wk.status[3] = 0;
   }
   __syncthreads();
-  if (fail) {
-    for (int s = tid; s < 2 * M; s += 256) wk.dx[s] = 0.0f;
-    if (tid == 0) {
-      atomicOr(&wk.status[0], BA_ST_CHOL_FAILED);
-      atomicAdd(&wk.status[2], 1);
-    }
-  }
+  if (!last) return;
+  __threadfence();
+  dspo2_solve(wk, a, M, nchunks, lm, ep, &fail);
 }
 
 __global__ __launch_bounds__(kBaThreads) void dspo2_update_kernel(BaWork wk, Dspo2Args a, int HW,
@@ -189,6 +205,10 @@ __global__ __launch_bounds__(kBaThreads) void dspo2_update_kernel(BaWork wk, Dsp
   if (!frame_enabled(wk, a.edge_on, s)) return;
   const int k = wk.kx[s];
   const float ds = wk.dx[2 * s + 0], dq = wk.dx[2 * s + 1];
+  if (blockIdx.x == 0 && tid == 0) {        // the frame's scale / shift step (nobody reads them in this launch)
+    a.scales[k] += ds;
+    a.shifts[k] += dq;
+  }
   const int px = blockIdx.x * kBaThreads + tid;
   if (px >= HW) return;
   const PriorJ J = prior_jacobians(a.mono[(size_t)k * HW + px], a.vmask[(size_t)k * HW + px] != 0, a.alpha);
@@ -197,15 +217,6 @@ __global__ __launch_bounds__(kBaThreads) void dspo2_update_kernel(BaWork wk, Dsp
   // disp_retr then clamp(min=0) (ba.py:210-214)
   a.disps[(size_t)k * HW + px] = fmaxf(a.disps[(size_t)k * HW + px] + dz, 0.0f);
   if (dz_out) dz_out[(size_t)s * HW + px] = dz;
-}
-
-__global__ __launch_bounds__(256) void dspo2_wq_kernel(BaWork wk, Dspo2Args a, int M) {
-  const int s = blockIdx.x * 256 + threadIdx.x;
-  if (s >= M || (wk.status[0] & BA_ST_M_MISMATCH)) return;
-  if (!frame_enabled(wk, a.edge_on, s)) return;
-  const int k = wk.kx[s];
-  a.scales[k] += wk.dx[2 * s + 0];
-  a.shifts[k] += wk.dx[2 * s + 1];
 }
 
 }  // namespace glorie
@@ -255,10 +266,9 @@ extern "C" int glorie_dspo_scale_shift(glorie_ctx* ctx, const float* poses, floa
   Dspo2Args a{poses, disps, intrinsics, mono_disps, scales, shifts, valid_mask, target, weight, eta,
               ii, jj, edge_on, alpha};
   for (int it = 0; it < iterations; ++it) {
-    hipLaunchKernelGGL(dspo2_accum_kernel, dim3(nchunks, M), dim3(kBaThreads), 0, st, wk, a, HW, w, nchunks);
-    hipLaunchKernelGGL(dspo2_solve_kernel, dim3(1), dim3(256), 0, st, wk, a, M, nchunks, lm, ep);
+    // two launches per iteration: pixel sums + (last workgroup) the per-frame solves; disparity + scale/shift steps
+    hipLaunchKernelGGL(dspo2_accum_kernel, dim3(nchunks, M), dim3(kBaThreads), 0, st, wk, a, HW, w, nchunks, M, lm, ep);
     hipLaunchKernelGGL(dspo2_update_kernel, dim3(nchunks, M), dim3(kBaThreads), 0, st, wk, a, HW, dz_out);
-    hipLaunchKernelGGL(dspo2_wq_kernel, dim3((M + 255) / 256), dim3(256), 0, st, wk, a, M);
     GLORIE_TRY(check_launch());
   }
   return GLORIE_OK;
