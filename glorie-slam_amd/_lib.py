@@ -53,7 +53,7 @@ SIGNATURES = {
     "glorie_flow_pad": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _vp]),
     "glorie_flow_conv7_padded": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp]),
     "glorie_publish_flag": (_c_int, [_vp, _vp, _vp, _vp]),
-    "glorie_dspo_prepare": (_c_int, [_vp] * 4 + [_c_int] * 4 + [ctypes.c_float, _c_int, ctypes.c_float, _vp, _vp, _c_int] + [_vp] * 7),
+    "glorie_dspo_prepare": (_c_int, [_vp] * 4 + [_c_int] * 4 + [ctypes.c_float, _c_int, ctypes.c_float, _vp, _vp, _c_int] + [_vp] * 9),
     "glorie_corr_lookup_pyramid_tiled": (_c_int, [_vp, _c_int, _vp, _vp] + [_c_int] * 5 + [_vp]),
     "glorie_corr_build": (_c_int, [_vp] * 5 + [_c_int] * 5 + [_vp]),
     "glorie_corr_lookup_arena": (_c_int, [_vp, _c_int, _vp, _vp, _vp] + [_c_int] * 5 + [_vp]),

@@ -179,12 +179,18 @@ __global__ __launch_bounds__(kBaThreads) void ba_jacobian_kernel(
     const float* __restrict__ intr, const float* __restrict__ disps_sens,
     const float* __restrict__ targets, const float* __restrict__ weights,
     const float* __restrict__ eta, const int64_t* __restrict__ ii,
-    const int64_t* __restrict__ jj, int HW, int w, int nchunks, int ppt, int motion_only, int hwc) {
+    const int64_t* __restrict__ jj, int HW, int w, int nchunks, int ppt, int motion_only, int hwc, long hd_doubles) {
   __shared__ float red[4][28];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wv = tid >> 6;
   const int chunk = blockIdx.x;
   const int s = blockIdx.y;
+  // the reduced system [H | v] the gram / assemble launches accumulate into starts at zero (nobody reads it in this launch:
+  // one memset node less per iteration)
+  {
+    const long nthreads = (long)gridDim.x * gridDim.y * kBaThreads;
+    for (long i = ((long)s * gridDim.x + chunk) * kBaThreads + tid; i < hd_doubles; i += nthreads) wk.Hd[i] = 0.0;
+  }
   if (wk.status[0] & BA_ST_M_MISMATCH) return;
   const int k = wk.kx[s];
   const int e0 = wk.csr_ptr[s], e1 = wk.csr_ptr[s + 1];
@@ -1281,10 +1287,9 @@ static int ba_build_system(const BaPlan& pl, const float* poses, const float* di
                            const int64_t* jj, int flags, hipStream_t st) {
   const BaWork& wk = pl.wk;
   const int motion_only = flags & 1, hwc = (flags & GLORIE_BA_TARGETS_HWC) ? 1 : 0;
-  GLORIE_TRY(check_hip(hipMemsetAsync(wk.Hd, 0, sizeof(double) * ((size_t)pl.n6 * pl.n6 + pl.n6), st)));
   hipLaunchKernelGGL(ba_jacobian_kernel, dim3(pl.nchunks, pl.M), dim3(kBaThreads), 0, st, wk, poses,
                      disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, pl.HW, pl.w,
-                     pl.nchunks, pl.ppt, motion_only, hwc);
+                     pl.nchunks, pl.ppt, motion_only, hwc, (long)pl.n6 * pl.n6 + pl.n6);
   if (!motion_only)
     hipLaunchKernelGGL(ba_gram_kernel, dim3(pl.nchunks, pl.M), dim3(kBaThreads), 0, st, wk, jj, pl.HW,
                        pl.chunk_px, pl.t0, pl.t1);

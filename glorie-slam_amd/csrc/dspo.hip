@@ -60,21 +60,24 @@ __device__ __forceinline__ bool frame_enabled(const BaWork& wk, const uint8_t* e
   return false;
 }
 
-// one workgroup (the LAST accumulation block to finish): per-frame 2x2 solve -> wk.dx [M][2]; all-or-nothing failure.
-// The partial sums of the other workgroups are read with agent-scope atomic loads (they were written under another XCD's L2).
-__device__ __forceinline__ void dspo2_solve(const BaWork& wk, const Dspo2Args& a, int M, int nchunks, float lm, float ep,
-                                            int* fail) {
+// one workgroup: per-frame 2x2 solve -> wk.dx [M][2]; all-or-nothing failure.  (Folding this into the last workgroup
+// of the accumulation launch was measured and is NOT used: the agent-scope release every workgroup then needs writes back
+// its XCD's L2 - 9 + 7 us became 25.)
+__global__ __launch_bounds__(256) void dspo2_solve_kernel(BaWork wk, Dspo2Args a, int M, int nchunks,
+                                                          float lm, float ep) {
+  __shared__ int fail;
   const int tid = threadIdx.x;
-  for (int s = tid; s < M; s += kBaThreads) {
+  if (tid == 0) fail = 0;
+  __syncthreads();
+  if (wk.status[0] & BA_ST_M_MISMATCH) return;
+  for (int s = tid; s < M; s += 256) {
     const bool on = frame_enabled(wk, a.edge_on, s);
     double x1 = 0.0, x2 = 0.0;
     if (on) {
       double v[10];
       for (int q = 0; q < 10; ++q) v[q] = 0.0;
       for (int c = 0; c < nchunks; ++c)
-        for (int q = 0; q < 10; ++q)
-          v[q] += (double)__hip_atomic_load(&wk.Hpart[((size_t)s * nchunks + c) * 10 + q], __ATOMIC_RELAXED,
-                                            __HIP_MEMORY_SCOPE_AGENT);
+        for (int q = 0; q < 10; ++q) v[q] += (double)wk.Hpart[((size_t)s * nchunks + c) * 10 + q];
       // damping BEFORE the Schur complement (chol.py:68-69)
       const double H11 = v[0] + ep + lm * v[0], H22 = v[2] + ep + lm * v[2];
       const double S11 = H11 - v[3], S12 = v[1] - v[4], S22 = H22 - v[5];
@@ -82,7 +85,7 @@ __device__ __forceinline__ void dspo2_solve(const BaWork& wk, const Dspo2Args& a
       const double l21 = (S11 > 0.0) ? S12 / sqrt(S11) : 0.0;
       const double l22sq = S22 - l21 * l21;
       if (!(S11 > 0.0) || !(l22sq > 0.0)) {
-        atomicOr(fail, 1);
+        atomicOr(&fail, 1);
       } else {
         const double det = S11 * S22 - S12 * S12;
         x1 = (S22 * b1 - S12 * b2) / det;
@@ -93,8 +96,8 @@ __device__ __forceinline__ void dspo2_solve(const BaWork& wk, const Dspo2Args& a
     wk.dx[2 * s + 1] = (float)x2;
   }
   __syncthreads();
-  if (*fail) {
-    for (int s = tid; s < 2 * M; s += kBaThreads) wk.dx[s] = 0.0f;
+  if (fail) {
+    for (int s = tid; s < 2 * M; s += 256) wk.dx[s] = 0.0f;
     if (tid == 0) {
       atomicOr(&wk.status[0], BA_ST_CHOL_FAILED);
       atomicAdd(&wk.status[2], 1);
@@ -103,14 +106,12 @@ __device__ __forceinline__ void dspo2_solve(const BaWork& wk, const Dspo2Args& a
 }
 
 // per-frame pixel sums: H11 H12 H22 | G11 G12 G22 | u1 u2 | g1 g2   (grid: chunks x M)
-// + the reduced solve by the last workgroup to finish (one launch instead of two: these kernels are launch-bound)
 __global__ __launch_bounds__(kBaThreads) void dspo2_accum_kernel(BaWork wk, Dspo2Args a, int HW,
-                                                                 int w, int nchunks, int M, float lm, float ep) {
+                                                                 int w, int nchunks) {
   __shared__ float red[4][10];
-  __shared__ int last, fail;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int chunk = blockIdx.x, s = blockIdx.y;
-  if (wk.status[0] & BA_ST_M_MISMATCH) return;          // uniform over the grid: nobody counts, nobody solves
+  if (wk.status[0] & BA_ST_M_MISMATCH) return;
   const int k = wk.kx[s];
   const int e0 = wk.csr_ptr[s], e1 = wk.csr_ptr[s + 1];
   const int px = chunk * kBaThreads + tid;
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(kBaThreads) void dspo2_accum_kernel(BaWork wk, Dspo
     Cp += wu * Jzu * Jzu + wvv * Jzv * Jzv;
     Wp += wu * ru * Jzu + wvv * rv * Jzv;
   }
-  if (n_on != 0) {          // a frame without enabled edges is not in kx of the reference: no sums, its block only counts
+  if (n_on != 0) {          // a frame without enabled edges is not in kx of the reference: no sums
     float sums[10];
 #pragma unroll
     for (int q = 0; q < 10; ++q) sums[q] = 0.0f;
@@ -181,20 +182,6 @@ __global__ __launch_bounds__(kBaThreads) void dspo2_accum_kernel(BaWork wk, Dspo
       wk.Hpart[((size_t)s * nchunks + chunk) * 10 + tid] =
           (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
   }
-  // the last workgroup to get here solves the reduced systems (status[3] counts arrivals and is left at 0)
-  __threadfence();
-  __syncthreads();
-  if (tid == 0) {
-    const int total = (int)(gridDim.x * gridDim.y);
-    const int seen = atomicAdd(&wk.status[3], 1);
-    last = seen == total - 1;
-    fail = 0;
-    if (last) wk.status[3] = 0;
-  }
-  __syncthreads();
-  if (!last) return;
-  __threadfence();
-  dspo2_solve(wk, a, M, nchunks, lm, ep, &fail);
 }
 
 __global__ __launch_bounds__(kBaThreads) void dspo2_update_kernel(BaWork wk, Dspo2Args a, int HW,
@@ -266,8 +253,9 @@ extern "C" int glorie_dspo_scale_shift(glorie_ctx* ctx, const float* poses, floa
   Dspo2Args a{poses, disps, intrinsics, mono_disps, scales, shifts, valid_mask, target, weight, eta,
               ii, jj, edge_on, alpha};
   for (int it = 0; it < iterations; ++it) {
-    // two launches per iteration: pixel sums + (last workgroup) the per-frame solves; disparity + scale/shift steps
-    hipLaunchKernelGGL(dspo2_accum_kernel, dim3(nchunks, M), dim3(kBaThreads), 0, st, wk, a, HW, w, nchunks, M, lm, ep);
+    // three launches per iteration: pixel sums, per-frame solves, disparity + scale/shift steps
+    hipLaunchKernelGGL(dspo2_accum_kernel, dim3(nchunks, M), dim3(kBaThreads), 0, st, wk, a, HW, w, nchunks);
+    hipLaunchKernelGGL(dspo2_solve_kernel, dim3(1), dim3(256), 0, st, wk, a, M, nchunks, lm, ep);
     hipLaunchKernelGGL(dspo2_update_kernel, dim3(nchunks, M), dim3(kBaThreads), 0, st, wk, a, HW, dz_out);
     GLORIE_TRY(check_launch());
   }

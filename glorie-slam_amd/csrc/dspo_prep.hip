@@ -159,15 +159,32 @@ __global__ __launch_bounds__(1024) void prep_align_kernel(
 __global__ __launch_bounds__(256) void prep_edges_kernel(const uint8_t* __restrict__ bad,
                                                          const int64_t* __restrict__ ii,
                                                          const int64_t* __restrict__ jj, int N, int n,
-                                                         uint8_t* __restrict__ edge_on, int* __restrict__ any_on) {
+                                                         uint8_t* __restrict__ edge_on, int* __restrict__ any_on,
+                                                         int* __restrict__ pub /* null | [launch count, arrivals] */,
+                                                         int* host_word) {
   const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= N) return;
-  const int i = (int)ii[e], j = (int)jj[e];
-  const bool bi = (i >= 0 && i < n) ? bad[i] != 0 : false;      // frames beyond the counter are never "bad"
-  const bool bj = (j >= 0 && j < n) ? bad[j] != 0 : false;
-  const bool on = !(bi || bj);
-  edge_on[e] = on ? 1 : 0;
-  if (on) atomicOr(any_on, 1);
+  if (e < N) {
+    const int i = (int)ii[e], j = (int)jj[e];
+    const bool bi = (i >= 0 && i < n) ? bad[i] != 0 : false;      // frames beyond the counter are never "bad"
+    const bool bj = (j >= 0 && j < n) ? bad[j] != 0 : false;
+    const bool on = !(bi || bj);
+    edge_on[e] = on ? 1 : 0;
+    if (on) atomicOr(any_on, 1);
+  }
+  if (!pub) return;
+  // the last workgroup publishes (launch count << 1 | any_on) to pinned host memory (see publish_flag_kernel below)
+  __shared__ int last;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) last = atomicAdd(&pub[1], 1) == (int)gridDim.x - 1;
+  __syncthreads();
+  if (last && threadIdx.x == 0) {
+    pub[1] = 0;
+    const int c = pub[0] + 1;
+    pub[0] = c;
+    const int flag = __hip_atomic_load(any_on, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(host_word, (c << 1) | (flag != 0 ? 1 : 0), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 // The one host decision of a depth_scale stage recorded into a hipGraph (`any edge enabled`, depth_video.py:290-294)
@@ -268,13 +285,19 @@ extern "C" int glorie_dspo_prepare(const float* poses, const float* disps, const
                                    const float* mono_disps, int B, int n, int h, int w, float mv_thresh,
                                    int visible_num, float mono_thres, const int64_t* ii, const int64_t* jj,
                                    int N, uint8_t* valid_mask, float* scales, float* shifts,
-                                   uint8_t* edge_on, int* any_on, void* scratch, void* stream) {
+                                   uint8_t* edge_on, int* any_on, void* scratch, int* publish_state,
+                                   int* publish_host_word, void* stream) {
   if (B < 0 || n < 0 || n > B || h <= 0 || w <= 0 || N < 0) return GLORIE_EINVAL;
   const int HW = h * w;
   if ((size_t)HW * 4 > 150 * 1024) return GLORIE_EUNSUPPORTED;
   if (!any_on) return GLORIE_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  if (n == 0) return check_hip(hipMemsetAsync(any_on, 0, sizeof(int), st));
+  const bool publish = publish_state && publish_host_word;
+  if (n == 0) {
+    GLORIE_TRY(check_hip(hipMemsetAsync(any_on, 0, sizeof(int), st)));
+    if (publish) hipLaunchKernelGGL(publish_flag_kernel, dim3(1), dim3(1), 0, st, any_on, publish_state, publish_host_word);
+    return check_launch();
+  }
   if (!poses || !disps || !intrinsics || !mono_disps || !valid_mask || !scales || !shifts || !scratch ||
       (N > 0 && (!ii || !jj || !edge_on)))
     return GLORIE_EINVAL;
@@ -297,7 +320,9 @@ extern "C" int glorie_dspo_prepare(const float* poses, const float* disps, const
                      HW, (float)visible_num, mono_thres, valid_mask, scales, shifts, bad);
   if (N > 0)
     hipLaunchKernelGGL(prep_edges_kernel, dim3((N + 255) / 256), dim3(256), 0, st, bad, ii, jj, N, n, edge_on,
-                       any_on);
+                       any_on, publish ? publish_state : nullptr, publish_host_word);
+  else if (publish)
+    hipLaunchKernelGGL(publish_flag_kernel, dim3(1), dim3(1), 0, st, any_on, publish_state, publish_host_word);
   return check_launch();
 }
 

@@ -211,8 +211,13 @@ class DepthVideo:
         if getattr(self, "_flag_host", None) is None:
             self._flag_host = torch.zeros(1, dtype=torch.int32).pin_memory()
             self._flag_np = self._flag_host.numpy()
-            self._flag_count = torch.zeros(1, dtype=torch.int32, device=self.device)
+            self._flag_count = torch.zeros(2, dtype=torch.int32, device=self.device)      # launch count, arrivals
             self._flag_expected = 0
+
+    def publish_target(self):
+        """(state, host word address) for droid_backends.dspo_prepare(publish=...): the preparation publishes itself"""
+        self.deferred_flag_init()
+        return self._flag_count, self._flag_host.data_ptr()
 
     def publish_any_on(self, any_on):
         """record the store of a depth_scale stage's `any edge enabled` into the pinned word (csrc/dspo_prep.hip)"""

@@ -261,11 +261,12 @@ def valid_depth_mask(poses, disps, intrinsics, ix, mv_thresh, visible_num):
 
 
 def dspo_prepare(poses, disps, intrinsics, mono_disps, n, mv_thresh, visible_num, mono_thres, ii, jj,
-                 valid_mask, depth_scale, depth_shift):
+                 valid_mask, depth_scale, depth_shift, publish=None):
     """update_valid_depth_mask(up=False) + align_scale_and_shift + the mono_thres edge filter of the
     depth_scale stage (depth_video.py:228-247,326-361) in 4 launches and without a host sync.
     Writes valid_mask[:n] (bool), depth_scale[:n], depth_shift[:n]; returns (edge_on uint8 [N],
-    any_on int32 [1])."""
+    any_on int32 [1]).  publish = (state int32 [2] on the device, address of a pinned host word): the last launch
+    also stores (launch count << 1 | any_on) there (DepthVideo.await_any_on polls it)."""
     L.need_cuda(poses, disps, intrinsics, mono_disps, ii, jj, valid_mask, depth_scale, depth_shift)
     L.need_contiguous(poses=poses, disps=disps, intrinsics=intrinsics, mono_disps=mono_disps, ii=ii, jj=jj,
                       valid_mask=valid_mask, depth_scale=depth_scale, depth_shift=depth_shift)
@@ -282,7 +283,8 @@ def dspo_prepare(poses, disps, intrinsics, mono_disps, n, mv_thresh, visible_num
                                          int(n), h, w, float(mv_thresh), int(visible_num),
                                          float(mono_thres or 0.0), L.ptr(ii), L.ptr(jj), N, L.ptr(valid_mask),
                                          L.ptr(depth_scale), L.ptr(depth_shift), L.ptr(edge_on), L.ptr(any_on),
-                                         L.ptr(scratch), L.stream_ptr()), "glorie_dspo_prepare")
+                                         L.ptr(scratch), L.ptr(publish[0]) if publish else None,
+                                         publish[1] if publish else None, L.stream_ptr()), "glorie_dspo_prepare")
     return edge_on, any_on
 
 

@@ -53,13 +53,19 @@ def _prepare_torch(video, n, ii, jj):
 def depth_scale_stage(video, target, weight, eta, ii, jj, itrs, lm, ep, fused=True):
     """returns `success` like DepthVideo.dspo(opt_type='depth_scale')"""
     n = video.counter.value
+    self_publish = False
     if fused and video.disps.is_cuda and n > 0:
         from . import droid_backends
         mv = video.cfg['tracking']['multiview_filter']
+        shard_ = getattr(video, "shard", None)
+        # under hipGraph capture the stage-1 decision is left to the owner of the graph: the preparation's last launch
+        # publishes the flag itself (a sharded run all-reduces it first and publishes below)
+        self_publish = bool(video.mono_thres and torch.cuda.is_current_stream_capturing()
+                            and not (shard_ is not None and shard_["world"] > 1))
         edge_on, any_on = droid_backends.dspo_prepare(
             video.poses, video.disps, video.intrinsics[0].contiguous(), video.mono_disps, n, mv['thresh'],
             mv['visible_num'], video.mono_thres, ii.contiguous(), jj.contiguous(), video.valid_depth_mask_small,
-            video.depth_scale, video.depth_shift)
+            video.depth_scale, video.depth_shift, publish=video.publish_target() if self_publish else None)
         if not video.mono_thres:
             edge_on = None
     else:
@@ -75,7 +81,8 @@ def depth_scale_stage(video, target, weight, eta, ii, jj, itrs, lm, ep, fused=Tr
             # launch below leaves all frames untouched, so it is recorded unconditionally; the flag
             # goes to pinned memory (tagged with a launch count, DepthVideo.publish_any_on) and the owner
             # of the graph (FactorGraph.update) runs the stage-1 fallback after the replay if it reads 0.
-            video.publish_any_on(any_on)
+            if not self_publish:
+                video.publish_any_on(any_on)
             video.deferred_fallback = True
         elif not bool(any_on.item()):   # the one scalar sync: decides the stage-1 fallback
             return False

@@ -410,12 +410,14 @@ int glorie_dspo_scale_shift(glorie_ctx* ctx, const float* poses, float* disps,
  * bad(f) = err/mean(disp) > mono_thres | isnan(err) | scale < 0 | valid pixels < HW/2;
  * edge_on[e] = !(bad[ii[e]] | bad[jj[e]]); *any_on = any(edge_on).  mono_thres <= 0 disables the
  * filter (all edges on).  Outputs: valid_mask [n,h,w] bytes, scales/shifts [n], edge_on [N] bytes,
- * any_on device int.  scratch: >= n*h*w*4 + n*32 + 64 bytes.  No host synchronisation. */
+ * any_on device int.  scratch: >= n*h*w*4 + n*32 + 64 bytes.  No host synchronisation.
+ * publish_state / publish_host_word (both or neither; may be NULL): the last launch also does what glorie_publish_flag
+ * does with counter = &publish_state[0] (publish_state = device int[2], zero-initialised: launch count, arrivals). */
 int glorie_dspo_prepare(const float* poses, const float* disps, const float* intrinsics,
                         const float* mono_disps, int B, int n, int h, int w, float mv_thresh,
                         int visible_num, float mono_thres, const int64_t* ii, const int64_t* jj, int N,
                         uint8_t* valid_mask, float* scales, float* shifts, uint8_t* edge_on,
-                        int* any_on, void* scratch, void* stream);
+                        int* any_on, void* scratch, int* publish_state, int* publish_host_word, void* stream);
 
 /* *host_word = (++*counter << 1) | (*flag != 0), stored by the device into pinned (device-mapped) host memory: a host
  * that counts its launches can poll the word for the flag of a given launch instead of synchronising the stream
