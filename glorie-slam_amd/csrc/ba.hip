@@ -312,6 +312,7 @@ __global__ __launch_bounds__(kBaThreads) void ba_gram_kernel(
     BaWork wk, const int64_t* __restrict__ jj, int HW, int chunk_px, int t0, int t1) {
   __shared__ float lds[(kRowsA + kRowsB) * kGramLd];
   __shared__ float Xs[kGS * 36];
+  __shared__ int eA[kGS], eB[kGS];          // edge ids of the two row groups being multiplied
   const int tid = threadIdx.x;
   const int lane = tid & 63, wv = tid >> 6;
   const int chunk = blockIdx.x;
@@ -344,31 +345,59 @@ __global__ __launch_bounds__(kBaThreads) void ba_gram_kernel(
       f32x4 acc[3];
 #pragma unroll
       for (int q = 0; q < 3; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // slots past a group's degree repeat its last edge (their rows are never read); published by the barrier that
+      // opens the pixel loop
+      __syncthreads();
+      if (tid < kGS) eA[tid] = wk.csr_edge[e0 + A * kGS + min(tid, degA - 1)];
+      else if (tid < 2 * kGS) eB[tid - kGS] = wk.csr_edge[e0 + Bg * kGS + min(tid - kGS, degB - 1)];
 
       for (int p0 = pbeg; p0 < pend; p0 += kGramKC) {
         __syncthreads();
-        {  // stage sqrt(Q)-scaled rows; thread = (pixel c, row parity)
+        {  // stage sqrt(Q)-scaled rows; thread = (pixel c, row parity): rows 6a + half + {0, 2, 4} of every edge a.
+          // All loads of a side are issued before the first LDS store (edge slots past the group's degree re-read its
+          // last edge and land in rows no tile reads): a loop "index load -> row load -> store" per row was a chain
+          // of ~27 dependent memory round trips per sub-chunk and made this launch latency-bound (33 -> 22 us).
           const int c = tid & (kGramKC - 1);
           const int half = tid >> 7;
           const int px = p0 + c;
           const bool ok = px < pend;
-          const float sq = ok ? sqrtf(wk.Q[(size_t)s * HW + px]) : 0.0f;
-          for (int r = half; r < rowsA; r += 2) {
-            const int n = wk.csr_edge[e0 + A * kGS + r / 6];
-            Fa[r * kGramLd + c] = ok ? wk.Eij[((size_t)n * 6 + r % 6) * HW + px] * sq : 0.0f;
+          const int pxc = ok ? px : pbeg;
+          const float sq = ok ? sqrtf(wk.Q[(size_t)s * HW + pxc]) : 0.0f;
+          const float wv_ = wk.W[(size_t)s * HW + pxc];
+          float va[kGS][3];
+#pragma unroll
+          for (int a = 0; a < kGS; ++a) {
+            const int n = eA[a];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) va[a][q] = wk.Eij[((size_t)n * 6 + half + 2 * q) * HW + pxc];
           }
-          for (int r = half; r < rowsB; r += 2) {
-            float v = 0.0f;
-            if (ok) {
-              if (r < wcol) {
-                const int n = wk.csr_edge[e0 + Bg * kGS + r / 6];
-                v = wk.Eij[((size_t)n * 6 + r % 6) * HW + px] * sq;
-              } else {
-                v = wk.W[(size_t)s * HW + px] * sq;
+          if (A == Bg) {
+#pragma unroll
+            for (int a = 0; a < kGS; ++a)
+#pragma unroll
+              for (int q = 0; q < 3; ++q) {
+                const float v = va[a][q] * sq;
+                Fa[(6 * a + half + 2 * q) * kGramLd + c] = v;
+                Fb[(6 * a + half + 2 * q) * kGramLd + c] = v;
               }
+          } else {
+            float vb[kGS][3];
+#pragma unroll
+            for (int a = 0; a < kGS; ++a) {
+              const int n = eB[a];
+#pragma unroll
+              for (int q = 0; q < 3; ++q) vb[a][q] = wk.Eij[((size_t)n * 6 + half + 2 * q) * HW + pxc];
             }
-            Fb[r * kGramLd + c] = v;
+#pragma unroll
+            for (int a = 0; a < kGS; ++a)
+#pragma unroll
+              for (int q = 0; q < 3; ++q) {
+                Fa[(6 * a + half + 2 * q) * kGramLd + c] = va[a][q] * sq;
+                Fb[(6 * a + half + 2 * q) * kGramLd + c] = vb[a][q] * sq;
+              }
           }
+          // the w row of the B side (after the edge rows: slot degB of a full group would be row 48, also in range)
+          if (Bg == 0 && half == (wcol & 1)) Fb[wcol * kGramLd + c] = wv_ * sq;
         }
         __syncthreads();
 #pragma unroll
