@@ -200,12 +200,44 @@ __global__ __launch_bounds__(kBaThreads) void ba_jacobian_kernel(
   // C and w accumulators for up to 4 pixels per thread
   float Cacc[4] = {0, 0, 0, 0}, Wacc[4] = {0, 0, 0, 0};
 
+  // The edge loop used to be a chain of dependent memory round trips per edge (edge id -> target frame -> its pose ->
+  // the pixel's target / weight): the ids of a group of edges go to LDS first, and an edge's target / weight rows are
+  // requested before its pose arithmetic instead of inside the per-pixel branch.
+  constexpr int kJG = 8;
+  __shared__ int s_n[kJG], s_j[kJG];
+  const Pose gk = load_pose(poses + k * 7);
+  float dsp[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) dsp[t] = t < ppt ? disps[(size_t)k * HW + min(pbase + t * kBaThreads + tid, HW - 1)] : 1.0f;
   for (int ei = e0; ei < e1; ++ei) {
-    const int n = wk.csr_edge[ei];
-    const int jx = (int)jj[n];
+    const int slot = (ei - e0) & (kJG - 1);
+    if (slot == 0) {
+      __syncthreads();
+      if (tid < kJG && ei + tid < e1) {
+        const int nn = wk.csr_edge[ei + tid];
+        s_n[tid] = nn;
+        s_j[tid] = (int)jj[nn];
+      }
+      __syncthreads();
+    }
+    const int n = s_n[slot];
+    const int jx = s_j[slot];
+    float2 tgv[4], wgv[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (t < ppt) {                 // uniform
+        const int pxc = min(pbase + t * kBaThreads + tid, HW - 1);
+        if (hwc) {                   // [N][h][w][2]: the layout FactorGraph keeps them in
+          tgv[t] = reinterpret_cast<const float2*>(targets)[(size_t)n * HW + pxc];
+          wgv[t] = reinterpret_cast<const float2*>(weights)[(size_t)n * HW + pxc];
+        } else {                     // [N][2][h][w]: the layout of droid_backends.ba
+          tgv[t] = make_float2(targets[((size_t)n * 2 + 0) * HW + pxc], targets[((size_t)n * 2 + 1) * HW + pxc]);
+          wgv[t] = make_float2(weights[((size_t)n * 2 + 0) * HW + pxc], weights[((size_t)n * 2 + 1) * HW + pxc]);
+        }
+      }
+    }
     const bool stereo = (jx == k);
-    const Pose g = stereo ? stereo_pose()
-                          : relative_pose(load_pose(poses + k * 7), load_pose(poses + jx * 7));
+    const Pose g = stereo ? stereo_pose() : relative_pose(gk, load_pose(poses + jx * 7));
     if (chunk == 0 && tid == 0) {
       float L[36];
       edge_adjoint(g, L);
@@ -224,15 +256,8 @@ __global__ __launch_bounds__(kBaThreads) void ba_jacobian_kernel(
       if (t < ppt && px < HW) {
         const int yy = px / w, xx = px - yy * w;
         PixJ J;
-        float2 tg, wg;
-        if (hwc) {                   // [N][h][w][2]: the layout FactorGraph keeps them in
-          tg = reinterpret_cast<const float2*>(targets)[(size_t)n * HW + px];
-          wg = reinterpret_cast<const float2*>(weights)[(size_t)n * HW + px];
-        } else {                     // [N][2][h][w]: the layout of droid_backends.ba
-          tg = make_float2(targets[((size_t)n * 2 + 0) * HW + px], targets[((size_t)n * 2 + 1) * HW + px]);
-          wg = make_float2(weights[((size_t)n * 2 + 0) * HW + px], weights[((size_t)n * 2 + 1) * HW + px]);
-        }
-        pixel_terms(g, fx, fy, cx, cy, (float)xx, (float)yy, disps[(size_t)k * HW + px], tg.x, tg.y, wg.x,
+        const float2 tg = tgv[t], wg = wgv[t];
+        pixel_terms(g, fx, fy, cx, cy, (float)xx, (float)yy, dsp[t], tg.x, tg.y, wg.x,
                     wg.y, J);
         Cacc[t] += J.wu * J.Jzu * J.Jzu + J.wv * J.Jzv * J.Jzv;
         Wacc[t] += J.wu * J.ru * J.Jzu + J.wv * J.rv * J.Jzv;
