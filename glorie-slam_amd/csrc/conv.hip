@@ -43,7 +43,7 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-enum { EPI_BIAS_ACT = 0, EPI_GRU_ZR = 1, EPI_GRU_Q = 2, EPI_GLO = 3, EPI_HEADS = 4 };
+enum { EPI_BIAS_ACT = 0, EPI_GRU_ZR = 1, EPI_GRU_Q = 2, EPI_GLO = 3, EPI_HEADS = 4, EPI_UPSAMPLE = 5 };
 enum { CACT_NONE = 0, CACT_RELU = 1, CACT_SIGMOID = 2 };
 
 struct ConvArgs {
@@ -65,6 +65,8 @@ struct ConvArgs {
   unsigned long long* stamps;                   // dbg & 128: s_memtime checkpoints of workgroup 0, tiles 10-12, [8 waves][128]
   // EPI_HEADS: the first tap_groups 128-channel tiles feed the tap GEMM of a 3x3 head instead of being stored
   const f16x8* tap_w; float* tap_out; int tap_groups, tap_ncols;
+  // EPI_UPSAMPLE: convex upsampling of the disparity maps with the tile's logits as the mask
+  const float* up_disps; const int64_t* up_ix; float* up_out; int up_f32;
 };
 
 constexpr int kTileN = 128;       // output channels per workgroup
@@ -337,6 +339,81 @@ __device__ __forceinline__ void conv_epilogue_glo(const ConvArgs& a, f32x4 (&acc
   if (tid < 128) reinterpret_cast<float*>(a.out)[(size_t)tile * 128 + tid] = red[tid] + red[128 + tid];
 }
 
+// EPI_UPSAMPLE: GraphAgg's upmask convolution (droid_net.py:46-48,62-64: 1x1, 128 -> 576 = 9 taps x 8 x 8 sub-pixels) with the
+// convex upsampling of the disparity map (droid_net.py:9-23, depth_video.py:140-144) as its epilogue: the 44 MB of fp16 logits
+// are never written and read back.  The weight rows are packed as channel' = a*128 + b*16 + tap (sub-row a, sub-column b,
+// taps padded 9 -> 16 with zero rows; update_ops.pack_upmask_conv), so the workgroup of channel tile a holds, for its 128
+// pixels, all 9 taps of the 8 sub-pixels of sub-row a.  The logits (+ bias) go to LDS as fp16 - the rounding the stored map
+// had - and 128 x 2 threads each finish 4 sub-pixels of one pixel with the arithmetic of cvx_upsample_nhwc_kernel, in its
+// order: the same bits as the two-launch form.
+__device__ __forceinline__ float round_prob(float v, bool f32) { return f32 ? v : (float)(_Float16)v; }
+
+template <int MB, int NB>
+__device__ __forceinline__ void conv_epilogue_upsample(const ConvArgs& a, f32x4 (&acc)[MB][NB], long p0, int n0, int wm,
+                                                       int wn, int kg, int col, char* smem) {
+  static_assert(MB == 4 && NB == 4, "128 x 128 tile");
+  _Float16* T = reinterpret_cast<_Float16*>(smem);      // [128 pixels][8 chunks of 16 halfs], chunk b at b ^ (pixel & 7)
+  float4 bias[MB];
+#pragma unroll
+  for (int mi = 0; mi < MB; ++mi) bias[mi] = *reinterpret_cast<const float4*>(a.terms + n0 + wm * 64 + mi * 16 + kg * 4);
+  __syncthreads();                                      // the stage is no longer read
+#pragma unroll
+  for (int ni = 0; ni < NB; ++ni) {
+    const int pl = wn * 64 + ni * 16 + col;
+#pragma unroll
+    for (int mi = 0; mi < MB; ++mi) {
+      const int b = wm * 4 + mi;
+      const f32x4 v = acc[mi][ni];
+      const f16x4 h = {(_Float16)(v[0] + bias[mi].x), (_Float16)(v[1] + bias[mi].y), (_Float16)(v[2] + bias[mi].z),
+                       (_Float16)(v[3] + bias[mi].w)};
+      *reinterpret_cast<f16x4*>(T + pl * 128 + ((b ^ (pl & 7)) * 16 + kg * 4)) = h;
+    }
+  }
+  __syncthreads();
+  const int tid = threadIdx.x;
+  const int pl = tid & 127, hb = tid >> 7;              // pixel of the tile, sub-columns 4*hb .. 4*hb + 3
+  const long p = p0 + pl;
+  if (p >= a.P) return;
+  const int asub = n0 >> 7;
+  const int m = (int)(p / a.HW);
+  const int q = (int)(p - (long)m * a.HW);
+  const int y = q / a.W, x = q - y * a.W;
+  const int frame = (int)a.up_ix[m];
+  const float* dmap = a.up_disps + (size_t)frame * a.HW;
+  float nb[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
+    const bool in = yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+    nb[k] = dmap[in ? yy * a.W + xx : q];
+    if (!in) nb[k] = 0.0f;
+  }
+  float outv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int b = hb * 4 + j;
+    const f16x8* src = reinterpret_cast<const f16x8*>(T + pl * 128 + (b ^ (pl & 7)) * 16);
+    const f16x8 lo = src[0], hi = src[1];
+    float v[9];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = (float)lo[k];
+    v[8] = (float)hi[0];
+    float mx = v[0];
+#pragma unroll
+    for (int k = 1; k < 9; ++k) mx = fmaxf(mx, v[k]);
+    float e[9], sum = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { e[k] = expf(v[k] - mx); sum += e[k]; }
+    float o = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k)                          // product and sum rounded separately (no contraction), like the
+      o = __fadd_rn(o, __fmul_rn(round_prob(e[k] / sum, a.up_f32 != 0), nb[k]));   // stand-alone kernel and torch
+    outv[j] = o;
+  }
+  float* dst = a.up_out + (size_t)frame * 64 * a.HW + (size_t)(8 * y + asub) * (8 * a.W) + 8 * x + hb * 4;
+  *reinterpret_cast<float4*>(dst) = make_float4(outv[0], outv[1], outv[2], outv[3]);
+}
+
 // NB = 16-pixel blocks per wave, BK = channels per K step (32 | 64), NW = waves (2 channel halves x
 // NW/2 pixel groups: pixel tile = NW/2 * 16*NB), ST = LDS stages (1: single stage + register-resident
 // fragments, the shipped form; 2: classic double buffering with one __syncthreads per step)
@@ -551,6 +628,9 @@ __global__ __launch_bounds__(64 * NW, (ST == 1 && MB * NB <= 16) ? 3 : 2) void c
   if constexpr (EPI == EPI_GLO) {
     if constexpr (MB == 4 && NB == 4 && NW == 4 && ST == 1)
       conv_epilogue_glo<MB, NB>(a, acc, p0, p0 + wn * (16 * NB) + col, wm, wn, kg, col, smem, pt);
+  } else if constexpr (EPI == EPI_UPSAMPLE) {
+    if constexpr (MB == 4 && NB == 4 && NW == 4 && ST == 1)
+      conv_epilogue_upsample<MB, NB>(a, acc, p0, n0, wm, wn, kg, col, smem);
   } else if constexpr (EPI == EPI_HEADS) {
     if constexpr (MB == 4 && NB == 4 && NW == 4 && ST == 1) {
       if (nt < a.tap_groups)                                                    // workgroup-uniform
@@ -1037,6 +1117,10 @@ static int launch_conv(const ConvArgs& a, int epilogue, hipStream_t st, long max
       if constexpr (MB == 4 && NB == 4 && NW == 4 && ST == 1) launch_one<EPI_HEADS, NB, BK, NW, ST, MB>(a, grid, st);
       else return GLORIE_EUNSUPPORTED;
       break;
+    case EPI_UPSAMPLE:
+      if constexpr (MB == 4 && NB == 4 && NW == 4 && ST == 1) launch_one<EPI_UPSAMPLE, NB, BK, NW, ST, MB>(a, grid, st);
+      else return GLORIE_EUNSUPPORTED;
+      break;
     default: launch_one<EPI_GRU_Q, NB, BK, NW, ST, MB>(a, grid, st); break;
   }
   return check_launch();
@@ -1052,10 +1136,13 @@ static int conv_igemm_impl(const void* xa, int xa_stride, int ca, const void* xb
                            int net_stride, const void* z, int z_stride, void* out, int out_stride,
                            void* out2, int out2_stride, const void* pre, int pre_stride, const int* pre_map,
                            int N, int H, int W, void* stream, const void* tap_w, float* tap_out, int tap_groups,
-                           int tap_ncols) {
+                           int tap_ncols, const float* up_disps = nullptr, const int64_t* up_ix = nullptr,
+                           float* up_out = nullptr, int up_f32 = 0) {
   if (N < 0 || H <= 0 || W <= 0 || (taps != 1 && taps != 9) || nout <= 0 || (nout & 3)) return GLORIE_EINVAL;
   if (ca < 0 || cb < 0 || (ca % 64) || (cb % 64) || ca + cb == 0) return GLORIE_EINVAL;
-  if (epilogue < 0 || epilogue > 4) return GLORIE_EINVAL;
+  if (epilogue < 0 || epilogue > 5) return GLORIE_EINVAL;
+  if (epilogue == EPI_UPSAMPLE && (!up_disps || !up_ix || !up_out || !terms || nout != 1024 || taps != 1 || pre))
+    return GLORIE_EINVAL;
   if (epilogue == EPI_HEADS && (!tap_w || !tap_out || !terms || tap_groups < 1 || tap_ncols < 1 || tap_ncols > 32 ||
                                 nout < 128 * tap_groups || (nout & 127) || act != CACT_RELU || pre))
     return GLORIE_EINVAL;
@@ -1081,6 +1168,7 @@ static int conv_igemm_impl(const void* xa, int xa_stride, int ca, const void* xb
   a.pbeg = 0;
   a.tap_w = reinterpret_cast<const f16x8*>(tap_w); a.tap_out = tap_out; a.tap_groups = tap_groups;
   a.tap_ncols = tap_ncols;
+  a.up_disps = up_disps; a.up_ix = up_ix; a.up_out = up_out; a.up_f32 = up_f32;
   // the context term is added in the epilogue when it is the shared per-keyframe map (pre_map: 8 maps read by 36 edges in
   // every iteration, L2 resident - its loads ride with the epilogue's other loads, 277 -> 274 us in the steps) and seeds the
   // accumulators through LDS when it is a per-edge tensor streamed from HBM; GLORIE_CONV_PRE=e|s forces either
@@ -1107,7 +1195,7 @@ static int conv_igemm_impl(const void* xa, int xa_stride, int ca, const void* xb
   // 385 vs 345 us.  It stays opt-in; tests/test_gpu_update_op.py pins it bit for bit against the 128 x 128 kernel.
   const char* c8 = getenv("GLORIE_CONV8");
   const bool conv8_on = c8 && c8[0] == '1';
-  if (epilogue == EPI_HEADS) return launch_conv<4, 64, 4, 1>(a, epilogue, st);
+  if (epilogue == EPI_HEADS || epilogue == EPI_UPSAMPLE) return launch_conv<4, 64, 4, 1>(a, epilogue, st);
   if (conv8_on && (nout & 255) == 0 && a.P >= 256) return launch_conv8(a, epilogue, st);
   // layers with <= 64 output channels (flow_encoder[2]) use a 64-channel tile instead of padding to 128
   if (nout <= 64 && epilogue == EPI_BIAS_ACT) return launch_conv<4, 64, 4, 1, 2>(a, epilogue, st);
@@ -1147,7 +1235,7 @@ extern "C" int glorie_conv_igemm(const void* xa, int xa_stride, int ca, const vo
                                  int net_stride, const void* z, int z_stride, void* out, int out_stride,
                                  void* out2, int out2_stride, const void* pre, int pre_stride, const int* pre_map,
                                  int N, int H, int W, void* stream) {
-  if (epilogue == EPI_HEADS) return GLORIE_EINVAL;          // has its own entry point
+  if (epilogue == EPI_HEADS || epilogue == EPI_UPSAMPLE) return GLORIE_EINVAL;          // have their own entry points
   return conv_igemm_impl(xa, xa_stride, ca, xb, xb_stride, cb, w_packed, taps, nout, epilogue, terms, terms_stride, act,
                          net, net_stride, z, z_stride, out, out_stride, out2, out2_stride, pre, pre_stride, pre_map, N, H,
                          W, stream, nullptr, nullptr, 0, 0);
@@ -1163,4 +1251,14 @@ extern "C" int glorie_conv_igemm_heads(const void* x, int x_stride, int c, const
   return conv_igemm_impl(x, x_stride, c, nullptr, 0, 0, w_packed, taps, nout, EPI_HEADS, bias, 0, CACT_RELU, nullptr, 0,
                          nullptr, 0, o, out ? out_stride : 4, nullptr, 0, nullptr, 0, nullptr, N, H, W, stream, tap_w,
                          tap_out, groups, 9 * K);
+}
+
+extern "C" int glorie_conv_upsample(const void* x, int x_stride, int c, const void* w_packed, const float* bias,
+                                    const float* disps, const int64_t* ix, float* disps_up, int softmax_f32, int M,
+                                    int H, int W, void* stream) {
+  if (!disps || !ix || !disps_up || !bias) return GLORIE_EINVAL;
+  // no per-pixel output: `out` only has to pass the pointer checks
+  return conv_igemm_impl(x, x_stride, c, nullptr, 0, 0, w_packed, 1, 1024, EPI_UPSAMPLE, bias, 0, CACT_NONE, nullptr, 0,
+                         nullptr, 0, disps_up, 4, nullptr, 0, nullptr, 0, nullptr, M, H, W, stream, nullptr, nullptr, 0,
+                         0, disps, ix, disps_up, softmax_f32);
 }

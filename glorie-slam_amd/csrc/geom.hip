@@ -285,7 +285,8 @@ __global__ __launch_bounds__(256) void cvx_upsample_kernel(
       for (int k = 0; k < 9; ++k) { e[k] = expf(lg[q][k] - mx); sum += e[k]; }
       float acc = 0.0f;
 #pragma unroll
-      for (int k = 0; k < 9; ++k) acc += round_like_mask<MT>(e[k] / sum, softmax_f32 != 0) * nb[q][k];
+      for (int k = 0; k < 9; ++k)    // product and sum rounded separately (mask * up_data, then sum: droid_net.py:19-20)
+        acc = __fadd_rn(acc, __fmul_rn(round_like_mask<MT>(e[k] / sum, softmax_f32 != 0), nb[q][k]));
       outv[q][b] = acc;
     }
   }
@@ -379,7 +380,8 @@ __global__ __launch_bounds__(256) void cvx_upsample_nhwc_kernel(
     for (int k = 0; k < 9; ++k) { e[k] = expf((float)v[k][b] - mx); sum += e[k]; }
     float acc = 0.0f;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) acc += round_like_mask<_Float16>(e[k] / sum, softmax_f32 != 0) * nb[k];
+    for (int k = 0; k < 9; ++k)      // product and sum rounded separately (glorie_conv_upsample does the same: same bits)
+      acc = __fadd_rn(acc, __fmul_rn(round_like_mask<_Float16>(e[k] / sum, softmax_f32 != 0), nb[k]));
     outv[b] = acc;
   }
   float* o = disps_up + (size_t)frame * 64 * HW + (size_t)(8 * y + a) * (8 * w) + 8 * x;

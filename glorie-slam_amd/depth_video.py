@@ -166,7 +166,12 @@ class DepthVideo:
 
     # ---- geometry --------------------------------------------------------------------
     def upsample(self, ix, mask, softmax_f32=False):
-        """disps_up[ix] = cvx_upsample(disps[ix], mask)  (depth_video.py:140-144)"""
+        """disps_up[ix] = cvx_upsample(disps[ix], mask)  (depth_video.py:140-144); mask may be the unevaluated logits of
+        FusedUpdate (update_ops.LazyUpmask): convolution and upsampling are then one launch"""
+        from .update_ops import LazyUpmask, conv_upsample
+        if isinstance(mask, LazyUpmask):
+            conv_upsample(mask, self.disps, ix.contiguous(), self.disps_up, softmax_f32=softmax_f32)
+            return
         m = mask.reshape(-1, 576, mask.shape[-2], mask.shape[-1])
         if not m.is_contiguous() and not (m.dtype == torch.float16 and
                                           m.is_contiguous(memory_format=torch.channels_last)):

@@ -317,6 +317,7 @@ class FusedUpdate:
         W["a2"], W["a2_b"] = U.pack_conv_igemm(m.agg.conv2.weight), f32(m.agg.conv2.bias)
         W["eta"], W["eta_b"] = U.pack_conv3x3_small([m.agg.eta[0].weight]), f32(m.agg.eta[0].bias)
         W["up"], W["up_b"] = U.pack_conv_igemm(m.agg.upmask[0].weight), f32(m.agg.upmask[0].bias)
+        W["up_cvx"], W["up_cvx_b"] = U.pack_upmask_conv(m.agg.upmask[0].weight, m.agg.upmask[0].bias)
         self.W = W
         self._ver = ver
         self._inp_key = None        # the hoisted context term was computed with the old weights
@@ -379,10 +380,11 @@ class FusedUpdate:
         return self._pre_kf[:int(frames.shape[0])], self._pre_map[:int(index.shape[0])]
 
     @torch.no_grad()
-    def __call__(self, net, inp, corr, flow=None, ii=None, jj=None, groups=None, context=None):
+    def __call__(self, net, inp, corr, flow=None, ii=None, jj=None, groups=None, context=None, lazy_up=False):
         """corr: the looked-up correlation features [1,N,196,h,w], or a callable returning them (it is
         invoked on the caller's stream after the independent branches were forked).
-        context (not in the reference): see precompute_shared_context; `inp` is then not read."""
+        context (not in the reference): see precompute_shared_context; `inp` is then not read.
+        lazy_up: return the upmask logits unevaluated (update_ops.LazyUpmask) for DepthVideo.upsample."""
         from . import update_ops as U
         self._sync()
         W = self.W
@@ -500,6 +502,10 @@ class FusedUpdate:
                          memory_format=torch.channels_last)
         U.conv_igemm(agg, None, W["a2"], 9, 128, a2, terms=W["a2_b"], act=U.ACT_RELU)
         eta = U.conv3x3_small(a2, W["eta"], W["eta_b"], 1, (U.ACT_SOFTPLUS,), scale=0.01)
+        if lazy_up:
+            # the caller only hands the logits to DepthVideo.upsample: convolution + convex upsampling run there as one
+            # launch (glorie_conv_upsample), the 576-channel map is never stored
+            return net_out, delta, weight, eta.view(batch, ngroups, ht, wd), U.LazyUpmask(a2, W["up_cvx"], W["up_cvx_b"])
         up = torch.empty((ngroups, 576, ht, wd), dtype=torch.float16, device=dev,
                          memory_format=torch.channels_last)
         U.conv_igemm(a2, None, W["up"], 1, 576, up, terms=W["up_b"])

@@ -373,7 +373,8 @@ class FactorGraph:
             ix, _ = self._groups()
             self.net, delta, weight, damping, upmask = \
                 self.fast_update(self.net, self.inp, lookup, motn, self.ii, self.jj, self._groups(),
-                                 context=(self.video.inps, uniq, ix) if self.share_context else None)
+                                 context=(self.video.inps, uniq, ix) if self.share_context else None,
+                                 lazy_up=True)
         else:
             corr = lookup()
             with torch.autocast("cuda", enabled=True):

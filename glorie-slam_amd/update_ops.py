@@ -303,6 +303,45 @@ def pack_flow_conv7(weight):
     return w.reshape(128, 224).contiguous()
 
 
+def pack_upmask_conv(weight, bias):
+    """GraphAgg.upmask[0] (droid_net.py:46-48) weight [576, C, 1, 1], bias [576] -> (packed 1x1 operand of 1024 rows,
+    bias [1024]) for glorie_conv_upsample: row a*128 + b*16 + t = channel t*64 + a*8 + b (t < 9), zero rows for t >= 9"""
+    if weight.shape[0] != 576 or tuple(weight.shape[2:]) != (1, 1):
+        raise RuntimeError("pack_upmask_conv: expected a [576, C, 1, 1] weight")
+    C = weight.shape[1]
+    w = weight.detach().reshape(9, 8, 8, C)                    # [t][a][b][C]
+    wp = torch.zeros(8, 8, 16, C, dtype=w.dtype, device=w.device)
+    wp[:, :, :9] = w.permute(1, 2, 0, 3)                        # [a][b][t][C]
+    bp = torch.zeros(8, 8, 16, dtype=torch.float32, device=w.device)
+    bp[:, :, :9] = bias.detach().float().reshape(9, 8, 8).permute(1, 2, 0)
+    return pack_conv_igemm(wp.reshape(1024, C, 1, 1)), bp.reshape(1024).contiguous()
+
+
+class LazyUpmask:
+    """the upmask logits of FusedUpdate NOT evaluated: the input of the 1x1 convolution and its packed weights.
+    DepthVideo.upsample runs convolution + convex upsampling as one launch (conv_upsample)"""
+
+    def __init__(self, x, w_packed, bias):
+        self.x, self.w_packed, self.bias = x, w_packed, bias
+
+
+def conv_upsample(up, disps, ix, disps_up, softmax_f32=False):
+    """disps_up[ix] = cvx_upsample(disps[ix], conv1x1(up.x) + bias) (glorie_conv_upsample); up: LazyUpmask"""
+    L.need_cuda(up.x, up.w_packed, up.bias, disps, ix, disps_up)
+    m, c, h, w = up.x.shape
+    if ix.dtype != torch.int64 or ix.numel() != m or not ix.is_contiguous():
+        raise RuntimeError("conv_upsample: ix must be a contiguous int64 [M]")
+    if tuple(disps.shape[1:]) != (h, w) or tuple(disps_up.shape[1:]) != (8 * h, 8 * w) or disps.dtype != torch.float32 \
+            or disps_up.dtype != torch.float32 or not disps.is_contiguous() or not disps_up.is_contiguous():
+        raise RuntimeError("conv_upsample: disps [B,h,w] / disps_up [B,8h,8w] float32 contiguous expected")
+    if up.w_packed.numel() != 1024 * c + 64 or up.bias.numel() != 1024:
+        raise RuntimeError("conv_upsample: weights must come from pack_upmask_conv")
+    L.check(L.load().glorie_conv_upsample(L.ptr(up.x), _rows(up.x, "x"), c, L.ptr(up.w_packed), L.ptr(up.bias),
+                                          L.ptr(disps), L.ptr(ix), L.ptr(disps_up), int(bool(softmax_f32)), m, h, w,
+                                          L.stream_ptr()), "glorie_conv_upsample")
+    return disps_up
+
+
 class PaddedFlow:
     """the motion map of N edges as zero-padded fp16 [N, h+6, w+8, 4] (include/glorie_hip.h: glorie_flow_conv7_padded);
     the borders are zeroed once here and never written again"""

@@ -257,6 +257,17 @@ int glorie_conv_igemm(const void* xa, int xa_stride, int ca, const void* xb, int
 int glorie_conv_igemm_heads(const void* x, int x_stride, int c, const void* w_packed, int taps, int nout,
                             const float* bias, const void* tap_w, int groups, int K, float* tap_out, void* out,
                             int out_stride, int N, int H, int W, void* stream);
+/* GraphAgg's upmask convolution (droid_net.py:46-48: 1x1, c -> 576 = 9 taps x 8 x 8 sub-pixels, bias) and the convex
+ * upsampling of depth_video.py:140-144 / droid_net.py:9-23 in one launch:
+ *   disps_up[ix[m]] = cvx_upsample(disps[ix[m]], conv1x1(x[m]) + bias),   m < M,
+ * the logits rounded to fp16 as the stored map of glorie_conv_igemm + glorie_cvx_upsample_nhwc would be, and the same
+ * arithmetic in the same order: same bits, without writing and re-reading M*H*W*576 halfs.
+ * x: fp16 rows [M*H*W][c] (x_stride halfs apart).  w_packed: glorie_conv_igemm's 1x1 operand for 1024 output rows,
+ * row a*128 + b*16 + t = the convolution's output channel t*64 + a*8 + b for tap t < 9 (sub-row a, sub-column b), zero
+ * rows for t >= 9; bias [1024] in the same order.  disps [B][H][W], disps_up [B][8H][8W] float, ix int64 [M]. */
+int glorie_conv_upsample(const void* x, int x_stride, int c, const void* w_packed, const float* bias,
+                         const float* disps, const int64_t* ix, float* disps_up, int softmax_f32, int M, int H, int W,
+                         void* stream);
 /* second half of glorie_conv3x3_small on the tap planes of glorie_conv_igemm_heads: out float [groups][N*H*W][K] */
 int glorie_conv_stencil(const float* taps, const float* out_bias, int groups, int K, int act_packed, float scale,
                         float* out, int N, int H, int W, void* stream);

@@ -262,6 +262,30 @@ def test_head_taps_fused_into_the_hidden_convolution(gpu, n, h, w):
         torch.testing.assert_close(fused[k], ref.permute(0, 2, 3, 1), atol=3e-3, rtol=3e-3)
 
 
+@pytest.mark.parametrize("m,h,w,f32", [(3, 9, 11, False), (2, 10, 13, True), (8, 60, 80, False)])
+def test_upmask_convolution_with_the_convex_upsampling_as_its_epilogue(gpu, m, h, w, f32):
+    """glorie_conv_upsample against conv_igemm (stored fp16 logits) + cvx_upsample: same bits; frames that are not in ix
+    stay untouched"""
+    from glorie_slam_amd import update_ops as U, droid_backends as db
+    g = torch.Generator(device="cpu").manual_seed(81)
+    x = _cl_half(m, 128, h, w, gpu, 82)
+    wt = (torch.randn(576, 128, 1, 1, generator=g) / 6).to(gpu)
+    bias = torch.randn(576, generator=g).to(gpu)
+    B = m + 3
+    disps = (torch.rand(B, h, w, generator=g) + 0.2).to(gpu)
+    ix = torch.randperm(B, generator=g)[:m].sort().values.to(gpu)
+    logits = torch.empty((m, 576, h, w), dtype=torch.float16, device=gpu).contiguous(memory_format=torch.channels_last)
+    U.conv_igemm(x, None, U.pack_conv_igemm(wt), 1, 576, logits, terms=bias.contiguous())
+    ref = torch.full((B, 8 * h, 8 * w), -1.0, device=gpu)
+    db.cvx_upsample(disps, ix, logits, ref, softmax_f32=f32)
+    got = torch.full((B, 8 * h, 8 * w), -1.0, device=gpu)
+    wp, bp = U.pack_upmask_conv(wt, bias)
+    U.conv_upsample(U.LazyUpmask(x, wp, bp), disps, ix, got, softmax_f32=f32)
+    assert torch.equal(got, ref)
+    untouched = [f for f in range(B) if f not in set(ix.tolist())]
+    assert float((got[untouched] + 1.0).abs().max()) == 0.0
+
+
 def test_fused_update_on_the_channels_last_lookup(gpu):
     """corr_encoder[0] as a 1x1 implicit-GEMM convolution over the channels-last lookup (permuted weight columns, bias and
     ReLU in the epilogue) against the library GEMM over the planar map: same operator, only the fp16 GEMM's summation order
