@@ -324,6 +324,13 @@ class LazyUpmask:
     def __init__(self, x, w_packed, bias):
         self.x, self.w_packed, self.bias = x, w_packed, bias
 
+    def evaluate(self):
+        """the logits themselves, fp16 [M, 576, h, w] in the reference's channel order (tests, callers that need the map)"""
+        m, c, h, w = self.x.shape
+        wide = torch.empty((m, 1024, h, w), dtype=torch.float16, device=self.x.device, memory_format=torch.channels_last)
+        conv_igemm(self.x, None, self.w_packed, 1, 1024, wide, terms=self.bias)
+        return wide.view(m, 8, 8, 16, h, w)[:, :, :, :9].permute(0, 3, 1, 2, 4, 5).reshape(m, 576, h, w)
+
 
 def conv_upsample(up, disps, ix, disps_up, softmax_f32=False):
     """disps_up[ix] = cvx_upsample(disps[ix], conv1x1(up.x) + bias) (glorie_conv_upsample); up: LazyUpmask"""
