@@ -366,7 +366,9 @@ def main():
         tm = torch.tensor([sustained_ms], device=device)
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
         sustained_ms = float(tm.item())
-    assert video.ctx().ba_status()[0] == 0 and bool(torch.isfinite(video.poses).all())
+    ba_st2 = video.ctx().ba_status()
+    assert ba_st2[0] == 0 and bool(torch.isfinite(video.poses).all()), \
+        f"after {sustained_steps} sustained steps: BA status {ba_st2}, finite poses {bool(torch.isfinite(video.poses).all())}"
 
     # ---- sub-metric: Gauss-Newton iterations/s of the BA step alone (B2-B7) on G8 ----
     ba_gn_per_s = None

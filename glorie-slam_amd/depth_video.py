@@ -278,12 +278,16 @@ class DepthVideo:
             raise NotImplementedError(opt_type)
 
     def ba(self, target, weight, eta, ii, jj, t0=1, t1=None, iters=2, lm=1e-4, ep=0.1,
-           motion_only=False, opt_type="pose_depth"):
+           motion_only=False, opt_type="pose_depth", eta_fallback=None):
+        """eta_fallback: damping for the pose_depth slots, used when a depth_scale stage falls back to stage 1 and the
+        two stages do not see the same depth frames (a shard's depth_scale stage covers the source frames of its own
+        edges, its pose_depth BA the whole window: dist.ba_sharded)"""
         if self.BA_type == "DSPO":
             ok = self.dspo(target, weight, eta, ii, jj, t0, t1, iters, lm, ep, motion_only, opt_type)
             if not ok:
                 self.stage2_fallbacks += 1
-                self.dspo(target, weight, eta, ii, jj, t0, t1, iters, lm, ep, motion_only, "pose_depth")
+                self.dspo(target, weight, eta if eta_fallback is None else eta_fallback, ii, jj, t0, t1, iters, lm, ep,
+                          motion_only, "pose_depth")
         elif self.BA_type == "DBA":
             self.dspo(target, weight, eta, ii, jj, t0, t1, iters, lm, ep, motion_only, "pose_depth")
         else:

@@ -286,13 +286,14 @@ class FactorGraph:
                       and isinstance(v[0], torch.cuda.CUDAGraph)]:
                 self._graphs[k] = "seen"
             return self._update_eager(t0, t1, itrs, use_inactive, EP, motion_only, opt_type)
-        graph, s_net, s_target, s_weight, ba_args, deferred, _gen = ent
+        graph, s_net, s_target, s_weight, ba_args, deferred, eta_fb, _gen = ent
         for dst, src in ((s_net, self.net), (s_target, self.target), (s_weight, self.weight)):
             if src is not dst:
                 dst.copy_(src)
         graph.replay()
         self.net, self.target, self.weight = s_net, s_target, s_weight
         self._ba_args = ba_args
+        self._eta_fb = eta_fb
         if sharded:
             return self._update_finish(itrs, motion_only, opt_type)
         if deferred:
@@ -342,7 +343,7 @@ class FactorGraph:
             # the capture did not execute anything: restore the state the caller had
             self.net, self.target, self.weight = keep
         ent = (graph, s_net, s_target, s_weight, ba_args, bool(self.video.deferred_fallback),
-               self._arena_generations())
+               getattr(self, "_eta_fb", None), self._arena_generations())
         self._graphs[key] = ent
         return ent
 
@@ -454,6 +455,15 @@ class FactorGraph:
                 raise RuntimeError(f"FactorGraph.update: eta has {damping.shape[0]} frames, the BA window "
                                    f"[{t0}, {t1}) + the source frames of the edges span {self._graphs[ck]}")
         self._ba_args = (target, weight, damping, ii, jj, uniq, upmask, t0, t1)
+        self._eta_fb = None
+        if sharded and opt_type == "depth_scale":
+            # a stage-1 fallback of this stage is a sharded pose_depth BA: its slots are the whole window + the source
+            # frames of the local edges, not the frames `damping` was gathered for
+            assert t1 is not None, "sharded BA needs an explicit (global) t1"
+            ck = ("uq", self._topo, t0, t1)
+            if ck not in self._graphs:
+                self._graphs[ck] = torch.unique(torch.cat([torch.arange(t0, t1, device=ii.device), ii]))
+            self._eta_fb = .2 * self.damping[self._graphs[ck]].contiguous() + EP
         if run_ba:
             self._update_finish(itrs, motion_only, opt_type)
 
@@ -461,7 +471,7 @@ class FactorGraph:
         """BA + upsampling (+ exchange of the owned rows when sharded) on the outputs of the update operator"""
         target, weight, damping, ii, jj, uniq, upmask, t0, t1 = self._ba_args
         self.video.ba(target, weight, damping, ii, jj, t0, t1, iters=itrs, lm=1e-4, ep=0.1,
-                      motion_only=motion_only, opt_type=opt_type)
+                      motion_only=motion_only, opt_type=opt_type, eta_fallback=getattr(self, "_eta_fb", None))
         self.video.upsample(uniq, upmask)
         if getattr(self.video, "shard", None) is not None and self.video.shard["world"] > 1:
             self.video.sync_owned_state()

@@ -21,7 +21,7 @@ def _run_updates(graph, K, n_updates):
         graph.update(t0=1, t1=K, itrs=2, use_inactive=False, opt_type="pose_depth" if i % 2 == 0 else "depth_scale")
 
 
-def _worker(rank, world, port, K, use_graphs, out_path):
+def _worker(rank, world, port, K, use_graphs, out_path, thresh=None):
     sys.path.insert(0, ROOT)
     import bench
     torch.cuda.set_device(0)
@@ -29,12 +29,15 @@ def _worker(rank, world, port, K, use_graphs, out_path):
     try:
         g, video, graph = bench.build_graph(torch.device("cuda", 0), K=K, h=24, w=32, rank=rank, world=world,
                                             use_graphs=use_graphs)
+        if thresh is not None:
+            video.cfg["tracking"]["multiview_filter"]["thresh"] = thresh
         _run_updates(graph, K, 6)
         video.fresh_disps_up()                      # collective: the deferred exchange of the upsampled rows
         torch.cuda.synchronize()
         if rank == 0:
             torch.save({"poses": video.poses[:K].cpu(), "disps": video.disps[:K].cpu(),
-                        "disps_up": video.disps_up[:K].cpu(), "scale": video.depth_scale[:K].cpu()}, out_path)
+                        "disps_up": video.disps_up[:K].cpu(), "scale": video.depth_scale[:K].cpu(),
+                        "status": video.ctx().ba_status(), "fallbacks": video.stage2_fallbacks}, out_path)
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -60,3 +63,26 @@ def test_two_rank_update_matches_single_process(gpu, tmp_path, K, use_graphs):
         # same arithmetic up to the summation order of the all-reduced fp64 system and fp16 convolutions on
         # differently sized batches
         torch.testing.assert_close(got[name], ref[name], atol=2e-3, rtol=2e-3, msg=lambda m, n=name: f"{n}: {m}")
+
+
+def test_two_rank_stage1_fallback(gpu, tmp_path):
+    """every depth_scale stage falls back to pose_depth (depth_video.py:290-294) on both ranks: the fallback BA of a shard
+    spans the whole window, not the source frames its depth_scale stage saw - it needs its own damping rows (the device
+    flags an eta / slot mismatch and skips the solve otherwise)"""
+    sys.path.insert(0, ROOT)
+    import bench
+    K = 9
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "rank0.pt")
+    mp.spawn(_worker, args=(2, port, K, False, out, 1e-4), nprocs=2, join=True)
+    got = torch.load(out)
+    assert got["fallbacks"] == 3 and got["status"][0] == 0, (got["fallbacks"], got["status"])
+    g, video, graph = bench.build_graph(gpu, K=K, h=24, w=32, use_graphs=False)
+    video.cfg["tracking"]["multiview_filter"]["thresh"] = 1e-4
+    _run_updates(graph, K, 6)
+    torch.cuda.synchronize()
+    assert video.stage2_fallbacks == 3
+    for name, ref in (("poses", video.poses[:K].cpu()), ("disps", video.disps[:K].cpu())):
+        torch.testing.assert_close(got[name], ref, atol=2e-3, rtol=2e-3, msg=lambda m, n=name: f"{n}: {m}")
