@@ -323,6 +323,10 @@ __global__ __launch_bounds__(kBaThreads) void ba_jacobian_kernel(
 // ------------------------------------------------------------------------------------
 __device__ __forceinline__ void atomic_add_f64(double* p, double v) { unsafeAtomicAdd(p, v); }
 
+__device__ __forceinline__ void assemble_edge(const BaWork& wk, const int64_t* __restrict__ ii,
+                                              const int64_t* __restrict__ jj, int n, int nchunks, int t0, int t1,
+                                              double* sm);
+
 constexpr int kGS = 8;                 // edges per row group (48 rows)
 constexpr int kGramKC = 128;           // pixels staged per sub-chunk
 constexpr int kGramLd = kGramKC + 2;   // +2 keeps the MFMA operand ds_read_b32 conflict free
@@ -334,8 +338,9 @@ constexpr int kRowsA = 48, kRowsB = 64;  // B side carries the extra w row (+pad
 // (3 per wave), dropped into LDS and scattered.  Frames with <= 8 outgoing edges -- the
 // normal case -- are a single pair.
 __global__ __launch_bounds__(kBaThreads) void ba_gram_kernel(
-    BaWork wk, const int64_t* __restrict__ jj, int HW, int chunk_px, int t0, int t1) {
-  __shared__ float lds[(kRowsA + kRowsB) * kGramLd];
+    BaWork wk, const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, int HW, int chunk_px, int t0, int t1,
+    int nchunks) {
+  __shared__ __attribute__((aligned(16))) float lds[(kRowsA + kRowsB) * kGramLd];
   __shared__ float Xs[kGS * 36];
   __shared__ int eA[kGS], eB[kGS];          // edge ids of the two row groups being multiplied
   const int tid = threadIdx.x;
@@ -354,6 +359,10 @@ __global__ __launch_bounds__(kBaThreads) void ba_gram_kernel(
   const int pbeg = chunk * chunk_px;
   const int pend = min(pbeg + chunk_px, HW);
   if (pbeg >= HW) return;
+  // the pose-pose blocks of this frame's edges (what ba_assemble_kernel did in a launch of its own): edge i of the frame
+  // is taken by the workgroup of pixel chunk i mod nchunks, before its share of the gram products
+  for (int i = chunk; i < deg; i += nchunks)
+    assemble_edge(wk, ii, jj, wk.csr_edge[e0 + i], nchunks, t0, t1, reinterpret_cast<double*>(lds));
   const int NG = (deg + kGS - 1) / kGS;
   float* Fa = lds;
   float* Fb = lds + kRowsA * kGramLd;
@@ -517,18 +526,19 @@ __global__ __launch_bounds__(kBaThreads) void ba_gram_kernel(
 // ------------------------------------------------------------------------------------
 // assemble: pose-pose blocks.  one 64-thread workgroup per edge
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void ba_assemble_kernel(BaWork wk, const int64_t* __restrict__ ii,
-                                                         const int64_t* __restrict__ jj,
-                                                         int nchunks, int t0, int t1) {
-  __shared__ double Hjj[36], Hij[36], Hii[36], vj[6], vi[6], L[36];
-  const int n = blockIdx.x;
+// the pose-pose blocks of edge n: executed by threads 0..63 of the calling workgroup, every thread of the workgroup
+// must call it (barriers); sm = 192 doubles of LDS
+__device__ __forceinline__ void assemble_edge(const BaWork& wk, const int64_t* __restrict__ ii,
+                                              const int64_t* __restrict__ jj, int n, int nchunks, int t0, int t1,
+                                              double* sm) {
+  double* Hjj = sm; double* Hij = sm + 36; double* Hii = sm + 72; double* L = sm + 108;
+  double* vj = sm + 144; double* vi = sm + 150; double* red = sm + 156;      // 27
   const int tid = threadIdx.x;
-  if (wk.status[0] & BA_ST_M_MISMATCH) return;
   const int P = t1 - t0;
   const int pi = (int)ii[n] - t0, pj = (int)jj[n] - t0;
   const bool ai = pi >= 0 && pi < P, aj = pj >= 0 && pj < P;
-  if (!ai && !aj) return;
-  __shared__ double red[27];
+  if (!ai && !aj) return;                          // uniform
+  __syncthreads();                                 // sm may still be read from the previous edge
   if (tid < 27) {
     double acc = 0.0;
     for (int c = 0; c < nchunks; ++c) acc += (double)wk.Hpart[((size_t)n * nchunks + c) * 27 + tid];
@@ -580,6 +590,16 @@ __global__ __launch_bounds__(64) void ba_assemble_kernel(BaWork wk, const int64_
     if (ai) atomic_add_f64(&wk.vd[6 * pi + tid], vi[tid]);
     if (aj) atomic_add_f64(&wk.vd[6 * pj + tid], vj[tid]);
   }
+}
+
+// stand-alone form (motion-only BA, where the gram launch that otherwise does this work is skipped): one 64-thread
+// workgroup per edge
+__global__ __launch_bounds__(64) void ba_assemble_kernel(BaWork wk, const int64_t* __restrict__ ii,
+                                                         const int64_t* __restrict__ jj,
+                                                         int nchunks, int t0, int t1) {
+  __shared__ double sm[192];
+  if (wk.status[0] & BA_ST_M_MISMATCH) return;
+  assemble_edge(wk, ii, jj, blockIdx.x, nchunks, t0, t1, sm);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1344,10 +1364,11 @@ static int ba_build_system(const BaPlan& pl, const float* poses, const float* di
   hipLaunchKernelGGL(ba_jacobian_kernel, dim3(pl.nchunks, pl.M), dim3(kBaThreads), 0, st, wk, poses,
                      disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, pl.HW, pl.w,
                      pl.nchunks, pl.ppt, motion_only, hwc, (long)pl.n6 * pl.n6 + pl.n6);
-  if (!motion_only)
-    hipLaunchKernelGGL(ba_gram_kernel, dim3(pl.nchunks, pl.M), dim3(kBaThreads), 0, st, wk, jj, pl.HW,
-                       pl.chunk_px, pl.t0, pl.t1);
-  hipLaunchKernelGGL(ba_assemble_kernel, dim3(pl.N), dim3(64), 0, st, wk, ii, jj, pl.nchunks, pl.t0, pl.t1);
+  if (!motion_only)        // Schur products AND the pose-pose blocks (one launch less per iteration)
+    hipLaunchKernelGGL(ba_gram_kernel, dim3(pl.nchunks, pl.M), dim3(kBaThreads), 0, st, wk, ii, jj, pl.HW,
+                       pl.chunk_px, pl.t0, pl.t1, pl.nchunks);
+  else
+    hipLaunchKernelGGL(ba_assemble_kernel, dim3(pl.N), dim3(64), 0, st, wk, ii, jj, pl.nchunks, pl.t0, pl.t1);
   return check_launch();
 }
 
