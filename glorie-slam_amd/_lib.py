@@ -61,6 +61,7 @@ SIGNATURES = {
     "glorie_corr_lookup_tiled_cl": (_c_int, [_vp, _c_int, _vp, _vp, _c_int, _vp] + [_c_int] * 5 + [_vp]),
     "glorie_valid_depth_mask": (_c_int, [_vp] * 4 + [_c_int] * 4 + [ctypes.c_float, _c_int, _vp, _vp, _vp]),
     "glorie_reproject": (_c_int, [_vp] * 7 + [_c_int] * 3 + [_vp]),
+    "glorie_reproject_motion": (_c_int, [_vp] * 9 + [_c_int] * 3 + [ctypes.c_float, _vp]),
     "glorie_frame_distance": (_c_int, [_vp] * 6 + [_c_int] * 3 + [_c_f, _vp]),
     "glorie_iproj": (_c_int, [_vp] * 4 + [_c_int] * 3 + [_vp]),
     "glorie_depth_filter": (_c_int, [_vp] * 6 + [_c_int] * 4 + [_vp]),

@@ -24,11 +24,15 @@ namespace glorie {
 // reproject: coords1 = pi_j( Gj Gi^-1 * pi_i^-1(disp_i) ),  valid = Z1 > 0.2
 // grid (ceil(HW/256), N); edge-uniform data (poses, intrinsics) are scalar loads.
 // ------------------------------------------------------------------------------------
+// target / motion (both or neither): the motion features of the update operator (factor_graph.py:219-221;
+// motion_padded_kernel below) for the same pixel, written as the zero-padded fp16 map of glorie_flow_conv7_padded - the
+// pixel grid coords0 is (x, y) itself, so they come for free with the reprojection
 __global__ __launch_bounds__(256) void reproject_kernel(
     const float* __restrict__ poses, const float* __restrict__ disps,
     const float* __restrict__ intr, const int64_t* __restrict__ ii,
     const int64_t* __restrict__ jj, float* __restrict__ coords, float* __restrict__ valid,
-    int h, int w) {
+    int h, int w, const float2* __restrict__ target = nullptr, _Float16* __restrict__ motion = nullptr,
+    float lim = 64.0f) {
   const int n = blockIdx.y;
   const int HW = h * w;
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -60,6 +64,16 @@ __global__ __launch_bounds__(256) void reproject_kernel(
   c.y = fyj * (X1[1] * d) + cyj;
   reinterpret_cast<float2*>(coords)[(size_t)n * HW + k] = c;
   if (valid) valid[(size_t)n * HW + k] = (X1[2] > 0.2f) ? 1.0f : 0.0f;  // X0.z == 1 > 0.2
+  if (motion) {
+    typedef __attribute__((ext_vector_type(4))) _Float16 h4;
+    const float2 t = target[(size_t)n * HW + k];
+    h4 o;
+    o[0] = (_Float16)fminf(fmaxf(c.x - (float)x, -lim), lim);
+    o[1] = (_Float16)fminf(fmaxf(c.y - (float)y, -lim), lim);
+    o[2] = (_Float16)fminf(fmaxf(t.x - c.x, -lim), lim);
+    o[3] = (_Float16)fminf(fmaxf(t.y - c.y, -lim), lim);
+    *reinterpret_cast<h4*>(motion + ((((size_t)n * (h + 6) + y + 3) * (w + 8)) + x + 3) * 4) = o;
+  }
 }
 
 // ------------------------------------------------------------------------------------
@@ -402,6 +416,20 @@ extern "C" int glorie_reproject(const float* poses, const float* disps, const fl
   dim3 grid((h * w + 255) / 256, N);
   hipLaunchKernelGGL(reproject_kernel, grid, dim3(256), 0, (hipStream_t)stream, poses, disps,
                      intrinsics, ii, jj, coords, valid, h, w);
+  return check_launch();
+}
+
+extern "C" int glorie_reproject_motion(const float* poses, const float* disps, const float* intrinsics,
+                                       const int64_t* ii, const int64_t* jj, float* coords, float* valid,
+                                       const float* target, void* padded_motion, int N, int h, int w, float limit,
+                                       void* stream) {
+  if (N < 0 || h < 0 || w < 0) return GLORIE_EINVAL;
+  if (N == 0 || h * w == 0) return GLORIE_OK;
+  if (!poses || !disps || !intrinsics || !ii || !jj || !coords || !target || !padded_motion) return GLORIE_EINVAL;
+  dim3 grid((h * w + 255) / 256, N);
+  hipLaunchKernelGGL(reproject_kernel, grid, dim3(256), 0, (hipStream_t)stream, poses, disps, intrinsics, ii, jj, coords,
+                     valid, h, w, reinterpret_cast<const float2*>(target), reinterpret_cast<_Float16*>(padded_motion),
+                     limit);
   return check_launch();
 }
 

@@ -186,10 +186,10 @@ class DepthVideo:
             self.poses[:n, :3] *= s
             self.set_dirty(0, n)
 
-    def reproject(self, ii, jj):
-        """coords [1,N,h,w,2], valid [1,N,h,w,1]  (depth_video.py:156-164)"""
+    def reproject(self, ii, jj, motion=None):
+        """coords [1,N,h,w,2], valid [1,N,h,w,1]  (depth_video.py:156-164); motion: see droid_backends.reproject"""
         ii, jj = DepthVideo.format_indicies(ii, jj, self.device)
-        coords, valid = droid_backends.reproject(self.poses, self.disps, self.intrinsics, ii, jj)
+        coords, valid = droid_backends.reproject(self.poses, self.disps, self.intrinsics, ii, jj, motion=motion)
         return coords[None], valid[None]
 
     def distance(self, ii=None, jj=None, beta=0.3, bidirectional=True):

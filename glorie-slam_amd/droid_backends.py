@@ -199,9 +199,11 @@ def depth_filter(poses, disps, intrinsics, ix, thresh):
     return count
 
 
-def reproject(poses, disps, intrinsics, ii, jj, return_valid=True):
+def reproject(poses, disps, intrinsics, ii, jj, return_valid=True, motion=None):
     """Fused pops.projective_transform(jacobian=False) (projective_ops.py:96-125).
-    poses [B,7], disps [B,h,w], intrinsics [B,4] -> coords [N,h,w,2], valid [N,h,w,1]"""
+    poses [B,7], disps [B,h,w], intrinsics [B,4] -> coords [N,h,w,2], valid [N,h,w,1].
+    motion = (target [.., N, h, w, 2] f32, update_ops.PaddedFlow): the same launch also writes the motion features
+    [coords - grid, target - coords].clamp(+-64) (factor_graph.py:219-221) into the padded fp16 map"""
     L.need_cuda(poses, disps, intrinsics, ii, jj)
     L.need_contiguous(poses=poses, disps=disps, intrinsics=intrinsics, ii=ii, jj=jj)
     _i64(ii, "ii"), _i64(jj, "jj")
@@ -209,6 +211,16 @@ def reproject(poses, disps, intrinsics, ii, jj, return_valid=True):
     h, w = disps.shape[1:]
     coords = torch.empty((N, h, w, 2), dtype=torch.float32, device=poses.device)
     valid = torch.empty((N, h, w, 1), dtype=torch.float32, device=poses.device) if return_valid else None
+    if motion is not None:
+        target, padded = motion
+        L.need_cuda(target, padded.buf)
+        if not target.is_contiguous() or target.dtype != torch.float32 or target.numel() != N * h * w * 2 \
+                or not padded.fits(N, h, w, poses.device):
+            raise RuntimeError("reproject: motion needs a contiguous float32 target [N,h,w,2] and a matching PaddedFlow")
+        L.check(L.load().glorie_reproject_motion(L.ptr(poses), L.ptr(disps), L.ptr(intrinsics), L.ptr(ii), L.ptr(jj),
+                                                 L.ptr(coords), L.ptr(valid), L.ptr(target), L.ptr(padded.buf), N, h, w,
+                                                 64.0, L.stream_ptr()), "glorie_reproject_motion")
+        return coords, valid
     L.check(L.load().glorie_reproject(L.ptr(poses), L.ptr(disps), L.ptr(intrinsics), L.ptr(ii),
                                       L.ptr(jj), L.ptr(coords), L.ptr(valid), N, h, w,
                                       L.stream_ptr()), "glorie_reproject")

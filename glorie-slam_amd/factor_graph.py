@@ -208,15 +208,23 @@ class FactorGraph:
         self.rm_factors(m, store=False)
 
     # ---- one BA-update iteration -----------------------------------------------------
+    def poses_on_device(self):
+        return self.video.poses.is_cuda
+
+    def _padded_flow(self, n, device):
+        """the zero-padded fp16 motion map of the current edge set (update_ops.PaddedFlow), kept with the edge set"""
+        from .update_ops import PaddedFlow
+        pf = self._graphs.get("flow_pad")
+        if pf is None or not pf.fits(n, self.ht, self.wd, device):
+            pf = self._graphs["flow_pad"] = PaddedFlow(n, self.ht, self.wd, device)
+        return pf
+
     def _motion(self, coords1, padded=False):
         """[1, N, 4, h, w] view of the channels-last motion map (factor_graph.py:219-221); padded=True: the zero-padded
         fp16 form FusedUpdate's flow encoder reads (update_ops.PaddedFlow), written directly"""
         if coords1.is_cuda and padded:
-            from .update_ops import PaddedFlow
             n = coords1.numel() // (self.ht * self.wd * 2)
-            pf = self._graphs.get("flow_pad")
-            if pf is None or not pf.fits(n, self.ht, self.wd, coords1.device):
-                pf = self._graphs["flow_pad"] = PaddedFlow(n, self.ht, self.wd, coords1.device)
+            pf = self._padded_flow(n, coords1.device)
             return droid_backends.motion_padded(coords1.contiguous(), self.coords0.contiguous(), self.target.contiguous(), pf)
         if coords1.is_cuda:
             m = droid_backends.motion(coords1.contiguous(), self.coords0.contiguous(), self.target.contiguous())
@@ -350,8 +358,15 @@ class FactorGraph:
     @torch.no_grad()
     def _update_eager(self, t0=None, t1=None, itrs=2, use_inactive=False, EP=1e-7, motion_only=False,
                       opt_type="pose_depth", run_ba=True):
-        coords1, mask = self.video.reproject(self.ii, self.jj)
-        motn = self._motion(coords1, padded=self.fast_update is not None)
+        if self.fast_update is not None and self.poses_on_device() and self.target.is_contiguous() \
+                and self.target.dtype == torch.float32:
+            # reprojection + motion features of the flow encoder (padded fp16 map) in one launch
+            pf = self._padded_flow(int(self.ii.shape[0]), self.target.device)
+            coords1, mask = self.video.reproject(self.ii, self.jj, motion=(self.target, pf))
+            motn = pf
+        else:
+            coords1, mask = self.video.reproject(self.ii, self.jj)
+            motn = self._motion(coords1, padded=self.fast_update is not None)
         if self.corr_impl == "otf":
             blk = self._otf_block()
             rig = self._otf_rig

@@ -338,6 +338,11 @@ int glorie_motion(const float* coords1, const float* coords0, const float* targe
 /* glorie_motion with the zero-padded fp16 map of glorie_flow_conv7_padded as its output (interior only) */
 int glorie_motion_padded(const float* coords1, const float* coords0, const float* target, void* padded, int N, int h,
                          int w, float limit, void* stream);
+/* glorie_reproject and glorie_motion_padded in one launch (coords0 of factor_graph.py:219 is the pixel grid itself):
+ * coords / valid as glorie_reproject, padded_motion as glorie_motion_padded for target [N][h][w][2]. */
+int glorie_reproject_motion(const float* poses, const float* disps, const float* intrinsics, const int64_t* ii,
+                            const int64_t* jj, float* coords, float* valid, const float* target, void* padded_motion,
+                            int N, int h, int w, float limit, void* stream);
 
 /* same operator, mask given channels-last in fp16: row (m*h*w + pixel) holds the 576 logits,
  * rows `mask_stride` halfs apart -- the layout the 1x1 upmask convolution produces */

@@ -191,6 +191,24 @@ def test_normalize_and_valid_mask(gpu):
     assert video.valid_depth_mask_small[:7].any()
 
 
+def test_reprojection_writes_the_motion_features(gpu):
+    """DepthVideo.reproject(motion=...) = reproject + FactorGraph._motion (factor_graph.py:205-221) in one launch: the pixel
+    grid coords0 is (x, y) itself; same coordinates, same fp16 motion map"""
+    from glorie_slam_amd.update_ops import PaddedFlow
+    g, video = make_video(gpu, 6, 24, 32)
+    graph = make_graph(gpu, video)
+    graph.add_factors(torch.as_tensor(g["ii"], device=gpu), torch.as_tensor(g["jj"], device=gpu))
+    n = int(graph.ii.shape[0])
+    graph.target = (graph.target + 3.0 * torch.randn_like(graph.target)).contiguous()
+    coords, _ = video.reproject(graph.ii, graph.jj)
+    two = graph._motion(coords, padded=True)
+    ref = two.buf.clone()
+    pf = PaddedFlow(n, 24, 32, gpu)
+    fused, _ = video.reproject(graph.ii, graph.jj, motion=(graph.target, pf))
+    assert torch.equal(fused, coords)
+    assert torch.equal(pf.buf, ref)
+
+
 @pytest.mark.parametrize("stage2", [True, False])
 def test_graph_replay_matches_eager(gpu, stage2):
     """use_graphs=True (hipGraph replay of update()) walks the same states as eager launches - also when every
