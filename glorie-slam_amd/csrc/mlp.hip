@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "common.hiph"
 
 namespace glorie {
@@ -427,6 +428,193 @@ __global__ __launch_bounds__(512, 4) void mlp_col_v3_kernel(ColParams P, const f
   }
 }
 
+// ---- colour decoder on the fp16 matrix cores with fp32 accuracy (3-term split) -------------------------------------
+// The fp32 MFMA (16x16x4, 64 flops per cycle and SIMD) is the slowest matrix path of the chip; the fp16 one (16x16x32) is
+// 16x faster.  Every weight and activation is split as x = hi + lo (hi = fp16(x), lo = fp16(x - hi): 22 mantissa bits) and
+// a product is accumulated as hi*hi + hi*lo + lo*hi in fp32 - the dropped lo*lo term is 2^-22 relative, the fp16 products
+// are exact in the fp32 accumulator - so a 32-row chunk costs 3 x 8 MFMAs of 16 cycles instead of 64 of 32.  The
+// transposed formulation carries over: the accumulator blocks (2t, 2t+1) of a layer, split and packed, are the eight
+// k-slots of a lane's B operand for chunk t of the next layer (slot s <-> chunk row 16 (s >> 2) + 4 g + (s & 3), the same
+// row order as the fp32 chunks); the weights are packed once per chunk as A fragments
+// [hi|lo][out block 8][lane 64][8 halfs] (point_ops.pack_decoders) and streamed through LDS as they are (linear copy,
+// conflict-free ds_read_b128).  Softplus, biases and the 128 -> 3 output layer stay fp32 as in mlp_col_v3_kernel.
+typedef __attribute__((ext_vector_type(8))) _Float16 h16x8;
+constexpr int kChunkFloats16 = 4096;          // 2 x 8 x 64 x 8 halfs
+
+__device__ __forceinline__ ChunkRegs chunk_load16(const float* __restrict__ W16, int chunk) {
+  const float4* src = reinterpret_cast<const float4*>(W16 + (size_t)chunk * kChunkFloats16 + threadIdx.x * 8);
+  ChunkRegs r;
+  r.a = src[0];
+  r.b = src[1];
+  return r;
+}
+__device__ __forceinline__ void chunk_store16(float* Wb, const ChunkRegs& r) {
+  float4* dst = reinterpret_cast<float4*>(Wb + threadIdx.x * 8);
+  dst[0] = r.a;
+  dst[1] = r.b;
+}
+// split two accumulator blocks (channels 4g + rr of block 0 -> slots 0..3, of block 1 -> slots 4..7) into hi / lo halfs
+__device__ __forceinline__ void split2(const f32x4 a, const f32x4 b, h16x8& hi, h16x8& lo) {
+  const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    hi[s] = (_Float16)v[s];
+    lo[s] = (_Float16)(v[s] - (float)hi[s]);
+  }
+}
+// acc[to] += W_chunk[:, 16 to ..] . b   with b given as split halfs
+__device__ __forceinline__ void mma_h3(f32x4 (&acc)[8], const h16x8 bhi, const h16x8 blo, const float* Wb) {
+  const int lane = threadIdx.x & 63;
+  const h16x8* wp = reinterpret_cast<const h16x8*>(Wb) + lane;
+#pragma unroll
+  for (int to = 0; to < 8; ++to) {
+    const h16x8 ahi = wp[to * 64], alo = wp[(8 + to) * 64];
+    acc[to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, bhi, acc[to], 0, 0, 0);
+    acc[to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, blo, acc[to], 0, 0, 0);
+    acc[to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, bhi, acc[to], 0, 0, 0);
+  }
+}
+
+__global__ __launch_bounds__(512, 4) void mlp_col_v4_kernel(ColParams P, const float* __restrict__ W16,
+                                                            const float* __restrict__ pts,
+                                                            const float* __restrict__ views,
+                                                            const float* __restrict__ c_col, int Q,
+                                                            float* __restrict__ raw) {
+  extern __shared__ float smem[];
+  float* Wbuf = smem;                         // [2][4096]
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  const int r = lane & 15, g = lane >> 4;
+  const int q0 = blockIdx.x * kTM2;
+  const int qs = q0 + wv * 16 + r;            // this lane's sample (all four k-slots of a column share it)
+  const int q = min(qs, Q - 1);
+
+  // ---- B operands: embedding (80 channels = blocks 0..4 -> chunks {0,1}, {2,3}, {4,-}) and colour feature (32) ----
+  h16x8 ehi[3], elo[3], chi, clo;
+  auto load_c = [&]() {
+    const float4 v0 = *reinterpret_cast<const float4*>(c_col + (size_t)q * 32 + 4 * g);
+    const float4 v1 = *reinterpret_cast<const float4*>(c_col + (size_t)q * 32 + 16 + 4 * g);
+    split2(f32x4{v0.x, v0.y, v0.z, v0.w}, f32x4{v1.x, v1.y, v1.z, v1.w}, chi, clo);
+  };
+  {
+    // phases in revolutions: the 2 pi of the reference's embedding is the period of v_sin / v_cos
+    const float px = pts[(size_t)q * 3 + 0], py = pts[(size_t)q * 3 + 1], pz = pts[(size_t)q * 3 + 2];
+    float vx = views[(size_t)q * 3 + 0], vy = views[(size_t)q * 3 + 1], vz = views[(size_t)q * 3 + 2];
+    const float nrm = fmaxf(sqrtf(vx * vx + vy * vy + vz * vz), 1e-12f);
+    vx = vx / nrm; vy = vy / nrm; vz = vz / nrm;
+    f32x4 e[6];
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int f = 16 * t + 4 * g + rr;   // feature index 0..79: [sin p | cos p | sin v | cos v] x 20
+        const int blk = f / 20, ff = f - blk * 20;
+        const float* Bm = blk < 2 ? P.Bp : P.Bv;
+        const float x = blk < 2 ? px : vx, y = blk < 2 ? py : vy, z = blk < 2 ? pz : vz;
+        const float a = fmaf(z, Bm[40 + ff], fmaf(y, Bm[20 + ff], x * Bm[ff]));
+        e[t][rr] = (blk & 1) ? cos_rev(a) : sin_rev(a);
+      }
+    e[5] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) split2(e[2 * c], e[2 * c + 1], ehi[c], elo[c]);
+  }
+
+  f32x4 acc[8];
+  h16x8 hhi[4], hlo[4];
+  constexpr int NC = 27;
+  ChunkRegs nxt = chunk_load16(W16, 0);
+  chunk_store16(Wbuf, nxt);
+  __syncthreads();
+
+  auto act = [&](int li) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const float4 bb = *reinterpret_cast<const float4*>(P.bias + li * 128 + 16 * t + 4 * g);
+      const float4 fb = *reinterpret_cast<const float4*>(P.fcb + li * 128 + 16 * t + 4 * g);
+      acc[t][0] = softplus100_fast(acc[t][0] + bb.x) + fb.x;
+      acc[t][1] = softplus100_fast(acc[t][1] + bb.y) + fb.y;
+      acc[t][2] = softplus100_fast(acc[t][2] + bb.z) + fb.z;
+      acc[t][3] = softplus100_fast(acc[t][3] + bb.w) + fb.w;
+    }
+  };
+  auto next_layer = [&]() {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) split2(acc[2 * c], acc[2 * c + 1], hhi[c], hlo[c]);
+    zero<8>(acc);
+  };
+
+#define GL_CHUNK(cidx, BHI, BLO)                                    \
+  {                                                                 \
+    if ((cidx) + 1 < NC) nxt = chunk_load16(W16, (cidx) + 1);       \
+    mma_h3(acc, BHI, BLO, Wbuf + ((cidx) & 1) * kChunkFloats16);    \
+    if ((cidx) + 1 < NC) chunk_store16(Wbuf + (((cidx) + 1) & 1) * kChunkFloats16, nxt); \
+    __syncthreads();                                                \
+  }
+
+  // layer 0: W0 (80 rows -> chunks 0..2), Fc0 (chunk 3)
+  zero<8>(acc);
+  GL_CHUNK(0, ehi[0], elo[0])
+  GL_CHUNK(1, ehi[1], elo[1])
+  GL_CHUNK(2, ehi[2], elo[2])
+  load_c();
+  act(0);
+  GL_CHUNK(3, chi, clo)
+  // layer 1
+  next_layer();
+  GL_CHUNK(4, hhi[0], hlo[0])
+  GL_CHUNK(5, hhi[1], hlo[1])
+  GL_CHUNK(6, hhi[2], hlo[2])
+  GL_CHUNK(7, hhi[3], hlo[3])
+  load_c();
+  act(1);
+  GL_CHUNK(8, chi, clo)
+  // layer 2
+  next_layer();
+  GL_CHUNK(9, hhi[0], hlo[0])
+  GL_CHUNK(10, hhi[1], hlo[1])
+  GL_CHUNK(11, hhi[2], hlo[2])
+  GL_CHUNK(12, hhi[3], hlo[3])
+  load_c();
+  act(2);
+  GL_CHUNK(13, chi, clo)
+  // layer 3 (skip): W3e on the embedding, W3h on the hidden state
+  next_layer();
+  GL_CHUNK(14, ehi[0], elo[0])
+  GL_CHUNK(15, ehi[1], elo[1])
+  GL_CHUNK(16, ehi[2], elo[2])
+  GL_CHUNK(17, hhi[0], hlo[0])
+  GL_CHUNK(18, hhi[1], hlo[1])
+  GL_CHUNK(19, hhi[2], hlo[2])
+  GL_CHUNK(20, hhi[3], hlo[3])
+  load_c();
+  act(3);
+  GL_CHUNK(21, chi, clo)
+  // layer 4
+  next_layer();
+  GL_CHUNK(22, hhi[0], hlo[0])
+  GL_CHUNK(23, hhi[1], hlo[1])
+  GL_CHUNK(24, hhi[2], hlo[2])
+  GL_CHUNK(25, hhi[3], hlo[3])
+  load_c();
+  act(4);
+  GL_CHUNK(26, chi, clo)
+#undef GL_CHUNK
+  // output layer 128 -> 3 in fp32 as in mlp_col_v3_kernel
+  f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+  {
+    const float* wp = P.Wout + (4 * g) * 16 + r;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr)
+        o = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[(16 * t + rr) * 16], acc[t][rr], o, 0, 0, 0);
+  }
+  if (g == 0 && qs < Q) {
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch)
+      raw[(size_t)qs * 4 + ch] = 1.0f / (1.0f + __expf(-(o[ch] + P.bout[ch])));
+  }
+}
+
 // per-neighbour F_theta, transposed formulation (see mlp_col_v3_kernel): W1 (52 x 128) resident in LDS with
 // the permuted column order, the 52 input channels of neighbour k built directly as B fragments - lane
 // (r, g) owns sample r and supplies, for k-slot g, colour-feature channels 16t + 4g + rr (two 16-byte loads
@@ -584,7 +772,7 @@ extern "C" size_t glorie_decoder_pack_floats(void) {
   size_t nb = 3 * 10 + 2 + 52 * 128 + 128 + 128 * 32 + 32;
   size_t col = 3 * 20 * 2 + 80 * 128 + 128 * 128 * 2 + 80 * 128 + 128 * 128 * 2 + 128 * 16 + 5 * 32 * 128 +
                5 * 128 * 2 + 4;
-  return geo + nb + col + (size_t)27 * 32 * 128 + (size_t)(480 * 32 + 32 * 16);
+  return geo + nb + col + (size_t)27 * 32 * 128 + (size_t)(480 * 32 + 32 * 16) + (size_t)27 * kChunkFloats16;
 }
 
 extern "C" int glorie_render_mlp(const float* packed, const float* pts, const float* views,
@@ -615,6 +803,7 @@ extern "C" int glorie_render_mlp(const float* packed, const float* pts, const fl
   k.bout = c.take(4);
   const float* col_chunks = c.take((size_t)27 * 32 * 128);
   const float* geo_image = c.take((size_t)kGeoImage);
+  const float* col_chunks16 = c.take((size_t)27 * kChunkFloats16);
   const int blocks2 = (Q + kTM2 - 1) / kTM2;
   const size_t geo_lds = sizeof(float) * kGeoImage;
   static bool geo_attr = false;
@@ -638,8 +827,14 @@ extern "C" int glorie_render_mlp(const float* packed, const float* pts, const fl
     }
     hipLaunchKernelGGL(mlp_nb_v3_kernel, dim3(blocks2), dim3(512), nb_lds, st, n, pts, cloud_pos, col_feats,
                        I, weights, has, Q, c_col_scratch);
-    hipLaunchKernelGGL(mlp_col_v3_kernel, dim3(blocks2), dim3(512), col_lds, st, k, col_chunks, pts, views,
-                       c_col_scratch, Q, raw);
+    // colour decoder: fp16 matrix cores with the 3-term split (fp32 accuracy); GLORIE_MLP_F32=1 keeps the fp32 MFMA kernel
+    const char* f32 = getenv("GLORIE_MLP_F32");
+    if (f32 && f32[0] == '1')
+      hipLaunchKernelGGL(mlp_col_v3_kernel, dim3(blocks2), dim3(512), col_lds, st, k, col_chunks, pts, views,
+                         c_col_scratch, Q, raw);
+    else
+      hipLaunchKernelGGL(mlp_col_v4_kernel, dim3(blocks2), dim3(512), sizeof(float) * 2 * kChunkFloats16, st, k,
+                         col_chunks16, pts, views, c_col_scratch, Q, raw);
   }
   return check_launch();
 }

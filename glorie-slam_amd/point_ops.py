@@ -293,6 +293,7 @@ def pack_decoders(decoders):
            _t(c.pts_linears[4].weight), fc[4]]
     chunks = torch.cat([m.to(dev) for m in seq], 0)
     assert chunks.shape == (27 * 32, 128), chunks.shape
+    chunks16 = chunks.detach().float()
     chunks = chunks.reshape(-1, 2, 4, 16).permute(0, 1, 3, 2).reshape(-1, 128)
     parts.append(f(chunks))
     # geometry weights once more, as the LDS image of the geometry kernel: 480 K-rows
@@ -307,6 +308,14 @@ def pack_decoders(decoders):
     assert rows.shape == (480, 32), rows.shape
     parts.append(f(rows.reshape(480, 2, 16).permute(0, 2, 1)))
     parts.append(f(_pad_cols(_t(g.output_linear.weight), 16)))
+    # the colour chunks a third time, as fp16 MFMA A fragments of the 3-term split (mlp_col_v4_kernel):
+    # [chunk][hi|lo][out block to][lane = 16 g + i][slot s] halfs, chunk row 16 (s >> 2) + 4 g + (s & 3), output 16 to + i;
+    # hi = fp16(w), lo = fp16(w - hi); carried as raw bits in the float buffer (4096 floats per chunk)
+    t6 = chunks16.reshape(27, 2, 4, 4, 8, 16).permute(0, 4, 2, 5, 1, 3)       # [chunk][to][g][i][s >> 2][s & 3]
+    hi = t6.half()
+    lo = (t6 - hi.float()).half()
+    frag = torch.stack([hi, lo], 1).reshape(27, -1).contiguous()              # [chunk][2 * 8 * 64 * 8]
+    parts.append(frag.view(torch.float32).reshape(-1))
     packed = torch.cat(parts).contiguous()
     expect = int(L.load().glorie_decoder_pack_floats())
     if packed.numel() != expect:
