@@ -754,6 +754,146 @@ __global__ __launch_bounds__(512, 4) void mlp_nb_v3_kernel(NbParams P, const flo
   }
 }
 
+// per-neighbour F_theta on the fp16 matrix cores with the 3-term split (see mlp_col_v4_kernel).  The 52 input channels of a
+// neighbour are two 32-slot chunks: chunk 0 = the 20 embedding features (lane slot s < 5 <-> feature 4s + g, slots 5..7
+// zero), chunk 1 = the 32 colour-feature channels (slot s <-> channel 16 (s >> 2) + 4 g + (s & 3), the two 16-byte loads of
+// the feature row).  W1 is split and laid out as A fragments [chunk][hi|lo][out block][lane][8] in LDS once per workgroup.
+__global__ __launch_bounds__(512, 4) void mlp_nb_v4_kernel(NbParams P, const float* __restrict__ pts,
+                                                           const float* __restrict__ cloud,
+                                                           const float* __restrict__ col_feats,
+                                                           const int64_t* __restrict__ I,
+                                                           const float* __restrict__ wts,
+                                                           const uint8_t* __restrict__ has, int Q,
+                                                           float* __restrict__ c_col) {
+  extern __shared__ float smem[];
+  h16x8* W1f = reinterpret_cast<h16x8*>(smem);   // [2 chunks][2 hi|lo][8][64] fragments of 8 halfs = 32 KB
+  float* b1s = smem + 8192;                   // [128]
+  float* wbuf = b1s + 128;                    // [128][8] IDW weights (0 for an absent neighbour)
+  int* ibuf = reinterpret_cast<int*>(wbuf + kTM2 * 8);  // [128][8] neighbour ids (0 for an absent one)
+  float* bs = reinterpret_cast<float*>(ibuf + kTM2 * 8);  // [20][4] B[:, f mod 10] (revolutions per metre)
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  const int r = lane & 15, g = lane >> 4;
+  const int q0 = blockIdx.x * kTM2;
+  if (tid < 80) {
+    const int f = tid >> 2, d = tid & 3;
+    bs[tid] = d < 3 ? P.B[d * 10 + (f < 10 ? f : f - 10)] : 0.0f;
+  }
+  for (int idx = tid; idx < 2 * 8 * 64; idx += 512) {       // one (chunk, out block, lane) fragment pair per iteration
+    const int ln = idx & 63, to = (idx >> 6) & 7, ch = idx >> 9;
+    const int i = ln & 15, gg = ln >> 4;
+    h16x8 hi, lo;
+#pragma unroll
+    for (int sl = 0; sl < 8; ++sl) {
+      int row = -1;
+      if (ch == 0) { if (sl < 5) row = 4 * sl + gg; }
+      else row = 20 + 16 * (sl >> 2) + 4 * gg + (sl & 3);
+      const float w = row >= 0 ? P.W1[row * 128 + 16 * to + i] : 0.0f;
+      hi[sl] = (_Float16)w;
+      lo[sl] = (_Float16)(w - (float)hi[sl]);
+    }
+    W1f[((ch * 2 + 0) * 8 + to) * 64 + ln] = hi;
+    W1f[((ch * 2 + 1) * 8 + to) * 64 + ln] = lo;
+  }
+  if (tid < 128) b1s[tid] = P.b1[tid];
+  for (int idx = tid; idx < kTM2 * 8; idx += 512) {
+    const int row = idx >> 3;
+    const int q = min(q0 + row, Q - 1);
+    const int ii = (int)I[(size_t)q * 8 + (idx & 7)];
+    wbuf[idx] = (q0 + row < Q && ii >= 0) ? wts[(size_t)q * 8 + (idx & 7)] : 0.0f;
+    ibuf[idx] = ii < 0 ? 0 : ii;
+  }
+  __syncthreads();
+  const int srow = wv * 16 + r;               // this lane's sample row inside the workgroup
+  const int qs = q0 + srow;
+  const int q = min(qs, Q - 1);
+  const float qx = pts[(size_t)q * 3 + 0], qy = pts[(size_t)q * 3 + 1], qz = pts[(size_t)q * 3 + 2];
+  const float* bsl = bs + 4 * g;
+  f32x4 ysum[8];
+  zero<8>(ysum);
+  float sw = 0.0f;
+  const h16x8* wl = W1f + lane;
+#pragma unroll 1
+  for (int k = 0; k < 8; ++k) {
+    const int pt = ibuf[srow * 8 + k];
+    const float w = wbuf[srow * 8 + k];
+    const float4 c0 = *reinterpret_cast<const float4*>(col_feats + (size_t)pt * 32 + 4 * g);
+    const float4 c1 = *reinterpret_cast<const float4*>(col_feats + (size_t)pt * 32 + 16 + 4 * g);
+    const float rx = cloud[(size_t)pt * 3 + 0] - qx, ry = cloud[(size_t)pt * 3 + 1] - qy,
+                rz = cloud[(size_t)pt * 3 + 2] - qz;
+    f32x4 acc[8];
+    zero<8>(acc);
+    // chunk 0: embedding features 4s + g (sin for feature < 10), phases in revolutions
+    {
+      float ev[8];
+#pragma unroll
+      for (int sidx = 0; sidx < 5; ++sidx) {
+        const float4 bf = *reinterpret_cast<const float4*>(bsl + 16 * sidx);
+        const float a = fmaf(rz, bf.z, fmaf(ry, bf.y, rx * bf.x));
+        ev[sidx] = (4 * sidx + g >= 10) ? cos_rev(a) : sin_rev(a);
+      }
+      ev[5] = ev[6] = ev[7] = 0.0f;
+      h16x8 bhi, blo;
+      split2(f32x4{ev[0], ev[1], ev[2], ev[3]}, f32x4{ev[4], ev[5], ev[6], ev[7]}, bhi, blo);
+#pragma unroll
+      for (int to = 0; to < 8; ++to) {
+        const h16x8 ahi = wl[to * 64], alo = wl[(8 + to) * 64];
+        acc[to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, bhi, acc[to], 0, 0, 0);
+        acc[to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, blo, acc[to], 0, 0, 0);
+        acc[to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, bhi, acc[to], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);     // keeps the compiler from hoisting all 32 fragment reads (128 registers)
+      }
+    }
+    // chunk 1: the neighbour's colour feature (a full L2 round trip behind the index: issued above, used here)
+    {
+      h16x8 bhi, blo;
+      split2(f32x4{c0.x, c0.y, c0.z, c0.w}, f32x4{c1.x, c1.y, c1.z, c1.w}, bhi, blo);
+#pragma unroll
+      for (int to = 0; to < 8; ++to) {
+        const h16x8 ahi = wl[(16 + to) * 64], alo = wl[(24 + to) * 64];
+        acc[to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, bhi, acc[to], 0, 0, 0);
+        acc[to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, blo, acc[to], 0, 0, 0);
+        acc[to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, bhi, acc[to], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);     // keeps the compiler from hoisting all 32 fragment reads (128 registers)
+      }
+    }
+    sw += w;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const float4 bb = *reinterpret_cast<const float4*>(b1s + 16 * t + 4 * g);
+      ysum[t][0] += w * softplus100_fast(acc[t][0] + bb.x);
+      ysum[t][1] += w * softplus100_fast(acc[t][1] + bb.y);
+      ysum[t][2] += w * softplus100_fast(acc[t][2] + bb.z);
+      ysum[t][3] += w * softplus100_fast(acc[t][3] + bb.w);
+    }
+  }
+  // second layer 128 -> 32 in fp32 as in mlp_nb_v3_kernel (A = W2 straight from global / L2)
+  f32x4 o[2];
+  zero<2>(o);
+  {
+    const float* wp = P.W2 + (4 * g) * 32 + r;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        o[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[(16 * t + rr) * 32], ysum[t][rr], o[0], 0, 0, 0);
+        o[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[(16 * t + rr) * 32 + 16], ysum[t][rr], o[1], 0, 0, 0);
+      }
+  }
+  if (qs < Q) {
+    const bool h = has[qs] != 0;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const float4 b2 = *reinterpret_cast<const float4*>(P.b2 + 16 * t + 4 * g);
+      float4 v;
+      v.x = h ? o[t][0] + b2.x * sw : 0.0f;
+      v.y = h ? o[t][1] + b2.y * sw : 0.0f;
+      v.z = h ? o[t][2] + b2.z * sw : 0.0f;
+      v.w = h ? o[t][3] + b2.w * sw : 0.0f;
+      *reinterpret_cast<float4*>(c_col + (size_t)qs * 32 + 16 * t + 4 * g) = v;
+    }
+  }
+}
+
 }  // namespace glorie
 
 using namespace glorie;
@@ -825,10 +965,22 @@ extern "C" int glorie_render_mlp(const float* packed, const float* pts, const fl
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)col_lds);
       attr = true;
     }
-    hipLaunchKernelGGL(mlp_nb_v3_kernel, dim3(blocks2), dim3(512), nb_lds, st, n, pts, cloud_pos, col_feats,
-                       I, weights, has, Q, c_col_scratch);
-    // colour decoder: fp16 matrix cores with the 3-term split (fp32 accuracy); GLORIE_MLP_F32=1 keeps the fp32 MFMA kernel
+    // per-neighbour and colour decoders: fp16 matrix cores with the 3-term split (fp32 accuracy); GLORIE_MLP_F32=1 keeps
+    // the fp32 MFMA kernels
     const char* f32 = getenv("GLORIE_MLP_F32");
+    const size_t nb4_lds = sizeof(float) * (8192 + 128 + kTM2 * 8 + 80) + sizeof(int) * kTM2 * 8;
+    static bool attr4 = false;
+    if (!attr4) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_nb_v4_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)nb4_lds);
+      attr4 = true;
+    }
+    if (f32 && f32[0] == '1')
+      hipLaunchKernelGGL(mlp_nb_v3_kernel, dim3(blocks2), dim3(512), nb_lds, st, n, pts, cloud_pos, col_feats,
+                         I, weights, has, Q, c_col_scratch);
+    else
+      hipLaunchKernelGGL(mlp_nb_v4_kernel, dim3(blocks2), dim3(512), nb4_lds, st, n, pts, cloud_pos, col_feats,
+                         I, weights, has, Q, c_col_scratch);
     if (f32 && f32[0] == '1')
       hipLaunchKernelGGL(mlp_col_v3_kernel, dim3(blocks2), dim3(512), col_lds, st, k, col_chunks, pts, views,
                          c_col_scratch, Q, raw);
