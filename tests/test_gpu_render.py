@@ -198,6 +198,30 @@ def test_decoders_on_gpu_match_reference_fixture(gpu):
     np.testing.assert_allclose(raw[pm, :3], f["rgb"][pm], rtol=1e-3, atol=1e-3)   # colours: 1e-3
 
 
+def test_decoders_on_the_fp16_matrix_cores_keep_fp32_accuracy(gpu, monkeypatch):
+    """per-neighbour and colour decoders as 3-term hi/lo splits on the fp16 MFMA (mlp_nb_v4 / mlp_col_v4, the default) against
+    the fp32-MFMA kernels (GLORIE_MLP_F32=1): 2e-6 on colours in [0, 1] - two orders below the fixture tolerance"""
+    from glorie_slam_amd.decoder import POINT
+    from glorie_slam_amd.neural_point import NeuralPointCloud
+    f = np.load(os.path.join(GOLD, "decoders.npz"))
+    t = lambda k: torch.from_numpy(f[k]).to(gpu)
+    torch.manual_seed(43)
+    dec = POINT(_cfg(gpu), c_dim=32, hidden_size=128, use_view_direction=True).eval().to(gpu)
+    npc = NeuralPointCloud(_cfg(gpu))
+    npc.add_points(t("cloud"), t("geo"), t("col"))
+    outs = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("GLORIE_MLP_F32", mode)
+        with torch.no_grad():
+            raw, _, point_mask, _ = dec(t("p")[None], npc, "color", npc.geo_feats, npc.col_feats, pts_num=10,
+                                        cloud_pos=npc.cloud_pos(), pts_views_d=t("views"), dynamic_r_query=t("radius"))
+        outs.append(raw.cpu().numpy())
+    pm = f["point_mask"]
+    assert np.array_equal(outs[0][pm, 3], outs[1][pm, 3])                 # occupancy: the same (fp32) geometry kernel
+    np.testing.assert_allclose(outs[1][pm, :3], outs[0][pm, :3], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(outs[1][pm, :3], f["rgb"][pm], rtol=1e-3, atol=1e-3)
+
+
 def test_render_batch_ray_end_to_end(gpu):
     """render a small view of the synthetic box; rays that hit the cloud are valid, depth is
     close to the surface depth, zero-depth rays go through sample_near_pcl"""
