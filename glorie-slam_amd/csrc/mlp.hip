@@ -488,7 +488,8 @@ __global__ __launch_bounds__(512, 4) void mlp_col_v4_kernel(ColParams P, const f
   const int qs = q0 + wv * 16 + r;            // this lane's sample (all four k-slots of a column share it)
   const int q = min(qs, Q - 1);
 
-  // ---- B operands: embedding (80 channels = blocks 0..4 -> chunks {0,1}, {2,3}, {4,-}) and colour feature (32) ----
+  // ---- B operands: embedding (80 channels = blocks 0..4 -> chunks {0,1}, {2,3}, {4,-}) and colour feature (32, read
+  // and split once: the fp32 kernel re-read it before each of its five uses for lack of registers) ----
   h16x8 ehi[3], elo[3], chi, clo;
   auto load_c = [&]() {
     const float4 v0 = *reinterpret_cast<const float4*>(c_col + (size_t)q * 32 + 4 * g);
@@ -564,7 +565,6 @@ __global__ __launch_bounds__(512, 4) void mlp_col_v4_kernel(ColParams P, const f
   GL_CHUNK(5, hhi[1], hlo[1])
   GL_CHUNK(6, hhi[2], hlo[2])
   GL_CHUNK(7, hhi[3], hlo[3])
-  load_c();
   act(1);
   GL_CHUNK(8, chi, clo)
   // layer 2
@@ -573,7 +573,6 @@ __global__ __launch_bounds__(512, 4) void mlp_col_v4_kernel(ColParams P, const f
   GL_CHUNK(10, hhi[1], hlo[1])
   GL_CHUNK(11, hhi[2], hlo[2])
   GL_CHUNK(12, hhi[3], hlo[3])
-  load_c();
   act(2);
   GL_CHUNK(13, chi, clo)
   // layer 3 (skip): W3e on the embedding, W3h on the hidden state
@@ -585,7 +584,6 @@ __global__ __launch_bounds__(512, 4) void mlp_col_v4_kernel(ColParams P, const f
   GL_CHUNK(18, hhi[1], hlo[1])
   GL_CHUNK(19, hhi[2], hlo[2])
   GL_CHUNK(20, hhi[3], hlo[3])
-  load_c();
   act(3);
   GL_CHUNK(21, chi, clo)
   // layer 4
@@ -594,7 +592,6 @@ __global__ __launch_bounds__(512, 4) void mlp_col_v4_kernel(ColParams P, const f
   GL_CHUNK(23, hhi[1], hlo[1])
   GL_CHUNK(24, hhi[2], hlo[2])
   GL_CHUNK(25, hhi[3], hlo[3])
-  load_c();
   act(4);
   GL_CHUNK(26, chi, clo)
 #undef GL_CHUNK
@@ -757,8 +754,10 @@ __global__ __launch_bounds__(512, 4) void mlp_nb_v3_kernel(NbParams P, const flo
 // per-neighbour F_theta on the fp16 matrix cores with the 3-term split (see mlp_col_v4_kernel).  The 52 input channels of a
 // neighbour are two 32-slot chunks: chunk 0 = the 20 embedding features (lane slot s < 5 <-> feature 4s + g, slots 5..7
 // zero), chunk 1 = the 32 colour-feature channels (slot s <-> channel 16 (s >> 2) + 4 g + (s & 3), the two 16-byte loads of
-// the feature row).  W1 is split and laid out as A fragments [chunk][hi|lo][out block][lane][8] in LDS once per workgroup.
-__global__ __launch_bounds__(512, 4) void mlp_nb_v4_kernel(NbParams P, const float* __restrict__ pts,
+// the feature row).  W1 is packed split, as A fragments [chunk][hi|lo][out block][lane][8] (point_ops.pack_decoders), and copied
+// to LDS once per workgroup.
+__global__ __launch_bounds__(512, 4) void mlp_nb_v4_kernel(NbParams P, const float* __restrict__ W1frag,
+                                                           const float* __restrict__ pts,
                                                            const float* __restrict__ cloud,
                                                            const float* __restrict__ col_feats,
                                                            const int64_t* __restrict__ I,
@@ -778,22 +777,8 @@ __global__ __launch_bounds__(512, 4) void mlp_nb_v4_kernel(NbParams P, const flo
     const int f = tid >> 2, d = tid & 3;
     bs[tid] = d < 3 ? P.B[d * 10 + (f < 10 ? f : f - 10)] : 0.0f;
   }
-  for (int idx = tid; idx < 2 * 8 * 64; idx += 512) {       // one (chunk, out block, lane) fragment pair per iteration
-    const int ln = idx & 63, to = (idx >> 6) & 7, ch = idx >> 9;
-    const int i = ln & 15, gg = ln >> 4;
-    h16x8 hi, lo;
-#pragma unroll
-    for (int sl = 0; sl < 8; ++sl) {
-      int row = -1;
-      if (ch == 0) { if (sl < 5) row = 4 * sl + gg; }
-      else row = 20 + 16 * (sl >> 2) + 4 * gg + (sl & 3);
-      const float w = row >= 0 ? P.W1[row * 128 + 16 * to + i] : 0.0f;
-      hi[sl] = (_Float16)w;
-      lo[sl] = (_Float16)(w - (float)hi[sl]);
-    }
-    W1f[((ch * 2 + 0) * 8 + to) * 64 + ln] = hi;
-    W1f[((ch * 2 + 1) * 8 + to) * 64 + ln] = lo;
-  }
+  for (int idx = tid; idx < 8192 / 4; idx += 512)             // the split fragments as packed (point_ops.pack_decoders)
+    reinterpret_cast<float4*>(smem)[idx] = reinterpret_cast<const float4*>(W1frag)[idx];
   if (tid < 128) b1s[tid] = P.b1[tid];
   for (int idx = tid; idx < kTM2 * 8; idx += 512) {
     const int row = idx >> 3;
@@ -912,7 +897,7 @@ extern "C" size_t glorie_decoder_pack_floats(void) {
   size_t nb = 3 * 10 + 2 + 52 * 128 + 128 + 128 * 32 + 32;
   size_t col = 3 * 20 * 2 + 80 * 128 + 128 * 128 * 2 + 80 * 128 + 128 * 128 * 2 + 128 * 16 + 5 * 32 * 128 +
                5 * 128 * 2 + 4;
-  return geo + nb + col + (size_t)27 * 32 * 128 + (size_t)(480 * 32 + 32 * 16) + (size_t)27 * kChunkFloats16;
+  return geo + nb + col + (size_t)27 * 32 * 128 + (size_t)(480 * 32 + 32 * 16) + (size_t)27 * kChunkFloats16 + (size_t)8192;
 }
 
 extern "C" int glorie_render_mlp(const float* packed, const float* pts, const float* views,
@@ -944,6 +929,7 @@ extern "C" int glorie_render_mlp(const float* packed, const float* pts, const fl
   const float* col_chunks = c.take((size_t)27 * 32 * 128);
   const float* geo_image = c.take((size_t)kGeoImage);
   const float* col_chunks16 = c.take((size_t)27 * kChunkFloats16);
+  const float* nb_frags = c.take((size_t)8192);
   const int blocks2 = (Q + kTM2 - 1) / kTM2;
   const size_t geo_lds = sizeof(float) * kGeoImage;
   static bool geo_attr = false;
@@ -979,7 +965,7 @@ extern "C" int glorie_render_mlp(const float* packed, const float* pts, const fl
       hipLaunchKernelGGL(mlp_nb_v3_kernel, dim3(blocks2), dim3(512), nb_lds, st, n, pts, cloud_pos, col_feats,
                          I, weights, has, Q, c_col_scratch);
     else
-      hipLaunchKernelGGL(mlp_nb_v4_kernel, dim3(blocks2), dim3(512), nb4_lds, st, n, pts, cloud_pos, col_feats,
+      hipLaunchKernelGGL(mlp_nb_v4_kernel, dim3(blocks2), dim3(512), nb4_lds, st, n, nb_frags, pts, cloud_pos, col_feats,
                          I, weights, has, Q, c_col_scratch);
     if (f32 && f32[0] == '1')
       hipLaunchKernelGGL(mlp_col_v3_kernel, dim3(blocks2), dim3(512), col_lds, st, k, col_chunks, pts, views,

@@ -316,6 +316,17 @@ def pack_decoders(decoders):
     lo = (t6 - hi.float()).half()
     frag = torch.stack([hi, lo], 1).reshape(27, -1).contiguous()              # [chunk][2 * 8 * 64 * 8]
     parts.append(frag.view(torch.float32).reshape(-1))
+    # per-neighbour W1 [52, 128] the same way (mlp_nb_v4_kernel): chunk 0 = the 20 embedding rows (slot s < 5 <-> row 4 s + g,
+    # slots 5..7 zero), chunk 1 = the 32 colour-feature rows (slot s <-> row 20 + 16 (s >> 2) + 4 g + (s & 3))
+    w1 = _t(n.linear1.weight).detach().float().to(dev)                        # [52, 128]
+    c0 = torch.zeros(8, 4, 128, device=dev)                                   # [s][g][out]
+    c0[:5] = w1[:20].reshape(5, 4, 128)
+    c1 = w1[20:52].reshape(2, 4, 4, 128).permute(0, 2, 1, 3).reshape(8, 4, 128)   # [sh][g][sl] -> [s = 4 sh + sl][g]
+    both = torch.stack([c0, c1], 0).reshape(2, 8, 4, 8, 16).permute(0, 3, 2, 4, 1)  # [chunk][to][g][i][s]
+    hi = both.half()
+    lo = (both - hi.float()).half()
+    frag = torch.stack([hi, lo], 1).reshape(-1).contiguous()                  # [chunk][hi|lo][to][g][i][s]
+    parts.append(frag.view(torch.float32).reshape(-1))
     packed = torch.cat(parts).contiguous()
     expect = int(L.load().glorie_decoder_pack_floats())
     if packed.numel() != expect:
