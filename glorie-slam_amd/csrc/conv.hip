@@ -591,6 +591,11 @@ __global__ __launch_bounds__(64 * NW, (ST == 1 && MB * NB <= 16) ? 3 : 2) void c
   stage(0, 0);
   int cur = 0;                                 // LDS stage holding tile t
   for (int t = 0; t < T; ++t) {
+    // every DMA piece of tile t must have landed before anybody reads it.  The compiler's own wait in front of the barrier
+    // counts register-spill traffic into vmcnt: a halo-staged experiment of the 256-channel variant (9 spilled VGPRs) got
+    // `s_waitcnt vmcnt(5)` here, left its last weight pieces in flight and produced non-repeatable upper channels.  None
+    // of the shipped variants spills, but the wait is explicit now.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                           // tile t landed (vmcnt(0) + barrier); ST = 2: the other stage is free
     const char* base = smem + cur * (XBYTES + WBYTES);
     // all fragment reads of the step go out first (one exposed LDS latency per step, not per kk), the
