@@ -660,10 +660,10 @@ def main():
                          "alg_bytes_per_launch": knn_bytes, "ms_per_launch": knn_ms,
                          "measured_hbm_gbs": (knn_traffic / (knn_ms * 1e-3) / 1e9) if (world == 1 and knn_traffic) else None},
         # decoders: fp32-accurate matmuls as hi*hi + hi*lo + lo*hi on the fp16 matrix cores (per-neighbour and colour
-        # kernels; the 32-wide geometry decoder stays on the fp32 MFMA).  `achieved` counts ALGORITHMIC (fp32) FLOPs; the
+        # all three kernels; the narrow output layers stay fp32).  `achieved` counts ALGORITHMIC (fp32) FLOPs; the
         # ceiling of a 3-product split is the dense fp16 peak / 3; the fp32 MFMA path it replaced peaks at 157.3.
-        "roofline_mlp": {"bound": "mfma", "kernel": "mlp_geo_v3 (fp32 MFMA 16x16x4) + mlp_nb_v4 + mlp_col_v4 (fp16 MFMA 16x16x32, "
-                                                    "3-term hi/lo split, fp32 accumulate; transposed form)",
+        "roofline_mlp": {"bound": "mfma", "kernel": "mlp_geo_v4 + mlp_nb_v4 + mlp_col_v4 (fp16 MFMA 16x16x32, 3-term hi/lo split, "
+                                                    "fp32 accumulate; transposed form)",
                          "achieved": mlp_tf, "peak": 2500.0 / 3.0, "unit": "TFLOP/s", "frac": mlp_tf / (2500.0 / 3.0),
                          "vs_fp32_mfma_peak": mlp_tf / 157.3,
                          "traffic": None, "flops_per_launch": mlp_flops, "ms_per_launch": mlp_ms},

@@ -751,6 +751,148 @@ __global__ __launch_bounds__(512, 4) void mlp_nb_v3_kernel(NbParams P, const flo
   }
 }
 
+// geometry decoder on the fp16 matrix cores with the 3-term split (see mlp_col_v4_kernel): the 480 K-rows are 15 chunks
+// of 32, packed by point_ops.pack_decoders as A fragments [chunk][hi|lo][out block 2][lane 64][8 halfs] (1024 floats per
+// chunk) and staged once per workgroup; the 32 -> 1 output layer stays fp32.  The 96-channel embedding is evaluated where
+// it is consumed (layer 0 and again at the skip layer) instead of being kept: 24 v_sin per sample against 24 registers
+// that the 128-register budget of four waves per SIMD does not have.
+constexpr int kGeoFrag = 15 * 1024;            // floats
+
+__device__ __forceinline__ void mma_g3(f32x4 (&acc)[2], const h16x8 bhi, const h16x8 blo, const float* chunk) {
+  const h16x8* wp = reinterpret_cast<const h16x8*>(chunk) + (threadIdx.x & 63);
+#pragma unroll
+  for (int to = 0; to < 2; ++to) {
+    const h16x8 ahi = wp[to * 64], alo = wp[(2 + to) * 64];
+    acc[to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, bhi, acc[to], 0, 0, 0);
+    acc[to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, blo, acc[to], 0, 0, 0);
+    acc[to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, bhi, acc[to], 0, 0, 0);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+__global__ __launch_bounds__(512, 4) void mlp_geo_v4_kernel(GeoParams P, const float* __restrict__ frags,
+                                                            const float* __restrict__ wout,
+                                                            const float* __restrict__ pts,
+                                                            const float* __restrict__ c_geo,
+                                                            const float* __restrict__ geo_feats,
+                                                            const int64_t* __restrict__ I,
+                                                            const float* __restrict__ wts,
+                                                            const uint8_t* __restrict__ has, int Q,
+                                                            float* __restrict__ raw) {
+  extern __shared__ float smem[];              // [15][1024] fragments | [32][16] output layer
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  const int r = lane & 15, g = lane >> 4;
+  const int qs = blockIdx.x * kTM2 + wv * 16 + r;
+  const int q = min(qs, Q - 1);
+#pragma unroll 2
+  for (int idx = tid; idx < kGeoFrag / 4; idx += 512)
+    reinterpret_cast<float4*>(smem)[idx] = reinterpret_cast<const float4*>(frags)[idx];
+  if (tid < 128) reinterpret_cast<float4*>(smem + kGeoFrag)[tid] = reinterpret_cast<const float4*>(wout)[tid];
+  h16x8 chi, clo, hhi, hlo;
+  f32x4 acc[2];
+  const float x = pts[(size_t)q * 3 + 0], y = pts[(size_t)q * 3 + 1], z = pts[(size_t)q * 3 + 2];
+  {
+    f32x4 c[2];
+    if (geo_feats) {
+      // IDW interpolation of the neighbours' features (decoder.py:130-173), as in mlp_geo_v3_kernel
+      c[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+      c[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const bool on = has[q] != 0;
+      constexpr int GEO_NB = GLORIE_GEO_NB;
+#pragma unroll
+      for (int k0 = 0; k0 < 8; k0 += GEO_NB) {
+        float wk[GEO_NB];
+        float4 v[GEO_NB][2];
+#pragma unroll
+        for (int k = 0; k < GEO_NB; ++k) {
+          wk[k] = wts[(size_t)q * 8 + k0 + k];
+          const long ik = max(I[(size_t)q * 8 + k0 + k], 0L);
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+            v[k][t] = *reinterpret_cast<const float4*>(geo_feats + (size_t)ik * 32 + 16 * t + 4 * g);
+        }
+#pragma unroll
+        for (int k = 0; k < GEO_NB; ++k) {
+          const bool use = on && wk[k] != 0.0f;
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            c[t][0] = use ? c[t][0] + wk[k] * v[k][t].x : c[t][0];
+            c[t][1] = use ? c[t][1] + wk[k] * v[k][t].y : c[t][1];
+            c[t][2] = use ? c[t][2] + wk[k] * v[k][t].z : c[t][2];
+            c[t][3] = use ? c[t][3] + wk[k] * v[k][t].w : c[t][3];
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const float4 v = *reinterpret_cast<const float4*>(c_geo + (size_t)q * 32 + 16 * t + 4 * g);
+        c[t][0] = v.x; c[t][1] = v.y; c[t][2] = v.z; c[t][3] = v.w;
+      }
+    }
+    split2(c[0], c[1], chi, clo);
+  }
+  __syncthreads();
+  auto act = [&](int li) {   // ReLU(acc + bias) + fc_c bias
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const float4 bb = *reinterpret_cast<const float4*>(P.bias + li * 32 + 16 * t + 4 * g);
+      const float4 fb = *reinterpret_cast<const float4*>(P.fcb + li * 32 + 16 * t + 4 * g);
+      acc[t][0] = fmaxf(acc[t][0] + bb.x, 0.0f) + fb.x;
+      acc[t][1] = fmaxf(acc[t][1] + bb.y, 0.0f) + fb.y;
+      acc[t][2] = fmaxf(acc[t][2] + bb.z, 0.0f) + fb.z;
+      acc[t][3] = fmaxf(acc[t][3] + bb.w, 0.0f) + fb.w;
+    }
+  };
+  auto next_layer = [&]() {
+    split2(acc[0], acc[1], hhi, hlo);
+    zero<2>(acc);
+  };
+  auto ch = [&](int c) { return smem + c * 1024; };
+  // embedding blocks (2cc, 2cc + 1) -> chunk `chunk`: evaluated, split, multiplied, forgotten
+  auto embed = [&](int cc, int chunk) {
+    f32x4 e[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int t = 2 * cc + u;
+      const float4 b0 = *reinterpret_cast<const float4*>(P.B + 16 * t + 4 * g);
+      const float4 b1 = *reinterpret_cast<const float4*>(P.B + 96 + 16 * t + 4 * g);
+      const float4 b2 = *reinterpret_cast<const float4*>(P.B + 192 + 16 * t + 4 * g);
+      e[u][0] = sin_rev(fmaf(z, b2.x, fmaf(y, b1.x, x * b0.x)));
+      e[u][1] = sin_rev(fmaf(z, b2.y, fmaf(y, b1.y, x * b0.y)));
+      e[u][2] = sin_rev(fmaf(z, b2.z, fmaf(y, b1.z, x * b0.z)));
+      e[u][3] = sin_rev(fmaf(z, b2.w, fmaf(y, b1.w, x * b0.w)));
+    }
+    h16x8 ehi, elo;
+    split2(e[0], e[1], ehi, elo);
+    mma_g3(acc, ehi, elo, ch(chunk));
+  };
+  // chunks: W0 0-2 | Fc0 3 | W1 4 | Fc1 5 | W2 6 | Fc2 7 | W3e 8-10 | W3h 11 | Fc3 12 | W4 13 | Fc4 14
+  zero<2>(acc);
+  embed(0, 0); embed(1, 1); embed(2, 2);
+  act(0); mma_g3(acc, chi, clo, ch(3));
+  next_layer();
+  mma_g3(acc, hhi, hlo, ch(4));  act(1); mma_g3(acc, chi, clo, ch(5));
+  next_layer();
+  mma_g3(acc, hhi, hlo, ch(6));  act(2); mma_g3(acc, chi, clo, ch(7));
+  next_layer();
+  embed(0, 8); embed(1, 9); embed(2, 10);
+  mma_g3(acc, hhi, hlo, ch(11)); act(3); mma_g3(acc, chi, clo, ch(12));
+  next_layer();
+  mma_g3(acc, hhi, hlo, ch(13)); act(4); mma_g3(acc, chi, clo, ch(14));
+  // output layer 32 -> 1 (16 padded columns) in fp32: lanes with g == 0 get channel 0 of their sample in o[0]
+  f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+  {
+    const float* wp = smem + kGeoFrag + (4 * g) * 16 + r;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr)
+        o = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[(16 * t + rr) * 16], acc[t][rr], o, 0, 0, 0);
+  }
+  if (g == 0 && qs < Q) raw[(size_t)qs * 4 + 3] = has[qs] ? o[0] + P.bout[0] : -100.0f;  // Renderer.py:206-207
+}
+
 // per-neighbour F_theta on the fp16 matrix cores with the 3-term split (see mlp_col_v4_kernel).  The 52 input channels of a
 // neighbour are two 32-slot chunks: chunk 0 = the 20 embedding features (lane slot s < 5 <-> feature 4s + g, slots 5..7
 // zero), chunk 1 = the 32 colour-feature channels (slot s <-> channel 16 (s >> 2) + 4 g + (s & 3), the two 16-byte loads of
@@ -897,7 +1039,7 @@ extern "C" size_t glorie_decoder_pack_floats(void) {
   size_t nb = 3 * 10 + 2 + 52 * 128 + 128 + 128 * 32 + 32;
   size_t col = 3 * 20 * 2 + 80 * 128 + 128 * 128 * 2 + 80 * 128 + 128 * 128 * 2 + 128 * 16 + 5 * 32 * 128 +
                5 * 128 * 2 + 4;
-  return geo + nb + col + (size_t)27 * 32 * 128 + (size_t)(480 * 32 + 32 * 16) + (size_t)27 * kChunkFloats16 + (size_t)8192;
+  return geo + nb + col + (size_t)27 * 32 * 128 + (size_t)(480 * 32 + 32 * 16) + (size_t)27 * kChunkFloats16 + (size_t)8192 + (size_t)kGeoFrag;
 }
 
 extern "C" int glorie_render_mlp(const float* packed, const float* pts, const float* views,
@@ -930,6 +1072,7 @@ extern "C" int glorie_render_mlp(const float* packed, const float* pts, const fl
   const float* geo_image = c.take((size_t)kGeoImage);
   const float* col_chunks16 = c.take((size_t)27 * kChunkFloats16);
   const float* nb_frags = c.take((size_t)8192);
+  const float* geo_frags = c.take((size_t)kGeoFrag);
   const int blocks2 = (Q + kTM2 - 1) / kTM2;
   const size_t geo_lds = sizeof(float) * kGeoImage;
   static bool geo_attr = false;
@@ -938,8 +1081,21 @@ extern "C" int glorie_render_mlp(const float* packed, const float* pts, const fl
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)geo_lds);
     geo_attr = true;
   }
-  hipLaunchKernelGGL(mlp_geo_v3_kernel, dim3(blocks2), dim3(512), geo_lds, st, g, geo_image, pts, c_geo,
-                     c_geo ? nullptr : geo_feats, I, weights, has, Q, raw);
+  const char* f32env = getenv("GLORIE_MLP_F32");
+  const bool geo_f32 = f32env && f32env[0] == '1';
+  const size_t geo4_lds = sizeof(float) * (kGeoFrag + 32 * 16);
+  static bool geo4_attr = false;
+  if (!geo4_attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_geo_v4_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)geo4_lds);
+    geo4_attr = true;
+  }
+  if (geo_f32)
+    hipLaunchKernelGGL(mlp_geo_v3_kernel, dim3(blocks2), dim3(512), geo_lds, st, g, geo_image, pts, c_geo,
+                       c_geo ? nullptr : geo_feats, I, weights, has, Q, raw);
+  else
+    hipLaunchKernelGGL(mlp_geo_v4_kernel, dim3(blocks2), dim3(512), geo4_lds, st, g, geo_frags,
+                       geo_image + kGeoRows * 32, pts, c_geo, c_geo ? nullptr : geo_feats, I, weights, has, Q, raw);
   if (stage_color) {
     const size_t nb_lds = sizeof(float) * (52 * kLdw3 + 128 + kTM2 * 8 + 80) + sizeof(int) * kTM2 * 8;
     const size_t col_lds = sizeof(float) * 2 * kChunkFloats3;

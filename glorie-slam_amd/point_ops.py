@@ -306,6 +306,7 @@ def pack_decoders(decoders):
            _t(g.pts_linears[4].weight), fc[4]]
     rows = torch.cat([m.to(dev) for m in seq], 0)
     assert rows.shape == (480, 32), rows.shape
+    geo_rows16 = rows.detach().float()
     parts.append(f(rows.reshape(480, 2, 16).permute(0, 2, 1)))
     parts.append(f(_pad_cols(_t(g.output_linear.weight), 16)))
     # the colour chunks a third time, as fp16 MFMA A fragments of the 3-term split (mlp_col_v4_kernel):
@@ -326,6 +327,12 @@ def pack_decoders(decoders):
     hi = both.half()
     lo = (both - hi.float()).half()
     frag = torch.stack([hi, lo], 1).reshape(-1).contiguous()                  # [chunk][hi|lo][to][g][i][s]
+    parts.append(frag.view(torch.float32).reshape(-1))
+    # ... and the geometry K-rows (mlp_geo_v4_kernel): 15 chunks, 2 output blocks, 1024 floats per chunk
+    t6 = geo_rows16.reshape(15, 2, 4, 4, 2, 16).permute(0, 4, 2, 5, 1, 3)     # [chunk][to][g][i][s >> 2][s & 3]
+    hi = t6.half()
+    lo = (t6 - hi.float()).half()
+    frag = torch.stack([hi, lo], 1).reshape(15, -1).contiguous()              # [chunk][2 * 2 * 64 * 8]
     parts.append(frag.view(torch.float32).reshape(-1))
     packed = torch.cat(parts).contiguous()
     expect = int(L.load().glorie_decoder_pack_floats())

@@ -30,3 +30,6 @@ a, b = outs["1"][pm, :3], outs["0"][pm, :3]
 print("rgb fp32-MFMA vs fixture  max abs %.3e" % np.abs(a - f["rgb"][pm]).max())
 print("rgb f16x3     vs fixture  max abs %.3e" % np.abs(b - f["rgb"][pm]).max())
 print("rgb f16x3 vs fp32-MFMA    max abs %.3e   (values in [%.3f, %.3f])" % (np.abs(a - b).max(), a.min(), a.max()))
+oa, ob = outs["1"][pm, 3], outs["0"][pm, 3]
+print("occ f16x3 vs fp32-MFMA    max abs %.3e   vs fixture %.3e (values in [%.2f, %.2f])" % (
+    np.abs(oa - ob).max(), np.abs(ob - f["occ"][pm]).max(), oa.min(), oa.max()))
