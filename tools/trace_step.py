@@ -1,6 +1,6 @@
 """Prints the kernels of one BA-update step of a rocprofv3 kernel trace (csv): everything between two consecutive launches
 of a marker kernel.  Usage: python tools/trace_step.py <kernel_trace.csv> [marker] [k]
-k omitted: the fullest window (latest wins); k given: the k-th window that holds 30..120 kernels (a regular step)."""
+k omitted: the fullest window (latest wins); k given: the k-th window that holds 25..60 kernels (a regular step)."""
 import csv
 import sys
 
@@ -10,7 +10,7 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"]]
 pairs = list(zip(idx[:-1], idx[1:]))
 if len(sys.argv) > 3:
-    a, b = [ab for ab in pairs if 30 <= ab[1] - ab[0] <= 120][int(sys.argv[3])]
+    a, b = [ab for ab in pairs if 25 <= ab[1] - ab[0] <= 60][int(sys.argv[3])]
 else:
     a, b = max(pairs, key=lambda ab: (ab[1] - ab[0], ab[0]))
 tot = 0.0
