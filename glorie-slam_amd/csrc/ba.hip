@@ -184,44 +184,24 @@ __global__ __launch_bounds__(kBaThreads) void ba_jacobian_kernel(
   const int tid = threadIdx.x;
   const int lane = tid & 63, wv = tid >> 6;
   const int chunk = blockIdx.x;
-  const int s = blockIdx.y;
-  // the reduced system [H | v] the gram / assemble launches accumulate into starts at zero (nobody reads it in this launch:
+  const int n = blockIdx.y;                       // ONE EDGE per workgroup row (a frame's edges used to be walked serially
+                                                  // by one workgroup: 152 latency-bound workgroups at G8, now 36 x 19)
+  // the reduced system [H | v] the gram launch accumulates into starts at zero (nobody reads it in this launch:
   // one memset node less per iteration)
   {
     const long nthreads = (long)gridDim.x * gridDim.y * kBaThreads;
-    for (long i = ((long)s * gridDim.x + chunk) * kBaThreads + tid; i < hd_doubles; i += nthreads) wk.Hd[i] = 0.0;
+    for (long i = ((long)n * gridDim.x + chunk) * kBaThreads + tid; i < hd_doubles; i += nthreads) wk.Hd[i] = 0.0;
   }
   if (wk.status[0] & BA_ST_M_MISMATCH) return;
-  const int k = wk.kx[s];
-  const int e0 = wk.csr_ptr[s], e1 = wk.csr_ptr[s + 1];
+  const int k = (int)ii[n];
   const float fx = intr[0], fy = intr[1], cx = intr[2], cy = intr[3];
   const int pbase = chunk * kBaThreads * ppt;
-
-  // C and w accumulators for up to 4 pixels per thread
-  float Cacc[4] = {0, 0, 0, 0}, Wacc[4] = {0, 0, 0, 0};
-
-  // The edge loop used to be a chain of dependent memory round trips per edge (edge id -> target frame -> its pose ->
-  // the pixel's target / weight): the ids of a group of edges go to LDS first, and an edge's target / weight rows are
-  // requested before its pose arithmetic instead of inside the per-pixel branch.
-  constexpr int kJG = 8;
-  __shared__ int s_n[kJG], s_j[kJG];
   const Pose gk = load_pose(poses + k * 7);
   float dsp[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) dsp[t] = t < ppt ? disps[(size_t)k * HW + min(pbase + t * kBaThreads + tid, HW - 1)] : 1.0f;
-  for (int ei = e0; ei < e1; ++ei) {
-    const int slot = (ei - e0) & (kJG - 1);
-    if (slot == 0) {
-      __syncthreads();
-      if (tid < kJG && ei + tid < e1) {
-        const int nn = wk.csr_edge[ei + tid];
-        s_n[tid] = nn;
-        s_j[tid] = (int)jj[nn];
-      }
-      __syncthreads();
-    }
-    const int n = s_n[slot];
-    const int jx = s_j[slot];
+  {
+    const int jx = (int)jj[n];
     float2 tgv[4], wgv[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -259,8 +239,10 @@ __global__ __launch_bounds__(kBaThreads) void ba_jacobian_kernel(
         const float2 tg = tgv[t], wg = wgv[t];
         pixel_terms(g, fx, fy, cx, cy, (float)xx, (float)yy, dsp[t], tg.x, tg.y, wg.x,
                     wg.y, J);
-        Cacc[t] += J.wu * J.Jzu * J.Jzu + J.wv * J.Jzv * J.Jzv;
-        Wacc[t] += J.wu * J.ru * J.Jzu + J.wv * J.rv * J.Jzv;
+        // this edge's share of C_k and w_k: the frame's sum is formed, in CSR order, by the gram launch
+        if (!motion_only)
+          reinterpret_cast<float2*>(wk.CWpart)[(size_t)n * HW + px] =
+              make_float2(J.wu * J.Jzu * J.Jzu + J.wv * J.Jzv * J.Jzv, J.wu * J.ru * J.Jzu + J.wv * J.rv * J.Jzv);
         const float wu = stereo ? 0.0f : J.wu;
         const float wvv = stereo ? 0.0f : J.wv;
         int l = 0;
@@ -284,7 +266,6 @@ __global__ __launch_bounds__(kBaThreads) void ba_jacobian_kernel(
     for (int q = 0; q < 21; ++q) Hjj[q] = wave_sum(Hjj[q]);
 #pragma unroll
     for (int q = 0; q < 6; ++q) vj[q] = wave_sum(vj[q]);
-    __syncthreads();  // previous edge's readers are done with red[]
     if (lane == 0) {
 #pragma unroll
       for (int q = 0; q < 21; ++q) red[wv][q] = Hjj[q];
@@ -297,25 +278,6 @@ __global__ __launch_bounds__(kBaThreads) void ba_jacobian_kernel(
           (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
   }
 
-  if (motion_only) return;
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int px = pbase + t * kBaThreads + tid;
-    if (t < ppt && px < HW) {
-      float C = Cacc[t], Wv = Wacc[t];
-      const float et = eta[(size_t)s * HW + px];
-      if (disps_sens) {  // depth-sensor prior, alpha = 0.05 (droid_kernels.cu:1397-1400)
-        const float ds = disps_sens[(size_t)k * HW + px];
-        const float m = ds > 0.0f ? 1.0f : 0.0f;
-        C = C + m * 0.05f + (1.0f - m) * et;
-        Wv = Wv - m * 0.05f * (disps[(size_t)k * HW + px] - ds);
-      } else {
-        C = C + et;
-      }
-      wk.Q[(size_t)s * HW + px] = 1.0f / C;
-      wk.W[(size_t)s * HW + px] = Wv;
-    }
-  }
 }
 
 // ------------------------------------------------------------------------------------
@@ -339,10 +301,11 @@ constexpr int kRowsA = 48, kRowsB = 64;  // B side carries the extra w row (+pad
 // normal case -- are a single pair.
 __global__ __launch_bounds__(kBaThreads) void ba_gram_kernel(
     BaWork wk, const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, int HW, int chunk_px, int t0, int t1,
-    int nchunks) {
+    int nchunks, const float* __restrict__ eta, const float* __restrict__ disps, const float* __restrict__ disps_sens) {
   __shared__ __attribute__((aligned(16))) float lds[(kRowsA + kRowsB) * kGramLd];
   __shared__ float Xs[kGS * 36];
   __shared__ int eA[kGS], eB[kGS];          // edge ids of the two row groups being multiplied
+  __shared__ float qw[4 * kBaThreads][2];   // Q and w of this workgroup's pixels
   const int tid = threadIdx.x;
   const int lane = tid & 63, wv = tid >> 6;
   const int chunk = blockIdx.x;
@@ -351,6 +314,36 @@ __global__ __launch_bounds__(kBaThreads) void ba_gram_kernel(
   const int k = wk.kx[s];
   const int e0 = wk.csr_ptr[s];
   const int deg = wk.csr_ptr[s + 1] - e0;
+  // C_k = sum of the per-edge shares (ba_jacobian_kernel, one workgroup row per edge) in CSR order + damping, Q = 1 / C, w:
+  // for every depth frame, also those without outgoing edges (droid_kernels.cu:1385-1400)
+  for (int l = tid; l < chunk_px; l += kBaThreads) {
+    const int px = chunk * chunk_px + l;
+    if (px >= HW) break;
+    float C = 0.0f, Wv = 0.0f;
+    for (int a0 = 0; a0 < deg; a0 += 4) {      // four edges' rows in flight
+      float2 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        v[u] = reinterpret_cast<const float2*>(wk.CWpart)[(size_t)wk.csr_edge[e0 + min(a0 + u, deg - 1)] * HW + px];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (a0 + u < deg) { C += v[u].x; Wv += v[u].y; }
+    }
+    const float et = eta[(size_t)s * HW + px];
+    if (disps_sens) {  // depth-sensor prior, alpha = 0.05 (droid_kernels.cu:1397-1400)
+      const float ds = disps_sens[(size_t)k * HW + px];
+      const float m = ds > 0.0f ? 1.0f : 0.0f;
+      C = C + m * 0.05f + (1.0f - m) * et;
+      Wv = Wv - m * 0.05f * (disps[(size_t)k * HW + px] - ds);
+    } else {
+      C = C + et;
+    }
+    const float Q = 1.0f / C;
+    wk.Q[(size_t)s * HW + px] = Q;
+    wk.W[(size_t)s * HW + px] = Wv;
+    qw[l][0] = Q;
+    qw[l][1] = Wv;
+  }
   if (deg == 0) return;
   const int P = t1 - t0;
   const int n6 = 6 * P;
@@ -396,8 +389,8 @@ __global__ __launch_bounds__(kBaThreads) void ba_gram_kernel(
           const int px = p0 + c;
           const bool ok = px < pend;
           const int pxc = ok ? px : pbeg;
-          const float sq = ok ? sqrtf(wk.Q[(size_t)s * HW + pxc]) : 0.0f;
-          const float wv_ = wk.W[(size_t)s * HW + pxc];
+          const float sq = ok ? sqrtf(qw[pxc - pbeg][0]) : 0.0f;     // published by the barrier in front of the staging
+          const float wv_ = qw[pxc - pbeg][1];
           float va[kGS][3];
 #pragma unroll
           for (int a = 0; a < kGS; ++a) {
@@ -1323,6 +1316,7 @@ static int ba_plan(glorie_ctx* ctx, int B, int N, int M, int h, int w, int t0, i
   const size_t o_Hp = carve(sizeof(float) * 27 * (size_t)N * pl.nchunks);
   const size_t o_Q = carve(sizeof(float) * (size_t)M * HW);
   const size_t o_W = carve(sizeof(float) * (size_t)M * HW);
+  const size_t o_CW = carve(sizeof(float) * 2 * (size_t)N * HW);
   const size_t o_Hd = carve(sizeof(double) * (n6 * n6 + n6));
   const size_t o_dx = carve(sizeof(float) * n6);
   GLORIE_TRY(ctx_reserve(ctx, off));
@@ -1338,6 +1332,7 @@ static int ba_plan(glorie_ctx* ctx, int B, int N, int M, int h, int w, int t0, i
   wk.Hpart = reinterpret_cast<float*>(base + o_Hp);
   wk.Q = reinterpret_cast<float*>(base + o_Q);
   wk.W = reinterpret_cast<float*>(base + o_W);
+  wk.CWpart = reinterpret_cast<float*>(base + o_CW);
   // the dense system [H (n6 x n6) | v (n6)] is one contiguous fp64 buffer so that a
   // multi-GPU caller can all-reduce it in a single collective
   wk.Hd = hv_ext ? hv_ext : reinterpret_cast<double*>(base + o_Hd);
@@ -1361,12 +1356,12 @@ static int ba_build_system(const BaPlan& pl, const float* poses, const float* di
                            const int64_t* jj, int flags, hipStream_t st) {
   const BaWork& wk = pl.wk;
   const int motion_only = flags & 1, hwc = (flags & GLORIE_BA_TARGETS_HWC) ? 1 : 0;
-  hipLaunchKernelGGL(ba_jacobian_kernel, dim3(pl.nchunks, pl.M), dim3(kBaThreads), 0, st, wk, poses,
+  hipLaunchKernelGGL(ba_jacobian_kernel, dim3(pl.nchunks, pl.N), dim3(kBaThreads), 0, st, wk, poses,
                      disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, pl.HW, pl.w,
                      pl.nchunks, pl.ppt, motion_only, hwc, (long)pl.n6 * pl.n6 + pl.n6);
   if (!motion_only)        // Schur products AND the pose-pose blocks (one launch less per iteration)
     hipLaunchKernelGGL(ba_gram_kernel, dim3(pl.nchunks, pl.M), dim3(kBaThreads), 0, st, wk, ii, jj, pl.HW,
-                       pl.chunk_px, pl.t0, pl.t1, pl.nchunks);
+                       pl.chunk_px, pl.t0, pl.t1, pl.nchunks, eta, disps, disps_sens);
   else
     hipLaunchKernelGGL(ba_assemble_kernel, dim3(pl.N), dim3(64), 0, st, wk, ii, jj, pl.nchunks, pl.t0, pl.t1);
   return check_launch();
