@@ -10,15 +10,16 @@
 // implementation keeps the whole iteration on the device, with no host synchronisation:
 //
 //   prepare   (1 WG)        frame slots (kx), CSR of edges by source frame -- once per call
-//   jacobian  (chunks x M)  frame-centric: a workgroup owns (depth frame k, pixel chunk) and
-//                           walks the edges leaving k, so C_k, w_k are accumulated in
-//                           registers with no atomics and no segmented-sum pass.  Per edge
-//                           it stores E_ij (6 x HW) and the block-reduced H_jj (21) / v_j (6).
-//   gram      (chunks x M)  G_k = F diag(Q) F^T on the matrix cores
+//   jacobian  (chunks x N)  a workgroup owns (edge, pixel chunk): it stores E_ij (6 x HW), the edge's
+//                           shares of C_k and w_k per pixel and the block-reduced H_jj (21) / v_j (6);
+//                           also zeroes the reduced system.  (Until the end of round 2 a workgroup
+//                           owned a depth frame and walked its edges serially.)
+//   gram      (chunks x M)  prologue: C_k, w_k = sum of the frame's edge shares in CSR order (no atomics),
+//                           Q_k = 1 / (C_k + damping); then G_k = F diag(Q) F^T on the matrix cores
 //                           (v_mfma_f32_16x16x4_f32, exact fp32), F = the E_ij rows of frame
 //                           k plus the w row; scattered into the dense reduced system with
-//                           fp64 atomics.
-//   assemble  (N WGs)       pose-pose blocks from H_jj / v_j.
+//                           fp64 atomics.  The pose-pose blocks from H_jj / v_j (edge i of a frame by the
+//                           workgroup of chunk i mod nchunks; a launch of its own, `assemble`, in motion-only mode).
 //   solve     (1 WG)        fp64 damping + Cholesky + triangular solves (zero update on
 //                           failure, like Eigen's LLT info != Success branch).
 //   update    (chunks x M)  dz = Q (w - sum_e E_e^T y_e), disparity and pose retraction.
