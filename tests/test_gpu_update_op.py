@@ -286,6 +286,34 @@ def test_upmask_convolution_with_the_convex_upsampling_as_its_epilogue(gpu, m, h
     assert float((got[untouched] + 1.0).abs().max()) == 0.0
 
 
+def test_wide_convolutions_are_repeatable_at_full_size(gpu):
+    """the LDS-DMA pieces of a K tile must all have landed before the tile is read: a wait that counts something else
+    into vmcnt shows up as run-to-run differences in the upper channel half once two workgroups share a CU (1350 pixel
+    tiles here).  Four runs of the z|r gate launch and of the plain 320 -> 256 layer give the same bits."""
+    from glorie_slam_amd import update_ops as U
+    n, h, w = 36, 60, 80
+    net, wide, pre = _cl_half(n, 128, h, w, gpu, 91), _cl_half(n, 320, h, w, gpu, 92), _cl_half(n, 256, h, w, gpu, 93)
+    dynx = wide[:, 128:320]
+    g = torch.Generator(device="cpu").manual_seed(94)
+    wzr = U.pack_conv_igemm((torch.randn(256, 320, 3, 3, generator=g) / 54).to(gpu))
+    terms = torch.randn(n, 256, generator=g).to(gpu)
+    bias = torch.randn(256, generator=g).to(gpu)
+    ref = None
+    for rep in range(4):
+        z = torch.empty_like(net)
+        rnet = torch.empty_like(net)
+        U.conv_igemm(net, dynx, wzr, 9, 256, z, epilogue=U.EPI_GRU_ZR, terms=terms, net=net, out2=rnet, pre=pre)
+        o = torch.empty((n, 256, h, w), dtype=torch.float16, device=gpu).contiguous(memory_format=torch.channels_last)
+        U.conv_igemm(net, dynx, wzr, 9, 256, o, terms=bias, act=U.ACT_RELU)
+        torch.cuda.synchronize()
+        cur = (z.clone(), rnet.clone(), o.clone())
+        if ref is None:
+            ref = cur
+        else:
+            for a, b in zip(ref, cur):
+                assert torch.equal(a, b)
+
+
 def test_fused_update_on_the_channels_last_lookup(gpu):
     """corr_encoder[0] as a 1x1 implicit-GEMM convolution over the channels-last lookup (permuted weight columns, bias and
     ReLU in the epilogue) against the library GEMM over the planar map: same operator, only the fp16 GEMM's summation order
