@@ -184,14 +184,67 @@ __global__ __launch_bounds__(kBaThreads) void dspo2_accum_kernel(BaWork wk, Dspo
   }
 }
 
+// INLINE (M <= 25 frames): every workgroup repeats the per-frame 2x2 solves of dspo2_solve_kernel itself (10 threads per
+// frame sum the chunk partials in the same order, one thread per frame solves, all-or-nothing failure) instead of reading
+// wk.dx from a launch of its own - these launches are a few microseconds each and launch-bound.
+template <bool INLINE>
 __global__ __launch_bounds__(kBaThreads) void dspo2_update_kernel(BaWork wk, Dspo2Args a, int HW,
-                                                                  float* __restrict__ dz_out) {
+                                                                  float* __restrict__ dz_out, int M, int nchunks,
+                                                                  float lm, float ep) {
+  __shared__ double vsum[INLINE ? 25 * 10 : 1];
+  __shared__ float sdx[INLINE ? 2 * 25 : 1];
+  __shared__ int fail;
   const int tid = threadIdx.x;
   const int s = blockIdx.y;
   if (wk.status[0] & BA_ST_M_MISMATCH) return;
+  float ds, dq;
+  if constexpr (INLINE) {
+    if (tid == 0) fail = 0;
+    if (tid < 10 * M) {
+      const int f = tid / 10, q = tid - f * 10;
+      double v = 0.0;
+      for (int c = 0; c < nchunks; ++c) v += (double)wk.Hpart[((size_t)f * nchunks + c) * 10 + q];
+      vsum[tid] = v;
+    }
+    __syncthreads();
+    if (tid < M) {
+      const bool on = frame_enabled(wk, a.edge_on, tid);
+      double x1 = 0.0, x2 = 0.0;
+      if (on) {
+        const double* v = vsum + tid * 10;
+        // damping BEFORE the Schur complement (chol.py:68-69)
+        const double H11 = v[0] + ep + lm * v[0], H22 = v[2] + ep + lm * v[2];
+        const double S11 = H11 - v[3], S12 = v[1] - v[4], S22 = H22 - v[5];
+        const double b1 = v[6] - v[8], b2 = v[7] - v[9];
+        const double l21 = (S11 > 0.0) ? S12 / sqrt(S11) : 0.0;
+        const double l22sq = S22 - l21 * l21;
+        if (!(S11 > 0.0) || !(l22sq > 0.0)) {
+          atomicOr(&fail, 1);
+        } else {
+          const double det = S11 * S22 - S12 * S12;
+          x1 = (S22 * b1 - S12 * b2) / det;
+          x2 = (S11 * b2 - S12 * b1) / det;
+        }
+      }
+      sdx[2 * tid + 0] = (float)x1;
+      sdx[2 * tid + 1] = (float)x2;
+    }
+    __syncthreads();
+    ds = fail ? 0.0f : sdx[2 * s + 0];
+    dq = fail ? 0.0f : sdx[2 * s + 1];
+    if (blockIdx.x == 0 && s == 0) {          // diagnostics and the record of the step, once
+      if (tid < 2 * M) wk.dx[tid] = fail ? 0.0f : sdx[tid];
+      if (tid == 0 && fail) {
+        atomicOr(&wk.status[0], BA_ST_CHOL_FAILED);
+        atomicAdd(&wk.status[2], 1);
+      }
+    }
+  } else {
+    ds = wk.dx[2 * s + 0];
+    dq = wk.dx[2 * s + 1];
+  }
   if (!frame_enabled(wk, a.edge_on, s)) return;
   const int k = wk.kx[s];
-  const float ds = wk.dx[2 * s + 0], dq = wk.dx[2 * s + 1];
   if (blockIdx.x == 0 && tid == 0) {        // the frame's scale / shift step (nobody reads them in this launch)
     a.scales[k] += ds;
     a.shifts[k] += dq;
@@ -253,10 +306,16 @@ extern "C" int glorie_dspo_scale_shift(glorie_ctx* ctx, const float* poses, floa
   Dspo2Args a{poses, disps, intrinsics, mono_disps, scales, shifts, valid_mask, target, weight, eta,
               ii, jj, edge_on, alpha};
   for (int it = 0; it < iterations; ++it) {
-    // three launches per iteration: pixel sums, per-frame solves, disparity + scale/shift steps
+    // per iteration: pixel sums, per-frame solves (inside the update launch for small M), disparity + scale/shift steps
     hipLaunchKernelGGL(dspo2_accum_kernel, dim3(nchunks, M), dim3(kBaThreads), 0, st, wk, a, HW, w, nchunks);
-    hipLaunchKernelGGL(dspo2_solve_kernel, dim3(1), dim3(256), 0, st, wk, a, M, nchunks, lm, ep);
-    hipLaunchKernelGGL(dspo2_update_kernel, dim3(nchunks, M), dim3(kBaThreads), 0, st, wk, a, HW, dz_out);
+    if (M <= 25) {
+      hipLaunchKernelGGL(dspo2_update_kernel<true>, dim3(nchunks, M), dim3(kBaThreads), 0, st, wk, a, HW, dz_out, M,
+                         nchunks, lm, ep);
+    } else {
+      hipLaunchKernelGGL(dspo2_solve_kernel, dim3(1), dim3(256), 0, st, wk, a, M, nchunks, lm, ep);
+      hipLaunchKernelGGL(dspo2_update_kernel<false>, dim3(nchunks, M), dim3(kBaThreads), 0, st, wk, a, HW, dz_out, M,
+                         nchunks, lm, ep);
+    }
     GLORIE_TRY(check_launch());
   }
   return GLORIE_OK;
