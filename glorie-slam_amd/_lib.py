@@ -44,7 +44,7 @@ SIGNATURES = {
     "glorie_conv_igemm_heads": (_c_int, [_vp, _c_int, _c_int, _vp, _c_int, _c_int, _vp, _vp, _c_int, _c_int, _vp, _vp,
                                          _c_int, _c_int, _c_int, _c_int, _vp]),
     "glorie_conv_upsample": (_c_int, [_vp, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp]),
-    "glorie_conv_stencil": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, ctypes.c_float, _vp, _c_int, _c_int, _c_int, _vp]),
+    "glorie_conv_stencil": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, ctypes.c_float, _vp, _vp, _c_int, _c_int, _c_int, _vp]),
     "glorie_conv_igemm": (_c_int, [_vp, _c_int, _c_int, _vp, _c_int, _c_int, _vp, _c_int, _c_int, _c_int, _vp,
                                    _c_int, _c_int, _vp, _c_int, _vp, _c_int, _vp, _c_int, _vp, _c_int, _vp, _c_int, _vp,
                                    _c_int, _c_int, _c_int, _vp]),

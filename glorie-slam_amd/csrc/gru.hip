@@ -309,7 +309,8 @@ template <bool PLANAR>
 __global__ __launch_bounds__(256) void conv_stencil_kernel(const float* __restrict__ taps, int ncols,
                                                            int tstride, const float* __restrict__ bias,
                                                            int K, int groups, int act_packed, float scale,
-                                                           float* __restrict__ out, long P, int H, int W) {
+                                                           float* __restrict__ out, long P, int H, int W,
+                                                           float* __restrict__ out_last = nullptr) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= P * K * groups) return;
   const int gk = PLANAR ? (int)(idx / P) : (int)(idx % (K * groups));
@@ -328,7 +329,9 @@ __global__ __launch_bounds__(256) void conv_stencil_kernel(const float* __restri
   if (act == ACT_RELU) acc = fmaxf(acc, 0.0f);
   else if (act == ACT_SIGMOID) acc = sigmoidf_(acc);
   else if (act == ACT_SOFTPLUS) acc = softplusf_(acc);
-  out[((size_t)grp * P + p) * K + j] = acc * scale;
+  // out_last: the last group goes to a tensor of its own ([P][K]; e.g. the confidence weights straight into the caller's buffer)
+  if (out_last && grp == groups - 1) out_last[(size_t)p * K + j] = acc * scale;
+  else out[((size_t)grp * P + p) * K + j] = acc * scale;
 }
 
 }  // namespace glorie
@@ -537,12 +540,12 @@ extern "C" int glorie_conv3x3_small(const void* x, int x_stride, const float* in
 
 // second half of glorie_conv3x3_small alone, on the tap PLANES written by glorie_conv_igemm_heads
 extern "C" int glorie_conv_stencil(const float* taps, const float* out_bias, int groups, int K, int act_packed,
-                                   float scale, float* out, int N, int H, int W, void* stream) {
+                                   float scale, float* out, float* out_last, int N, int H, int W, void* stream) {
   if (N < 0 || H <= 0 || W <= 0 || groups < 1 || groups > 4 || K < 1 || K > 3) return GLORIE_EINVAL;
   if (N == 0) return GLORIE_OK;
   if (!taps || !out) return GLORIE_EINVAL;
   const long P = (long)N * H * W, total = P * K * groups;
   hipLaunchKernelGGL(conv_stencil_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     taps, 9 * K, 9 * K * groups, out_bias, K, groups, act_packed, scale, out, P, H, W);
+                     taps, 9 * K, 9 * K * groups, out_bias, K, groups, act_packed, scale, out, P, H, W, out_last);
   return check_launch();
 }

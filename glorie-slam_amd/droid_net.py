@@ -380,11 +380,13 @@ class FusedUpdate:
         return self._pre_kf[:int(frames.shape[0])], self._pre_map[:int(index.shape[0])]
 
     @torch.no_grad()
-    def __call__(self, net, inp, corr, flow=None, ii=None, jj=None, groups=None, context=None, lazy_up=False):
+    def __call__(self, net, inp, corr, flow=None, ii=None, jj=None, groups=None, context=None, lazy_up=False,
+                 weight_out=None):
         """corr: the looked-up correlation features [1,N,196,h,w], or a callable returning them (it is
         invoked on the caller's stream after the independent branches were forked).
         context (not in the reference): see precompute_shared_context; `inp` is then not read.
-        lazy_up: return the upmask logits unevaluated (update_ops.LazyUpmask) for DepthVideo.upsample."""
+        lazy_up: return the upmask logits unevaluated (update_ops.LazyUpmask) for DepthVideo.upsample.
+        weight_out: float32 buffer of the confidence weights' size: they are written there (and returned as a view of it)."""
         from . import update_ops as U
         self._sync()
         W = self.W
@@ -482,13 +484,16 @@ class FusedUpdate:
             # the heads' hidden maps are consumed in the epilogue of their convolution (tap rows), only the GraphAgg third is stored
             agg_in = cl_map(128)
             rows = U.conv_igemm_heads(new, W["h1"], 9, 384, W["h1_b"], W["h2_taps"], 2, out=agg_in)
-            dw = U.conv_stencil(rows, W["h2_b"], n, ht, wd, 2, 2, (U.ACT_NONE, U.ACT_SIGMOID))
+            wo = weight_out if (weight_out is not None and weight_out.is_cuda and weight_out.dtype == torch.float32
+                                and weight_out.is_contiguous() and weight_out.numel() == n * ht * wd * 2) else None
+            dw = U.conv_stencil(rows, W["h2_b"], n, ht, wd, 2, 2, (U.ACT_NONE, U.ACT_SIGMOID), out_last=wo)
         else:
             h1 = U.conv_igemm(new, None, W["h1"], 9, 384, cl_map(384), terms=W["h1_b"], act=U.ACT_RELU)
             dw = U.conv3x3_small(h1, W["h2"], W["h2_b"], 2, (U.ACT_NONE, U.ACT_SIGMOID))
             agg_in = h1[:, 256:384]
         delta = dw[0].view(batch, num, ht, wd, 2)
-        weight = dw[1].view(batch, num, ht, wd, 2)
+        weight = dw[1].view(batch, num, ht, wd, 2) if (not self.fuse_heads or wo is None) else \
+            weight_out.view(batch, num, ht, wd, 2)
         if ii is None:
             return net_out, delta, weight
         # GraphAgg (droid_net.py:50-66): mean over edges with the same source keyframe

@@ -390,7 +390,7 @@ class FactorGraph:
             self.net, delta, weight, damping, upmask = \
                 self.fast_update(self.net, self.inp, lookup, motn, self.ii, self.jj, self._groups(),
                                  context=(self.video.inps, uniq, ix) if self.share_context else None,
-                                 lazy_up=True)
+                                 lazy_up=True, weight_out=self.weight)
         else:
             corr = lookup()
             with torch.autocast("cuda", enabled=True):

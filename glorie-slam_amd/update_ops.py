@@ -279,8 +279,9 @@ def conv_igemm_heads(x, w_packed, taps, nout, bias, tap_w, K, out=None):
     return rows
 
 
-def conv_stencil(rows, out_bias, n, h, w, groups, K, acts, scale=1.0):
-    """the 9-point stencil half of conv3x3_small on tap planes [groups*9K, n*h*w] -> float32 [groups, n, h, w, K]"""
+def conv_stencil(rows, out_bias, n, h, w, groups, K, acts, scale=1.0, out_last=None):
+    """the 9-point stencil half of conv3x3_small on tap planes [groups*9K, n*h*w] -> float32 [groups, n, h, w, K];
+    out_last: contiguous float32 tensor of n*h*w*K elements that receives the LAST group instead of its slice of the result"""
     L.need_cuda(rows)
     if rows.dtype != torch.float32 or tuple(rows.shape) != (groups * 9 * K, n * h * w) or not rows.is_contiguous() \
             or len(acts) != groups:
@@ -289,8 +290,11 @@ def conv_stencil(rows, out_bias, n, h, w, groups, K, acts, scale=1.0):
     packed = 0
     for gidx, a in enumerate(acts):
         packed |= int(a) << (4 * gidx)
+    if out_last is not None and (out_last.dtype != torch.float32 or not out_last.is_contiguous() or not out_last.is_cuda
+                                 or out_last.numel() != n * h * w * K):
+        raise RuntimeError("conv_stencil: out_last must be a contiguous float32 CUDA tensor of n*h*w*K elements")
     L.check(L.load().glorie_conv_stencil(L.ptr(rows), L.ptr(out_bias), groups, K, packed, float(scale), L.ptr(out),
-                                         n, h, w, L.stream_ptr()), "glorie_conv_stencil")
+                                         L.ptr(out_last), n, h, w, L.stream_ptr()), "glorie_conv_stencil")
     return out
 
 

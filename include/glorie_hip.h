@@ -268,9 +268,10 @@ int glorie_conv_igemm_heads(const void* x, int x_stride, int c, const void* w_pa
 int glorie_conv_upsample(const void* x, int x_stride, int c, const void* w_packed, const float* bias,
                          const float* disps, const int64_t* ix, float* disps_up, int softmax_f32, int M, int H, int W,
                          void* stream);
-/* second half of glorie_conv3x3_small on the tap planes of glorie_conv_igemm_heads: out float [groups][N*H*W][K] */
+/* second half of glorie_conv3x3_small on the tap planes of glorie_conv_igemm_heads: out float [groups][N*H*W][K];
+ * out_last (may be NULL): the LAST group is written there ([N*H*W][K]) instead of into its slice of out. */
 int glorie_conv_stencil(const float* taps, const float* out_bias, int groups, int K, int act_packed, float scale,
-                        float* out, int N, int H, int W, void* stream);
+                        float* out, float* out_last, int N, int H, int W, void* stream);
 
 /* flow_encoder[0] (droid_net.py:79-81): 7x7 convolution, zero padding 3, 4 -> 128 channels, + bias
  * + ReLU.  flow: float32 channels-last motion map [N*H*W][4]; out: fp16 rows of 128 channels,
