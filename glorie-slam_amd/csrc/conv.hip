@@ -1223,6 +1223,9 @@ static int conv_igemm_impl(const void* xa, int xa_stride, int ca, const void* xb
   // small launches (GraphAgg's convolutions run on the 8 keyframe maps, 300 pixel tiles): 128-pixel tiles would leave most
   // of the 768 workgroup slots empty and every CU with one latency-bound workgroup - 64-pixel tiles double the workgroups
   if (t0c == 0 && epilogue == EPI_BIAS_ACT && (a.P + 127) / 128 * ntn <= 384) return launch_conv<2, 64, 4, 1>(a, epilogue, st);
+  // 1x1 layers have two to four K steps: prologue and epilogue dominate and more, smaller workgroups hide them better
+  // (corr_encoder[0] 256 -> 128 at 36x60x80: 33.7 -> 31.8 us)
+  if (t0c == 0 && epilogue == EPI_BIAS_ACT && taps == 1) return launch_conv<2, 64, 4, 1>(a, epilogue, st);
   if (t0c == 'w') return launch_conv<8, 64, 4, 1, 4>(a, epilogue, st);
   if (t0c == '6') return launch_conv<2, 64, 4, 1>(a, epilogue, st);
   if (t0c == 's' && full_rounds >= 1) {
