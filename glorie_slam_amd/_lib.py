@@ -111,7 +111,7 @@ def load():
         if _lib is None:
             if not os.path.exists(LIB_PATH):
                 raise GlorieError(
-                    f"{LIB_PATH} is missing: build it with `python glorie-slam_amd/build.py` "
+                    f"{LIB_PATH} is missing: build it with `python glorie_slam_amd/build.py` "
                     "(or __graft_entry__.build()); there is no CPU fallback for the hot path")
             lib = ctypes.CDLL(LIB_PATH)
             for name, (res, args) in SIGNATURES.items():

@@ -1,10 +1,10 @@
 """Build recipe for libglorie_hip.so (gfx950 only, in-tree).
 
-    python glorie-slam_amd/build.py            # incremental
-    python glorie-slam_amd/build.py --force
+    python glorie_slam_amd/build.py            # incremental
+    python glorie_slam_amd/build.py --force
 
 hipcc cross-compiles without a GPU; the resulting .so is git-ignored but travels with the
-gpurun snapshot.  Objects are cached under glorie-slam_amd/lib/obj keyed by source mtime.
+gpurun snapshot.  Objects are cached under glorie_slam_amd/lib/obj keyed by source mtime.
 """
 import hashlib
 import os

@@ -35,7 +35,7 @@ def test_version_string():
 
 
 def test_product_path_does_not_import_oracle():
-    pkg = os.path.join(ROOT, "glorie-slam_amd")
+    pkg = os.path.join(ROOT, "glorie_slam_amd")
     for dp, _, fs in os.walk(pkg):
         for f in fs:
             if f.endswith(".py"):
