@@ -59,6 +59,9 @@ SIGNATURES = {
     "glorie_corr_build": (_c_int, [_vp] * 5 + [_c_int] * 5 + [_vp]),
     "glorie_corr_lookup_arena": (_c_int, [_vp, _c_int, _vp, _vp, _vp] + [_c_int] * 5 + [_vp]),
     "glorie_corr_lookup_tiled_cl": (_c_int, [_vp, _c_int, _vp, _vp, _c_int, _vp] + [_c_int] * 5 + [_vp]),
+    "glorie_corr_dm_level_halfs": (ctypes.c_long, [_c_int, _c_int, _c_int]),
+    "glorie_corr_dm_build": (_c_int, [_vp] * 5 + [_c_int] * 5 + [_vp]),
+    "glorie_corr_dm_lookup": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_int, _vp]),
     "glorie_valid_depth_mask": (_c_int, [_vp] * 4 + [_c_int] * 4 + [ctypes.c_float, _c_int, _vp, _vp, _vp]),
     "glorie_reproject": (_c_int, [_vp] * 7 + [_c_int] * 3 + [_vp]),
     "glorie_reproject_motion": (_c_int, [_vp] * 9 + [_c_int] * 3 + [ctypes.c_float, _vp]),

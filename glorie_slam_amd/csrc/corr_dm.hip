@@ -1,0 +1,487 @@
+// Correlation pyramid in the DISPLACEMENT-MAJOR, source-tiled layout and its lookup (scope rows A1 + A2, round 3).
+//
+// Reference:
+//   CorrBlock.__init__ / .corr            /root/reference/src/modules/droid_net/corr.py:26-41,67-76   (builder)
+//   CorrBlock.__call__ -> corr_index_forward_kernel
+//                                         /root/reference/src/modules/droid_net/corr.py:43-53,
+//                                         /root/reference/src/lib/correlation_kernels.cu:19-70        (lookup)
+//   UpdateModule.corr_encoder[0] (1x1, 196 -> 128, ReLU)   /root/reference/src/modules/droid_net/droid_net.py:73-77
+//
+// Why a new layout.  The reference (and rounds 1-2 of this repo) keep one (h>>l) x (w>>l) plane per SOURCE pixel.  The 8 x 8
+// window a pixel reads shares no cache line with the window of its neighbour - their planes are different - so a lookup
+// fetches ~3.5 128-byte lines per (pixel, level) for 128 useful bytes (profiles/r02_pmc_kernels.json: 311 MB read for 88.5 MB).
+// Here the SAME values are stored so that neighbouring source pixels that look at the same displacement share a line:
+//
+//   D_l[slot][tile][dy][dx][lane]      fp16, one 128-byte line per (tile, dy, dx)
+//     tile = 8 x 8 block of source pixels (row-major over ceil(h/8) x ceil(w/8)),  lane = (sy & 7) * 8 + (sx & 7)
+//     dy   = (ty - (sy >> l) + ((h>>l) >> 1)) mod (h>>l)          (ty, tx) = target pixel of level l
+//     dx   = (tx - (sx >> l) + ((w>>l) >> 1)) mod (w>>l)
+//
+// which is a bijection of every source pixel's plane (a cyclic shift by the pixel's own level-l position, centred so that
+// zero flow sits mid-plane and the wrap is at +-half an image of displacement).  A wave owns one tile; for window tap
+// (i, j) lane s reads D_l[tile][by(s) + j][bx(s) + i][s] with a 2-byte buffer load: wherever the flow is locally constant
+// all 64 lanes hit ONE line, and the union over the 8 x 8 window is ~(8 + spread)^2 lines per 64 pixels instead of 64 x 3.5.
+// Same footprint (planes are padded to whole tiles: +6.7 % at 60 x 80), same values, so the arithmetic of the lookup
+// (c10::Half products and sums, see corr.hip) is reproduced bit for bit.
+//
+// The lookup keeps a pixel's 4 x 7 x 7 outputs in its lane, so corr_encoder[0] runs as an MFMA epilogue in the same launch
+// (out^T[128 ch x 64 px] = W[128 x 256] corr^T, K ordered l*64 + j*8 + i with zero padding rows/taps): the lane's packed
+// window rows ARE the B fragments of v_mfma_f32_32x32x16_f16 after one v_permlane32_swap per register pair, the weights sit
+// in LDS, and the 196-channel map never exists in HBM (it can still be written, channels-last, for tests and for callers
+// that want the reference's tensor).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "common.hiph"
+
+namespace glorie {
+
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+struct DmArgs {
+  const _Float16* lvl[4];     // arena levels [capacity][ntiles][(h>>l)*(w>>l)][64]
+  const int* slots;           // slot of edge n (NULL: n itself)
+  const float* coords;        // [N][HW][2] (coords_xy) or [N][2][HW], UNscaled
+  int coords_xy;
+  int N, h, w, ntx, nty;
+  _Float16* corr_cl;          // NULL or [N*HW][256] channels-last lookup (channel l*64 + j*8 + i, i <-> x)
+  const _Float16* enc_w;      // NULL or [128][256] fp16, column l*64 + j*8 + i (zero for i == 7 or j == 7)
+  const float* enc_b;         // [128]
+  _Float16* enc_out;          // rows of enc_stride halfs per edge-pixel
+  int enc_stride;
+};
+
+constexpr int kEncLds = 264;   // halfs per weight row in LDS (256 + 8: conflict-free ds_read_b128 fragments)
+constexpr unsigned kOob = 0x40000000u;   // byte offset far beyond any plane: the buffer load returns 0 without a memory access
+
+__device__ __forceinline__ _Float16 to_half_rn(float prod) {
+  // the reference rounds the fp32 weight product to fp32 first and then to fp16 (`scalar_t(dx * dy)`); the empty asm keeps hipcc
+  // from fusing mul + cvt into one v_fma_mixlo_f16 (single rounding, differs in rare near-ties) - same as corr.hip
+  asm volatile("" : "+v"(prod));
+  return (_Float16)prod;
+}
+__device__ __forceinline__ h2 splat(_Float16 v) { return h2{v, v}; }
+__device__ __forceinline__ h2 pk(unsigned lo, unsigned hi) { return __builtin_bit_cast(h2, lo | (hi << 16)); }
+
+// one term of the reference's accumulation: products and sums individually rounded to fp16 (no contraction)
+__device__ __forceinline__ h2 acc_term(h2 acc, h2 s, h2 w) {
+#pragma clang fp contract(off)
+  const h2 t = s * w;
+  return acc + t;
+}
+
+// ---- one level of one tile: gather the 8 x 8 window of every lane's pixel ------------------------------------------
+template <int L>
+__device__ __forceinline__ void dm_gather(const DmArgs& a, size_t slot_tile, int sy, int sx, int lane, float x0, float y0,
+                                          unsigned (&raw)[8][8], float& fdx, float& fdy) {
+  const int hl = a.h >> L, wl = a.w >> L;
+  const float inv = 1.0f / (float)(1 << L);
+  const float xs = x0 * inv, ys = y0 * inv;
+  const float fx = floorf(xs), fy = floorf(ys);
+  fdx = xs - fx;
+  fdy = ys - fy;
+  const int ix0 = static_cast<int>(fx) - 3, iy0 = static_cast<int>(fy) - 3;
+  const int bx = ix0 - (sx >> L) + (wl >> 1), by = iy0 - (sy >> L) + (hl >> 1);
+  const _Float16* base = a.lvl[L] + slot_tile * ((size_t)hl * wl * 64);
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, hl * wl * 128, 0x00020000);
+  unsigned coff[8], roff[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int tx = ix0 + i;
+    int d = bx + i;
+    d = d < 0 ? d + wl : (d >= wl ? d - wl : d);
+    coff[i] = (tx >= 0 && tx < wl) ? (unsigned)d * 128u : kOob;
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int ty = iy0 + j;
+    int d = by + j;
+    d = d < 0 ? d + hl : (d >= hl ? d - hl : d);
+    roff[j] = (ty >= 0 && ty < hl) ? (unsigned)(d * wl) * 128u + (unsigned)lane * 2u : kOob;
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      raw[j][i] = __builtin_amdgcn_raw_buffer_load_b16(rs, (int)(roff[j] + coff[i]), 0, 0);
+}
+
+// ---- bilinear blend of one level: 7 window rows of 8 packed taps (tap 7 zero) ---------------------------------------
+// out(i, j) = (((0 + s(i,j) w00) + s(i,j+1) w01) + s(i+1,j) w10) + s(i+1,j+1) w11   (correlation_kernels.cu:52-64: the four
+// contributions reach corr[i][j] in exactly this order), evaluated for taps (2k, 2k+1) at once on the packed fp16 pipes
+__device__ __forceinline__ void dm_blend(const unsigned (&raw)[8][8], float fdx, float fdy, u32x4 (&rows)[7]) {
+  const h2 w00 = splat(to_half_rn((1.0f - fdx) * (1.0f - fdy)));
+  const h2 w01 = splat(to_half_rn((1.0f - fdx) * fdy));
+  const h2 w10 = splat(to_half_rn(fdx * (1.0f - fdy)));
+  const h2 w11 = splat(to_half_rn(fdx * fdy));
+  h2 P[2][4], Q[2][4];            // window rows j, j + 1: pairs (2k, 2k+1) and (2k+1, 2k+2)
+  auto pack_row = [&](int j, h2 (&p)[4], h2 (&q)[4]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) p[k] = pk(raw[j][2 * k], raw[j][2 * k + 1]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) q[k] = pk(raw[j][2 * k + 1], raw[j][2 * k + 2]);
+    q[3] = pk(raw[j][7], 0u);
+  };
+  pack_row(0, P[0], Q[0]);
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    pack_row(j + 1, P[(j + 1) & 1], Q[(j + 1) & 1]);
+    const h2(&p0)[4] = P[j & 1];
+    const h2(&q0)[4] = Q[j & 1];
+    const h2(&p1)[4] = P[(j + 1) & 1];
+    const h2(&q1)[4] = Q[(j + 1) & 1];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      h2 acc = h2{(_Float16)0.0f, (_Float16)0.0f};
+      acc = acc_term(acc, p0[k], w00);
+      acc = acc_term(acc, p1[k], w01);
+      acc = acc_term(acc, q0[k], w10);
+      acc = acc_term(acc, q1[k], w11);
+      unsigned u = __builtin_bit_cast(unsigned, acc);
+      if (k == 3) u &= 0xffffu;           // tap 7 is padding
+      rows[j][k] = u;
+    }
+  }
+}
+
+// ---- corr_encoder[0] on the matrix cores: acc[mb][nb] += W[32 mb .. +31][64 L .. +63] * rows^T ----------------------
+template <int L>
+__device__ __forceinline__ void dm_encode(const u32x4 (&rows)[7], const _Float16* wlds, int lane, f32x16 (&acc)[4][2]) {
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    u32x4 lo = rows[2 * ks];
+    u32x4 hi = (2 * ks + 1 < 7) ? rows[2 * ks + 1] : u32x4{0u, 0u, 0u, 0u};
+    // B fragment of pixel block nb: lanes 0-31 hold k = 0..7 (row 2ks) of pixel 32 nb + lane, lanes 32-63 hold k = 8..15
+    // (row 2ks+1) of pixel 32 nb + lane - 32.  Every lane computed both rows of ITS pixel: swapping the upper half of
+    // `lo` with the lower half of `hi` yields exactly the fragments of block 0 (in lo) and block 1 (in hi).
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const auto sw = __builtin_amdgcn_permlane32_swap(lo[v], hi[v], false, false);
+      lo[v] = sw[0];
+      hi[v] = sw[1];
+    }
+    const f16x8 b0 = __builtin_bit_cast(f16x8, lo), b1 = __builtin_bit_cast(f16x8, hi);
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+      const f16x8 af = *reinterpret_cast<const f16x8*>(wlds + (mb * 32 + (lane & 31)) * kEncLds + L * 64 + ks * 16 +
+                                                        (lane >> 5) * 8);
+      acc[mb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, b0, acc[mb][0], 0, 0, 0);
+      acc[mb][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, b1, acc[mb][1], 0, 0, 0);
+    }
+  }
+}
+
+template <int L, bool CORR, bool ENC>
+__device__ __forceinline__ void dm_level(const DmArgs& a, size_t slot_tile, int sy, int sx, int lane, float x0, float y0,
+                                         bool live, size_t row, const _Float16* wlds, f32x16 (&acc)[4][2]) {
+  unsigned raw[8][8];
+  float fdx, fdy;
+  dm_gather<L>(a, slot_tile, sy, sx, lane, x0, y0, raw, fdx, fdy);
+  u32x4 rows[7];
+  dm_blend(raw, fdx, fdy, rows);
+  if (CORR && live) {
+    u32x4* op = reinterpret_cast<u32x4*>(a.corr_cl + row * 256 + L * 64);
+#pragma unroll
+    for (int j = 0; j < 7; ++j) op[j] = rows[j];
+    op[7] = u32x4{0u, 0u, 0u, 0u};
+  }
+  if (ENC) dm_encode<L>(rows, wlds, lane, acc);
+}
+
+// grid (ceil(ntiles / 4), N); 256 threads = 4 waves = 4 consecutive tiles of edge blockIdx.y
+template <bool CORR, bool ENC>
+__global__ __launch_bounds__(256, 2) void corr_dm_lookup_kernel(DmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) _Float16 wlds[];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ntiles = a.ntx * a.nty;
+  const int n = blockIdx.y;
+  const int tile_raw = blockIdx.x * 4 + wv;
+  const bool wave_on = tile_raw < ntiles;
+  const int tile = wave_on ? tile_raw : ntiles - 1;
+  const int ty = tile / a.ntx, tx = tile - ty * a.ntx;
+  const int sy = ty * 8 + (lane >> 3), sx = tx * 8 + (lane & 7);
+  const bool live = wave_on && sy < a.h && sx < a.w;
+  const int HW = a.h * a.w;
+  const int p = min(sy, a.h - 1) * a.w + min(sx, a.w - 1);
+  float x0, y0;
+  if (a.coords_xy) {
+    const float2 c = *reinterpret_cast<const float2*>(a.coords + ((size_t)n * HW + p) * 2);
+    x0 = c.x; y0 = c.y;
+  } else {
+    x0 = a.coords[((size_t)n * 2 + 0) * HW + p];
+    y0 = a.coords[((size_t)n * 2 + 1) * HW + p];
+  }
+  if (!live) { x0 = -1.0e6f; y0 = -1.0e6f; }          // padding lanes: every tap out of range, no memory access
+  const size_t slot = a.slots ? (size_t)a.slots[n] : (size_t)n;
+  const size_t slot_tile = slot * (size_t)ntiles + (size_t)tile;
+  const size_t row = (size_t)n * HW + p;
+
+  if (ENC) {
+    // stage the encoder weights [128][256] -> LDS rows of kEncLds halfs (16-byte pieces)
+    for (int idx = threadIdx.x; idx < 128 * 32; idx += 256) {
+      const int r = idx >> 5, c = idx & 31;
+      *reinterpret_cast<u32x4*>(wlds + r * kEncLds + c * 8) = *reinterpret_cast<const u32x4*>(a.enc_w + r * 256 + c * 8);
+    }
+    __syncthreads();
+  }
+  f32x16 acc[4][2];
+  if (ENC) {
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.0f;
+  }
+  dm_level<0, CORR, ENC>(a, slot_tile, sy, sx, lane, x0, y0, live, row, wlds, acc);
+  dm_level<1, CORR, ENC>(a, slot_tile, sy, sx, lane, x0, y0, live, row, wlds, acc);
+  dm_level<2, CORR, ENC>(a, slot_tile, sy, sx, lane, x0, y0, live, row, wlds, acc);
+  dm_level<3, CORR, ENC>(a, slot_tile, sy, sx, lane, x0, y0, live, row, wlds, acc);
+
+  if (ENC) {
+    // C/D of 32x32: lane holds channel 32 mb + 8 (r >> 2) + 4 (lane >> 5) + (r & 3) of pixel 32 nb + (lane & 31).  Swapping the
+    // upper half of block 0 with the lower half of block 1 leaves every lane with ITS pixel: acc[mb][0][r] = channels
+    // 32 mb + 8 g + (r & 3), acc[mb][1][r] = the same + 4 -> 8 consecutive channels = one 16-byte store.
+    _Float16* op = a.enc_out + row * (size_t)a.enc_stride;
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[mb][0][4 * g + r]),
+                                                           __float_as_uint(acc[mb][1][4 * g + r]), false, false);
+          v[r] = __uint_as_float(sw[0]);
+          v[4 + r] = __uint_as_float(sw[1]);
+        }
+        const int ch = 32 * mb + 8 * g;
+        f16x8 o;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) o[c] = (_Float16)fmaxf(v[c] + a.enc_b[ch + c], 0.0f);
+        if (live) *reinterpret_cast<f16x8*>(op + ch) = o;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Builder: all-pairs <f1/4, f2/4> (fp16 GEMM, fp32 accumulate, rounded to fp16) + three avg_pool2d levels, written in the
+// displacement-major layout.  Workgroup = half a source tile (4 x 8 pixels) x 8 aligned target rows: level 0 on the matrix
+// cores into LDS R[px][8 rows][W8], the pooled levels reduced in LDS from the fp16 values of the level below (what
+// avg_pool2d of the fp16 volume computes), then every (pixel, target) value is emitted to its line: a thread gathers the 8
+// pixels of one tile row that share (dy, dx) and writes their 16 bytes.
+// ---------------------------------------------------------------------------------------------------------------------
+struct DmBuildArgs {
+  const _Float16* f;          // [F][HW][128] channels-last feature maps, already scaled by 1/4
+  const int64_t* ii; const int64_t* jj;
+  const int* slot;
+  _Float16* lvl[4];
+  int h, w, ntx, nty, num_levels;
+};
+
+__device__ __forceinline__ unsigned pk2h(_Float16 a, _Float16 b) {
+  return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+}
+__device__ __forceinline__ _Float16 pool4h(_Float16 a, _Float16 b, _Float16 c, _Float16 d) {
+  // avg_pool2d on half: float accumulation over (0,0),(0,1),(1,0),(1,1), times 1/4, rounded to half
+  const float s = (((float)a + (float)b) + (float)c) + (float)d;
+  return (_Float16)(s * 0.25f);
+}
+
+__global__ __launch_bounds__(256, 2) void corr_dm_build_kernel(DmBuildArgs a) {
+  constexpr int C = 128, PX = 32;
+  extern __shared__ __attribute__((aligned(16))) _Float16 bsm[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = lane & 15, kg = lane >> 4;
+  const int h = a.h, w = a.w, HW = h * w;
+  const int e = blockIdx.z, grp = blockIdx.y;
+  const int tile = blockIdx.x >> 1, half = blockIdx.x & 1;
+  const int tyi = tile / a.ntx, txi = tile - tyi * a.ntx;
+  const int ntiles = a.ntx * a.nty;
+  const int fi = (int)a.ii[e], fj = (int)a.jj[e];
+  const size_t sl = (size_t)a.slot[e];
+  const int W8 = ((w + 7) >> 3) << 3;
+  const int w1 = w >> 1, w2 = w >> 2, w3 = w >> 3, h1 = h >> 1, h2 = h >> 2, h3 = h >> 3;
+  const int W81 = ((w1 + 7) >> 3) << 3, W82 = ((w2 + 7) >> 3) << 3, W83 = ((w3 + 7) >> 3) << 3;
+  const int RS = 8 * W8 + 4, L1S = 4 * W81 + 2, L2S = 2 * W82 + 2, L3S = W83 + 2;   // per-pixel strides (padded: bank spread)
+  _Float16* R = bsm;
+  _Float16* L1 = R + PX * RS;
+  _Float16* L2 = L1 + PX * L1S;
+  _Float16* L3 = L2 + PX * L2S;
+
+  // B operand: the 32 source pixels of this half tile (row syh = k >> 3 of the half, column k & 7), clamped into the map
+  f16x8 bfrag[2][4];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int k = nt * 16 + col;
+    const int sy = min(tyi * 8 + half * 4 + (k >> 3), h - 1), sx = min(txi * 8 + (k & 7), w - 1);
+    const f16x8* src = reinterpret_cast<const f16x8*>(a.f + ((size_t)fi * HW + sy * w + sx) * C + kg * 8);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) bfrag[nt][kk] = src[kk * 4];
+  }
+  // ---- level 0: targets t = local row * W8 + x of rows 8 grp .. 8 grp + 7 ----
+  const int ntile = (8 * W8) >> 4;
+  const _Float16* f2 = a.f + (size_t)fj * HW * C;
+  for (int t16 = wv; t16 < ntile; t16 += 4) {
+    const int t = t16 * 16 + col;
+    const int ly = t / W8, x = t - ly * W8, y = 8 * grp + ly;
+    const bool ok = y < h && x < w;
+    const f16x8* src = reinterpret_cast<const f16x8*>(f2 + ((size_t)(ok ? y * w + x : 0)) * C + kg * 8);
+    f16x8 af[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) af[kk] = src[kk * 4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) if (!ok) af[kk] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[kk], bfrag[nt][kk], acc, 0, 0, 0);
+      *reinterpret_cast<uint2*>(R + (nt * 16 + col) * RS + t16 * 16 + kg * 4) =
+          make_uint2(pk2h((_Float16)acc[0], (_Float16)acc[1]), pk2h((_Float16)acc[2], (_Float16)acc[3]));
+    }
+  }
+  __syncthreads();
+  // ---- pooled levels in LDS (each from the fp16 values of the level below) ----
+  if (a.num_levels > 1) {
+    for (int idx = tid; idx < PX * 4 * W81; idx += 256) {
+      const int px = idx / (4 * W81), r = idx - px * (4 * W81), y = r / W81, x = r - y * W81;
+      const _Float16* s = R + px * RS + (2 * y) * W8 + 2 * x;
+      L1[px * L1S + r] = (x < w1) ? pool4h(s[0], s[1], s[W8], s[W8 + 1]) : (_Float16)0.0f;
+    }
+    __syncthreads();
+  }
+  if (a.num_levels > 2) {
+    for (int idx = tid; idx < PX * 2 * W82; idx += 256) {
+      const int px = idx / (2 * W82), r = idx - px * (2 * W82), y = r / W82, x = r - y * W82;
+      const _Float16* s = L1 + px * L1S + (2 * y) * W81 + 2 * x;
+      L2[px * L2S + r] = (x < w2) ? pool4h(s[0], s[1], s[W81], s[W81 + 1]) : (_Float16)0.0f;
+    }
+    __syncthreads();
+  }
+  if (a.num_levels > 3) {
+    for (int idx = tid; idx < PX * W83; idx += 256) {
+      const int px = idx / W83, x = idx - px * W83;
+      const _Float16* s = L2 + px * L2S + 2 * x;
+      L3[px * L3S + x] = (x < w3) ? pool4h(s[0], s[1], s[W82], s[W82 + 1]) : (_Float16)0.0f;
+    }
+    __syncthreads();
+  }
+  // ---- emission: segment = (source row syh of the half tile, local target row r, displacement column dx) -> 8 lanes ----
+  auto emit = [&](const _Float16* src, int stride, int Wp, int lvl, int rows, int hl, int wl) {
+    const int cy = hl >> 1, cx = wl >> 1;
+    const int y0 = (8 * grp) >> lvl;
+    _Float16* dst = a.lvl[lvl] + (sl * ntiles + tile) * ((size_t)hl * wl * 64);
+    const int nseg = 4 * rows * wl;
+    for (int idx = tid; idx < nseg; idx += 256) {
+      const int dx = idx % wl, t = idx / wl, r = t % rows, syh = t / rows;
+      const int tyl = y0 + r, sy = tyi * 8 + half * 4 + syh;
+      if (tyl >= hl || sy >= h) continue;
+      int dy = tyl - (sy >> lvl) + cy;
+      dy = dy < 0 ? dy + hl : (dy >= hl ? dy - hl : dy);
+      _Float16 v[8];
+#pragma unroll
+      for (int lx = 0; lx < 8; ++lx) {
+        const int sxl = min(txi * 8 + lx, w - 1) >> lvl;
+        int txl = dx - cx + sxl;
+        txl = txl < 0 ? txl + wl : (txl >= wl ? txl - wl : txl);
+        v[lx] = src[(syh * 8 + lx) * stride + r * Wp + txl];
+      }
+      u32x4 o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = pk2h(v[2 * k], v[2 * k + 1]);
+      *reinterpret_cast<u32x4*>(dst + ((size_t)dy * wl + dx) * 64 + (half * 4 + syh) * 8) = o;
+    }
+  };
+  emit(R, RS, W8, 0, 8, h, w);
+  if (a.num_levels > 1) emit(L1, L1S, W81, 1, 4, h1, w1);
+  if (a.num_levels > 2) emit(L2, L2S, W82, 2, 2, h2, w2);
+  if (a.num_levels > 3) emit(L3, L3S, W83, 3, 1, h3, w3);
+}
+
+}  // namespace glorie
+
+using namespace glorie;
+
+extern "C" long glorie_corr_dm_level_halfs(int h, int w, int level) {
+  if (h <= 0 || w <= 0 || level < 0 || level > 3) return -1;
+  const long ntiles = (long)((h + 7) / 8) * ((w + 7) / 8);
+  return ntiles * (long)(h >> level) * (long)(w >> level) * 64;
+}
+
+extern "C" int glorie_corr_dm_build(const void* fmaps_cl, const int64_t* ii, const int64_t* jj, const int* slots,
+                                    void* const* levels, int num_levels, int n_new, int h, int w, int C, void* stream) {
+  if (n_new < 0 || h <= 0 || w <= 0 || num_levels < 1 || num_levels > 4) return GLORIE_EINVAL;
+  if (n_new == 0) return GLORIE_OK;
+  if (!fmaps_cl || !ii || !jj || !slots || !levels) return GLORIE_EINVAL;
+  if (C != 128 || (h >> (num_levels - 1)) < 1 || (w >> (num_levels - 1)) < 1) return GLORIE_EUNSUPPORTED;
+  DmBuildArgs a{};
+  a.f = reinterpret_cast<const _Float16*>(fmaps_cl);
+  a.ii = ii; a.jj = jj; a.slot = slots; a.h = h; a.w = w; a.num_levels = num_levels;
+  a.ntx = (w + 7) / 8; a.nty = (h + 7) / 8;
+  for (int l = 0; l < num_levels; ++l) {
+    if (!levels[l]) return GLORIE_EINVAL;
+    a.lvl[l] = reinterpret_cast<_Float16*>(levels[l]);
+  }
+  auto pad8 = [](int v) { return ((v + 7) >> 3) << 3; };
+  const size_t lds = sizeof(_Float16) * 32 *
+                     (size_t)((8 * pad8(w) + 4) + (4 * pad8(w >> 1) + 2) + (2 * pad8(w >> 2) + 2) + (pad8(w >> 3) + 2));
+  if (lds > 80 * 1024) return GLORIE_EUNSUPPORTED;
+  static bool attr = false;
+  if (!attr) {
+    GLORIE_TRY(check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(corr_dm_build_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)));
+    attr = true;
+  }
+  const dim3 grid(a.ntx * a.nty * 2, (h + 7) / 8, n_new);
+  hipLaunchKernelGGL(corr_dm_build_kernel, grid, dim3(256), lds, (hipStream_t)stream, a);
+  return check_launch();
+}
+
+extern "C" int glorie_corr_dm_lookup(const void* const* levels, const int* slots, const float* coords, int coords_xy, int N,
+                                     int h, int w, void* corr_cl, const void* enc_w, const float* enc_b, void* enc_out,
+                                     int enc_stride, void* stream) {
+  if (N < 0 || h <= 0 || w <= 0) return GLORIE_EINVAL;
+  if (N == 0) return GLORIE_OK;
+  if (!levels || !coords || (!corr_cl && !enc_out)) return GLORIE_EINVAL;
+  if ((h >> 3) < 1 || (w >> 3) < 1) return GLORIE_EUNSUPPORTED;
+  const bool enc = enc_out != nullptr;
+  if (enc && (!enc_w || !enc_b || enc_stride < 128 || (enc_stride & 7) || (reinterpret_cast<uintptr_t>(enc_out) & 15) ||
+              (reinterpret_cast<uintptr_t>(enc_w) & 15)))
+    return GLORIE_EINVAL;
+  if (corr_cl && (reinterpret_cast<uintptr_t>(corr_cl) & 15)) return GLORIE_EINVAL;
+  if (coords_xy && (reinterpret_cast<uintptr_t>(coords) & 7)) return GLORIE_EINVAL;
+  DmArgs a{};
+  for (int l = 0; l < 4; ++l) {
+    if (!levels[l]) return GLORIE_EINVAL;
+    a.lvl[l] = reinterpret_cast<const _Float16*>(levels[l]);
+  }
+  a.slots = slots; a.coords = coords; a.coords_xy = coords_xy; a.N = N; a.h = h; a.w = w;
+  a.ntx = (w + 7) / 8; a.nty = (h + 7) / 8;
+  a.corr_cl = reinterpret_cast<_Float16*>(corr_cl);
+  a.enc_w = reinterpret_cast<const _Float16*>(enc_w); a.enc_b = enc_b;
+  a.enc_out = reinterpret_cast<_Float16*>(enc_out); a.enc_stride = enc_stride;
+  const dim3 grid((a.ntx * a.nty + 3) / 4, N);
+  const size_t lds = enc ? sizeof(_Float16) * 128 * kEncLds : 0;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (enc) {
+    static bool attr = false;
+    if (!attr) {
+      GLORIE_TRY(check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(corr_dm_lookup_kernel<false, true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)));
+      GLORIE_TRY(check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(corr_dm_lookup_kernel<true, true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)));
+      attr = true;
+    }
+  }
+  if (enc && corr_cl) hipLaunchKernelGGL((corr_dm_lookup_kernel<true, true>), grid, dim3(256), lds, st, a);
+  else if (enc) hipLaunchKernelGGL((corr_dm_lookup_kernel<false, true>), grid, dim3(256), lds, st, a);
+  else hipLaunchKernelGGL((corr_dm_lookup_kernel<true, false>), grid, dim3(256), 0, st, a);
+  return check_launch();
+}

@@ -125,6 +125,100 @@ def corr_lookup_tiled_cl(pyramid, coords, h2, w2, slots=None, interleaved=False)
     return out
 
 
+# ---- displacement-major, source-tiled pyramid (csrc/corr_dm.hip) ---------------------------------------------
+def dm_shape(h, w, l):
+    """(ntiles, h>>l, w>>l) of level l: levels are [slots][ntiles][(h>>l)*(w>>l)][64] fp16"""
+    return ((h + 7) // 8) * ((w + 7) // 8), h >> l, w >> l
+
+
+def _dm_index(n_src, n_dst, l, device):
+    """[source coordinate s][displacement index d] -> target coordinate t, i.e. the inverse of
+    d = (t - (s >> l) + (n_dst >> 1)) mod n_dst (include/glorie_hip.h: glorie_corr_dm_build)"""
+    s = torch.arange(n_src, device=device)[:, None] >> l
+    d = torch.arange(n_dst, device=device)[None, :]
+    return (d - (n_dst >> 1) + s) % n_dst
+
+
+def dm_corr_level(vol, l):
+    """row-major level [N, h, w, h>>l, w>>l] -> displacement-major [N, ntiles * (h>>l) * (w>>l) * 64] (a torch
+    restatement of the layout for tests and for CorrBlock pyramids built with torch; the product path builds the
+    layout directly with glorie_corr_dm_build)"""
+    N, h, w, hl, wl = vol.shape
+    nty, ntx = (h + 7) // 8, (w + 7) // 8
+    H8, W8 = nty * 8, ntx * 8
+    vp = torch.zeros((N, H8, W8, hl, wl), dtype=vol.dtype, device=vol.device)
+    vp[:, :h, :w] = vol
+    ty = _dm_index(H8, hl, l, vol.device)            # [sy][dy] -> ty
+    tx = _dm_index(W8, wl, l, vol.device)            # [sx][dx] -> tx
+    sy = torch.arange(H8, device=vol.device)[:, None, None, None]
+    sx = torch.arange(W8, device=vol.device)[None, :, None, None]
+    d = vp[:, sy, sx, ty[:, None, :, None], tx[None, :, None, :]]              # [N, sy, sx, dy, dx]
+    d = d.view(N, nty, 8, ntx, 8, hl, wl).permute(0, 1, 3, 5, 6, 2, 4)         # [N, ty, tx, dy, dx, ly, lx]
+    return d.reshape(N, -1).contiguous()
+
+
+def dm_to_rowmajor(dm, h, w, l):
+    """inverse of dm_corr_level: [N, ntiles*(h>>l)*(w>>l)*64] -> [N, h, w, h>>l, w>>l]"""
+    N = dm.shape[0]
+    hl, wl = h >> l, w >> l
+    nty, ntx = (h + 7) // 8, (w + 7) // 8
+    d = dm.view(N, nty, ntx, hl, wl, 8, 8).permute(0, 1, 5, 2, 6, 3, 4).reshape(N, nty * 8, ntx * 8, hl, wl)[:, :h, :w]
+    dy = (torch.arange(hl, device=dm.device)[None, :] - (torch.arange(h, device=dm.device)[:, None] >> l) + (hl >> 1)) % hl
+    dx = (torch.arange(wl, device=dm.device)[None, :] - (torch.arange(w, device=dm.device)[:, None] >> l) + (wl >> 1)) % wl
+    sy = torch.arange(h, device=dm.device)[:, None, None, None]
+    sx = torch.arange(w, device=dm.device)[None, :, None, None]
+    return d[:, sy, sx, dy[:, None, :, None], dx[None, :, None, :]].contiguous()
+
+
+def corr_dm_lookup(levels, coords, h, w, slots=None, interleaved=False, want_corr=True, enc_w=None, enc_b=None,
+                   enc_out=None):
+    """glorie_corr_dm_lookup: levels = 4 displacement-major level tensors (stacked in edge order, or arena tensors with
+    `slots` int32 [N]); coords f32 UNscaled, planar [N,2,h,w] or - interleaved - [N,h,w,2].
+    want_corr: return the lookup as fp16 [N,256,h,w] channels_last (channel l*64 + j*8 + i, as corr_lookup_tiled_cl).
+    enc_w / enc_b / enc_out: run corr_encoder[0] behind the lookup (update_ops.pack_corr_encoder_dm(weight), bias f32 [128],
+    enc_out a channels-last fp16 [N,128,h,w] map or a 128-channel slice of a wider one)."""
+    L.need_cuda(coords, *levels)
+    if len(levels) != 4:
+        raise RuntimeError("corr_dm_lookup: 4 levels expected")
+    if coords.dim() != 4 or coords.shape[3 if interleaved else 1] != 2:
+        raise RuntimeError("coords must be [N,2,h,w] (planar) or [N,h,w,2] (interleaved)")
+    if not coords.is_contiguous() or coords.dtype != torch.float32:
+        raise RuntimeError("coords must be contiguous float32")
+    N = coords.shape[0]
+    if tuple(coords.shape[1:3] if interleaved else coords.shape[2:4]) != (h, w):
+        raise RuntimeError("coords do not match the map size")
+    for l, v in enumerate(levels):
+        nt, hl, wl = dm_shape(h, w, l)
+        if v.dtype != torch.float16 or not v.is_contiguous() or v.numel() % (nt * hl * wl * 64) or \
+                (slots is None and v.numel() != N * nt * hl * wl * 64):
+            raise RuntimeError(f"displacement-major level {l} has {v.numel()} elements")
+    out = None
+    if want_corr:
+        out = torch.empty((N, 256, h, w), dtype=torch.float16, device=coords.device, memory_format=torch.channels_last)
+    stride = 0
+    if enc_out is not None:
+        if enc_w is None or enc_b is None or tuple(enc_out.shape) != (N, 128, h, w) or enc_out.dtype != torch.float16:
+            raise RuntimeError("corr_dm_lookup: enc_out must be an fp16 [N,128,h,w] map, with enc_w and enc_b")
+        from .update_ops import _rows
+        stride = _rows(enc_out, "enc_out")
+        if tuple(enc_w.shape) != (128, 256) or enc_w.dtype != torch.float16 or not enc_w.is_contiguous():
+            raise RuntimeError("corr_dm_lookup: enc_w must be fp16 [128,256] (update_ops.pack_corr_encoder_dm)")
+    elif not want_corr:
+        raise RuntimeError("corr_dm_lookup: nothing to compute")
+    arr = (ctypes.c_void_p * 4)(*[v.data_ptr() for v in levels])
+    L.check(L.load().glorie_corr_dm_lookup(ctypes.cast(arr, ctypes.c_void_p), L.ptr(slots), L.ptr(coords),
+                                           int(bool(interleaved)), N, h, w, L.ptr(out), L.ptr(enc_w), L.ptr(enc_b),
+                                           L.ptr(enc_out), stride, L.stream_ptr()), "glorie_corr_dm_lookup")
+    return out
+
+
+def cl_to_planar(cl):
+    """[N,256,h,w] channels-last lookup (channel l*64 + j*8 + i) -> the reference's [N,196,h,w] (channel l*49 + i*7 + j)"""
+    N, _, h, w = cl.shape
+    v = cl.view(N, 4, 8, 8, h, w)[:, :, :7, :7]                    # [n][l][j][i][y][x]
+    return v.permute(0, 1, 3, 2, 4, 5).reshape(N, 196, h, w).contiguous()
+
+
 def corr_index_backward(volume, coords, corr_grad, radius):
     raise NotImplementedError("corr_index_backward: training-only; the SLAM hot path runs under "
                               "no_grad (factor_graph.py:213)")

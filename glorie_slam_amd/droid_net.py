@@ -8,6 +8,9 @@ the fp32 reference of the parity tests); the product path is `FusedUpdate`, whic
 on libglorie_hip kernels (csrc/conv.hip, gru.hip, flowenc.hip: implicit-GEMM MFMA convolutions with fused gate
 epilogues), and the correlation blocks (`CorrBlock`, `CorrArena`, `OtfCorrBlock`, `AltCorrBlock`) on csrc/corr*.hip.
 """
+import os
+
+import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -291,6 +294,7 @@ class FusedUpdate:
         W["ce1_b"] = f32(m.corr_encoder[0].bias)
         W["ce1_p"] = OtfCorrBlock.pack_encoder(m.corr_encoder[0].weight)
         W["ce1_cl"] = U.pack_corr_encoder(m.corr_encoder[0].weight)
+        W["ce1_dm"] = U.pack_corr_encoder_dm(m.corr_encoder[0].weight)
         W["ce2"], W["ce2_b"] = U.pack_conv_igemm(m.corr_encoder[2].weight), f32(m.corr_encoder[2].bias)
         W["fe1"], W["fe1_b"] = U.pack_flow_conv7(m.flow_encoder[0].weight), f32(m.flow_encoder[0].bias)
         W["fe2"], W["fe2_b"] = U.pack_conv_igemm(m.flow_encoder[2].weight), f32(m.flow_encoder[2].bias)
@@ -441,7 +445,7 @@ class FusedUpdate:
             # volume-free lookup with corr_encoder[0] fused behind it (csrc/corr_otf.hip): the 196-channel map
             # never exists in HBM
             c1 = cl_map(128)
-            corr.encode_into(W["ce1_p"], W["ce1_b"], c1)
+            corr.encode_into(W, c1)
         else:
             if callable(corr):
                 corr = corr()                          # the lookup itself, issued behind the forks
@@ -605,15 +609,29 @@ class CorrArena:
 
     The reference keeps a CorrBlock per graph whose `cat` / `__getitem__` copy every volume of every level through
     torch.cat and boolean masks whenever an edge is added or removed (corr.py:55-65, factor_graph.py:126,161:
-    61 MB per edge at 60x80).  Here an edge is built ONCE (glorie_corr_build: all four levels in the lookup's
-    tiled layout) into a free slot and stays there; adding / removing edges edits the int32 slot list the lookup
-    kernel indirects through.  Capacity grows geometrically (the only copy that can ever happen)."""
+    61 MB per edge at 60x80).  Here an edge is built ONCE (one launch: all four levels in the lookup's layout) into a
+    free slot and stays there; adding / removing edges edits the int32 slot list the lookup kernel indirects through.
+    Capacity grows geometrically (the only copy that can ever happen).
 
-    def __init__(self, h, w, device, num_levels=4, radius=3, capacity=16):
+    layout "dm" (default for 4 levels): displacement-major, source-tiled lines (csrc/corr_dm.hip) - neighbouring source
+    pixels share the 128-byte lines their windows read, and corr_encoder[0] can run inside the lookup launch
+    (`lookup_encode`).  layout "tiled": per-pixel planes in 4x8 blocks (csrc/corr.hip, rounds 1-2; GLORIE_CORR_LAYOUT=tiled)."""
+
+    def __init__(self, h, w, device, num_levels=4, radius=3, capacity=16, layout=None):
         assert radius == 3
         self.h, self.w, self.num_levels, self.radius = h, w, num_levels, radius
         self.device = torch.device(device)
-        self.planes = [(((h >> l) + 3) // 4) * (((w >> l) + 7) // 8) * 32 for l in range(num_levels)]
+        if layout is None:
+            layout = os.environ.get("GLORIE_CORR_LAYOUT", "dm")
+        if num_levels != 4 or (h >> 3) < 1 or (w >> 3) < 1 or w > 112:
+            layout = "tiled"                 # the displacement-major lookup is the 4-level, radius-3 form only
+        if layout not in ("dm", "tiled"):
+            raise ValueError(f"CorrArena: unknown layout {layout!r}")
+        self.layout = layout
+        if layout == "dm":
+            self.planes = [int(np.prod(droid_backends.dm_shape(h, w, l))) * 64 for l in range(num_levels)]
+        else:
+            self.planes = [(((h >> l) + 3) // 4) * (((w >> l) + 7) // 8) * 32 for l in range(num_levels)]
         self.capacity = 0
         self.levels = None
         self.free = []
@@ -632,15 +650,22 @@ class CorrArena:
         hw = self.h * self.w
         new = []
         for l, pl in enumerate(self.planes):
-            # one spare plane on either side: read slack of the unaligned block-row loads of the lookup
-            t = torch.zeros((capacity * hw + 2, pl), dtype=torch.float16, device=self.device)
-            if self.levels is not None:
-                t[1:self.capacity * hw + 1] = self.levels[l][1:self.capacity * hw + 1]
+            if self.layout == "dm":
+                t = torch.zeros((capacity, pl), dtype=torch.float16, device=self.device)
+                if self.levels is not None:
+                    t[:self.capacity] = self.levels[l]
+            else:
+                # one spare plane on either side: read slack of the unaligned block-row loads of the lookup
+                t = torch.zeros((capacity * hw + 2, pl), dtype=torch.float16, device=self.device)
+                if self.levels is not None:
+                    t[1:self.capacity * hw + 1] = self.levels[l][1:self.capacity * hw + 1]
             new.append(t)
         self.free += list(range(capacity - 1, self.capacity - 1, -1))
         self.levels, self.capacity = new, capacity
 
     def views(self):
+        if self.layout == "dm":
+            return list(self.levels)
         hw = self.h * self.w
         return [t[1:self.capacity * hw + 1] for t in self.levels]
 
@@ -658,9 +683,10 @@ class CorrArena:
         new_slots = torch.tensor(take, dtype=torch.int32, device=self.device)
         v = self.views()
         arr = (ctypes.c_void_p * self.num_levels)(*[t.data_ptr() for t in v])
-        L.check(L.load().glorie_corr_build(L.ptr(fmaps_cl), L.ptr(fi.contiguous()), L.ptr(fj.contiguous()), L.ptr(new_slots),
-                                           ctypes.cast(arr, ctypes.c_void_p), self.num_levels, n, self.h, self.w,
-                                           int(fmaps_cl.shape[-1]), L.stream_ptr()), "glorie_corr_build")
+        fn = L.load().glorie_corr_dm_build if self.layout == "dm" else L.load().glorie_corr_build
+        L.check(fn(L.ptr(fmaps_cl), L.ptr(fi.contiguous()), L.ptr(fj.contiguous()), L.ptr(new_slots),
+                   ctypes.cast(arr, ctypes.c_void_p), self.num_levels, n, self.h, self.w,
+                   int(fmaps_cl.shape[-1]), L.stream_ptr()), "glorie_corr_build")
         self._host_slots += take
         self.slots = torch.cat([self.slots, new_slots])
 
@@ -675,13 +701,24 @@ class CorrArena:
         self._host_slots = kept
         self.slots = torch.tensor(kept, dtype=torch.int32, device=self.device)
 
+    def _coords4(self, coords):
+        batch, num, ht, wd, _ = coords.shape
+        N = batch * num
+        if N != len(self._host_slots):
+            raise RuntimeError(f"CorrArena holds {len(self._host_slots)} edges, coords has {N}")
+        return coords.reshape(N, ht, wd, 2).float().contiguous()
+
     def __call__(self, coords, channels_last=False):
-        """channels_last: the [N,256,h,w] fp16 map of droid_backends.corr_lookup_tiled_cl (what FusedUpdate consumes)
+        """channels_last: the [N,256,h,w] fp16 map (channel l*64 + dy*8 + dx, what FusedUpdate's 1x1 encoder consumes)
         instead of the reference's [batch, num, 196, h, w]"""
         import ctypes
         from . import _lib as L
         batch, num, ht, wd, _ = coords.shape
         N = batch * num
+        if self.layout == "dm":
+            cl = droid_backends.corr_dm_lookup(self.views(), self._coords4(coords), self.h, self.w, slots=self.slots,
+                                               interleaved=True)
+            return cl if channels_last else droid_backends.cl_to_planar(cl).view(batch, num, -1, ht, wd)
         if N != len(self._host_slots):
             raise RuntimeError(f"CorrArena holds {len(self._host_slots)} edges, coords has {N}")
         if channels_last and self.num_levels == 4:
@@ -696,14 +733,38 @@ class CorrArena:
                 "glorie_corr_lookup_arena")
         return out.view(batch, num, -1, ht, wd)
 
+    def lookup_encode(self, coords, enc_w, enc_b, enc_out, want_corr=False):
+        """layout "dm" only: lookup + corr_encoder[0] in one launch; relu(W corr + b) goes to `enc_out` (channels-last fp16
+        [N,128,h,w] or a 128-channel slice), the 256-channel lookup itself is returned only if asked for"""
+        if self.layout != "dm":
+            raise RuntimeError("lookup_encode needs the displacement-major layout")
+        return droid_backends.corr_dm_lookup(self.views(), self._coords4(coords), self.h, self.w, slots=self.slots,
+                                             interleaved=True, want_corr=want_corr, enc_w=enc_w, enc_b=enc_b,
+                                             enc_out=enc_out)
+
     def level(self, l):
         """row-major volumes [N, h, w, h>>l, w>>l] of the current edges (tests / debugging: copies)"""
         hw = self.h * self.w
         hl, wl = self.h >> l, self.w >> l
+        if self.layout == "dm":
+            return droid_backends.dm_to_rowmajor(self.views()[l][self.slots.long()], self.h, self.w, l)
         nby, nbx = (hl + 3) // 4, (wl + 7) // 8
         v = self.views()[l].view(self.capacity, hw, nby, nbx, 4, 8)[self.slots.long()]
         v = v.permute(0, 1, 2, 4, 3, 5).reshape(len(self), hw, nby * 4, nbx * 8)[:, :, :hl, :wl]
         return v.reshape(len(self), self.h, self.w, hl, wl)
+
+
+class ArenaLookup:
+    """one pending lookup of a displacement-major CorrArena that FusedUpdate runs with corr_encoder[0] fused behind it"""
+
+    def __init__(self, arena, coords):
+        self.arena, self.coords = arena, coords
+
+    def encode_into(self, W, out):
+        self.arena.lookup_encode(self.coords, W["ce1_dm"], W["ce1_b"], out)
+
+    def __call__(self):
+        return self.arena(self.coords, channels_last=True)
 
 
 class AltCorrBlock:
@@ -749,8 +810,8 @@ class FusedLookup:
     def __init__(self, block, coords, ii, jj):
         self.block, self.coords, self.ii, self.jj = block, coords, ii, jj
 
-    def encode_into(self, enc_w, enc_b, out):
-        self.block.lookup_encode(self.coords, self.ii, self.jj, enc_w, enc_b, out)
+    def encode_into(self, W, out):
+        self.block.lookup_encode(self.coords, self.ii, self.jj, W["ce1_p"], W["ce1_b"], out)
 
     def __call__(self):
         return self.block(self.coords, self.ii, self.jj)

@@ -16,7 +16,7 @@ import os
 import torch
 
 from . import droid_backends
-from .droid_net import CorrArena, CorrBlock, AltCorrBlock, FusedUpdate, FusedLookup, OtfCorrBlock
+from .droid_net import ArenaLookup, CorrArena, CorrBlock, AltCorrBlock, FusedUpdate, FusedLookup, OtfCorrBlock
 
 
 def coords_grid(ht, wd, device):
@@ -133,13 +133,18 @@ class FactorGraph:
         if self.corr_impl == "volume":
             c = (ii == jj).long()
             if self._use_arena():
-                # slot-indexed store: the new edges are built into free slots (one launch), nothing else moves
-                blk = self._otf_block()             # channels-last, 1/4-scaled copies of the stored feature maps
-                rig = self._otf_rig
+                # slot-indexed store: the new edges are built into free slots (one launch), nothing else moves.  Only the
+                # maps of the frames these edges touch are converted (channels-last, scaled by 1/4 as corr.py:70-71): the
+                # buffer holds hundreds of frames and is written for every new keyframe
+                num, rig, ch, fht, fwd = self.video.fmaps.shape
+                n_new = int(ii.shape[0])
+                frames, inv = torch.unique(torch.cat([rig * ii, rig * jj + c]), return_inverse=True)
+                fm = self.video.fmaps.view(num * rig, ch, fht, fwd)[frames].to(self.device)
+                fcl = (fm.half() / 4.0).permute(0, 2, 3, 1).reshape(int(frames.shape[0]), fht * fwd, ch).contiguous()
                 if self.corr is None:
                     self.corr = CorrArena(self.ht, self.wd, self.device,
-                                          capacity=max(16, self.max_factors + 8 if self.max_factors > 0 else int(ii.shape[0])))
-                self.corr.add(blk.levels[0], rig * ii, rig * jj + c)
+                                          capacity=max(16, self.max_factors + 8 if self.max_factors > 0 else n_new))
+                self.corr.add(fcl, inv[:n_new].contiguous(), inv[n_new:].contiguous())
             else:
                 fmap1 = self.video.fmaps[ii, 0].to(self.device).unsqueeze(0)
                 fmap2 = self.video.fmaps[jj, c].to(self.device).unsqueeze(0)
@@ -376,6 +381,8 @@ class FactorGraph:
             oi, oj = self._graphs[ck]
             lookup = FusedLookup(blk, coords1, oi, oj) if (self.fast_update is not None and blk.num_levels == 4) \
                 else (lambda: blk(coords1, oi, oj))
+        elif self.fast_update is not None and isinstance(self.corr, CorrArena) and self.corr.layout == "dm":
+            lookup = ArenaLookup(self.corr, coords1)      # lookup + corr_encoder[0] in one launch (csrc/corr_dm.hip)
         elif self.fast_update is not None and isinstance(self.corr, (CorrArena, CorrBlock)):
             lookup = lambda: self.corr(coords1, channels_last=True)      # what FusedUpdate's 1x1 encoder consumes
         else:

@@ -227,7 +227,10 @@ class FeatureAdam:
         elif small:
             # glorie_adam_multi: one 80-byte table entry per tensor; re-packed and re-sent only when a pointer moved (the
             # caching allocator hands the gradient buffer of the previous iteration back most of the time)
-            key = tuple(p.grad.data_ptr() for p, _, _ in small) + (len(small),)
+            # the key covers EVERYTHING an entry holds: the mapper rewrites param_groups[i]['lr'] between its stages
+            # (mapper.py:412-414) while the allocator keeps handing back the same gradient buffers
+            key = tuple((p.data_ptr(), p.grad.data_ptr(), st["m"].data_ptr(), st["v"].data_ptr(), p.numel(), float(g["lr"]),
+                         float(g["betas"][0]), float(g["betas"][1]), float(g["eps"])) for p, st, g in small)
             dev = small[0][0].device
             if getattr(self, "_table_key", None) != key:
                 buf = b"".join(struct.pack("<qqqqqffffqqq", p.data_ptr(), p.grad.data_ptr(), st["m"].data_ptr(),

@@ -115,6 +115,34 @@ int glorie_corr_lookup_arena(const void* const* levels, int num_levels, const in
 int glorie_corr_lookup_tiled_cl(const void* const* levels, int num_levels, const int* slots, const float* coords,
                                 int coords_xy, void* out, int N, int h1, int w1, int h2, int w2, void* stream);
 
+/* The pyramid in the DISPLACEMENT-MAJOR, source-tiled layout (round 3; csrc/corr_dm.hip) - the same fp16 values as the
+ * reference's per-pixel planes [N,h,w,h>>l,w>>l] (corr.py:26-41), stored so that neighbouring source pixels that look at the
+ * same displacement share a 128-byte line:
+ *   levels[l] = [capacity][ntiles][(h>>l)*(w>>l)][64] fp16,  ntiles = ceil(h/8)*ceil(w/8)  (8 x 8 source tiles, row-major),
+ *   element [slot][tile][dy*(w>>l) + dx][(sy&7)*8 + (sx&7)] = volume_l[slot][sy][sx][ty][tx] with
+ *   dy = (ty - (sy>>l) + ((h>>l)>>1)) mod (h>>l), dx = (tx - (sx>>l) + ((w>>l)>>1)) mod (w>>l).
+ * glorie_corr_dm_level_halfs: halfs per slot of level l (-1 for bad arguments).
+ * glorie_corr_dm_build: CorrBlock.__init__ for a batch of new edges into arena slots; arguments as glorie_corr_build (any
+ *   width whose staging fits LDS, w <= ~112; C must be 128); lanes of padding source pixels (sy >= h or sx >= w) are
+ *   never read by the lookup.
+ * glorie_corr_dm_lookup: CorrBlock.__call__ (corr.py:43-53 -> correlation_kernels.cu:19-70; radius 3, 4 levels, fp16,
+ *   bit-identical to glorie_corr_lookup_pyramid on the same volumes) with, optionally, corr_encoder[0] of the update
+ *   operator (droid_net.py:73-77: 1x1 convolution 196 -> 128, bias, ReLU) as an MFMA epilogue of the same launch.
+ *   coords: UNscaled, [N][h*w][2] (coords_xy != 0, the reprojection's layout) or planar [N][2][h*w]; slots int32 [N] or NULL.
+ *   corr_cl: NULL or fp16 [N*h*w][256], channel l*64 + j*8 + i = the reference's channel l*49 + i*7 + j (i <-> x), 8th row /
+ *   tap zero (the layout of glorie_corr_lookup_tiled_cl).
+ *   enc_out: NULL or fp16 rows of enc_stride halfs per edge-pixel (a channels-last [N,128,h,w] map or a 128-channel slice of
+ *   a wider one; enc_stride % 8 == 0, 16-byte aligned): enc_out[(n*h*w + p)*enc_stride + o] = relu(sum_k enc_w[o][k] corr[k] +
+ *   enc_b[o]), fp32 accumulation over the fp16 lookup values; enc_w fp16 [128][256] with column l*64 + j*8 + i =
+ *   W[o][l*49 + i*7 + j], zero for i == 7 or j == 7 (update_ops.pack_corr_encoder_dm); enc_b f32 [128].
+ *   At least one of corr_cl / enc_out must be given. */
+long glorie_corr_dm_level_halfs(int h, int w, int level);
+int glorie_corr_dm_build(const void* fmaps_cl, const int64_t* ii, const int64_t* jj, const int* slots,
+                         void* const* levels, int num_levels, int n_new, int h, int w, int C, void* stream);
+int glorie_corr_dm_lookup(const void* const* levels, const int* slots, const float* coords, int coords_xy, int N,
+                          int h, int w, void* corr_cl, const void* enc_w, const float* enc_b, void* enc_out,
+                          int enc_stride, void* stream);
+
 /* Volume-free form of CorrBlock.__call__ / AltCorrBlock.__call__
  *   reference: src/modules/droid_net/corr.py:43-53 (volume lookup), :79-145 (alt-corr),
  *   src/lib/altcorr_kernel.cu:27-149

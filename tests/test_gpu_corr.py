@@ -241,8 +241,9 @@ def _fp16_ulp_diff(a, b):
     return torch.where(ok, torch.zeros_like(diff), diff / ulp).to(torch.int32) + (~ok).to(torch.int32)
 
 
+@pytest.mark.parametrize("layout", ["dm", "tiled"])
 @pytest.mark.parametrize("h,w", [(30, 40), (60, 80), (12, 16), (21, 24)])
-def test_corr_arena_build_matches_oracle_pyramid(gpu, h, w):
+def test_corr_arena_build_matches_oracle_pyramid(gpu, h, w, layout):
     """glorie_corr_build: level 0 = fp16 all-pairs correlation (one fp16 ulp of the oracle's: fp32 summation order),
     levels 1..3 = exactly avg_pool2d of the level below on the fp16 values; a removed edge frees its slot and the next
     edge is built into it without touching the others; growth keeps every volume"""
@@ -254,7 +255,8 @@ def test_corr_arena_build_matches_oracle_pyramid(gpu, h, w):
     fcl = (torch.from_numpy(fm).to(gpu) / 4.0).permute(0, 2, 3, 1).reshape(F_, h * w, 128).contiguous()
     ii = np.array([0, 1, 2, 4, 3], np.int64)
     jj = np.array([1, 0, 4, 2, 3], np.int64)
-    arena = CorrArena(h, w, gpu, capacity=4)                       # 5 edges: grows once
+    arena = CorrArena(h, w, gpu, capacity=4, layout=layout)        # 5 edges: grows once
+    assert arena.layout == layout
     arena.add(fcl, torch.from_numpy(ii[:3]).to(gpu), torch.from_numpy(jj[:3]).to(gpu))
     arena.add(fcl, torch.from_numpy(ii[3:]).to(gpu), torch.from_numpy(jj[3:]).to(gpu))
     assert len(arena) == 5 and arena.capacity >= 5
@@ -304,3 +306,106 @@ def test_corr_arena_against_reference_fixture(gpu):
     for l in range(3):
         got = arena.level(l).float().cpu().numpy()
         np.testing.assert_allclose(got, f[f"level{l}"], rtol=4e-3, atol=4e-3)
+
+
+# ---- displacement-major, source-tiled pyramid (csrc/corr_dm.hip) -----------------------------------------------------
+@pytest.mark.parametrize("N,h,w,margin", [(2, 30, 40, 5.0), (3, 24, 32, 12.0), (1, 60, 80, 3.0), (2, 12, 14, 20.0),
+                                          (2, 9, 17, 6.0)])
+def test_corr_dm_lookup_bit_exact(gpu, N, h, w, margin):
+    """the displacement-major lookup == the oracle's lookup on the reference's row-major volumes, bit for bit: windows that
+    leave the map on every side, displacements that wrap around the cyclic shift, map sizes that are not multiples of the
+    8 x 8 source tile, level planes down to 1 x 2"""
+    from glorie_slam_amd import droid_backends as db
+    rng = np.random.default_rng(21)
+    levels = [rng.standard_normal((N, h, w, h >> l, w >> l)).astype(np.float16) for l in range(4)]
+    coords = _coords(rng, N, h, w, h, w, margin=margin)
+    coords[0, :, 0, :4] = np.array([[-3.0, -2.5, 0.0, w - 0.25], [-3.0, 0.49, h + 2.0, h - 1.0]], np.float32)
+    # smooth flow on the last edge (the regime the layout is built for) incl. exact integers
+    y, x = np.meshgrid(np.arange(h, dtype=np.float32), np.arange(w, dtype=np.float32), indexing="ij")
+    coords[-1] = np.stack([x + 2.0 + 0.05 * y, y - 1.25 + 0.02 * x])
+    ref = ocorr.corr_lookup_pyramid(levels, coords, 3)
+    vols = [torch.from_numpy(v).to(gpu) for v in levels]
+    dm = [db.dm_corr_level(v, l) for l, v in enumerate(vols)]
+    for l in range(4):
+        assert torch.equal(db.dm_to_rowmajor(dm[l], h, w, l), vols[l])
+    ct = torch.from_numpy(coords).to(gpu)
+    cl = db.corr_dm_lookup(dm, ct, h, w)
+    assert cl.shape == (N, 256, h, w) and cl.is_contiguous(memory_format=torch.channels_last)
+    v = cl.view(N, 4, 8, 8, h, w)
+    assert float(v[:, :, 7].abs().max()) == 0.0 and float(v[:, :, :, 7].abs().max()) == 0.0
+    got = db.cl_to_planar(cl).cpu().numpy()
+    assert np.array_equal(got.view(np.uint16), ref.view(np.uint16)), \
+        f"{(got.view(np.uint16) != ref.view(np.uint16)).mean()} of the values differ"
+    # interleaved coordinates and a slot list (edges stored in another order, with a hole)
+    xy = db.corr_dm_lookup(dm, ct.permute(0, 2, 3, 1).contiguous(), h, w, interleaved=True)
+    assert torch.equal(xy.view(torch.int16), cl.view(torch.int16))
+    perm = torch.randperm(N + 1, generator=torch.Generator().manual_seed(0))[:N]
+    store = []
+    for l in range(4):
+        t = torch.zeros((N + 1, dm[l].shape[1]), dtype=torch.float16, device=gpu)
+        t[perm.to(gpu)] = dm[l]
+        store.append(t)
+    sl = db.corr_dm_lookup(store, ct, h, w, slots=perm.to(gpu).int())
+    assert torch.equal(sl.view(torch.int16), cl.view(torch.int16))
+
+
+@pytest.mark.parametrize("N,h,w", [(3, 24, 32), (2, 21, 19), (2, 60, 80)])
+def test_corr_dm_fused_encoder(gpu, N, h, w):
+    """corr_encoder[0] as the MFMA epilogue of the lookup launch: relu(conv1x1(corr) + b) (droid_net.py:73-77) against torch
+    on the looked-up features; the lookup written by the same launch is bit-identical to the plain one; a channel slice of
+    a wider map is written in place"""
+    from glorie_slam_amd import droid_backends as db, update_ops as U
+    rng = np.random.default_rng(22)
+    levels = [torch.from_numpy(rng.standard_normal((N, h, w, h >> l, w >> l)).astype(np.float16)).to(gpu) for l in range(4)]
+    dm = [db.dm_corr_level(v, l) for l, v in enumerate(levels)]
+    y, x = np.meshgrid(np.arange(h, dtype=np.float32), np.arange(w, dtype=np.float32), indexing="ij")
+    coords = np.stack([np.stack([x + 1.7 * n + 0.05 * y, y - 0.9 * n + 0.03 * x], -1) for n in range(N)]).astype(np.float32)
+    coords[0] += rng.uniform(-4, 4, coords[0].shape).astype(np.float32)
+    ct = torch.from_numpy(coords).to(gpu)
+    g = torch.Generator().manual_seed(1)
+    wgt = (torch.randn(128, 196, 1, 1, generator=g) / 14).to(gpu)
+    bias = torch.randn(128, generator=g).to(gpu)
+    plain = db.corr_dm_lookup(dm, ct, h, w, interleaved=True)
+    wide = torch.zeros(N, 320, h, w, dtype=torch.float16, device=gpu).contiguous(memory_format=torch.channels_last)
+    both = db.corr_dm_lookup(dm, ct, h, w, interleaved=True, enc_w=U.pack_corr_encoder_dm(wgt), enc_b=bias,
+                             enc_out=wide[:, 128:256])
+    assert torch.equal(both.view(torch.int16), plain.view(torch.int16))
+    ref = torch.relu(torch.nn.functional.conv2d(db.cl_to_planar(plain).float(), wgt.half().float(), bias))
+    torch.testing.assert_close(wide[:, 128:256].float(), ref, rtol=4e-3, atol=4e-3)
+    assert float(wide[:, :128].abs().max()) == 0.0 and float(wide[:, 256:].abs().max()) == 0.0
+    only = torch.zeros(N, 128, h, w, dtype=torch.float16, device=gpu).contiguous(memory_format=torch.channels_last)
+    assert db.corr_dm_lookup(dm, ct, h, w, interleaved=True, want_corr=False, enc_w=U.pack_corr_encoder_dm(wgt),
+                             enc_b=bias, enc_out=only) is None
+    assert torch.equal(only, wide[:, 128:256])
+    # the implicit-GEMM 1x1 launch of rounds 1-2 on the same lookup: same operator, different summation order
+    old = U.conv_igemm(plain, None, U.pack_corr_encoder(wgt), 1, 128, torch.empty_like(only), terms=bias, act=U.ACT_RELU)
+    torch.testing.assert_close(only.float(), old.float(), rtol=2e-3, atol=2e-3)
+
+
+def test_corr_arena_layouts_agree(gpu):
+    """the two arena layouts hold the same pyramid: identical lookups (planar and channels-last), and the fused
+    lookup + encoder of the displacement-major arena matches the two-launch form of the tiled one"""
+    from glorie_slam_amd.droid_net import CorrArena
+    from glorie_slam_amd import update_ops as U
+    rng = np.random.default_rng(23)
+    h, w, F_ = 30, 40, 4
+    fm = rng.standard_normal((F_, 128, h, w)).astype(np.float16)
+    fcl = (torch.from_numpy(fm).to(gpu) / 4.0).permute(0, 2, 3, 1).reshape(F_, h * w, 128).contiguous()
+    ii = torch.tensor([0, 1, 2, 3, 1], device=gpu)
+    jj = torch.tensor([1, 0, 3, 2, 2], device=gpu)
+    a, b = CorrArena(h, w, gpu, layout="dm"), CorrArena(h, w, gpu, layout="tiled")
+    a.add(fcl, ii, jj)
+    b.add(fcl, ii, jj)
+    for l in range(4):
+        assert torch.equal(a.level(l), b.level(l)), f"level {l}"
+    coords = torch.from_numpy(_coords(rng, 5, h, w, h, w, margin=4.0)).to(gpu).permute(0, 2, 3, 1)[None].contiguous()
+    assert torch.equal(a(coords), b(coords))
+    assert torch.equal(a(coords, channels_last=True), b(coords, channels_last=True))
+    g = torch.Generator().manual_seed(2)
+    wgt = (torch.randn(128, 196, 1, 1, generator=g) / 14).to(gpu)
+    bias = torch.randn(128, generator=g).to(gpu)
+    out = torch.empty(5, 128, h, w, dtype=torch.float16, device=gpu).contiguous(memory_format=torch.channels_last)
+    a.lookup_encode(coords, U.pack_corr_encoder_dm(wgt), bias, out)
+    two = U.conv_igemm(b(coords, channels_last=True), None, U.pack_corr_encoder(wgt), 1, 128, torch.empty_like(out),
+                       terms=bias, act=U.ACT_RELU)
+    torch.testing.assert_close(out.float(), two.float(), rtol=2e-3, atol=2e-3)

@@ -123,3 +123,32 @@ def test_feature_adam_matches_torch_adam(gpu):
     pb.grad = torch.ones_like(pb)
     ob.step(row_masks={id(pb): mask})
     assert torch.equal(pb.detach()[~mask], before[~mask]) and not torch.equal(pb.detach()[mask], before[mask])
+
+
+def test_feature_adam_follows_lr_changes_between_steps(gpu):
+    """the mapper rewrites optimizer.param_groups[i]['lr'] every step (mapper.py:412-414: geometry stage -> colour stage);
+    the multi-tensor launch keeps a device table of (pointers, lr, betas, eps) per small tensor, and the gradient buffers
+    usually come back at the same address - the table must be rebuilt when only the hyper-parameters changed"""
+    from glorie_slam_amd.render_train import FeatureAdam
+    g = torch.Generator().manual_seed(3)
+    shapes = [(128, 32), (32,), (64, 93), (1, 7)]                    # small tensors: the glorie_adam_multi path
+    p0 = [torch.randn(*s, generator=g).to(gpu) for s in shapes]
+    pa = [p.clone().requires_grad_(True) for p in p0]
+    pb = [p.clone().requires_grad_(True) for p in p0]
+    oa = torch.optim.Adam([{"params": pa[:2], "lr": 1e-3}, {"params": pa[2:], "lr": 3e-2}])
+    ob = FeatureAdam([{"params": pb[:2], "lr": 1e-3}, {"params": pb[2:], "lr": 3e-2}])
+    grads = [torch.empty_like(p) for p in pb]                        # ONE gradient buffer per tensor for the whole loop
+    for it in range(6):
+        if it == 2:                                                  # stage switch: both groups change their rate
+            for o in (oa, ob):
+                o.param_groups[0]["lr"], o.param_groups[1]["lr"] = 5e-3, 5e-3
+        if it == 4:
+            for o in (oa, ob):
+                o.param_groups[1]["lr"] = 1e-4
+        for a, b, gb in zip(pa, pb, grads):
+            gb.copy_(torch.randn(a.shape, generator=g).to(gpu) * (0.2 + it))
+            a.grad, b.grad = gb.clone(), gb
+        oa.step()
+        ob.step()
+        for a, b in zip(pa, pb):
+            torch.testing.assert_close(b.detach(), a.detach(), rtol=1e-5, atol=1e-7)

@@ -41,7 +41,29 @@ def main():
     coords1, _ = video.reproject(graph.ii, graph.jj)
     N, HW = graph.ii.shape[0], graph.ht * graph.wd
     alg = 936.0 * N * HW
-    t_vol = timeit(lambda: graph.corr(coords1))
+    from glorie_slam_amd.droid_net import CorrArena
+    from glorie_slam_amd import update_ops as U
+    blk0 = graph._otf_block()
+    rig = graph._otf_rig
+    c = (graph.ii == graph.jj).long()
+    arenas = {}
+    for lay in ("tiled", "dm"):
+        arenas[lay] = CorrArena(graph.ht, graph.wd, dev, capacity=int(N), layout=lay)
+        arenas[lay].add(blk0.levels[0], rig * graph.ii, rig * graph.jj + c)
+    wgt0 = torch.randn(128, 196, 1, 1, device=dev) / 14
+    bias0 = torch.randn(128, device=dev)
+    c1 = torch.empty(N, 128, graph.ht, graph.wd, dtype=torch.float16, device=dev).contiguous(memory_format=torch.channels_last)
+    w_cl, w_dm = U.pack_corr_encoder(wgt0), U.pack_corr_encoder_dm(wgt0)
+    t_vol = timeit(lambda: arenas["tiled"](coords1, channels_last=True))
+    t_vol_enc = timeit(lambda: U.conv_igemm(arenas["tiled"](coords1, channels_last=True), None, w_cl, 1, 128, c1,
+                                            terms=bias0, act=U.ACT_RELU))
+    t_dm = timeit(lambda: arenas["dm"](coords1, channels_last=True))
+    t_dm_enc = timeit(lambda: arenas["dm"].lookup_encode(coords1, w_dm, bias0, c1))
+    for name, t in (("tiled gather (channels-last)", t_vol), ("tiled gather + 1x1 encoder launch", t_vol_enc),
+                    ("displacement-major gather", t_dm), ("displacement-major gather + encoder", t_dm_enc)):
+        print(f"{name:38s} {t:8.1f} us   {alg / t / 1e6:7.2f} TB/s of algorithmic bytes   frac {alg / t / 1e6 / 8.0:.3f}")
+    if os.environ.get("CORR_ONLY_VOLUME"):
+        return
     fm = video.fmaps
     blk = OtfCorrBlock(fm.view(1, fm.shape[0] * fm.shape[1], *fm.shape[2:]))
     t_otf = timeit(lambda: blk(coords1, graph.ii, graph.jj))
