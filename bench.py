@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 PMC_SUMMARY = "r02_pmc_kernels.json"   # refreshed per round by tools/pmc_passes.sh
+PMC_CORR_SUMMARY = "r03_pmc_corr.json"  # tools/pmc_corr.sh
 MFMA_F16_PEAK_TF = 2500.0  # same guide: ~2.5 PFLOP/s dense f16/bf16 (not the 2:1-sparsity figure)
 
 
@@ -455,6 +456,7 @@ def main():
     # ---- roofline of the correlation gather (the HBM-bound kernel north_star names)
     coords1, _ = video.reproject(graph.ii, graph.jj)
     reps = 20
+    corr_traffic_key = None
     if graph.corr_impl == "otf":
         # volume-free lookup with corr_encoder[0] fused behind it, as the step launches it
         from glorie_slam_amd.droid_net import FusedLookup
@@ -463,8 +465,21 @@ def main():
         fu = graph.fast_update
         c1buf = torch.empty((graph.ii.shape[0], 128, graph.ht, graph.wd), dtype=torch.float16, device=device,
                             memory_format=torch.channels_last)
-        corr_fn = lambda: fl.encode_into(fu.W["ce1_p"], fu.W["ce1_b"], c1buf)
+        fu._sync()
+        corr_fn = lambda: fl.encode_into(fu.W, c1buf)
         corr_kernel = "corr_otf8_kernel<false,true> (volume-free MFMA lookup, 8x8 source tiles, + fused corr_encoder[0])"
+    elif getattr(graph.corr, "layout", None) == "dm":
+        # displacement-major pyramid: lookup + corr_encoder[0] in one launch, as the step launches it
+        from glorie_slam_amd.droid_net import ArenaLookup
+        fu = graph.fast_update
+        fu._sync()
+        al = ArenaLookup(graph.corr, coords1)
+        c1buf = torch.empty((graph.ii.shape[0], 128, graph.ht, graph.wd), dtype=torch.float16, device=device,
+                            memory_format=torch.channels_last)
+        corr_fn = lambda: al.encode_into(fu.W, c1buf)
+        corr_kernel = ("corr_dm_encode_kernel<false> (fp16, displacement-major source-tiled pyramid, 4 levels, "
+                       "+ corr_encoder[0] as MFMA epilogue)")
+        corr_traffic_key = "dm_enc"
     else:
         corr_fn = lambda: graph.corr(coords1, channels_last=True)    # as the step launches it (FactorGraph.update)
         corr_kernel = "corr_lookup_r3_tiled_kernel (fp16, 4x8-tiled pyramid)"
@@ -605,6 +620,15 @@ def main():
     mlp_flops = 2.0 * 179424.0 * pq.shape[0]
     mlp_tf = mlp_flops / (mlp_ms * 1e-3) / 1e12
     conv_traffic, corr_traffic, knn_traffic = _pmc_traffic()
+    if corr_traffic_key is not None:
+        # the correlation kernels have their own passes (tools/pmc_corr.sh: calibrated on a streaming copy AND on a
+        # launch of known byte count in the kernel's own 2-byte-per-lane access pattern)
+        try:
+            with open(os.path.join(ROOT, "profiles", PMC_CORR_SUMMARY)) as f:
+                dd = json.load(f)[corr_traffic_key]
+            corr_traffic = dd["hbm_read_bytes"] + dd["hbm_write_bytes"]
+        except Exception:
+            corr_traffic = None
     full = world == 1 and N == 36
 
     out = {

@@ -23,11 +23,17 @@ INCLUDE = os.path.join(os.path.dirname(PKG_DIR), "include")
 HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
          "-Wall", "-Wno-unused-function", "-I", INCLUDE]
-FLAGS += os.environ.get("GLORIE_EXTRA_HIPFLAGS", "").split()   # kernel experiments (-DEXP_...)
+# kernel experiments (-DEXP_...): extra flags for every source, or - GLORIE_EXTRA_HIPFLAGS_ONLY=corr_dm.hip - for one file
+EXTRA = os.environ.get("GLORIE_EXTRA_HIPFLAGS", "").split()
+EXTRA_ONLY = os.environ.get("GLORIE_EXTRA_HIPFLAGS_ONLY", "")
 
 
 def _sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _flags(src):
+    return FLAGS + (EXTRA if (not EXTRA_ONLY or os.path.basename(src) == EXTRA_ONLY) else [])
 
 
 def _digest(paths):
@@ -35,7 +41,7 @@ def _digest(paths):
     for p in paths:
         with open(p, "rb") as f:
             h.update(f.read())
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join(_flags(paths[0])).encode())
     return h.hexdigest()
 
 
@@ -59,7 +65,7 @@ def build(force=False, verbose=False):
 
     def compile_one(job):
         src, obj, stamp, dig = job
-        cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [HIPCC] + _flags(src) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

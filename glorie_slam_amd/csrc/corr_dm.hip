@@ -25,7 +25,7 @@
 // (c10::Half products and sums, see corr.hip) is reproduced bit for bit.
 //
 // The lookup keeps a pixel's 4 x 7 x 7 outputs in its lane, so corr_encoder[0] runs as an MFMA epilogue in the same launch
-// (out^T[128 ch x 64 px] = W[128 x 256] corr^T, K ordered l*64 + j*8 + i with zero padding rows/taps): the lane's packed
+// (out^T[128 ch x 64 px] = W[128 x 224] corr^T, K ordered l*56 + j*8 + i, tap 7 of every row zero): the lane's packed
 // window rows ARE the B fragments of v_mfma_f32_32x32x16_f16 after one v_permlane32_swap per register pair, the weights sit
 // in LDS, and the 196-channel map never exists in HBM (it can still be written, channels-last, for tests and for callers
 // that want the reference's tensor).
@@ -48,13 +48,12 @@ struct DmArgs {
   int coords_xy;
   int N, h, w, ntx, nty;
   _Float16* corr_cl;          // NULL or [N*HW][256] channels-last lookup (channel l*64 + j*8 + i, i <-> x)
-  const _Float16* enc_w;      // NULL or [128][256] fp16, column l*64 + j*8 + i (zero for i == 7 or j == 7)
+  const _Float16* enc_w;      // NULL or [128][224] fp16, column l*56 + j*8 + i (zero for i == 7)
   const float* enc_b;         // [128]
   _Float16* enc_out;          // rows of enc_stride halfs per edge-pixel
   int enc_stride;
 };
 
-constexpr int kEncLds = 264;   // halfs per weight row in LDS (256 + 8: conflict-free ds_read_b128 fragments)
 constexpr unsigned kOob = 0x40000000u;   // byte offset far beyond any plane: the buffer load returns 0 without a memory access
 
 __device__ __forceinline__ _Float16 to_half_rn(float prod) {
@@ -64,7 +63,8 @@ __device__ __forceinline__ _Float16 to_half_rn(float prod) {
   return (_Float16)prod;
 }
 __device__ __forceinline__ h2 splat(_Float16 v) { return h2{v, v}; }
-__device__ __forceinline__ h2 pk(unsigned lo, unsigned hi) { return __builtin_bit_cast(h2, lo | (hi << 16)); }
+// (hi.lo16 << 16) | lo.lo16 in one v_perm_b32
+__device__ __forceinline__ h2 pk(unsigned lo, unsigned hi) { return __builtin_bit_cast(h2, __builtin_amdgcn_perm(hi, lo, 0x05040100u)); }
 
 // one term of the reference's accumulation: products and sums individually rounded to fp16 (no contraction)
 __device__ __forceinline__ h2 acc_term(h2 acc, h2 s, h2 w) {
@@ -147,64 +147,33 @@ __device__ __forceinline__ void dm_blend(const unsigned (&raw)[8][8], float fdx,
   }
 }
 
-// ---- corr_encoder[0] on the matrix cores: acc[mb][nb] += W[32 mb .. +31][64 L .. +63] * rows^T ----------------------
 template <int L>
-__device__ __forceinline__ void dm_encode(const u32x4 (&rows)[7], const _Float16* wlds, int lane, f32x16 (&acc)[4][2]) {
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    u32x4 lo = rows[2 * ks];
-    u32x4 hi = (2 * ks + 1 < 7) ? rows[2 * ks + 1] : u32x4{0u, 0u, 0u, 0u};
-    // B fragment of pixel block nb: lanes 0-31 hold k = 0..7 (row 2ks) of pixel 32 nb + lane, lanes 32-63 hold k = 8..15
-    // (row 2ks+1) of pixel 32 nb + lane - 32.  Every lane computed both rows of ITS pixel: swapping the upper half of
-    // `lo` with the lower half of `hi` yields exactly the fragments of block 0 (in lo) and block 1 (in hi).
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const auto sw = __builtin_amdgcn_permlane32_swap(lo[v], hi[v], false, false);
-      lo[v] = sw[0];
-      hi[v] = sw[1];
-    }
-    const f16x8 b0 = __builtin_bit_cast(f16x8, lo), b1 = __builtin_bit_cast(f16x8, hi);
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb) {
-      const f16x8 af = *reinterpret_cast<const f16x8*>(wlds + (mb * 32 + (lane & 31)) * kEncLds + L * 64 + ks * 16 +
-                                                        (lane >> 5) * 8);
-      acc[mb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, b0, acc[mb][0], 0, 0, 0);
-      acc[mb][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, b1, acc[mb][1], 0, 0, 0);
-    }
-  }
-}
-
-template <int L, bool CORR, bool ENC>
 __device__ __forceinline__ void dm_level(const DmArgs& a, size_t slot_tile, int sy, int sx, int lane, float x0, float y0,
-                                         bool live, size_t row, const _Float16* wlds, f32x16 (&acc)[4][2]) {
+                                         bool live, size_t row) {
   unsigned raw[8][8];
   float fdx, fdy;
   dm_gather<L>(a, slot_tile, sy, sx, lane, x0, y0, raw, fdx, fdy);
   u32x4 rows[7];
   dm_blend(raw, fdx, fdy, rows);
-  if (CORR && live) {
+  if (live) {
     u32x4* op = reinterpret_cast<u32x4*>(a.corr_cl + row * 256 + L * 64);
 #pragma unroll
     for (int j = 0; j < 7; ++j) op[j] = rows[j];
     op[7] = u32x4{0u, 0u, 0u, 0u};
   }
-  if (ENC) dm_encode<L>(rows, wlds, lane, acc);
 }
 
-// grid (ceil(ntiles / 4), N); 256 threads = 4 waves = 4 consecutive tiles of edge blockIdx.y
-template <bool CORR, bool ENC>
-__global__ __launch_bounds__(256, 2) void corr_dm_lookup_kernel(DmArgs a) {
-  extern __shared__ __attribute__((aligned(16))) _Float16 wlds[];
+// plain lookup (channels-last 256-channel result): grid (ceil(ntiles / 4), N); 256 threads = 4 waves = 4 consecutive tiles
+__global__ __launch_bounds__(256) void corr_dm_lookup_kernel(DmArgs a) {
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int ntiles = a.ntx * a.nty;
   const int n = blockIdx.y;
-  const int tile_raw = blockIdx.x * 4 + wv;
-  const bool wave_on = tile_raw < ntiles;
-  const int tile = wave_on ? tile_raw : ntiles - 1;
+  const int tile = blockIdx.x * 4 + wv;
+  if (tile >= ntiles) return;
   const int ty = tile / a.ntx, tx = tile - ty * a.ntx;
   const int sy = ty * 8 + (lane >> 3), sx = tx * 8 + (lane & 7);
-  const bool live = wave_on && sy < a.h && sx < a.w;
+  const bool live = sy < a.h && sx < a.w;
   const int HW = a.h * a.w;
   const int p = min(sy, a.h - 1) * a.w + min(sx, a.w - 1);
   float x0, y0;
@@ -219,52 +188,259 @@ __global__ __launch_bounds__(256, 2) void corr_dm_lookup_kernel(DmArgs a) {
   const size_t slot = a.slots ? (size_t)a.slots[n] : (size_t)n;
   const size_t slot_tile = slot * (size_t)ntiles + (size_t)tile;
   const size_t row = (size_t)n * HW + p;
+  dm_level<0>(a, slot_tile, sy, sx, lane, x0, y0, live, row);
+  dm_level<1>(a, slot_tile, sy, sx, lane, x0, y0, live, row);
+  dm_level<2>(a, slot_tile, sy, sx, lane, x0, y0, live, row);
+  dm_level<3>(a, slot_tile, sy, sx, lane, x0, y0, live, row);
+}
 
-  if (ENC) {
-    // stage the encoder weights [128][256] -> LDS rows of kEncLds halfs (16-byte pieces)
-    for (int idx = threadIdx.x; idx < 128 * 32; idx += 256) {
-      const int r = idx >> 5, c = idx & 31;
-      *reinterpret_cast<u32x4*>(wlds + r * kEncLds + c * 8) = *reinterpret_cast<const u32x4*>(a.enc_w + r * 256 + c * 8);
+// ---------------------------------------------------------------------------------------------------------------------
+// Fused lookup + encoder, software-pipelined (the form the update step launches).
+//   * a wave may have 63 vector-memory loads in flight (vmcnt), one level is 64: the loads of level l+1 are issued ROW BY
+//     ROW into the registers of the window rows of level l as the blend retires them, so ~56-64 loads stay outstanding
+//     from the first instruction to the last blend without a second register set;
+//   * K is ordered l*56 + j*8 + i (7 rows x 8 taps per level, tap 7 zero: 224 = 14 k-steps of 16, the packing of
+//     glorie_corr_otf_encode): a k-step is two consecutive window rows, pairs straddle levels (row 6 of level 0 waits for
+//     row 0 of level 1);
+//   * the encoder weights are staged into LDS behind the first 64 loads.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kEnc2Lds = 232;   // halfs per weight row in LDS (224 + 8)
+
+struct DmLevel {
+  __amdgpu_buffer_rsrc_t rs;
+  unsigned coff[8];
+  int iy0, by, hl, wl;
+  unsigned lane2;
+  h2 w00, w01, w10, w11;
+};
+
+template <int L>
+__device__ __forceinline__ void dm_setup(const DmArgs& a, size_t slot_tile, int sy, int sx, int lane, float x0, float y0,
+                                         DmLevel& st) {
+  const int hl = a.h >> L, wl = a.w >> L;
+  const float inv = 1.0f / (float)(1 << L);
+  const float xs = x0 * inv, ys = y0 * inv;
+  const float fx = floorf(xs), fy = floorf(ys);
+  const float fdx = xs - fx, fdy = ys - fy;
+  const int ix0 = static_cast<int>(fx) - 3;
+  st.iy0 = static_cast<int>(fy) - 3;
+  const int bx = ix0 - (sx >> L) + (wl >> 1);
+  st.by = st.iy0 - (sy >> L) + (hl >> 1);
+  st.hl = hl; st.wl = wl; st.lane2 = (unsigned)lane * 2u;
+  const _Float16* base = a.lvl[L] + slot_tile * ((size_t)hl * wl * 64);
+  st.rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, hl * wl * 128, 0x00020000);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int tx = ix0 + i;
+    int d = bx + i;
+    d = d < 0 ? d + wl : (d >= wl ? d - wl : d);
+    st.coff[i] = (tx >= 0 && tx < wl) ? (unsigned)d * 128u : kOob;
+  }
+  st.w00 = splat(to_half_rn((1.0f - fdx) * (1.0f - fdy)));
+  st.w01 = splat(to_half_rn((1.0f - fdx) * fdy));
+  st.w10 = splat(to_half_rn(fdx * (1.0f - fdy)));
+  st.w11 = splat(to_half_rn(fdx * fdy));
+}
+
+__device__ __forceinline__ void dm_load_row(const DmLevel& st, int j, unsigned (&row)[8]) {
+  const int ty = st.iy0 + j;
+  int d = st.by + j;
+  d = d < 0 ? d + st.hl : (d >= st.hl ? d - st.hl : d);
+  const unsigned roff = (ty >= 0 && ty < st.hl) ? (unsigned)(d * st.wl) * 128u + st.lane2 : kOob;
+#pragma unroll
+#ifdef EXP_DM_NO_GATHER
+  for (int i = 0; i < 8; ++i) row[i] = (roff + st.coff[i]) & 0x3c00u;          // ablation: arithmetic only, no memory
+#else
+  for (int i = 0; i < 8; ++i) row[i] = __builtin_amdgcn_raw_buffer_load_b16(st.rs, (int)(roff + st.coff[i]), 0, 0);
+#endif
+}
+
+// the 4 aligned tap pairs (2k, 2k+1) of a window row
+__device__ __forceinline__ void dm_pack_row(const unsigned (&row)[8], h2 (&p)[4]) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) p[k] = pk(row[2 * k], row[2 * k + 1]);
+}
+// the odd pair (2k+1, 2k+2) from two aligned pairs: (a.hi, b.lo) in one v_perm_b32; beyond the window: (tap 7, 0)
+__device__ __forceinline__ h2 dm_odd(const h2 (&p)[4], int k) {
+  const unsigned a = __builtin_bit_cast(unsigned, p[k]);
+  if (k == 3) return __builtin_bit_cast(h2, a >> 16);
+  return __builtin_bit_cast(h2, __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, p[k + 1]), a, 0x05040302u));
+}
+
+__device__ __forceinline__ u32x4 dm_blend_row(const DmLevel& st, const h2 (&p0)[4], const h2 (&p1)[4]) {
+  u32x4 r;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    h2 acc = h2{(_Float16)0.0f, (_Float16)0.0f};
+    acc = acc_term(acc, p0[k], st.w00);
+    acc = acc_term(acc, p1[k], st.w01);
+    acc = acc_term(acc, dm_odd(p0, k), st.w10);
+    acc = acc_term(acc, dm_odd(p1, k), st.w11);
+    unsigned u = __builtin_bit_cast(unsigned, acc);
+    if (k == 3) u &= 0xffffu;
+    r[k] = u;
+  }
+  return r;
+}
+
+// k-step ks: rows (2 ks, 2 ks + 1) in global row order g = 7 l + j
+__device__ __forceinline__ void dm_kstep(int ks, u32x4 lo, u32x4 hi, const _Float16* wlds, int lane, f32x16 (&acc)[4][2]) {
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const auto sw = __builtin_amdgcn_permlane32_swap(lo[v], hi[v], false, false);
+    lo[v] = sw[0];
+    hi[v] = sw[1];
+  }
+  const f16x8 b0 = __builtin_bit_cast(f16x8, lo), b1 = __builtin_bit_cast(f16x8, hi);
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) {
+    const f16x8 af = *reinterpret_cast<const f16x8*>(wlds + (mb * 32 + (lane & 31)) * kEnc2Lds + ks * 16 + (lane >> 5) * 8);
+    acc[mb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, b0, acc[mb][0], 0, 0, 0);
+    acc[mb][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, b1, acc[mb][1], 0, 0, 0);
+  }
+}
+
+// one level of the tile; `nxt` is the state of level L + 1: its window rows are requested into the registers this level
+// retires (nothing follows level 3)
+template <int L, bool CORR>
+__device__ __forceinline__ void dm_level_pipelined(const DmArgs& a, bool live, size_t row, const _Float16* wlds, int lane,
+                                                   unsigned (&raw)[8][8], const DmLevel& cur, const DmLevel& nxt,
+                                                   u32x4& pending, f32x16 (&acc)[4][2]) {
+  h2 P[2][4];
+  dm_pack_row(raw[0], P[0]);
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    dm_pack_row(raw[j + 1], P[(j + 1) & 1]);
+    const u32x4 out = dm_blend_row(cur, P[j & 1], P[(j + 1) & 1]);
+    if (L < 3) {                                    // window row j is retired: its registers take row j of what follows
+      dm_load_row(nxt, j, raw[j]);
+      if (j == 6) dm_load_row(nxt, 7, raw[7]);
     }
-    __syncthreads();
+    if (CORR && live) *reinterpret_cast<u32x4*>(a.corr_cl + row * 256 + L * 64 + j * 8) = out;
+    const int g = 7 * L + j;
+#ifdef EXP_DM_NO_MFMA
+    acc[0][0][g & 15] += __uint_as_float(out[0] ^ out[1] ^ out[2] ^ out[3]);      // ablation: keep the blend alive, no MFMA
+#else
+    if (g & 1) dm_kstep(g >> 1, pending, out, wlds, lane, acc);
+    else pending = out;
+#endif
   }
-  f32x16 acc[4][2];
-  if (ENC) {
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-      for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.0f;
-  }
-  dm_level<0, CORR, ENC>(a, slot_tile, sy, sx, lane, x0, y0, live, row, wlds, acc);
-  dm_level<1, CORR, ENC>(a, slot_tile, sy, sx, lane, x0, y0, live, row, wlds, acc);
-  dm_level<2, CORR, ENC>(a, slot_tile, sy, sx, lane, x0, y0, live, row, wlds, acc);
-  dm_level<3, CORR, ENC>(a, slot_tile, sy, sx, lane, x0, y0, live, row, wlds, acc);
+  if (CORR && live) *reinterpret_cast<u32x4*>(a.corr_cl + row * 256 + L * 64 + 56) = u32x4{0u, 0u, 0u, 0u};
+}
 
-  if (ENC) {
-    // C/D of 32x32: lane holds channel 32 mb + 8 (r >> 2) + 4 (lane >> 5) + (r & 3) of pixel 32 nb + (lane & 31).  Swapping the
-    // upper half of block 0 with the lower half of block 1 leaves every lane with ITS pixel: acc[mb][0][r] = channels
-    // 32 mb + 8 g + (r & 3), acc[mb][1][r] = the same + 4 -> 8 consecutive channels = one 16-byte store.
-    _Float16* op = a.enc_out + row * (size_t)a.enc_stride;
+// a work unit = (edge n, tile): only the wave-uniform part is kept across the pipeline, the lane's pixel is recomputed
+struct DmUnit { int n, tile, slot_tile; };
+struct DmPixel { int sy, sx, pix; bool live; };
+__device__ __forceinline__ void dm_unit(const DmArgs& a, int unit, DmUnit& u) {
+  const int ntiles = a.ntx * a.nty;
+  u.n = unit / ntiles;
+  u.tile = unit - u.n * ntiles;
+  const int slot = a.slots ? a.slots[u.n] : u.n;
+  u.slot_tile = __builtin_amdgcn_readfirstlane(slot * ntiles + u.tile);
+}
+__device__ __forceinline__ DmPixel dm_pixel(const DmArgs& a, const DmUnit& u, int lane) {
+  DmPixel p;
+  const int ty = u.tile / a.ntx, tx = u.tile - ty * a.ntx;
+  p.sy = ty * 8 + (lane >> 3);
+  p.sx = tx * 8 + (lane & 7);
+  p.live = p.sy < a.h && p.sx < a.w;
+  p.pix = min(p.sy, a.h - 1) * a.w + min(p.sx, a.w - 1);
+  return p;
+}
+__device__ __forceinline__ float2 dm_coords(const DmArgs& a, const DmUnit& u, const DmPixel& p, bool on) {
+  const int HW = a.h * a.w;
+  float2 c;
+  if (a.coords_xy) c = *reinterpret_cast<const float2*>(a.coords + ((size_t)u.n * HW + p.pix) * 2);
+  else c = make_float2(a.coords[((size_t)u.n * 2 + 0) * HW + p.pix], a.coords[((size_t)u.n * 2 + 1) * HW + p.pix]);
+  if (!(on && p.live)) { c.x = -1.0e6f; c.y = -1.0e6f; }          // padding lanes: every tap out of range, no memory access
+  return c;
+}
+
+// One tile per wave, 4 waves (consecutive tiles) per workgroup.  A persistent form (2 workgroups per CU, waves walking
+// their units with the next tile's level 0 prefetched under the epilogue) was measured and is not faster: the launch is
+// bound by the per-SIMD instruction stream (~3200 vector instructions per tile at 2 waves per SIMD), not by how the tiles
+// are dealt (45 vs 43 us at G8); a ticket counter is much slower (2048 waves hit one word at once: ~90 tickets/us).
+template <bool CORR>
+__global__ __launch_bounds__(256, 2) void corr_dm_encode_kernel(DmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) _Float16 wlds[];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int total = a.N * a.ntx * a.nty;
+  const int HW = a.h * a.w;
+  const int unit = blockIdx.x * 4 + wv;
+  const bool has = unit < total;
+
+  DmUnit u;
+  dm_unit(a, has ? unit : total - 1, u);
+  const DmPixel px = dm_pixel(a, u, lane);
+  const float2 c = dm_coords(a, u, px, has);
+  unsigned raw[8][8];
+  DmLevel cur;
+  dm_setup<0>(a, (size_t)u.slot_tile, px.sy, px.sx, lane, c.x, c.y, cur);
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb) {
+  for (int j = 0; j < 8; ++j) dm_load_row(cur, j, raw[j]);
+  // encoder weights [128][224] -> LDS rows of kEnc2Lds halfs + the bias, behind the first 64 loads
+  // (128 * 28 = 14 * 256 pieces of 16 bytes: all 14 loads of a thread are issued before the first LDS store)
+  {
+    u32x4 wreg[14];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float v[8];
+    for (int k = 0; k < 14; ++k)
+      wreg[k] = *reinterpret_cast<const u32x4*>(a.enc_w + (size_t)(threadIdx.x + 256 * k) * 8);
+    const float bias_in = threadIdx.x < 128 ? a.enc_b[threadIdx.x] : 0.0f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[mb][0][4 * g + r]),
-                                                           __float_as_uint(acc[mb][1][4 * g + r]), false, false);
-          v[r] = __uint_as_float(sw[0]);
-          v[4 + r] = __uint_as_float(sw[1]);
-        }
-        const int ch = 32 * mb + 8 * g;
-        f16x8 o;
+    for (int k = 0; k < 14; ++k) {
+      const int idx = threadIdx.x + 256 * k;
+      const int r = idx / 28, cc = idx - r * 28;
+      *reinterpret_cast<u32x4*>(wlds + r * kEnc2Lds + cc * 8) = wreg[k];
+    }
+    if (threadIdx.x < 128) reinterpret_cast<float*>(wlds + 128 * kEnc2Lds)[threadIdx.x] = bias_in;
+  }
+  __syncthreads();
+  if (!has) return;
+
+  f32x16 acc[4][2];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) o[c] = (_Float16)fmaxf(v[c] + a.enc_b[ch + c], 0.0f);
-        if (live) *reinterpret_cast<f16x8*>(op + ch) = o;
+  for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.0f;
+  u32x4 pending = u32x4{0u, 0u, 0u, 0u};
+  const bool live = px.live;
+  const size_t row = (size_t)u.n * HW + px.pix;
+  DmLevel nxt;
+  dm_setup<1>(a, (size_t)u.slot_tile, px.sy, px.sx, lane, c.x, c.y, nxt);
+  dm_level_pipelined<0, CORR>(a, live, row, wlds, lane, raw, cur, nxt, pending, acc);
+  cur = nxt;
+  dm_setup<2>(a, (size_t)u.slot_tile, px.sy, px.sx, lane, c.x, c.y, nxt);
+  dm_level_pipelined<1, CORR>(a, live, row, wlds, lane, raw, cur, nxt, pending, acc);
+  cur = nxt;
+  dm_setup<3>(a, (size_t)u.slot_tile, px.sy, px.sx, lane, c.x, c.y, nxt);
+  dm_level_pipelined<2, CORR>(a, live, row, wlds, lane, raw, cur, nxt, pending, acc);
+  dm_level_pipelined<3, CORR>(a, live, row, wlds, lane, raw, nxt, nxt, pending, acc);
+
+  // epilogue.  C/D of 32x32: a lane holds channel 32 mb + 8 (r >> 2) + 4 (lane >> 5) + (r & 3) of pixel 32 nb + (lane & 31);
+  // swapping the upper half of block 0 with the lower half of block 1 leaves every lane with ITS pixel: 8 consecutive
+  // channels = one 16-byte store
+  _Float16* op = a.enc_out + row * (size_t)a.enc_stride;
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float v[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[mb][0][4 * g + r]),
+                                                         __float_as_uint(acc[mb][1][4 * g + r]), false, false);
+        v[r] = __uint_as_float(sw[0]);
+        v[4 + r] = __uint_as_float(sw[1]);
       }
+      const int ch = 32 * mb + 8 * g;
+      const float* bl = reinterpret_cast<const float*>(wlds + 128 * kEnc2Lds) + ch;      // uniform address: LDS broadcast
+      f16x8 o;
+#pragma unroll
+      for (int cc = 0; cc < 8; ++cc) o[cc] = (_Float16)fmaxf(v[cc] + bl[cc], 0.0f);
+      if (live) *reinterpret_cast<f16x8*>(op + ch) = o;
     }
   }
 }
@@ -467,21 +643,24 @@ extern "C" int glorie_corr_dm_lookup(const void* const* levels, const int* slots
   a.corr_cl = reinterpret_cast<_Float16*>(corr_cl);
   a.enc_w = reinterpret_cast<const _Float16*>(enc_w); a.enc_b = enc_b;
   a.enc_out = reinterpret_cast<_Float16*>(enc_out); a.enc_stride = enc_stride;
-  const dim3 grid((a.ntx * a.nty + 3) / 4, N);
-  const size_t lds = enc ? sizeof(_Float16) * 128 * kEncLds : 0;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (enc) {
-    static bool attr = false;
-    if (!attr) {
-      GLORIE_TRY(check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(corr_dm_lookup_kernel<false, true>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)));
-      GLORIE_TRY(check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(corr_dm_lookup_kernel<true, true>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)));
-      attr = true;
-    }
+  const long units = (long)N * a.ntx * a.nty;
+  if (units > 0x7fffffffL / 4) return GLORIE_EUNSUPPORTED;
+  if (!enc) {
+    hipLaunchKernelGGL(corr_dm_lookup_kernel, dim3((a.ntx * a.nty + 3) / 4, N), dim3(256), 0, st, a);
+    return check_launch();
   }
-  if (enc && corr_cl) hipLaunchKernelGGL((corr_dm_lookup_kernel<true, true>), grid, dim3(256), lds, st, a);
-  else if (enc) hipLaunchKernelGGL((corr_dm_lookup_kernel<false, true>), grid, dim3(256), lds, st, a);
-  else hipLaunchKernelGGL((corr_dm_lookup_kernel<true, false>), grid, dim3(256), 0, st, a);
+  const size_t lds = sizeof(_Float16) * 128 * kEnc2Lds + 128 * sizeof(float);
+  static int cus = 0;
+  if (!cus) {
+    GLORIE_TRY(check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(corr_dm_encode_kernel<false>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)));
+    GLORIE_TRY(check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(corr_dm_encode_kernel<true>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)));
+    cus = 1;
+  }
+  const unsigned blocks = (unsigned)((units + 3) / 4);
+  if (corr_cl) hipLaunchKernelGGL((corr_dm_encode_kernel<true>), dim3(blocks), dim3(256), lds, st, a);
+  else hipLaunchKernelGGL((corr_dm_encode_kernel<false>), dim3(blocks), dim3(256), lds, st, a);
   return check_launch();
 }

@@ -201,8 +201,8 @@ def corr_dm_lookup(levels, coords, h, w, slots=None, interleaved=False, want_cor
             raise RuntimeError("corr_dm_lookup: enc_out must be an fp16 [N,128,h,w] map, with enc_w and enc_b")
         from .update_ops import _rows
         stride = _rows(enc_out, "enc_out")
-        if tuple(enc_w.shape) != (128, 256) or enc_w.dtype != torch.float16 or not enc_w.is_contiguous():
-            raise RuntimeError("corr_dm_lookup: enc_w must be fp16 [128,256] (update_ops.pack_corr_encoder_dm)")
+        if tuple(enc_w.shape) != (128, 224) or enc_w.dtype != torch.float16 or not enc_w.is_contiguous():
+            raise RuntimeError("corr_dm_lookup: enc_w must be fp16 [128,224] (update_ops.pack_corr_encoder_dm)")
     elif not want_corr:
         raise RuntimeError("corr_dm_lookup: nothing to compute")
     arr = (ctypes.c_void_p * 4)(*[v.data_ptr() for v in levels])

@@ -198,14 +198,15 @@ def pack_corr_encoder(weight):
 
 
 def pack_corr_encoder_dm(weight):
-    """corr_encoder[0] weight [128, 196, 1, 1] -> fp16 [128, 256] for glorie_corr_dm_lookup's fused encoder: column
-    l*64 + j*8 + i takes the reference's column l*49 + i*7 + j (i <-> x offset, j <-> y offset), padding columns zero"""
+    """corr_encoder[0] weight [128, 196, 1, 1] -> fp16 [128, 224] for the fused encoder of glorie_corr_dm_lookup (and of
+    glorie_corr_otf_encode): column l*56 + j*8 + i takes the reference's column l*49 + i*7 + j (i <-> x offset, j <-> y
+    offset), column i == 7 of every row is zero"""
     if tuple(weight.shape) != (128, 196, 1, 1):
         raise RuntimeError("pack_corr_encoder_dm: expected a [128, 196, 1, 1] weight")
     w = weight.detach().reshape(128, 4, 7, 7)                  # [n][level][i][j]
-    wp = torch.zeros(128, 4, 8, 8, dtype=torch.float16, device=w.device)
-    wp[:, :, :7, :7] = w.permute(0, 1, 3, 2).half()           # [n][level][j][i]
-    return wp.reshape(128, 256).contiguous()
+    wp = torch.zeros(128, 4, 7, 8, dtype=torch.float16, device=w.device)
+    wp[..., :7] = w.permute(0, 1, 3, 2).half()                # [n][level][j][i]
+    return wp.reshape(128, 224).contiguous()
 
 
 def conv_igemm(xa, xb, w_packed, taps, nout, out, epilogue=EPI_BIAS_ACT, terms=None, act=ACT_NONE,

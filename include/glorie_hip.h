@@ -133,8 +133,9 @@ int glorie_corr_lookup_tiled_cl(const void* const* levels, int num_levels, const
  *   tap zero (the layout of glorie_corr_lookup_tiled_cl).
  *   enc_out: NULL or fp16 rows of enc_stride halfs per edge-pixel (a channels-last [N,128,h,w] map or a 128-channel slice of
  *   a wider one; enc_stride % 8 == 0, 16-byte aligned): enc_out[(n*h*w + p)*enc_stride + o] = relu(sum_k enc_w[o][k] corr[k] +
- *   enc_b[o]), fp32 accumulation over the fp16 lookup values; enc_w fp16 [128][256] with column l*64 + j*8 + i =
- *   W[o][l*49 + i*7 + j], zero for i == 7 or j == 7 (update_ops.pack_corr_encoder_dm); enc_b f32 [128].
+ *   enc_b[o]), fp32 accumulation over the fp16 lookup values; enc_w fp16 [128][224] with column l*56 + j*8 + i =
+ *   W[o][l*49 + i*7 + j], zero for i == 7 (the packing of glorie_corr_otf_encode: update_ops.pack_corr_encoder_dm);
+ *   enc_b f32 [128].
  *   At least one of corr_cl / enc_out must be given. */
 long glorie_corr_dm_level_halfs(int h, int w, int level);
 int glorie_corr_dm_build(const void* fmaps_cl, const int64_t* ii, const int64_t* jj, const int* slots,

@@ -151,4 +151,5 @@ def test_feature_adam_follows_lr_changes_between_steps(gpu):
         oa.step()
         ob.step()
         for a, b in zip(pa, pb):
-            torch.testing.assert_close(b.detach(), a.detach(), rtol=1e-5, atol=1e-7)
+            # (a stale learning rate is an O(lr) = 1e-3 .. 3e-2 error per step; fp32 rounding of the update is ~1e-7)
+            torch.testing.assert_close(b.detach(), a.detach(), rtol=1e-5, atol=1e-6)

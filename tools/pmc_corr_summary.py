@@ -14,8 +14,8 @@ uni_bytes = int(re.search(r"uniform_flow_lines \d+ bytes (\d+)", open(f"{d}/fetc
 
 def groups(rs):
     copy = [r for r in rs if "copyBuffer" in r["Kernel_Name"]][-1]
-    dm_enc = [r for r in rs if "corr_dm_lookup_kernelILb0ELb1" in r["Kernel_Name"] or "corr_dm_lookup_kernel<false, true>" in r["Kernel_Name"]]
-    dm_cl = [r for r in rs if "corr_dm_lookup_kernelILb1ELb0" in r["Kernel_Name"] or "corr_dm_lookup_kernel<true, false>" in r["Kernel_Name"]]
+    dm_enc = [r for r in rs if "corr_dm_encode_kernel" in r["Kernel_Name"]]
+    dm_cl = [r for r in rs if "corr_dm_lookup_kernel" in r["Kernel_Name"]]
     tiled = [r for r in rs if "corr_lookup_r3_tiled" in r["Kernel_Name"]]
     v = lambda r: float(r["Counter_Value"])
     m = lambda q: sum(map(v, q)) / len(q)
