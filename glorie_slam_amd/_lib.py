@@ -84,7 +84,7 @@ SIGNATURES = {
     "glorie_idw_gather2": (_c_int, [_vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_f, _vp, _c_int,
                                     _c_int, _vp, _vp, _vp, _vp, _vp]),
     "glorie_decoder_pack_floats": (_sz, []),
-    "glorie_render_mlp": (_c_int, [_vp] * 10 + [_c_int, _vp, _vp, _c_int, _vp]),
+    "glorie_render_mlp": (_c_int, [_vp] * 10 + [_c_int, _vp, _vp, _c_int, _vp, _vp]),
     "glorie_composite": (_c_int, [_vp, _vp, _c_int, _c_int, _c_f, _vp, _vp, _vp, _vp, _vp]),
     "glorie_ray_samples": (_c_int, [_vp] * 5 + [_c_int, _c_int, _c_f, _c_f] + [_vp] * 6),
     "glorie_ray_samples_camera": (_c_int, [_vp, _c_int, ctypes.c_long] + [_vp] * 3 + [_c_int, _c_int, _c_f, _c_f] + [_vp] * 6),

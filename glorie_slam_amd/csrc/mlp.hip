@@ -462,6 +462,18 @@ __device__ __forceinline__ void split2(const f32x4 a, const f32x4 b, h16x8& hi, 
     lo[s] = (_Float16)(v[s] - (float)hi[s]);
   }
 }
+// Range guard of the split kernels.  The split holds |x| <= 65504 (fp16 max).  A larger operand becomes hi = inf,
+// lo = x - inf = -inf, and its products a.hi * inf + a.hi * (-inf) are NaN in EVERY output channel it feeds; softplus, the
+// (NaN-keeping) ReLU below, the biases, the next split and the fp32 output layers all pass a NaN on, so an overflow anywhere
+// in a network surfaces as a non-finite value at its output.  The kernels therefore test only what they are about to store
+// (a handful of values per lane - tracking max |x| at every split costs ~100 registers' worth of spills in the colour
+// kernel) and raise the caller's flag; the host then repeats the call on the exact-fp32 MFMA kernels.  (Small magnitudes are
+// safe: below 2^-3 the low half falls into fp16 subnormals and the split's error becomes ABSOLUTE, 2^-25 per operand.)
+__device__ __forceinline__ bool not_finite(float x) { return !(__builtin_fabsf(x) <= 3.0e38f); }
+__device__ __forceinline__ float relu_keep_nan(float x) { return x < 0.0f ? 0.0f : x; }
+__device__ __forceinline__ void report_range(bool bad, int* __restrict__ range_flag) {
+  if (range_flag && __builtin_amdgcn_ballot_w64(bad) != 0 && (threadIdx.x & 63) == 0) atomicOr(range_flag, 1);
+}
 // acc[to] += W_chunk[:, 16 to ..] . b   with b given as split halfs
 __device__ __forceinline__ void mma_h3(f32x4 (&acc)[8], const h16x8 bhi, const h16x8 blo, const float* Wb) {
   const int lane = threadIdx.x & 63;
@@ -479,7 +491,8 @@ __global__ __launch_bounds__(512, 4) void mlp_col_v4_kernel(ColParams P, const f
                                                             const float* __restrict__ pts,
                                                             const float* __restrict__ views,
                                                             const float* __restrict__ c_col, int Q,
-                                                            float* __restrict__ raw) {
+                                                            float* __restrict__ raw, int* __restrict__ range_flag) {
+  bool bad = false;
   extern __shared__ float smem[];
   float* Wbuf = smem;                         // [2][4096]
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
@@ -607,9 +620,193 @@ __global__ __launch_bounds__(512, 4) void mlp_col_v4_kernel(ColParams P, const f
   }
   if (g == 0 && qs < Q) {
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch)
+    for (int ch = 0; ch < 3; ++ch) {
+      bad = bad | not_finite(o[ch]);
       raw[(size_t)qs * 4 + ch] = 1.0f / (1.0f + __expf(-(o[ch] + P.bout[ch])));
+    }
   }
+  report_range(bad, range_flag);
+}
+
+// ---- colour decoder, round 3: NB column blocks (16 NB samples) per wave ------------------------------------------------
+// mlp_col_v4_kernel gives a wave 16 samples: every A fragment (weights) read from LDS feeds 3 MFMAs, and the 442 KB weight
+// stream is re-staged for every 128 samples - LDS reads (1 KB per 3 x 16 MFMA cycles and wave: 1024 LDS cycles against 768
+// matrix cycles per chunk and CU) and the L2 -> LDS stream (2.1 GB per 614k-sample batch) bound it, not the matrix pipe
+// (MfmaUtil 41 %).  Here a wave owns NB = 2 blocks of 16 samples: an A fragment feeds 6 MFMAs, a workgroup of WAVES waves
+// covers 32 WAVES samples per staged chunk, and the second block's vector work (softplus, splits) overlaps the first one's
+// MFMAs inside the same wave.  Same packed weights, same arithmetic per sample (bit-identical results to v4).
+template <int THREADS>
+__device__ __forceinline__ void chunk_copy16(const float* __restrict__ W16, int chunk, float4 (&regs)[4096 / 4 / THREADS]) {
+  const float4* src = reinterpret_cast<const float4*>(W16 + (size_t)chunk * kChunkFloats16);
+#pragma unroll
+  for (int i = 0; i < 4096 / 4 / THREADS; ++i) regs[i] = src[threadIdx.x + i * THREADS];
+}
+template <int THREADS>
+__device__ __forceinline__ void chunk_put16(float* Wb, const float4 (&regs)[4096 / 4 / THREADS]) {
+  float4* dst = reinterpret_cast<float4*>(Wb);
+#pragma unroll
+  for (int i = 0; i < 4096 / 4 / THREADS; ++i) dst[threadIdx.x + i * THREADS] = regs[i];
+}
+
+template <int NB>
+__device__ __forceinline__ void mma_h3n(f32x4 (&acc)[NB][8], const h16x8 (&bhi)[NB], const h16x8 (&blo)[NB], const float* Wb) {
+  const int lane = threadIdx.x & 63;
+  const h16x8* wp = reinterpret_cast<const h16x8*>(Wb) + lane;
+#pragma unroll
+  for (int to = 0; to < 8; ++to) {
+    const h16x8 ahi = wp[to * 64], alo = wp[(8 + to) * 64];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      acc[nb][to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, bhi[nb], acc[nb][to], 0, 0, 0);
+      acc[nb][to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, blo[nb], acc[nb][to], 0, 0, 0);
+      acc[nb][to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, bhi[nb], acc[nb][to], 0, 0, 0);
+    }
+  }
+}
+
+template <int NB, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, NB == 1 ? 4 : 2)
+void mlp_col_v5_kernel(ColParams P, const float* __restrict__ W16, const float* __restrict__ pts,
+                       const float* __restrict__ views, const float* __restrict__ c_col, int Q, float* __restrict__ raw,
+                       int* __restrict__ range_flag) {
+  bool bad = false;
+  constexpr int THREADS = WAVES * 64;
+  extern __shared__ float smem[];
+  float* Wbuf = smem;                         // [2][4096]
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  const int r = lane & 15, g = lane >> 4;
+  const int q0 = blockIdx.x * (WAVES * 16 * NB);
+  int qs[NB], q[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    qs[nb] = q0 + (wv * NB + nb) * 16 + r;    // this lane's sample of block nb (all four k-slots of a column share it)
+    q[nb] = min(qs[nb], Q - 1);
+  }
+  h16x8 ehi[3][NB], elo[3][NB], chi[NB], clo[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const size_t qq = (size_t)q[nb];
+    const float px = pts[qq * 3 + 0], py = pts[qq * 3 + 1], pz = pts[qq * 3 + 2];
+    float vx = views[qq * 3 + 0], vy = views[qq * 3 + 1], vz = views[qq * 3 + 2];
+    const float nrm = fmaxf(sqrtf(vx * vx + vy * vy + vz * vz), 1e-12f);
+    vx = vx / nrm; vy = vy / nrm; vz = vz / nrm;
+    f32x4 e[6];
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int f = 16 * t + 4 * g + rr;   // feature index 0..79: [sin p | cos p | sin v | cos v] x 20
+        const int blk = f / 20, ff = f - blk * 20;
+        const float* Bm = blk < 2 ? P.Bp : P.Bv;
+        const float x = blk < 2 ? px : vx, y = blk < 2 ? py : vy, z = blk < 2 ? pz : vz;
+        const float a = fmaf(z, Bm[40 + ff], fmaf(y, Bm[20 + ff], x * Bm[ff]));
+        e[t][rr] = (blk & 1) ? cos_rev(a) : sin_rev(a);
+      }
+    e[5] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) split2(e[2 * c], e[2 * c + 1], ehi[c][nb], elo[c][nb]);
+    const float4 v0 = *reinterpret_cast<const float4*>(c_col + qq * 32 + 4 * g);
+    const float4 v1 = *reinterpret_cast<const float4*>(c_col + qq * 32 + 16 + 4 * g);
+    split2(f32x4{v0.x, v0.y, v0.z, v0.w}, f32x4{v1.x, v1.y, v1.z, v1.w}, chi[nb], clo[nb]);
+  }
+
+  f32x4 acc[NB][8];
+  h16x8 hhi[4][NB], hlo[4][NB];
+  constexpr int NC = 27;
+  float4 nxt[4096 / 4 / THREADS];
+  chunk_copy16<THREADS>(W16, 0, nxt);
+  chunk_put16<THREADS>(Wbuf, nxt);
+  __syncthreads();
+
+  auto act = [&](int li) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const float4 bb = *reinterpret_cast<const float4*>(P.bias + li * 128 + 16 * t + 4 * g);
+      const float4 fb = *reinterpret_cast<const float4*>(P.fcb + li * 128 + 16 * t + 4 * g);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        acc[nb][t][0] = softplus100_fast(acc[nb][t][0] + bb.x) + fb.x;
+        acc[nb][t][1] = softplus100_fast(acc[nb][t][1] + bb.y) + fb.y;
+        acc[nb][t][2] = softplus100_fast(acc[nb][t][2] + bb.z) + fb.z;
+        acc[nb][t][3] = softplus100_fast(acc[nb][t][3] + bb.w) + fb.w;
+      }
+    }
+  };
+  auto next_layer = [&]() {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) split2(acc[nb][2 * c], acc[nb][2 * c + 1], hhi[c][nb], hlo[c][nb]);
+      zero<8>(acc[nb]);
+    }
+  };
+
+#define GL_CHUNK(cidx, BHI, BLO)                                    \
+  {                                                                 \
+    if ((cidx) + 1 < NC) chunk_copy16<THREADS>(W16, (cidx) + 1, nxt); \
+    mma_h3n<NB>(acc, BHI, BLO, Wbuf + ((cidx) & 1) * kChunkFloats16); \
+    if ((cidx) + 1 < NC) chunk_put16<THREADS>(Wbuf + (((cidx) + 1) & 1) * kChunkFloats16, nxt); \
+    __syncthreads();                                                \
+  }
+
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) zero<8>(acc[nb]);
+  GL_CHUNK(0, ehi[0], elo[0])
+  GL_CHUNK(1, ehi[1], elo[1])
+  GL_CHUNK(2, ehi[2], elo[2])
+  act(0);
+  GL_CHUNK(3, chi, clo)
+  next_layer();
+  GL_CHUNK(4, hhi[0], hlo[0])
+  GL_CHUNK(5, hhi[1], hlo[1])
+  GL_CHUNK(6, hhi[2], hlo[2])
+  GL_CHUNK(7, hhi[3], hlo[3])
+  act(1);
+  GL_CHUNK(8, chi, clo)
+  next_layer();
+  GL_CHUNK(9, hhi[0], hlo[0])
+  GL_CHUNK(10, hhi[1], hlo[1])
+  GL_CHUNK(11, hhi[2], hlo[2])
+  GL_CHUNK(12, hhi[3], hlo[3])
+  act(2);
+  GL_CHUNK(13, chi, clo)
+  next_layer();                               // layer 3 (skip): W3e on the embedding, W3h on the hidden state
+  GL_CHUNK(14, ehi[0], elo[0])
+  GL_CHUNK(15, ehi[1], elo[1])
+  GL_CHUNK(16, ehi[2], elo[2])
+  GL_CHUNK(17, hhi[0], hlo[0])
+  GL_CHUNK(18, hhi[1], hlo[1])
+  GL_CHUNK(19, hhi[2], hlo[2])
+  GL_CHUNK(20, hhi[3], hlo[3])
+  act(3);
+  GL_CHUNK(21, chi, clo)
+  next_layer();
+  GL_CHUNK(22, hhi[0], hlo[0])
+  GL_CHUNK(23, hhi[1], hlo[1])
+  GL_CHUNK(24, hhi[2], hlo[2])
+  GL_CHUNK(25, hhi[3], hlo[3])
+  act(4);
+  GL_CHUNK(26, chi, clo)
+#undef GL_CHUNK
+  // output layer 128 -> 3 in fp32 as in mlp_col_v3_kernel
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* wp = P.Wout + (4 * g) * 16 + r;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr)
+        o = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[(16 * t + rr) * 16], acc[nb][t][rr], o, 0, 0, 0);
+    if (g == 0 && qs[nb] < Q) {
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        bad = bad | not_finite(o[ch]);
+        raw[(size_t)qs[nb] * 4 + ch] = 1.0f / (1.0f + __expf(-(o[ch] + P.bout[ch])));
+      }
+    }
+  }
+  report_range(bad, range_flag);
 }
 
 // per-neighbour F_theta, transposed formulation (see mlp_col_v3_kernel): W1 (52 x 128) resident in LDS with
@@ -778,52 +975,76 @@ __global__ __launch_bounds__(512, 4) void mlp_geo_v4_kernel(GeoParams P, const f
                                                             const int64_t* __restrict__ I,
                                                             const float* __restrict__ wts,
                                                             const uint8_t* __restrict__ has, int Q,
-                                                            float* __restrict__ raw) {
+                                                            float* __restrict__ raw, int* __restrict__ range_flag) {
+  bool bad = false;
   extern __shared__ float smem[];              // [15][1024] fragments | [32][16] output layer
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   const int r = lane & 15, g = lane >> 4;
-  const int qs = blockIdx.x * kTM2 + wv * 16 + r;
-  const int q = min(qs, Q - 1);
 #pragma unroll 2
   for (int idx = tid; idx < kGeoFrag / 4; idx += 512)
     reinterpret_cast<float4*>(smem)[idx] = reinterpret_cast<const float4*>(frags)[idx];
   if (tid < 128) reinterpret_cast<float4*>(smem + kGeoFrag)[tid] = reinterpret_cast<const float4*>(wout)[tid];
+  __syncthreads();
+  // persistent over the sample blocks: the 61 KB of fragments are staged once per workgroup (a launch used to stage them
+  // for every 128 samples, 4800 times per 614k-sample batch, with the first MFMA of a workgroup waiting behind it)
+  const int nblk = (Q + kTM2 - 1) / kTM2;
+  // per-sample inputs of a block: position, neighbour ids, IDW weights.  They are requested one block AHEAD, so a block's
+  // feature gather (which needs the ids) starts at once instead of behind a second dependent memory round trip
+  struct Meta { float x, y, z; int id[8]; float wk[8]; bool on; };
+  auto load_meta = [&](int blk, Meta& m) {
+    const int qq = min(blk * kTM2 + wv * 16 + r, Q - 1);
+    m.x = pts[(size_t)qq * 3 + 0]; m.y = pts[(size_t)qq * 3 + 1]; m.z = pts[(size_t)qq * 3 + 2];
+    m.on = has[qq] != 0;
+    if (geo_feats) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        m.id[k] = (int)max(I[(size_t)qq * 8 + k], 0L);
+        m.wk[k] = wts[(size_t)qq * 8 + k];
+      }
+    }
+  };
+  Meta cur;
+  if ((int)blockIdx.x < nblk) load_meta(blockIdx.x, cur);
+  for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+  const int qs = blk * kTM2 + wv * 16 + r;
+  const int q = min(qs, Q - 1);
   h16x8 chi, clo, hhi, hlo;
   f32x4 acc[2];
-  const float x = pts[(size_t)q * 3 + 0], y = pts[(size_t)q * 3 + 1], z = pts[(size_t)q * 3 + 2];
+  const float x = cur.x, y = cur.y, z = cur.z;
+  const bool on = cur.on;
+  Meta nxt = cur;
   {
     f32x4 c[2];
     if (geo_feats) {
       // IDW interpolation of the neighbours' features (decoder.py:130-173), as in mlp_geo_v3_kernel
       c[0] = f32x4{0.f, 0.f, 0.f, 0.f};
       c[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const bool on = has[q] != 0;
       constexpr int GEO_NB = GLORIE_GEO_NB;
 #pragma unroll
       for (int k0 = 0; k0 < 8; k0 += GEO_NB) {
-        float wk[GEO_NB];
         float4 v[GEO_NB][2];
 #pragma unroll
         for (int k = 0; k < GEO_NB; ++k) {
-          wk[k] = wts[(size_t)q * 8 + k0 + k];
-          const long ik = max(I[(size_t)q * 8 + k0 + k], 0L);
 #pragma unroll
           for (int t = 0; t < 2; ++t)
-            v[k][t] = *reinterpret_cast<const float4*>(geo_feats + (size_t)ik * 32 + 16 * t + 4 * g);
+            v[k][t] = *reinterpret_cast<const float4*>(geo_feats + (size_t)cur.id[k0 + k] * 32 + 16 * t + 4 * g);
         }
+        if (k0 == 0 && blk + (int)gridDim.x < nblk) load_meta(blk + gridDim.x, nxt);   // behind the first gathers
 #pragma unroll
         for (int k = 0; k < GEO_NB; ++k) {
-          const bool use = on && wk[k] != 0.0f;
+          const float wk = cur.wk[k0 + k];
+          const bool use = on && wk != 0.0f;
 #pragma unroll
           for (int t = 0; t < 2; ++t) {
-            c[t][0] = use ? c[t][0] + wk[k] * v[k][t].x : c[t][0];
-            c[t][1] = use ? c[t][1] + wk[k] * v[k][t].y : c[t][1];
-            c[t][2] = use ? c[t][2] + wk[k] * v[k][t].z : c[t][2];
-            c[t][3] = use ? c[t][3] + wk[k] * v[k][t].w : c[t][3];
+            c[t][0] = use ? c[t][0] + wk * v[k][t].x : c[t][0];
+            c[t][1] = use ? c[t][1] + wk * v[k][t].y : c[t][1];
+            c[t][2] = use ? c[t][2] + wk * v[k][t].z : c[t][2];
+            c[t][3] = use ? c[t][3] + wk * v[k][t].w : c[t][3];
           }
         }
       }
     } else {
+      if (blk + (int)gridDim.x < nblk) load_meta(blk + gridDim.x, nxt);
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const float4 v = *reinterpret_cast<const float4*>(c_geo + (size_t)q * 32 + 16 * t + 4 * g);
@@ -832,16 +1053,15 @@ __global__ __launch_bounds__(512, 4) void mlp_geo_v4_kernel(GeoParams P, const f
     }
     split2(c[0], c[1], chi, clo);
   }
-  __syncthreads();
   auto act = [&](int li) {   // ReLU(acc + bias) + fc_c bias
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const float4 bb = *reinterpret_cast<const float4*>(P.bias + li * 32 + 16 * t + 4 * g);
       const float4 fb = *reinterpret_cast<const float4*>(P.fcb + li * 32 + 16 * t + 4 * g);
-      acc[t][0] = fmaxf(acc[t][0] + bb.x, 0.0f) + fb.x;
-      acc[t][1] = fmaxf(acc[t][1] + bb.y, 0.0f) + fb.y;
-      acc[t][2] = fmaxf(acc[t][2] + bb.z, 0.0f) + fb.z;
-      acc[t][3] = fmaxf(acc[t][3] + bb.w, 0.0f) + fb.w;
+      acc[t][0] = relu_keep_nan(acc[t][0] + bb.x) + fb.x;
+      acc[t][1] = relu_keep_nan(acc[t][1] + bb.y) + fb.y;
+      acc[t][2] = relu_keep_nan(acc[t][2] + bb.z) + fb.z;
+      acc[t][3] = relu_keep_nan(acc[t][3] + bb.w) + fb.w;
     }
   };
   auto next_layer = [&]() {
@@ -890,7 +1110,13 @@ __global__ __launch_bounds__(512, 4) void mlp_geo_v4_kernel(GeoParams P, const f
       for (int rr = 0; rr < 4; ++rr)
         o = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[(16 * t + rr) * 16], acc[t][rr], o, 0, 0, 0);
   }
-  if (g == 0 && qs < Q) raw[(size_t)qs * 4 + 3] = has[qs] ? o[0] + P.bout[0] : -100.0f;  // Renderer.py:206-207
+  if (g == 0 && qs < Q) {
+    bad = bad | (on && not_finite(o[0]));
+    raw[(size_t)qs * 4 + 3] = on ? o[0] + P.bout[0] : -100.0f;  // Renderer.py:206-207
+  }
+  cur = nxt;
+  }
+  report_range(bad, range_flag);
 }
 
 // per-neighbour F_theta on the fp16 matrix cores with the 3-term split (see mlp_col_v4_kernel).  The 52 input channels of a
@@ -905,7 +1131,8 @@ __global__ __launch_bounds__(512, 4) void mlp_nb_v4_kernel(NbParams P, const flo
                                                            const int64_t* __restrict__ I,
                                                            const float* __restrict__ wts,
                                                            const uint8_t* __restrict__ has, int Q,
-                                                           float* __restrict__ c_col) {
+                                                           float* __restrict__ c_col, int* __restrict__ range_flag) {
+  bool bad = false;
   extern __shared__ float smem[];
   h16x8* W1f = reinterpret_cast<h16x8*>(smem);   // [2 chunks][2 hi|lo][8][64] fragments of 8 halfs = 32 KB
   float* b1s = smem + 8192;                   // [128]
@@ -1016,9 +1243,146 @@ __global__ __launch_bounds__(512, 4) void mlp_nb_v4_kernel(NbParams P, const flo
       v.y = h ? o[t][1] + b2.y * sw : 0.0f;
       v.z = h ? o[t][2] + b2.z * sw : 0.0f;
       v.w = h ? o[t][3] + b2.w * sw : 0.0f;
+      bad = bad | not_finite(v.x + v.y + v.z + v.w);
       *reinterpret_cast<float4*>(c_col + (size_t)qs * 32 + 16 * t + 4 * g) = v;
     }
   }
+  report_range(bad, range_flag);
+}
+
+// per-neighbour F_theta, round 3: NB column blocks per wave (see mlp_col_v5_kernel): every W1 fragment read from LDS feeds
+// 3 NB MFMAs, and the softplus of one block runs under the MFMAs of the other inside the same wave.
+template <int NB, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, NB == 1 ? 4 : 2)
+void mlp_nb_v5_kernel(NbParams P, const float* __restrict__ W1frag, const float* __restrict__ pts,
+                      const float* __restrict__ cloud, const float* __restrict__ col_feats,
+                      const int64_t* __restrict__ I, const float* __restrict__ wts, const uint8_t* __restrict__ has,
+                      int Q, float* __restrict__ c_col, int* __restrict__ range_flag) {
+  bool bad = false;
+  constexpr int THREADS = WAVES * 64, SPW = WAVES * 16 * NB;     // samples per workgroup
+  extern __shared__ float smem[];
+  h16x8* W1f = reinterpret_cast<h16x8*>(smem);   // [2 chunks][2 hi|lo][8][64] fragments of 8 halfs = 32 KB
+  float* b1s = smem + 8192;                   // [128]
+  float* wbuf = b1s + 128;                    // [SPW][8] IDW weights (0 for an absent neighbour)
+  int* ibuf = reinterpret_cast<int*>(wbuf + SPW * 8);  // [SPW][8] neighbour ids (0 for an absent one)
+  float* bs = reinterpret_cast<float*>(ibuf + SPW * 8);  // [20][4] B[:, f mod 10] (revolutions per metre)
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  const int r = lane & 15, g = lane >> 4;
+  const int q0 = blockIdx.x * SPW;
+  if (tid < 80) {
+    const int f = tid >> 2, d = tid & 3;
+    bs[tid] = d < 3 ? P.B[d * 10 + (f < 10 ? f : f - 10)] : 0.0f;
+  }
+  for (int idx = tid; idx < 8192 / 4; idx += THREADS)        // the split fragments as packed (point_ops.pack_decoders)
+    reinterpret_cast<float4*>(smem)[idx] = reinterpret_cast<const float4*>(W1frag)[idx];
+  if (tid < 128) b1s[tid] = P.b1[tid];
+  for (int idx = tid; idx < SPW * 8; idx += THREADS) {
+    const int row = idx >> 3;
+    const int q = min(q0 + row, Q - 1);
+    const int ii = (int)I[(size_t)q * 8 + (idx & 7)];
+    wbuf[idx] = (q0 + row < Q && ii >= 0) ? wts[(size_t)q * 8 + (idx & 7)] : 0.0f;
+    ibuf[idx] = ii < 0 ? 0 : ii;
+  }
+  __syncthreads();
+  int srow[NB], qs[NB];
+  float qx[NB], qy[NB], qz[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    srow[nb] = (wv * NB + nb) * 16 + r;       // this lane's sample row inside the workgroup
+    qs[nb] = q0 + srow[nb];
+    const size_t q = (size_t)min(qs[nb], Q - 1);
+    qx[nb] = pts[q * 3 + 0]; qy[nb] = pts[q * 3 + 1]; qz[nb] = pts[q * 3 + 2];
+  }
+  const float* bsl = bs + 4 * g;
+  f32x4 ysum[NB][8];
+  float sw[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) { zero<8>(ysum[nb]); sw[nb] = 0.0f; }
+  const h16x8* wl = W1f + lane;
+#pragma unroll 1
+  for (int k = 0; k < 8; ++k) {
+    h16x8 ehi[NB], elo[NB], fhi[NB], flo[NB];
+    float w[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int pt = ibuf[srow[nb] * 8 + k];
+      w[nb] = wbuf[srow[nb] * 8 + k];
+      const float4 c0 = *reinterpret_cast<const float4*>(col_feats + (size_t)pt * 32 + 4 * g);
+      const float4 c1 = *reinterpret_cast<const float4*>(col_feats + (size_t)pt * 32 + 16 + 4 * g);
+      const float rx = cloud[(size_t)pt * 3 + 0] - qx[nb], ry = cloud[(size_t)pt * 3 + 1] - qy[nb],
+                  rz = cloud[(size_t)pt * 3 + 2] - qz[nb];
+      float ev[8];
+#pragma unroll
+      for (int sidx = 0; sidx < 5; ++sidx) {
+        const float4 bf = *reinterpret_cast<const float4*>(bsl + 16 * sidx);
+        const float a = fmaf(rz, bf.z, fmaf(ry, bf.y, rx * bf.x));
+        ev[sidx] = (4 * sidx + g >= 10) ? cos_rev(a) : sin_rev(a);
+      }
+      ev[5] = ev[6] = ev[7] = 0.0f;
+      split2(f32x4{ev[0], ev[1], ev[2], ev[3]}, f32x4{ev[4], ev[5], ev[6], ev[7]}, ehi[nb], elo[nb]);
+      split2(f32x4{c0.x, c0.y, c0.z, c0.w}, f32x4{c1.x, c1.y, c1.z, c1.w}, fhi[nb], flo[nb]);
+    }
+    f32x4 acc[NB][8];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) zero<8>(acc[nb]);
+    // chunk 0: embedding features; chunk 1: the neighbour's colour feature
+#pragma unroll
+    for (int to = 0; to < 8; ++to) {
+      const h16x8 ahi = wl[to * 64], alo = wl[(8 + to) * 64];
+      const h16x8 bhi = wl[(16 + to) * 64], blo = wl[(24 + to) * 64];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        acc[nb][to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, ehi[nb], acc[nb][to], 0, 0, 0);
+        acc[nb][to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, elo[nb], acc[nb][to], 0, 0, 0);
+        acc[nb][to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, ehi[nb], acc[nb][to], 0, 0, 0);
+        acc[nb][to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bhi, fhi[nb], acc[nb][to], 0, 0, 0);
+        acc[nb][to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bhi, flo[nb], acc[nb][to], 0, 0, 0);
+        acc[nb][to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(blo, fhi[nb], acc[nb][to], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);     // keeps the compiler from hoisting all 32 fragment reads (128 registers)
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      sw[nb] += w[nb];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const float4 bb = *reinterpret_cast<const float4*>(b1s + 16 * t + 4 * g);
+        ysum[nb][t][0] += w[nb] * softplus100_fast(acc[nb][t][0] + bb.x);
+        ysum[nb][t][1] += w[nb] * softplus100_fast(acc[nb][t][1] + bb.y);
+        ysum[nb][t][2] += w[nb] * softplus100_fast(acc[nb][t][2] + bb.z);
+        ysum[nb][t][3] += w[nb] * softplus100_fast(acc[nb][t][3] + bb.w);
+      }
+    }
+  }
+  // second layer 128 -> 32 in fp32 as in mlp_nb_v3_kernel (A = W2 straight from global / L2)
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    f32x4 o[2];
+    zero<2>(o);
+    const float* wp = P.W2 + (4 * g) * 32 + r;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        o[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[(16 * t + rr) * 32], ysum[nb][t][rr], o[0], 0, 0, 0);
+        o[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[(16 * t + rr) * 32 + 16], ysum[nb][t][rr], o[1], 0, 0, 0);
+      }
+    if (qs[nb] < Q) {
+      const bool h = has[qs[nb]] != 0;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const float4 b2 = *reinterpret_cast<const float4*>(P.b2 + 16 * t + 4 * g);
+        float4 v;
+        v.x = h ? o[t][0] + b2.x * sw[nb] : 0.0f;
+        v.y = h ? o[t][1] + b2.y * sw[nb] : 0.0f;
+        v.z = h ? o[t][2] + b2.z * sw[nb] : 0.0f;
+        v.w = h ? o[t][3] + b2.w * sw[nb] : 0.0f;
+        bad = bad | not_finite(v.x + v.y + v.z + v.w);
+        *reinterpret_cast<float4*>(c_col + (size_t)qs[nb] * 32 + 16 * t + 4 * g) = v;
+      }
+    }
+  }
+  report_range(bad, range_flag);
 }
 
 }  // namespace glorie
@@ -1046,7 +1410,9 @@ extern "C" int glorie_render_mlp(const float* packed, const float* pts, const fl
                                  const float* cloud_pos, const float* col_feats,
                                  const float* c_geo, const float* geo_feats, const int64_t* I,
                                  const float* weights, const uint8_t* has, int Q, float* c_col_scratch,
-                                 float* raw, int stage_color, void* stream) {
+                                 float* raw, int stage_flags, int* range_flag, void* stream) {
+  const int stage_color = stage_flags & 1;
+  const bool force_f32 = (stage_flags & 2) != 0;
   if (Q < 0) return GLORIE_EINVAL;
   if (Q == 0) return GLORIE_OK;
   if (!packed || !pts || !has || !raw) return GLORIE_EINVAL;
@@ -1082,7 +1448,7 @@ extern "C" int glorie_render_mlp(const float* packed, const float* pts, const fl
     geo_attr = true;
   }
   const char* f32env = getenv("GLORIE_MLP_F32");
-  const bool geo_f32 = f32env && f32env[0] == '1';
+  const bool geo_f32 = force_f32 || (f32env && f32env[0] == '1');
   const size_t geo4_lds = sizeof(float) * (kGeoFrag + 32 * 16);
   static bool geo4_attr = false;
   if (!geo4_attr) {
@@ -1094,8 +1460,9 @@ extern "C" int glorie_render_mlp(const float* packed, const float* pts, const fl
     hipLaunchKernelGGL(mlp_geo_v3_kernel, dim3(blocks2), dim3(512), geo_lds, st, g, geo_image, pts, c_geo,
                        c_geo ? nullptr : geo_feats, I, weights, has, Q, raw);
   else
-    hipLaunchKernelGGL(mlp_geo_v4_kernel, dim3(blocks2), dim3(512), geo4_lds, st, g, geo_frags,
-                       geo_image + kGeoRows * 32, pts, c_geo, c_geo ? nullptr : geo_feats, I, weights, has, Q, raw);
+    hipLaunchKernelGGL(mlp_geo_v4_kernel, dim3(blocks2 < 512 ? blocks2 : 512), dim3(512), geo4_lds, st, g, geo_frags,
+                       geo_image + kGeoRows * 32, pts, c_geo, c_geo ? nullptr : geo_feats, I, weights, has, Q, raw,
+                       range_flag);
   if (stage_color) {
     const size_t nb_lds = sizeof(float) * (52 * kLdw3 + 128 + kTM2 * 8 + 80) + sizeof(int) * kTM2 * 8;
     const size_t col_lds = sizeof(float) * 2 * kChunkFloats3;
@@ -1109,7 +1476,7 @@ extern "C" int glorie_render_mlp(const float* packed, const float* pts, const fl
     }
     // per-neighbour and colour decoders: fp16 matrix cores with the 3-term split (fp32 accuracy); GLORIE_MLP_F32=1 keeps
     // the fp32 MFMA kernels
-    const char* f32 = getenv("GLORIE_MLP_F32");
+    const char* f32 = force_f32 ? "1" : getenv("GLORIE_MLP_F32");
     const size_t nb4_lds = sizeof(float) * (8192 + 128 + kTM2 * 8 + 80) + sizeof(int) * kTM2 * 8;
     static bool attr4 = false;
     if (!attr4) {
@@ -1117,18 +1484,50 @@ extern "C" int glorie_render_mlp(const float* packed, const float* pts, const fl
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)nb4_lds);
       attr4 = true;
     }
+    // GLORIE_MLP_VARIANT: "v4" = 16 samples per wave (round 2), "n2w8" / "n2w4" = 32 samples per wave, 8 / 4 waves per workgroup
+    // (GLORIE_MLP_NB_VARIANT / GLORIE_MLP_COL_VARIANT select one kernel each).  Measured per 614k-sample batch: colour 495 /
+    // 485 / 440 us, per-neighbour 403 / 463 / 415 us -> defaults: colour n2w4, per-neighbour v4
+    auto pick = [](const char* name, int dflt) {
+      const char* v = getenv(name);
+      if (!v || !v[0]) v = getenv("GLORIE_MLP_VARIANT");
+      if (!v || !v[0]) return dflt;
+      return v[0] == 'v' ? 0 : ((v[0] == 'n' && v[1] == '2' && v[2] == 'w' && v[3] == '8') ? 1 : 2);
+    };
+    const int variant = pick("GLORIE_MLP_NB_VARIANT", 0), variant_col = pick("GLORIE_MLP_COL_VARIANT", 2);
+    auto nb5_lds = [](int spw) { return sizeof(float) * (8192 + 128 + spw * 8 + 80) + sizeof(int) * spw * 8; };
+    static bool attr5 = false;
+    if (!attr5) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_nb_v5_kernel<2, 8>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)nb5_lds(256));
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_nb_v5_kernel<2, 4>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)nb5_lds(128));
+      attr5 = true;
+    }
     if (f32 && f32[0] == '1')
       hipLaunchKernelGGL(mlp_nb_v3_kernel, dim3(blocks2), dim3(512), nb_lds, st, n, pts, cloud_pos, col_feats,
                          I, weights, has, Q, c_col_scratch);
+    else if (variant == 1)
+      hipLaunchKernelGGL((mlp_nb_v5_kernel<2, 8>), dim3((Q + 255) / 256), dim3(512), nb5_lds(256), st, n, nb_frags, pts,
+                         cloud_pos, col_feats, I, weights, has, Q, c_col_scratch, range_flag);
+    else if (variant == 2)
+      hipLaunchKernelGGL((mlp_nb_v5_kernel<2, 4>), dim3((Q + 127) / 128), dim3(256), nb5_lds(128), st, n, nb_frags, pts,
+                         cloud_pos, col_feats, I, weights, has, Q, c_col_scratch, range_flag);
     else
       hipLaunchKernelGGL(mlp_nb_v4_kernel, dim3(blocks2), dim3(512), nb4_lds, st, n, nb_frags, pts, cloud_pos, col_feats,
-                         I, weights, has, Q, c_col_scratch);
+                         I, weights, has, Q, c_col_scratch, range_flag);
+    const size_t col16_lds = sizeof(float) * 2 * kChunkFloats16;
     if (f32 && f32[0] == '1')
       hipLaunchKernelGGL(mlp_col_v3_kernel, dim3(blocks2), dim3(512), col_lds, st, k, col_chunks, pts, views,
                          c_col_scratch, Q, raw);
+    else if (variant_col == 1)
+      hipLaunchKernelGGL((mlp_col_v5_kernel<2, 8>), dim3((Q + 255) / 256), dim3(512), col16_lds, st, k, col_chunks16, pts,
+                         views, c_col_scratch, Q, raw, range_flag);
+    else if (variant_col == 2)
+      hipLaunchKernelGGL((mlp_col_v5_kernel<2, 4>), dim3((Q + 127) / 128), dim3(256), col16_lds, st, k, col_chunks16, pts,
+                         views, c_col_scratch, Q, raw, range_flag);
     else
-      hipLaunchKernelGGL(mlp_col_v4_kernel, dim3(blocks2), dim3(512), sizeof(float) * 2 * kChunkFloats16, st, k,
-                         col_chunks16, pts, views, c_col_scratch, Q, raw);
+      hipLaunchKernelGGL(mlp_col_v4_kernel, dim3(blocks2), dim3(512), col16_lds, st, k,
+                         col_chunks16, pts, views, c_col_scratch, Q, raw, range_flag);
   }
   return check_launch();
 }

@@ -255,6 +255,13 @@ class POINT(nn.Module):
             self._pack_ver = ver
         return self._pack
 
+    def range_guard(self, device):
+        """point_ops.RangeGuard of the fused kernels on `device` (include/glorie_hip.h: glorie_render_mlp range_flag)"""
+        g = getattr(self, "_guard", None)
+        if g is None or g.flag.device != torch.device(device):
+            g = self._guard = point_ops.RangeGuard(device)
+        return g
+
     def _fused_ok(self, p, npc_geo_feats, npc_col_feats, is_tracker, stage):
         g, c = self.geo_decoder, self.color_decoder
         return p.is_cuda and not is_tracker and not torch.is_grad_enabled() and \
@@ -276,8 +283,12 @@ class POINT(nn.Module):
             c_geo, has, w = point_ops.idw_gather(D, I, nn_num, npc_geo_feats, radius=radius,
                                                  radius_per_query=rq, min_nn=g.min_nn_num, return_weights=True)
             cp = cloud_pos if cloud_pos is not None else npc.cloud_pos()
+            guard = self.range_guard(pp.device)
             raw = point_ops.render_mlp(self._packed(), pp, pts_views_d, cp, npc_col_feats, c_geo, I, w, has,
-                                       stage=stage)
+                                       stage=stage, range_flag=guard.flag)
+            if guard.tripped():       # an operand outside the fp16 range: exact-fp32 kernels
+                raw = point_ops.render_mlp(self._packed(), pp, pts_views_d, cp, npc_col_feats, c_geo, I, w, has,
+                                           stage=stage, precise=True)
             per_ray = torch.sum(has.view(-1, pts_num), 1)
             return raw, ~(per_ray < 3), has, per_ray
         geo_occ, ray_mask, point_mask, ray_counter = self.geo_decoder(

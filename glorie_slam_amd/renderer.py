@@ -75,7 +75,7 @@ class Renderer(object):
         return z, near_mask, nz
 
     def _render_fast(self, npc, decoders, rays_d, rays_o, stage, gt_depth, npc_geo_feats, npc_col_feats,
-                     cloud_pos, dynamic_r_query, image_w=None, camera=None):
+                     cloud_pos, dynamic_r_query, image_w=None, camera=None, precise=False):
         """Inference path of render_batch_ray for batches in which every ray has a depth prior: seven HIP
         launches (samples, KNN, IDW gather, three decoders, per-ray counts, compositing) and no torch glue.
         Returns None when a ray has no depth (sample_near_pcl is needed: general path)."""
@@ -105,8 +105,10 @@ class Renderer(object):
                                          radius_per_query=rq if g.use_dynamic_radius else None,
                                          min_nn=g.min_nn_num, return_weights=True, raw_mask=True)
         cp = cloud_pos if cloud_pos is not None else npc.cloud_pos()
+        # (precise: exact-fp32 decoder kernels - the caller's answer to a tripped range guard of the fp16-split ones)
         raw = point_ops.render_mlp(decoders._packed(), pts, views, cp, npc_col_feats, None, I, w, has,
-                                   stage=stage, geo_feats=npc_geo_feats)
+                                   stage=stage, geo_feats=npc_geo_feats, precise=precise,
+                                   range_flag=None if precise else decoders.range_guard(pts.device).flag)
         counts, valid = point_ops.ray_counts(has, S, 3)
         depth, var, rgb, _ = point_ops.composite(raw.view(R, S, 4), z_vals, self.sigmoid_coefficient,
                                                  return_weights=False)
@@ -139,6 +141,10 @@ class Renderer(object):
         if self._fast_ok(decoders, rays_o, R, gt_depth, stage, npc_geo_feats, npc_col_feats, is_tracker, dynamic_r_query):
             out = self._render_fast(npc, decoders, rays_d, rays_o, stage, gt_depth, npc_geo_feats,
                                     npc_col_feats, cloud_pos, dynamic_r_query, image_w=image_w)
+            if out is not None and decoders.range_guard(rays_o.device).tripped():
+                # an activation, feature or weight outside the fp16 range: the split kernels' result is void
+                out = self._render_fast(npc, decoders, rays_d, rays_o, stage, gt_depth, npc_geo_feats,
+                                        npc_col_feats, cloud_pos, dynamic_r_query, image_w=image_w, precise=True)
             if out is not None:
                 return out
         if (torch.is_grad_enabled() and gt_depth is not None and R > 0 and torch.numel(gt_depth) == R and not is_tracker
@@ -175,7 +181,7 @@ class Renderer(object):
 
     @torch.no_grad()
     def render_img(self, npc, decoders, c2w, device, stage, gt_depth=None, npc_geo_feats=None,
-                   npc_col_feats=None, dynamic_r_query=None, cloud_pos=None):
+                   npc_col_feats=None, dynamic_r_query=None, cloud_pos=None, _precise=False):
         """Renderer.py:221-306"""
         H, W = self.H, self.W
         n_rays = H * W
@@ -193,6 +199,7 @@ class Renderer(object):
         cam = point_ops.camera_block(c2w, self.fx, self.fy, self.cx, self.cy, device) \
             if (image_w and gt is not None and gt.is_cuda and getattr(self, "fuse_get_rays", True)) else None
         rays = None
+        bad_any = False
         for i in range(0, n_rays, bs):
             g_i = gt[i:i + bs] if gt is not None else None
             r_i = dynamic_r_query[i:i + bs] if self.use_dynamic_radius else None
@@ -200,8 +207,11 @@ class Renderer(object):
             if cam is not None and self._fast_ok(decoders, g_i, g_i.shape[0], g_i, stage, npc_geo_feats, npc_col_feats,
                                                  False, r_i):
                 ret = self._render_fast(npc, decoders, None, None, stage, g_i, npc_geo_feats, npc_col_feats, cloud_pos,
-                                        r_i, image_w=image_w, camera=(cam, i))
+                                        r_i, image_w=image_w, camera=(cam, i), precise=_precise)
             if ret is None:
+                if cam is not None and not _precise:
+                    # the general path looks at (and clears) the range guard itself: keep what the strips so far raised
+                    bad_any = bad_any or decoders.range_guard(device).tripped()
                 if rays is None:
                     rays_o, rays_d = get_rays(H, W, self.fx, self.fy, self.cx, self.cy, c2w, device)
                     rays = (rays_o.reshape(-1, 3), rays_d.reshape(-1, 3))
@@ -211,6 +221,13 @@ class Renderer(object):
                     dynamic_r_query=r_i, image_w=image_w)
             for o, v in zip(outs, ret):
                 o.append(v)
+        if cam is not None and not _precise and (decoders.range_guard(device).tripped() or bad_any):
+            # the range guard of the fp16-split decoders is looked at once per frame (no stall between the strips): a trip
+            # voids the frame, which is rendered again on the exact-fp32 kernels
+            return self.render_img(npc, decoders, c2w, device, stage, gt_depth=gt_depth, npc_geo_feats=npc_geo_feats,
+                                   npc_col_feats=npc_col_feats,
+                                   dynamic_r_query=dynamic_r_query.reshape(H, W) if self.use_dynamic_radius else None,
+                                   cloud_pos=cloud_pos, _precise=True)
         depth = torch.cat(outs[0]).double().reshape(H, W)
         unc = torch.cat(outs[1]).double().reshape(H, W)
         color = torch.cat(outs[2]).reshape(H, W, 3)

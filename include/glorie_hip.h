@@ -540,7 +540,12 @@ int glorie_idw_gather2(const float* D, const int64_t* I, const int* nn, const fl
  * glorie_slam_amd.point_ops.pack_decoders from the state dict).  pts/views [Q,3]; cloud_pos
  * [Np,3]; col_feats [Np,32]; c_geo [Q,32] + weights [Q,8] + has [Q] from glorie_idw_gather;
  * I [Q,8] from glorie_knn_query; c_col_scratch [Q,32]; raw [Q,4] = (r,g,b,occ), rgb written
- * only when stage_color != 0 (caller zero-fills otherwise).  All fp32, MFMA 16x16x4 f32.
+ * only when (stage_flags & 1) (caller zero-fills otherwise).
+ * Arithmetic: fp32-accurate.  By default the matmuls run on the fp16 matrix cores as 3-term hi/lo splits with fp32
+ * accumulation (22 mantissa bits; csrc/mlp.hip); stage_flags & 2 (or GLORIE_MLP_F32=1) selects the exact-fp32 MFMA 16x16x4
+ * kernels.  The split needs every operand within the fp16 range: range_flag (NULL or a device int, zero-initialised by the
+ * caller) gets bit 0 set when a kernel met |x| > 65504 or a NaN - the results of that call are then invalid and the caller
+ * repeats it with stage_flags | 2 (glorie_slam_amd.renderer does).
  * c_geo [Q,32] is the IDW-interpolated geometry feature (glorie_idw_gather); pass NULL and the feature table
  * geo_feats [Np,32] instead to have the geometry kernel interpolate it itself from (I, weights) - then
  * glorie_idw_gather is only needed for the weights and the mask (c_out = NULL). */
@@ -548,7 +553,7 @@ size_t glorie_decoder_pack_floats(void);
 int glorie_render_mlp(const float* packed, const float* pts, const float* views,
                       const float* cloud_pos, const float* col_feats, const float* c_geo,
                       const float* geo_feats, const int64_t* I, const float* weights, const uint8_t* has,
-                      int Q, float* c_col_scratch, float* raw, int stage_color, void* stream);
+                      int Q, float* c_col_scratch, float* raw, int stage_flags, int* range_flag, void* stream);
 
 /* Sample placement of Renderer.render_batch_ray for rays with a depth prior
  *   reference: src/utils/Renderer.py:106-125 (z_vals), 177-179 (pts, per-sample view directions),

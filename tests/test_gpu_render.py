@@ -223,6 +223,71 @@ def test_decoders_on_the_fp16_matrix_cores_keep_fp32_accuracy(gpu, monkeypatch):
     np.testing.assert_allclose(outs[1][pm, :3], f["rgb"][pm], rtol=1e-3, atol=1e-3)
 
 
+@pytest.mark.parametrize("what", ["weights", "features", "positions"])
+def test_split_decoders_over_six_decades_of_magnitude(gpu, what):
+    """the 3-term fp16 split against the exact-fp32 MFMA kernels with the decoder weights, the point features or the scene
+    scaled by 1e-3 ... 1e3 (the reference loads a pretrained middle_fine.pt and trains the features: magnitudes are not those of
+    the default init).  While every operand fits fp16 the two agree to 1e-5 on colours (1e-4 above the default magnitudes)
+    and 2e-5 * max(1, max |occ|) on the occupancy logits (below 2^-3 the low half of the split is an fp16 subnormal: the error is absolute there, 2^-25 per
+    operand); when an operand leaves the fp16 range (|x| > 65504) the range guard trips and POINT.forward / the renderer
+    answer with the fp32 kernels' values - never with an inf, a NaN or silent garbage."""
+    from glorie_slam_amd.decoder import POINT
+    from glorie_slam_amd.neural_point import NeuralPointCloud
+    from glorie_slam_amd import point_ops
+    f = np.load(os.path.join(GOLD, "decoders.npz"))
+    t = lambda k: torch.from_numpy(f[k]).to(gpu)
+    pm = f["point_mask"]
+    tripped_any = False
+    # (features of 1e6 x N(0, 0.1) are beyond fp16 themselves: the guard must trip there at the latest)
+    for scale in (1e-3, 1e-2, 1e-1, 1.0, 1e1, 1e2, 1e3) + ((1e6,) if what == "features" else ()):
+        torch.manual_seed(43)
+        dec = POINT(_cfg(gpu), c_dim=32, hidden_size=128, use_view_direction=True).eval().to(gpu)
+        geo, col, cloud, p, radius = t("geo"), t("col"), t("cloud"), t("p"), t("radius")
+        if what == "weights":
+            with torch.no_grad():
+                for name, prm in dec.named_parameters():
+                    if name.endswith("weight"):
+                        prm.mul_(scale)
+        elif what == "features":
+            geo, col = geo * scale, col * scale
+        else:
+            cloud, p, radius = cloud * scale, p * scale, radius * scale
+        npc = NeuralPointCloud(_cfg(gpu))
+        npc.add_points(cloud, geo, col)
+        args = (p[None], npc, "color", npc.geo_feats, npc.col_feats)
+        kw = dict(pts_num=10, cloud_pos=npc.cloud_pos(), pts_views_d=t("views"), dynamic_r_query=radius)
+        # what the kernels do on their own: the split with its guard, and the exact kernels
+        D, I, nn = npc.find_neighbors_faiss(p.reshape(-1, 3).clone(), step="query", dynamic_radius=radius)
+        c_geo, has, w = point_ops.idw_gather(D, I, nn, npc.geo_feats, radius=0.0, radius_per_query=radius, min_nn=2,
+                                             return_weights=True)
+        guard = dec.range_guard(gpu)
+        call = lambda **k: point_ops.render_mlp(dec._packed(), p.reshape(-1, 3), t("views"), npc.cloud_pos(), npc.col_feats,
+                                                c_geo, I, w, has, stage="color", **k)
+        split = call(range_flag=guard.flag).cpu().numpy()
+        tripped = guard.tripped()
+        exact = call(precise=True).cpu().numpy()
+        assert np.isfinite(exact).all()
+        hm = has.cpu().numpy().astype(bool)
+        if not tripped:
+            assert np.isfinite(split).all(), (what, scale)
+            # 22 mantissa bits relative to the largest term of a dot product: the scale of a network's values, not of one output
+            big = max(1.0, float(np.abs(exact[hm, 3]).max()))
+            np.testing.assert_allclose(split[hm, :3], exact[hm, :3], rtol=0, atol=1e-5 if scale <= 1.0 else 2e-4,
+                                       err_msg=f"{what} x {scale}")
+            assert float(np.abs(split[hm, 3] - exact[hm, 3]).max()) <= 2e-5 * big, (what, scale)
+        tripped_any |= tripped
+        # what the product path returns: always the exact kernels' values where the guard trips
+        with torch.no_grad():
+            raw, _, point_mask, _ = dec(*args, **kw)
+        raw = raw.cpu().numpy()
+        assert np.isfinite(raw).all(), (what, scale)
+        if tripped:
+            np.testing.assert_array_equal(raw[hm], exact[hm])
+        assert not guard.tripped()                                   # POINT.forward consumed its own trip
+    if what in ("weights", "features"):
+        assert tripped_any, "1e3 x the default magnitudes must leave the fp16 range somewhere"
+
+
 def test_render_batch_ray_end_to_end(gpu):
     """render a small view of the synthetic box; rays that hit the cloud are valid, depth is
     close to the surface depth, zero-depth rays go through sample_near_pcl"""
