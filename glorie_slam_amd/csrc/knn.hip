@@ -343,7 +343,8 @@ __global__ __launch_bounds__(256) void knn_query_kernel(
     const float4* __restrict__ sorted, const int* __restrict__ starts,
     const KnnGrid* __restrict__ gp, const float* __restrict__ q, int Q, float radius,
     const float* __restrict__ radius_ptr, float* __restrict__ D, int64_t* __restrict__ I,
-    int* __restrict__ nn, int S, int image_w) {
+    int* __restrict__ nn, int S, int image_w, float* __restrict__ wout, uint8_t* __restrict__ has_out, int min_nn,
+    int expo_weighting) {
   // The 256 queries of a workgroup are processed in the order of their grid cells: lanes that sit in the same
   // cell walk the same shells over the same point ranges - identical trip counts and identical addresses
   // (one L1 transaction per wave instead of one per lane) - where in ray order a wave straddles ~5 cells
@@ -409,6 +410,23 @@ __global__ __launch_bounds__(256) void knn_query_kernel(
     cnt += (top.dist(s) < r2) ? 1 : 0;
   }
   if (nn) nn[t] = cnt;
+  if (K == 8 && wout) {
+    // the inverse-distance weights and the neighbour mask of get_feature_at_pos (decoder.py:130-173) while the list is
+    // still in registers - the arithmetic and the summation order of idw_weights_kernel (csrc/render.hip): same bits,
+    // one launch and one read of D / I / nn less per batch
+    float w[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const float d = top.dist(s & (K - 1));
+      w[s] = (top.index(s & (K - 1)) >= 0 && !(d > r2)) ? (expo_weighting ? expf(-20.0f * sqrtf(d)) : 1.0f / (d + 1e-10f)) : 0.0f;
+    }
+    const float s4[4] = {w[0] + w[4], w[1] + w[5], w[2] + w[6], w[3] + w[7]};
+    const float s2[2] = {s4[0] + s4[2], s4[1] + s4[3]};
+    const float den = fmaxf(s2[0] + s2[1], 1e-12f);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) wout[(size_t)t * 8 + s] = w[s] / den;
+    if (has_out) has_out[t] = cnt > min_nn - 1 ? 1 : 0;
+  }
 }
 
 }  // namespace glorie
@@ -459,7 +477,8 @@ extern "C" int glorie_knn_build(glorie_ctx* ctx, const float* points, int np, fl
 static int knn_query_launch(const float* sorted_pos, const int* cell_start, const void* grid,
                             const float* queries, int Q, int k, float radius,
                             const float* radius_ptr, float* D, int64_t* I, int* nn, int S, int image_w,
-                            void* stream) {
+                            void* stream, float* wout = nullptr, uint8_t* has_out = nullptr, int min_nn = 0,
+                            int expo = 0) {
   if (Q < 0 || k < 1) return GLORIE_EINVAL;
   if (Q == 0) return GLORIE_OK;
   if (!sorted_pos || !cell_start || !grid || !queries || !D || !I) return GLORIE_EINVAL;
@@ -473,7 +492,8 @@ static int knn_query_launch(const float* sorted_pos, const int* cell_start, cons
 #define LAUNCH_K(KK)                                                                              \
   hipLaunchKernelGGL(knn_query_kernel<KK>, gridDim, dim3(256), 0, st,                             \
                      reinterpret_cast<const float4*>(sorted_pos), cell_start,                     \
-                     reinterpret_cast<const KnnGrid*>(grid), queries, Q, radius, radius_ptr, D, I, nn, S, image_w)
+                     reinterpret_cast<const KnnGrid*>(grid), queries, Q, radius, radius_ptr, D, I, nn, S, image_w, \
+                     wout, has_out, min_nn, expo)
   switch (k) {
     case 1: LAUNCH_K(1); break;
     case 4: LAUNCH_K(4); break;
@@ -499,4 +519,13 @@ extern "C" int glorie_knn_query_image(const float* sorted_pos, const int* cell_s
   if (image_w < 1) return GLORIE_EINVAL;
   return knn_query_launch(sorted_pos, cell_start, grid, queries, Q, k, radius, radius_ptr, D, I, nn,
                           samples_per_ray, image_w, stream);
+}
+
+extern "C" int glorie_knn_query_weights(const float* sorted_pos, const int* cell_start, const void* grid,
+                                        const float* queries, int Q, float radius, const float* radius_ptr, float* D,
+                                        int64_t* I, int* nn, int samples_per_ray, int image_w, int min_nn,
+                                        int expo_weighting, float* weights, uint8_t* has, void* stream) {
+  if (!weights || !has || !nn || image_w < 0) return GLORIE_EINVAL;
+  return knn_query_launch(sorted_pos, cell_start, grid, queries, Q, 8, radius, radius_ptr, D, I, nn,
+                          image_w > 0 ? samples_per_ray : 1, image_w, stream, weights, has, min_nn, expo_weighting);
 }

@@ -257,9 +257,10 @@ class NeuralPointCloud(object):
 
     # ---- search -----------------------------------------------------------------------
     def find_neighbors_faiss(self, pos, step='add', retrain=False, is_pts_grad=False, dynamic_radius=None,
-                             image_layout=None):
+                             image_layout=None, weights=None):
         """neural_point.py:264-313 -> (D [Q,nn] squared distances, I [Q,nn] int64, neighbor_num [Q] int32).
-        image_layout: see KnnIndex.search (an ordering hint for image-shaped query batches, same result)"""
+        image_layout: see KnnIndex.search (an ordering hint for image-shaped query batches, same result);
+        weights = (min_nn, expo): the IDW weights and neighbour mask of the decoders from the same launch (two more returns)"""
         assert step in ['add', 'query']
         if retrain:
             self.index.set_points(self._cloud_pos)
@@ -270,7 +271,7 @@ class NeuralPointCloud(object):
         if dynamic_radius is not None:
             assert pos.shape[0] == dynamic_radius.shape[0], 'shape mis-match for input points and dynamic radius'
         return self.index.search(pos, self.nn_num, radius=radius, radius_per_query=dynamic_radius,
-                                 image_layout=image_layout)
+                                 image_layout=image_layout, weights=weights)
 
     def sample_near_pcl(self, rays_o, rays_d, near, far, num):
         """neural_point.py:315-375: z-samples for rays without depth, bracketed by the first two

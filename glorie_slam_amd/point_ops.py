@@ -58,10 +58,12 @@ class KnnIndex:
                                               L.ptr(self.cell_start), L.ptr(self.grid),
                                               L.stream_ptr()), "glorie_knn_build")
 
-    def search(self, q, k=8, radius=0.0, radius_per_query=None, image_layout=None):
+    def search(self, q, k=8, radius=0.0, radius_per_query=None, image_layout=None, weights=None):
         """-> D [Q,k] f32, I [Q,k] int64, neighbor_num [Q] int32 (count of D < r^2).
         image_layout = (samples_per_ray, image_w) when q holds the samples of row-major image rays (render_img): the same
-        result from a search that walks the image in 16 x 16 pixel patches (glorie_knn_query_image)."""
+        result from a search that walks the image in 16 x 16 pixel patches (glorie_knn_query_image).
+        weights = (min_nn, expo): also return the IDW weights [Q,8] and the neighbour mask [Q] uint8 of idw_gather, written
+        by the search launch itself (k == 8; glorie_knn_query_weights) -> (D, I, nn, w, has)."""
         q = q.detach().to(self.device, torch.float32).reshape(-1, 3).contiguous()
         Q = q.shape[0]
         D = torch.empty(Q, k, dtype=torch.float32, device=self.device)
@@ -72,6 +74,18 @@ class KnnIndex:
             rp = radius_per_query.detach().to(self.device, torch.float32).reshape(-1).contiguous()
             if rp.shape[0] != Q:
                 raise RuntimeError("shape mis-match for input points and dynamic radius")
+        if weights is not None:
+            if k != 8:
+                raise RuntimeError("KnnIndex.search: weights need k == 8")
+            w = torch.empty(Q, 8, dtype=torch.float32, device=self.device)
+            has = torch.empty(Q, dtype=torch.uint8, device=self.device)
+            S, image_w = (int(image_layout[0]), int(image_layout[1])) if image_layout is not None else (1, 0)
+            with torch.cuda.device(self.device):
+                L.check(L.load().glorie_knn_query_weights(L.ptr(self.sorted_pos), L.ptr(self.cell_start), L.ptr(self.grid),
+                                                          L.ptr(q), Q, float(radius), L.ptr(rp), L.ptr(D), L.ptr(I), L.ptr(nn),
+                                                          S, image_w, int(weights[0]), int(bool(weights[1])), L.ptr(w),
+                                                          L.ptr(has), L.stream_ptr()), "glorie_knn_query_weights")
+            return D, I, nn, w, has
         with torch.cuda.device(self.device):
             if image_layout is not None:
                 S, image_w = int(image_layout[0]), int(image_layout[1])

@@ -514,6 +514,15 @@ int glorie_knn_query_image(const float* sorted_pos, const int* cell_start, const
                            const float* queries, int Q, int k, float radius, const float* radius_ptr,
                            float* D, int64_t* I, int* nn, int samples_per_ray, int image_w, void* stream);
 
+/* glorie_knn_query (image_w == 0) / glorie_knn_query_image (image_w > 0) for k = 8 with the inverse-distance weights and the
+ * neighbour mask of get_feature_at_pos (reference: src/modules/conv_onet/models/decoder.py:130-173) produced by the same
+ * launch: weights [Q,8] = [I >= 0 and D <= r^2] / (D + 1e-10) (or exp(-20 sqrt(D)) with expo_weighting), L1-normalised
+ * (eps 1e-12); has [Q] = neighbour count (D < r^2) >= min_nn.  Bit-identical to glorie_idw_gather's weights / mask. */
+int glorie_knn_query_weights(const float* sorted_pos, const int* cell_start, const void* grid,
+                             const float* queries, int Q, float radius, const float* radius_ptr, float* D,
+                             int64_t* I, int* nn, int samples_per_ray, int image_w, int min_nn,
+                             int expo_weighting, float* weights, uint8_t* has, void* stream);
+
 /* Feature interpolation of MLP_geometry/MLP_color.get_feature_at_pos
  *   reference: src/modules/conv_onet/models/decoder.py:130-173 (geometry), :340-389 (colour)
  * w = L1-normalise( [D <= r^2] / (D + 1e-10) )  (or exp(-20 sqrt(D)) when expo_weighting),

@@ -156,6 +156,35 @@ def test_idw_gather(gpu):
     assert torch.equal(c2a, c) and torch.equal(c2b, cb) and torch.equal(has2, has) and torch.equal(w2, w)
 
 
+@pytest.mark.parametrize("image", [False, True])
+def test_knn_query_with_weights_equals_the_separate_weights_launch(gpu, image):
+    """glorie_knn_query_weights: the IDW weights and the neighbour mask written by the search launch are the bits of
+    glorie_idw_gather on the search's own output (fixed and per-query radius, both query orders, min_nn 1..3), and the
+    search results themselves do not change"""
+    import glorie_slam_amd.synth as synth
+    from glorie_slam_amd import point_ops
+    pts, _, _ = synth.box_cloud(n_hits=30000)
+    ro, rd, depth, _, _ = synth.box_rays(H=48, W=64, fx=32.0, fy=32.0, cx=31.5, cy=23.5)
+    S, W = 10, 64
+    z = depth[:, None] * np.linspace(0.95, 1.05, S, dtype=np.float32)[None]
+    q = (ro[:, None] + rd[:, None] * z[..., None]).reshape(-1, 3).astype(np.float32)
+    q[::37] += 5.0                                                        # samples without any neighbour in range
+    idx = _index(gpu, pts)
+    qd = torch.from_numpy(q).to(gpu)
+    rad = torch.from_numpy(np.random.default_rng(3).uniform(0.02, 0.2, len(q)).astype(np.float32)).to(gpu)
+    layout = (S, W) if image else None
+    for kw in (dict(radius_per_query=rad), dict(radius=0.07)):
+        D0, I0, n0 = idx.search(qd, 8, image_layout=layout, **kw)
+        for min_nn in (1, 2, 3):
+            D1, I1, n1, w1, has1 = idx.search(qd, 8, image_layout=layout, weights=(min_nn, False), **kw)
+            assert torch.equal(D0, D1) and torch.equal(I0, I1) and torch.equal(n0, n1)
+            _, has0, w0 = point_ops.idw_gather(D0, I0, n0, None, radius=kw.get("radius", 0.0),
+                                               radius_per_query=kw.get("radius_per_query"), min_nn=min_nn,
+                                               return_weights=True, raw_mask=True)
+            assert torch.equal(w1, w0) and torch.equal(has1, has0)
+            assert 0 < int(has1.sum()) < len(q)
+
+
 def test_composite_matches_reference_fixture(gpu):
     from glorie_slam_amd import point_ops
     f = np.load(os.path.join(GOLD, "raw2outputs.npz"))
