@@ -269,6 +269,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sequence", action="store_true", help="skip the 13-frame tracking + mapping sequence (config 3)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -579,6 +580,29 @@ def main():
         train[tag + "_rays_per_sec"] = 5000.0 / (ms * 1e-3)
     ren.use_train_path, dec.use_fused = True, True
     dec.eval()
+    # ---- BASELINE config 3 in miniature: 13 frames of a synthetic 640x480 stream through the tracker + mapper composition
+    # (glorie_slam_amd.pipeline: motion filter -> frontend with hipGraph replays -> periodic global BA -> 20 mapping
+    # iterations per kept keyframe -> final global BA); wall-clock per stage incl. the host control flow
+    sequence = None
+    if rank == 0 and world == 1 and not args.no_sequence:
+        from glorie_slam_amd.pipeline import synthetic_images, synthetic_runner
+        Ks = 13
+        srun, sc = synthetic_runner(device, Ks, zero_flow_head=True, map_iters=20, map_rays=1000)
+        simgs = synthetic_images(Ks)
+        torch.cuda.synchronize()
+        t_s = time.perf_counter()
+        ssum = srun.run(((k, simgs[k:k + 1]) for k in range(Ks)), sc["intrinsics"], final_ba_steps=7)
+        torch.cuda.synchronize()
+        t_s = time.perf_counter() - t_s
+        tr = srun.timing["track_ms"]
+        assert ssum["keyframes"] == Ks and ssum["mapped"] == Ks and sc["video"].ctx().ba_status()[0] == 0
+        assert sum(1 for a, b in ssum["losses"] if b < a) >= Ks - 2, "mapping iterations must reduce the loss"
+        sequence = {"frames": Ks, "resolution": "640x480 (60x80 BA)", "wall_s": t_s,
+                    "bootstrap_ms": tr[7], "ms_per_kept_keyframe": float(np.median(tr[8:])),
+                    "ms_per_mapping_iteration": float(np.mean(srun.timing["map_iter_ms"][2:])),
+                    "ms_per_global_ba_2steps": float(np.median(srun.timing["ba_ms"])), "cloud_points": ssum["points"],
+                    "note": "untrained networks, flow head zeroed (fixed point at the generating trajectory): costs, not accuracy"}
+        del srun, sc, simgs
     # KNN + feature gather alone (HIP events), 2156 B per sample
     S = ren.N_surface
     nq = min(rays["o"].shape[0], 61440)            # 96 image rows: the batch render_img evaluates
@@ -676,6 +700,7 @@ def main():
         "rays_scaling": "strong",
         "rays_per_sec_batch5000": 5000.0 / (batch_ms * 1e-3), "ms_per_batch5000": batch_ms,
         "train_batch5000": train,
+        "sequence": sequence,
         "render": {"rays_local": int(n_r // render_reps), "samples_per_ray": int(S), "cloud_points": int(npc.pts_num()),
                    "ms_per_frame_shard": 1e3 * t_r / render_reps},
         "roofline_knn": {"bound": "hbm", "kernel": "knn_query_kernel<8> (image-patch order) + idw_gather2_kernel (both feature tables)",

