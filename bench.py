@@ -270,6 +270,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sequence", action="store_true", help="skip the 13-frame tracking + mapping sequence (config 3)")
+    ap.add_argument("--no-strong", action="store_true", help="skip the fixed 128-keyframe graph (strong-scaling figure)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -371,6 +372,39 @@ def main():
     ba_st2 = video.ctx().ba_status()
     assert ba_st2[0] == 0 and bool(torch.isfinite(video.poses).all()), \
         f"after {sustained_steps} sustained steps: BA status {ba_st2}, finite poses {bool(torch.isfinite(video.poses).all())}"
+
+    # ---- strong scaling: ONE fixed long graph whatever the number of ranks (the case the sharding is for, BASELINE
+    # config 4: 30x40 maps, here 128 keyframes in a +-3 window = 756 edges, volume-free correlation), edges sharded by
+    # source keyframe, one step = one BA-update of the whole graph.  Reported next to the weak figure above.
+    strong = None
+    if not args.no_strong:
+        try:
+            KS = 128
+            gS, videoS, graphS = build_graph(device, K=KS, h=30, w=40, rank=rank, world=world, corr_impl="otf",
+                                             use_graphs=os.environ.get("GLORIE_NO_GRAPHS") is None)
+
+            def step_s(i):
+                graphS.update(t0=1, t1=KS, itrs=2, use_inactive=False, opt_type="pose_depth" if i % 2 == 0 else "depth_scale")
+            for i in range(6):
+                step_s(i)
+            barrier()
+            t_x = time.perf_counter()
+            n_s = 20
+            for i in range(n_s):
+                step_s(i)
+            barrier()
+            ms_s = 1e3 * (time.perf_counter() - t_x) / n_s
+            if world > 1:
+                tm = torch.tensor([ms_s], device=device)
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+                ms_s = float(tm.item())
+            ok_s = videoS.ctx().ba_status()[0] == 0 and bool(torch.isfinite(videoS.poses).all())
+            strong = {"scaling": "strong", "keyframes": KS, "edges_total": int(len(gS["ii"])), "edges_local": int(graphS.ii.numel()),
+                      "hw": 1200, "steps": n_s, "ms_per_step": ms_s, "updates_per_sec": 1e3 / ms_s, "state_ok": bool(ok_s)}
+            del graphS, videoS, gS
+            torch.cuda.empty_cache()
+        except Exception as exc:                       # never takes the headline down
+            strong = {"error": repr(exc)[:300]}
 
     # ---- sub-metric: Gauss-Newton iterations/s of the BA step alone (B2-B7) on G8 ----
     ba_gn_per_s = None
@@ -701,6 +735,7 @@ def main():
         "rays_per_sec_batch5000": 5000.0 / (batch_ms * 1e-3), "ms_per_batch5000": batch_ms,
         "train_batch5000": train,
         "sequence": sequence,
+        "strong_scaling_graph": strong,
         "render": {"rays_local": int(n_r // render_reps), "samples_per_ray": int(S), "cloud_points": int(npc.pts_num()),
                    "ms_per_frame_shard": 1e3 * t_r / render_reps},
         "roofline_knn": {"bound": "hbm", "kernel": "knn_query_kernel<8> (image-patch order) + idw_gather2_kernel (both feature tables)",
