@@ -82,7 +82,7 @@ SIGNATURES = {
     "glorie_knn_query_image": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_f, _vp, _vp, _vp, _vp, _c_int, _c_int,
                                         _vp]),
     "glorie_knn_query_weights": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_f, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int,
-                                          _vp, _vp, _vp]),
+                                          _c_int, _vp, _vp, _vp]),
     "glorie_idw_gather2": (_c_int, [_vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_f, _vp, _c_int,
                                     _c_int, _vp, _vp, _vp, _vp, _vp]),
     "glorie_decoder_pack_floats": (_sz, []),

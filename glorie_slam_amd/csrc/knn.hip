@@ -250,10 +250,14 @@ __device__ __forceinline__ float dist2_exact(float qx, float qy, float qz, float
   return s;
 }
 
+// lim2: squared radius beyond which the caller has no use for a neighbour (FLT_MAX: plain k-NN).  With a limit the search
+// treats min(k-th best, lim2) as its bound: cells outside the ball are skipped, and it stops as soon as the scanned cube
+// covers the ball - a sample with fewer than k points inside its radius no longer walks shell after shell (with its whole
+// wave waiting) to fill slots whose weight is zero anyway.  Every point with d <= lim2 is still found and ranked exactly.
 template <int K>
 __device__ __forceinline__ void knn_search(const float4* __restrict__ sorted,
                                            const int* __restrict__ starts, const KnnGrid& g,
-                                           float qx, float qy, float qz, TopK<K>& top) {
+                                           float qx, float qy, float qz, TopK<K>& top, float lim2 = FLT_MAX) {
   top.init();
   if (g.npoints <= 0) return;
   const int cx = cell_coord(qx, g.ox, g.inv_cs, g.nx);
@@ -297,7 +301,7 @@ __device__ __forceinline__ void knn_search(const float4* __restrict__ sorted,
         const float ylo = g.oy + y * g.cs;
         const float by = fmaxf(fmaxf(ylo - qy, qy - (ylo + g.cs)) - slack, 0.0f);
         const float byz2 = by * by + bz * bz;
-        const float kth = top.dist(K - 1);
+        const float kth = fminf(top.dist(K - 1), lim2);
         const bool full = kth < FLT_MAX;
         if (full && byz2 > 1.001f * kth) continue;
         // up to two cell ranges of this row: the whole (clipped) row on a face, else the end cells that lie on the shell
@@ -334,7 +338,7 @@ __device__ __forceinline__ void knn_search(const float4* __restrict__ sorted,
     if (cz - m > 0) rho = fminf(rho, qz - (g.oz + (cz - m) * g.cs));
     if (cz + m < g.nz - 1) rho = fminf(rho, (g.oz + (cz + m + 1) * g.cs) - qz);
     if (rho == FLT_MAX) break;                       // the cube covers the whole grid
-    if (rho > 0.0f && top.dist(K - 1) <= 0.998f * rho * rho) break;  // k-th best is inside
+    if (rho > 0.0f && fminf(top.dist(K - 1), lim2) <= 0.998f * rho * rho) break;  // k-th best (or the ball) is inside
   }
 }
 
@@ -344,7 +348,7 @@ __global__ __launch_bounds__(256) void knn_query_kernel(
     const KnnGrid* __restrict__ gp, const float* __restrict__ q, int Q, float radius,
     const float* __restrict__ radius_ptr, float* __restrict__ D, int64_t* __restrict__ I,
     int* __restrict__ nn, int S, int image_w, float* __restrict__ wout, uint8_t* __restrict__ has_out, int min_nn,
-    int expo_weighting) {
+    int expo_weighting, int ball_only) {
   // The 256 queries of a workgroup are processed in the order of their grid cells: lanes that sit in the same
   // cell walk the same shells over the same point ranges - identical trip counts and identical addresses
   // (one L1 transaction per wave instead of one per lane) - where in ray order a wave straddles ~5 cells
@@ -399,9 +403,12 @@ __global__ __launch_bounds__(256) void knn_query_kernel(
   if (mine == 0xffffffffu) return;           // past the end of the query array
   const int t = query_of((int)(mine & 255u));
   TopK<K> top;
-  knn_search<K>(sorted, starts, g, q[(size_t)t * 3 + 0], q[(size_t)t * 3 + 1], q[(size_t)t * 3 + 2], top);
   const float r = radius_ptr ? radius_ptr[t] : radius;
   const float r2 = r * r;
+  // ball_only: the caller only uses neighbours with d <= r^2 (the IDW weight of the others is zero): bound the search by
+  // the ball, a little generously so that the comparison d <= r2 below sees every candidate
+  knn_search<K>(sorted, starts, g, q[(size_t)t * 3 + 0], q[(size_t)t * 3 + 1], q[(size_t)t * 3 + 2], top,
+                ball_only ? r2 * 1.0001f + 1e-30f : FLT_MAX);
   int cnt = 0;
 #pragma unroll
   for (int s = 0; s < K; ++s) {
@@ -478,7 +485,7 @@ static int knn_query_launch(const float* sorted_pos, const int* cell_start, cons
                             const float* queries, int Q, int k, float radius,
                             const float* radius_ptr, float* D, int64_t* I, int* nn, int S, int image_w,
                             void* stream, float* wout = nullptr, uint8_t* has_out = nullptr, int min_nn = 0,
-                            int expo = 0) {
+                            int expo = 0, int ball_only = 0) {
   if (Q < 0 || k < 1) return GLORIE_EINVAL;
   if (Q == 0) return GLORIE_OK;
   if (!sorted_pos || !cell_start || !grid || !queries || !D || !I) return GLORIE_EINVAL;
@@ -493,7 +500,7 @@ static int knn_query_launch(const float* sorted_pos, const int* cell_start, cons
   hipLaunchKernelGGL(knn_query_kernel<KK>, gridDim, dim3(256), 0, st,                             \
                      reinterpret_cast<const float4*>(sorted_pos), cell_start,                     \
                      reinterpret_cast<const KnnGrid*>(grid), queries, Q, radius, radius_ptr, D, I, nn, S, image_w, \
-                     wout, has_out, min_nn, expo)
+                     wout, has_out, min_nn, expo, ball_only)
   switch (k) {
     case 1: LAUNCH_K(1); break;
     case 4: LAUNCH_K(4); break;
@@ -524,8 +531,9 @@ extern "C" int glorie_knn_query_image(const float* sorted_pos, const int* cell_s
 extern "C" int glorie_knn_query_weights(const float* sorted_pos, const int* cell_start, const void* grid,
                                         const float* queries, int Q, float radius, const float* radius_ptr, float* D,
                                         int64_t* I, int* nn, int samples_per_ray, int image_w, int min_nn,
-                                        int expo_weighting, float* weights, uint8_t* has, void* stream) {
+                                        int expo_weighting, int ball_only, float* weights, uint8_t* has, void* stream) {
   if (!weights || !has || !nn || image_w < 0) return GLORIE_EINVAL;
   return knn_query_launch(sorted_pos, cell_start, grid, queries, Q, 8, radius, radius_ptr, D, I, nn,
-                          image_w > 0 ? samples_per_ray : 1, image_w, stream, weights, has, min_nn, expo_weighting);
+                          image_w > 0 ? samples_per_ray : 1, image_w, stream, weights, has, min_nn, expo_weighting,
+                          ball_only);
 }

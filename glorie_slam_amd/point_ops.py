@@ -62,8 +62,9 @@ class KnnIndex:
         """-> D [Q,k] f32, I [Q,k] int64, neighbor_num [Q] int32 (count of D < r^2).
         image_layout = (samples_per_ray, image_w) when q holds the samples of row-major image rays (render_img): the same
         result from a search that walks the image in 16 x 16 pixel patches (glorie_knn_query_image).
-        weights = (min_nn, expo): also return the IDW weights [Q,8] and the neighbour mask [Q] uint8 of idw_gather, written
-        by the search launch itself (k == 8; glorie_knn_query_weights) -> (D, I, nn, w, has)."""
+        weights = (min_nn, expo[, ball_only]): also return the IDW weights [Q,8] and the neighbour mask [Q] uint8 of
+        idw_gather, written by the search launch itself (k == 8; glorie_knn_query_weights) -> (D, I, nn, w, has).
+        ball_only: the search stops at the query radius (slots beyond it - weight 0 - are then not the exact k-NN)."""
         q = q.detach().to(self.device, torch.float32).reshape(-1, 3).contiguous()
         Q = q.shape[0]
         D = torch.empty(Q, k, dtype=torch.float32, device=self.device)
@@ -83,7 +84,8 @@ class KnnIndex:
             with torch.cuda.device(self.device):
                 L.check(L.load().glorie_knn_query_weights(L.ptr(self.sorted_pos), L.ptr(self.cell_start), L.ptr(self.grid),
                                                           L.ptr(q), Q, float(radius), L.ptr(rp), L.ptr(D), L.ptr(I), L.ptr(nn),
-                                                          S, image_w, int(weights[0]), int(bool(weights[1])), L.ptr(w),
+                                                          S, image_w, int(weights[0]), int(bool(weights[1])),
+                                                          int(bool(weights[2])) if len(weights) > 2 else 0, L.ptr(w),
                                                           L.ptr(has), L.stream_ptr()), "glorie_knn_query_weights")
             return D, I, nn, w, has
         with torch.cuda.device(self.device):

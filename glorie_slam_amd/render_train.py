@@ -149,11 +149,9 @@ def render_rays(renderer, npc, decoders, rays_d, rays_o, stage, gt_depth, npc_ge
     with torch.no_grad():
         z_vals, pts, views, rq, n_zero = point_ops.ray_samples(rays_o, rays_d, gt_depth, rad, S,
                                                                renderer.near_end_surface, renderer.far_end_surface)
-        D, I, nn_num = npc.find_neighbors_faiss(pts, step='query', dynamic_radius=rq)
-        radius = 0.0 if g.use_dynamic_radius else npc.get_radius_query()
-        _, has8, w = point_ops.idw_gather(D, I, nn_num, None, radius=radius,
-                                          radius_per_query=rq if g.use_dynamic_radius else None,
-                                          min_nn=g.min_nn_num, return_weights=True, raw_mask=True)
+        # neighbours, IDW weights and mask from one launch, the search bounded by the query radius (point_ops.KnnIndex.search)
+        D, I, nn_num, w, has8 = npc.find_neighbors_faiss(pts, step='query', dynamic_radius=rq,
+                                                         weights=(g.min_nn_num, False, True))
         counts, valid = point_ops.ray_counts(has8, S, 3)
         # the zero-depth count travels to pinned memory behind the sampling kernel and is looked at after the forward pass
         # has been enqueued: `int(n_zero)` here would stall the host until the previous iteration's backward and Adam

@@ -104,7 +104,7 @@ class Renderer(object):
         if g.use_dynamic_radius or radius == npc.radius_query:
             D, I, nn_num, w, has = npc.find_neighbors_faiss(pts, step='query', dynamic_radius=rq,
                                                             image_layout=(S, image_w) if image_w else None,
-                                                            weights=(g.min_nn_num, expo))
+                                                            weights=(g.min_nn_num, expo, True))
         else:
             D, I, nn_num = npc.find_neighbors_faiss(pts, step='query', dynamic_radius=rq,
                                                     image_layout=(S, image_w) if image_w else None)

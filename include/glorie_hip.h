@@ -517,11 +517,15 @@ int glorie_knn_query_image(const float* sorted_pos, const int* cell_start, const
 /* glorie_knn_query (image_w == 0) / glorie_knn_query_image (image_w > 0) for k = 8 with the inverse-distance weights and the
  * neighbour mask of get_feature_at_pos (reference: src/modules/conv_onet/models/decoder.py:130-173) produced by the same
  * launch: weights [Q,8] = [I >= 0 and D <= r^2] / (D + 1e-10) (or exp(-20 sqrt(D)) with expo_weighting), L1-normalised
- * (eps 1e-12); has [Q] = neighbour count (D < r^2) >= min_nn.  Bit-identical to glorie_idw_gather's weights / mask. */
+ * (eps 1e-12); has [Q] = neighbour count (D < r^2) >= min_nn.  Bit-identical to glorie_idw_gather's weights / mask.
+ * ball_only != 0: the search is bounded by the query's radius - everything the decoders use (weights, has, nn, and every
+ * (D, I) slot with D <= r^2) is unchanged, slots BEYOND the radius (weight 0) hold whatever the bounded search had seen:
+ * farther points in (distance, index) order among those seen, or (FLT_MAX, -1).  A sample with fewer than 8 points in
+ * its ball then stops at the ball instead of walking outward until it has found 8. */
 int glorie_knn_query_weights(const float* sorted_pos, const int* cell_start, const void* grid,
                              const float* queries, int Q, float radius, const float* radius_ptr, float* D,
                              int64_t* I, int* nn, int samples_per_ray, int image_w, int min_nn,
-                             int expo_weighting, float* weights, uint8_t* has, void* stream);
+                             int expo_weighting, int ball_only, float* weights, uint8_t* has, void* stream);
 
 /* Feature interpolation of MLP_geometry/MLP_color.get_feature_at_pos
  *   reference: src/modules/conv_onet/models/decoder.py:130-173 (geometry), :340-389 (colour)

@@ -183,6 +183,14 @@ def test_knn_query_with_weights_equals_the_separate_weights_launch(gpu, image):
                                                return_weights=True, raw_mask=True)
             assert torch.equal(w1, w0) and torch.equal(has1, has0)
             assert 0 < int(has1.sum()) < len(q)
+            # the search bounded by the query radius (what the renderer asks for): weights, mask, counts and every slot
+            # inside the ball are those of the exact search; only slots beyond the radius (weight 0) may differ
+            D2, I2, n2, w2, has2 = idx.search(qd, 8, image_layout=layout, weights=(min_nn, False, True), **kw)
+            assert torch.equal(w2, w0) and torch.equal(has2, has0) and torch.equal(n2, n0)
+            r2 = (kw["radius_per_query"] if "radius_per_query" in kw else torch.full_like(rad, kw["radius"])) ** 2
+            inside = D0 <= r2[:, None]
+            assert torch.equal(D2[inside], D0[inside]) and torch.equal(I2[inside], I0[inside])
+            assert bool((~inside).any()) and bool(((D2 > r2[:, None]) | (I2 < 0))[~inside].all())
 
 
 def test_composite_matches_reference_fixture(gpu):
@@ -356,7 +364,7 @@ def test_render_batch_ray_end_to_end(gpu):
 def _reference_render_setup(gpu, ray_batch_size=65536):
     """scene, decoders and renderer of fixture F11 (tests/golden/render.npz, minted from the reference's
     Renderer by tests/golden/make_golden.py::make_render)"""
-    from golden.make_golden import render_scene, render_cfg
+    from golden.scenes import render_scene, render_cfg
     from glorie_slam_amd.decoder import POINT
     from glorie_slam_amd.neural_point import NeuralPointCloud
     from glorie_slam_amd.renderer import Renderer
