@@ -478,11 +478,18 @@ def main():
     for i in range(4):
         g3.update(t0=1, t1=8, itrs=2, use_inactive=False, opt_type="pose_depth" if i % 2 == 0 else "depth_scale")
     g3.fast_update.gate_events = []
+    g3.fast_update.q_events, g3.fast_update.heads_events = [], []
     for i in range(30):
         g3.update(t0=1, t1=8, itrs=2, use_inactive=False, opt_type="pose_depth" if i % 2 == 0 else "depth_scale")
     torch.cuda.synchronize()
     ev = g3.fast_update.gate_events
-    g3.fast_update.gate_events = None
+    evq, evh = g3.fast_update.q_events, g3.fast_update.heads_events
+    g3.fast_update.gate_events = g3.fast_update.q_events = g3.fast_update.heads_events = None
+    n3, hw3 = int(g3.ii.shape[0]), g3.ht * g3.wd
+    q_ms = sum(a.elapsed_time(b) for a, b in evq) / max(len(evq), 1)
+    heads_ms = sum(a.elapsed_time(b) for a, b in evh) / max(len(evh), 1)
+    q_flops = 2.0 * n3 * hw3 * 9 * 320 * 128                      # convq over [r*net | corr | flow] (+ hoisted context term)
+    heads_flops = 2.0 * n3 * hw3 * (9 * 128 * 384 + 2 * 128 * 18)  # delta[0] | weight[0] | agg.conv1 + the heads' tap GEMMs
     assert len(ev) == 30
     conv_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
     conv_flops = 2.0 * int(g3.ii.shape[0]) * g3.ht * g3.wd * 9 * 320 * 256
@@ -558,6 +565,21 @@ def main():
     if world > 1:
         dist.all_reduce(rays_total)
     rays_per_s = float(rays_total.item()) / t_r
+    # the same frame with the decoders on the exact-fp32 MFMA kernels (what the range guard of the split kernels falls back
+    # to; GLORIE_MLP_F32 is read at every launch)
+    rays_per_s_f32 = None
+    if world == 1:
+        os.environ["GLORIE_MLP_F32"] = "1"
+        try:
+            render_pass(npc, dec, ren, rays, device)
+            torch.cuda.synchronize()
+            t_f = time.perf_counter()
+            n_f = render_pass(npc, dec, ren, rays, device)
+            torch.cuda.synchronize()
+            rays_per_s_f32 = n_f / (time.perf_counter() - t_f)
+        finally:
+            del os.environ["GLORIE_MLP_F32"]
+    assert not dec.range_guard(device).tripped(), "the range guard of the fp16-split decoders tripped on the bench scene"
     # M2 on the 5000-ray training batch (mapper.py:390-515 samples 5000 pixels per iteration), forward
     gsel = torch.Generator(device="cpu").manual_seed(5)
     pick = torch.randperm(rays["o"].shape[0], generator=gsel)[:5000].to(device)
@@ -621,7 +643,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_sequence:
         from glorie_slam_amd.pipeline import synthetic_images, synthetic_runner
         Ks = 13
-        srun, sc = synthetic_runner(device, Ks, zero_flow_head=True, map_iters=20, map_rays=1000)
+        srun, sc = synthetic_runner(device, Ks, zero_flow_head=True, map_iters=20, map_rays=1000, buffer=512)
         simgs = synthetic_images(Ks)
         torch.cuda.synchronize()
         t_s = time.perf_counter()
@@ -631,7 +653,7 @@ def main():
         tr = srun.timing["track_ms"]
         assert ssum["keyframes"] == Ks and ssum["mapped"] == Ks and sc["video"].ctx().ba_status()[0] == 0
         assert sum(1 for a, b in ssum["losses"] if b < a) >= Ks - 2, "mapping iterations must reduce the loss"
-        sequence = {"frames": Ks, "resolution": "640x480 (60x80 BA)", "wall_s": t_s,
+        sequence = {"frames": Ks, "resolution": "640x480 (60x80 BA)", "video_buffer": 512, "wall_s": t_s,
                     "bootstrap_ms": tr[7], "ms_per_kept_keyframe": float(np.median(tr[8:])),
                     "ms_per_mapping_iteration": float(np.mean(srun.timing["map_iter_ms"][2:])),
                     "ms_per_global_ba_2steps": float(np.median(srun.timing["ba_ms"])), "cloud_points": ssum["points"],
@@ -648,18 +670,26 @@ def main():
     img_w = int(rays["W"]) if "W" in rays else None
     layout = (S, img_w) if (img_w and os.environ.get("GLORIE_BENCH_KNN_LAYOUT", "image") == "image") else None
 
-    def knn_gather():
-        D, I, nn = npc.index.search(pq, 8, radius_per_query=rq, image_layout=layout)
-        point_ops.idw_gather2(D, I, nn, npc.geo_feats, npc.col_feats, radius_per_query=rq)
+    # R1 as the renderer launches it: ONE launch = exact search bounded by the query radius + IDW weights + neighbour mask
+    # (glorie_knn_query_weights).  R2 (the 128-byte feature rows) is gathered inside the decoder kernels in the product;
+    # the stand-alone two-table gather is timed next to it so that the pair can be priced against SURVEY's 2156 B per sample.
+    def knn_product():
+        return npc.index.search(pq, 8, radius_per_query=rq, image_layout=layout, weights=(2, False, True))
 
-    knn_gather()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(5):
-        knn_gather()
-    e1.record()
-    torch.cuda.synchronize()
-    knn_ms = e0.elapsed_time(e1) / 5
+    def timed(fn, reps=5):
+        fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / reps
+
+    knn_search_ms = timed(knn_product)
+    Dk, Ik, nnk, _, _ = knn_product()
+    gather_ms = timed(lambda: point_ops.idw_gather2(Dk, Ik, nnk, npc.geo_feats, npc.col_feats, radius_per_query=rq))
+    knn_ms = knn_search_ms + gather_ms
     knn_bytes = 2156.0 * pq.shape[0]
     knn_gbs = knn_bytes / (knn_ms * 1e-3) / 1e9
     # fused decoders alone: executed FLOPs (post-sum F_theta form, 358,848 FLOP per sample)
@@ -667,14 +697,8 @@ def main():
     cg_, has_, w_ = point_ops.idw_gather(D_, I_, nn_, npc.geo_feats, radius_per_query=rq, return_weights=True)
     vq = rays["d"][:nq].repeat_interleave(S, dim=0).contiguous()
     packed = dec._packed()
-    for _ in range(2):
-        point_ops.render_mlp(packed, pq, vq, npc.cloud_pos(), npc.col_feats, cg_, I_, w_, has_)
-    e0.record()
-    for _ in range(5):
-        point_ops.render_mlp(packed, pq, vq, npc.cloud_pos(), npc.col_feats, cg_, I_, w_, has_)
-    e1.record()
-    torch.cuda.synchronize()
-    mlp_ms = e0.elapsed_time(e1) / 5
+    point_ops.render_mlp(packed, pq, vq, npc.cloud_pos(), npc.col_feats, cg_, I_, w_, has_)
+    mlp_ms = timed(lambda: point_ops.render_mlp(packed, pq, vq, npc.cloud_pos(), npc.col_feats, cg_, I_, w_, has_))
     mlp_flops = 2.0 * 179424.0 * pq.shape[0]
     mlp_tf = mlp_flops / (mlp_ms * 1e-3) / 1e12
     conv_traffic, corr_traffic, knn_traffic = _pmc_traffic()
@@ -721,6 +745,15 @@ def main():
                      # the reference evaluates all 448 input channels in every iteration (gru.py:20-24)
                      "reference_formulation": {"flops_per_launch": conv_flops * 448.0 / 320.0,
                                                "equiv_frac": conv_tf * 448.0 / 320.0 / MFMA_F16_PEAK_TF}},
+        "roofline_q": {"bound": "mfma", "kernel": "conv_igemm_kernel<EPI_GRU_Q,4,64> (ConvGRU convq, 320->128, 3x3, GRU blend epilogue)",
+                       "achieved": q_flops / (q_ms * 1e-3) / 1e12 if q_ms else None, "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s",
+                       "frac": (q_flops / (q_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TF) if q_ms else None, "traffic": None,
+                       "flops_per_launch": q_flops, "ms_per_launch": q_ms},
+        "roofline_heads": {"bound": "mfma", "kernel": "conv_igemm_kernel<EPI_HEADS,4,64> (delta[0] | weight[0] | agg.conv1, 128->384, "
+                                                      "3x3, tap GEMMs of the heads in the epilogue)",
+                           "achieved": heads_flops / (heads_ms * 1e-3) / 1e12 if heads_ms else None, "peak": MFMA_F16_PEAK_TF,
+                           "unit": "TFLOP/s", "frac": (heads_flops / (heads_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TF) if heads_ms else None,
+                           "traffic": None, "flops_per_launch": heads_flops, "ms_per_launch": heads_ms},
         "roofline_corr": {"bound": "hbm", "kernel": corr_kernel,
                           "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": achieved / HBM_PEAK_GBS, "traffic": corr_traffic if full else None,
@@ -730,6 +763,7 @@ def main():
                           "measured_hbm_frac": (corr_traffic / (corr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
                           if (full and corr_traffic) else None},
         "rays_per_sec": rays_per_s,
+        "rays_per_sec_f32_mfma": rays_per_s_f32,
         # the frame is a fixed ray budget split over the ranks (strong scaling); the BA-update graph grows with N (weak)
         "rays_scaling": "strong",
         "rays_per_sec_batch5000": 5000.0 / (batch_ms * 1e-3), "ms_per_batch5000": batch_ms,
@@ -738,7 +772,10 @@ def main():
         "strong_scaling_graph": strong,
         "render": {"rays_local": int(n_r // render_reps), "samples_per_ray": int(S), "cloud_points": int(npc.pts_num()),
                    "ms_per_frame_shard": 1e3 * t_r / render_reps},
-        "roofline_knn": {"bound": "hbm", "kernel": "knn_query_kernel<8> (image-patch order) + idw_gather2_kernel (both feature tables)",
+        "roofline_knn": {"bound": "hbm", "kernel": "knn_query_kernel<8> as the renderer launches it (image-patch order, bounded by the "
+                                                   "query radius, + IDW weights and mask) + stand-alone idw_gather2_kernel (both feature "
+                                                   "tables; the product gathers the rows inside mlp_geo_v4 / mlp_nb_v4)",
+                         "search_ms": knn_search_ms, "gather_ms": gather_ms,
                          "achieved": knn_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": knn_gbs / HBM_PEAK_GBS, "traffic": knn_traffic if world == 1 else None,
                          "alg_bytes_per_launch": knn_bytes, "ms_per_launch": knn_ms,

@@ -1250,141 +1250,13 @@ __global__ __launch_bounds__(512, 4) void mlp_nb_v4_kernel(NbParams P, const flo
   report_range(bad, range_flag);
 }
 
-// per-neighbour F_theta, round 3: NB column blocks per wave (see mlp_col_v5_kernel): every W1 fragment read from LDS feeds
-// 3 NB MFMAs, and the softplus of one block runs under the MFMAs of the other inside the same wave.
-template <int NB, int WAVES>
-__global__ __launch_bounds__(WAVES * 64, NB == 1 ? 4 : 2)
-void mlp_nb_v5_kernel(NbParams P, const float* __restrict__ W1frag, const float* __restrict__ pts,
-                      const float* __restrict__ cloud, const float* __restrict__ col_feats,
-                      const int64_t* __restrict__ I, const float* __restrict__ wts, const uint8_t* __restrict__ has,
-                      int Q, float* __restrict__ c_col, int* __restrict__ range_flag) {
-  bool bad = false;
-  constexpr int THREADS = WAVES * 64, SPW = WAVES * 16 * NB;     // samples per workgroup
-  extern __shared__ float smem[];
-  h16x8* W1f = reinterpret_cast<h16x8*>(smem);   // [2 chunks][2 hi|lo][8][64] fragments of 8 halfs = 32 KB
-  float* b1s = smem + 8192;                   // [128]
-  float* wbuf = b1s + 128;                    // [SPW][8] IDW weights (0 for an absent neighbour)
-  int* ibuf = reinterpret_cast<int*>(wbuf + SPW * 8);  // [SPW][8] neighbour ids (0 for an absent one)
-  float* bs = reinterpret_cast<float*>(ibuf + SPW * 8);  // [20][4] B[:, f mod 10] (revolutions per metre)
-  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-  const int r = lane & 15, g = lane >> 4;
-  const int q0 = blockIdx.x * SPW;
-  if (tid < 80) {
-    const int f = tid >> 2, d = tid & 3;
-    bs[tid] = d < 3 ? P.B[d * 10 + (f < 10 ? f : f - 10)] : 0.0f;
-  }
-  for (int idx = tid; idx < 8192 / 4; idx += THREADS)        // the split fragments as packed (point_ops.pack_decoders)
-    reinterpret_cast<float4*>(smem)[idx] = reinterpret_cast<const float4*>(W1frag)[idx];
-  if (tid < 128) b1s[tid] = P.b1[tid];
-  for (int idx = tid; idx < SPW * 8; idx += THREADS) {
-    const int row = idx >> 3;
-    const int q = min(q0 + row, Q - 1);
-    const int ii = (int)I[(size_t)q * 8 + (idx & 7)];
-    wbuf[idx] = (q0 + row < Q && ii >= 0) ? wts[(size_t)q * 8 + (idx & 7)] : 0.0f;
-    ibuf[idx] = ii < 0 ? 0 : ii;
-  }
-  __syncthreads();
-  int srow[NB], qs[NB];
-  float qx[NB], qy[NB], qz[NB];
-#pragma unroll
-  for (int nb = 0; nb < NB; ++nb) {
-    srow[nb] = (wv * NB + nb) * 16 + r;       // this lane's sample row inside the workgroup
-    qs[nb] = q0 + srow[nb];
-    const size_t q = (size_t)min(qs[nb], Q - 1);
-    qx[nb] = pts[q * 3 + 0]; qy[nb] = pts[q * 3 + 1]; qz[nb] = pts[q * 3 + 2];
-  }
-  const float* bsl = bs + 4 * g;
-  f32x4 ysum[NB][8];
-  float sw[NB];
-#pragma unroll
-  for (int nb = 0; nb < NB; ++nb) { zero<8>(ysum[nb]); sw[nb] = 0.0f; }
-  const h16x8* wl = W1f + lane;
-#pragma unroll 1
-  for (int k = 0; k < 8; ++k) {
-    h16x8 ehi[NB], elo[NB], fhi[NB], flo[NB];
-    float w[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      const int pt = ibuf[srow[nb] * 8 + k];
-      w[nb] = wbuf[srow[nb] * 8 + k];
-      const float4 c0 = *reinterpret_cast<const float4*>(col_feats + (size_t)pt * 32 + 4 * g);
-      const float4 c1 = *reinterpret_cast<const float4*>(col_feats + (size_t)pt * 32 + 16 + 4 * g);
-      const float rx = cloud[(size_t)pt * 3 + 0] - qx[nb], ry = cloud[(size_t)pt * 3 + 1] - qy[nb],
-                  rz = cloud[(size_t)pt * 3 + 2] - qz[nb];
-      float ev[8];
-#pragma unroll
-      for (int sidx = 0; sidx < 5; ++sidx) {
-        const float4 bf = *reinterpret_cast<const float4*>(bsl + 16 * sidx);
-        const float a = fmaf(rz, bf.z, fmaf(ry, bf.y, rx * bf.x));
-        ev[sidx] = (4 * sidx + g >= 10) ? cos_rev(a) : sin_rev(a);
-      }
-      ev[5] = ev[6] = ev[7] = 0.0f;
-      split2(f32x4{ev[0], ev[1], ev[2], ev[3]}, f32x4{ev[4], ev[5], ev[6], ev[7]}, ehi[nb], elo[nb]);
-      split2(f32x4{c0.x, c0.y, c0.z, c0.w}, f32x4{c1.x, c1.y, c1.z, c1.w}, fhi[nb], flo[nb]);
-    }
-    f32x4 acc[NB][8];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) zero<8>(acc[nb]);
-    // chunk 0: embedding features; chunk 1: the neighbour's colour feature
-#pragma unroll
-    for (int to = 0; to < 8; ++to) {
-      const h16x8 ahi = wl[to * 64], alo = wl[(8 + to) * 64];
-      const h16x8 bhi = wl[(16 + to) * 64], blo = wl[(24 + to) * 64];
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        acc[nb][to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, ehi[nb], acc[nb][to], 0, 0, 0);
-        acc[nb][to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, elo[nb], acc[nb][to], 0, 0, 0);
-        acc[nb][to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, ehi[nb], acc[nb][to], 0, 0, 0);
-        acc[nb][to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bhi, fhi[nb], acc[nb][to], 0, 0, 0);
-        acc[nb][to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bhi, flo[nb], acc[nb][to], 0, 0, 0);
-        acc[nb][to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(blo, fhi[nb], acc[nb][to], 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);     // keeps the compiler from hoisting all 32 fragment reads (128 registers)
-    }
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      sw[nb] += w[nb];
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const float4 bb = *reinterpret_cast<const float4*>(b1s + 16 * t + 4 * g);
-        ysum[nb][t][0] += w[nb] * softplus100_fast(acc[nb][t][0] + bb.x);
-        ysum[nb][t][1] += w[nb] * softplus100_fast(acc[nb][t][1] + bb.y);
-        ysum[nb][t][2] += w[nb] * softplus100_fast(acc[nb][t][2] + bb.z);
-        ysum[nb][t][3] += w[nb] * softplus100_fast(acc[nb][t][3] + bb.w);
-      }
-    }
-  }
-  // second layer 128 -> 32 in fp32 as in mlp_nb_v3_kernel (A = W2 straight from global / L2)
-#pragma unroll
-  for (int nb = 0; nb < NB; ++nb) {
-    f32x4 o[2];
-    zero<2>(o);
-    const float* wp = P.W2 + (4 * g) * 32 + r;
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        o[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[(16 * t + rr) * 32], ysum[nb][t][rr], o[0], 0, 0, 0);
-        o[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[(16 * t + rr) * 32 + 16], ysum[nb][t][rr], o[1], 0, 0, 0);
-      }
-    if (qs[nb] < Q) {
-      const bool h = has[qs[nb]] != 0;
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const float4 b2 = *reinterpret_cast<const float4*>(P.b2 + 16 * t + 4 * g);
-        float4 v;
-        v.x = h ? o[t][0] + b2.x * sw[nb] : 0.0f;
-        v.y = h ? o[t][1] + b2.y * sw[nb] : 0.0f;
-        v.z = h ? o[t][2] + b2.z * sw[nb] : 0.0f;
-        v.w = h ? o[t][3] + b2.w * sw[nb] : 0.0f;
-        bad = bad | not_finite(v.x + v.y + v.z + v.w);
-        *reinterpret_cast<float4*>(c_col + (size_t)qs[nb] * 32 + 16 * t + 4 * g) = v;
-      }
-    }
-  }
-  report_range(bad, range_flag);
-}
-
+// Round 3, measured and not kept for the per-neighbour kernel (614,400 samples, v4 = 394 us): two column blocks per wave in
+// lockstep 415-463 us; two accumulator sets with the MFMAs of neighbour k+1 issued between the softplus instructions of
+// neighbour k (software pipeline inside the wave) 495 us at 2 waves per SIMD, 624 us at 3 (spills) - four resident waves per
+// SIMD alternating their phases already overlap the matrix pipe with the vector ALU better than one wave can by itself;
+// the kernel sits on its vector floor (8 x 128 softplus per sample, two quarter-rate transcendentals each: ~340 us).  A
+// degree-6 polynomial for log2(1 + e) on packed fp32 FMAs instead of v_log_f32 was slower too (405 us: v_pk_fma_f32 beside
+// MFMAs is no faster than two v_fma_f32, MI355X_MICROARCH.md), as was the colour kernel with it (450 vs 427 us).
 }  // namespace glorie
 
 using namespace glorie;
@@ -1484,34 +1356,17 @@ extern "C" int glorie_render_mlp(const float* packed, const float* pts, const fl
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)nb4_lds);
       attr4 = true;
     }
-    // GLORIE_MLP_VARIANT: "v4" = 16 samples per wave (round 2), "n2w8" / "n2w4" = 32 samples per wave, 8 / 4 waves per workgroup
-    // (GLORIE_MLP_NB_VARIANT / GLORIE_MLP_COL_VARIANT select one kernel each).  Measured per 614k-sample batch: colour 495 /
-    // 485 / 440 us, per-neighbour 403 / 463 / 415 us -> defaults: colour n2w4, per-neighbour v4
+    // GLORIE_MLP_COL_VARIANT: "v4" = 16 samples per wave (round 2), "n2w8" / "n2w4" = 32 samples per wave, 8 / 4 waves per
+    // workgroup.  Measured per 614k-sample batch: 495 / 485 / 427 us -> default n2w4
     auto pick = [](const char* name, int dflt) {
       const char* v = getenv(name);
-      if (!v || !v[0]) v = getenv("GLORIE_MLP_VARIANT");
       if (!v || !v[0]) return dflt;
       return v[0] == 'v' ? 0 : ((v[0] == 'n' && v[1] == '2' && v[2] == 'w' && v[3] == '8') ? 1 : 2);
     };
-    const int variant = pick("GLORIE_MLP_NB_VARIANT", 0), variant_col = pick("GLORIE_MLP_COL_VARIANT", 2);
-    auto nb5_lds = [](int spw) { return sizeof(float) * (8192 + 128 + spw * 8 + 80) + sizeof(int) * spw * 8; };
-    static bool attr5 = false;
-    if (!attr5) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_nb_v5_kernel<2, 8>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)nb5_lds(256));
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_nb_v5_kernel<2, 4>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)nb5_lds(128));
-      attr5 = true;
-    }
+    const int variant_col = pick("GLORIE_MLP_COL_VARIANT", 2);
     if (f32 && f32[0] == '1')
       hipLaunchKernelGGL(mlp_nb_v3_kernel, dim3(blocks2), dim3(512), nb_lds, st, n, pts, cloud_pos, col_feats,
                          I, weights, has, Q, c_col_scratch);
-    else if (variant == 1)
-      hipLaunchKernelGGL((mlp_nb_v5_kernel<2, 8>), dim3((Q + 255) / 256), dim3(512), nb5_lds(256), st, n, nb_frags, pts,
-                         cloud_pos, col_feats, I, weights, has, Q, c_col_scratch, range_flag);
-    else if (variant == 2)
-      hipLaunchKernelGGL((mlp_nb_v5_kernel<2, 4>), dim3((Q + 127) / 128), dim3(256), nb5_lds(128), st, n, nb_frags, pts,
-                         cloud_pos, col_feats, I, weights, has, Q, c_col_scratch, range_flag);
     else
       hipLaunchKernelGGL(mlp_nb_v4_kernel, dim3(blocks2), dim3(512), nb4_lds, st, n, nb_frags, pts, cloud_pos, col_feats,
                          I, weights, has, Q, c_col_scratch, range_flag);

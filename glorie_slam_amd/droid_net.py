@@ -279,6 +279,8 @@ class FusedUpdate:
         self.fuse_glo = True      # global-context reduction inside the epilogue of its 1x1 convolution
         self.fuse_heads = True    # tap GEMMs of the delta / weight heads inside the epilogue of their hidden convolution
         self.gate_events = None   # a list: (start, end) events of every z|r gate launch are appended (eager steps only)
+        self.q_events = None      # the same for the q gate launch and for the heads' hidden convolution (bench.py)
+        self.heads_events = None
 
     # -- weight packing ----------------------------------------------------------------
     def _sync(self):
@@ -477,8 +479,15 @@ class FusedUpdate:
             if ev is not None:
                 e1.record()
                 ev.append((e0, e1))
+            evq = self.q_events
+            if evq is not None:
+                q0, q1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                q0.record()
             U.conv_igemm(rnet, dynx, W["q_dyn"], 9, 128, new, epilogue=U.EPI_GRU_Q, terms=g[:, 256:384], net=net0,
                          z=z, pre=pre[:, 256:384], pre_map=pmap)
+            if evq is not None:
+                q1.record()
+                evq.append((q0, q1))
         else:
             U.conv_igemm(net0, hx, W["zr"], 9, 256, z, epilogue=U.EPI_GRU_ZR, terms=g[:, 0:256], net=net0, out2=rnet)
             U.conv_igemm(rnet, hx, W["q"], 9, 128, new, epilogue=U.EPI_GRU_Q, terms=g[:, 256:384], net=net0, z=z)
@@ -487,7 +496,14 @@ class FusedUpdate:
         if self.fuse_heads:
             # the heads' hidden maps are consumed in the epilogue of their convolution (tap rows), only the GraphAgg third is stored
             agg_in = cl_map(128)
+            evh = self.heads_events
+            if evh is not None:
+                h0, h1e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                h0.record()
             rows = U.conv_igemm_heads(new, W["h1"], 9, 384, W["h1_b"], W["h2_taps"], 2, out=agg_in)
+            if evh is not None:
+                h1e.record()
+                evh.append((h0, h1e))
             wo = weight_out if (weight_out is not None and weight_out.is_cuda and weight_out.dtype == torch.float32
                                 and weight_out.is_contiguous() and weight_out.numel() == n * ht * wd * 2) else None
             dw = U.conv_stencil(rows, W["h2_b"], n, ht, wd, 2, 2, (U.ACT_NONE, U.ACT_SIGMOID), out_last=wo)

@@ -203,7 +203,8 @@ def synthetic_images(K, H=480, W=640, seed=5):
     return torch.nn.functional.interpolate(low, size=(H, W), mode="bilinear", align_corners=False).clamp(0, 1)
 
 
-def synthetic_runner(device, K, zero_flow_head=True, map_iters=20, map_rays=1000, use_graphs=True, H=480, W=640):
+def synthetic_runner(device, K, zero_flow_head=True, map_iters=20, map_rays=1000, use_graphs=True, H=480, W=640,
+                     buffer=None):
     """SequenceRunner over the keyframe arc of synth.keyframe_graph (the bench's graph G8 continued to K frames): seed-43
     default-init DroidNet and decoders, the mono prior = the true depth under an affine distortion, the tracker's initial
     guess of a new keyframe = its generating pose and disparity.  zero_flow_head: the last layer of the flow head is
@@ -220,7 +221,7 @@ def synthetic_runner(device, K, zero_flow_head=True, map_iters=20, map_rays=1000
     from .neural_point import NeuralPointCloud
     from .renderer import Renderer
     h, w = H // 8, W // 8
-    cfg = synthetic_cfg(device, K + 2, H, W)
+    cfg = synthetic_cfg(device, max(K + 2, buffer or 0), H, W)    # buffer: tracking.buffer of the shipped configs is 400-600
     g = synth.keyframe_graph(K=K, h=h, w=w, radius=3)
     torch.manual_seed(43)
     net = DroidNet().to(device).eval()
