@@ -72,6 +72,10 @@ __device__ __forceinline__ h2 acc_term(h2 acc, h2 s, h2 w) {
   const h2 t = s * w;
   return acc + t;
 }
+__device__ __forceinline__ h2 acc_term0(h2 s, h2 w) {
+#pragma clang fp contract(off)
+  return s * w;
+}
 
 // ---- one level of one tile: gather the 8 x 8 window of every lane's pixel ------------------------------------------
 template <int L>
@@ -206,11 +210,24 @@ __global__ __launch_bounds__(256) void corr_dm_lookup_kernel(DmArgs a) {
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kEnc2Lds = 232;   // halfs per weight row in LDS (224 + 8)
 
+// v_perm_b32 on 16-bit loads: hipcc zero-extends a buffer_load_ushort result before __builtin_amdgcn_perm (one v_and per
+// tap) although the selector never reads the upper half; the asm form takes the registers as they are
+__device__ __forceinline__ h2 perm16(unsigned short s0, unsigned short s1, unsigned sel) {
+  unsigned r;
+  asm("v_perm_b32 %0, %1, %2, %3" : "=v"(r) : "v"(s0), "v"(s1), "s"(sel));
+  return __builtin_bit_cast(h2, r);
+}
+
+// Per-level gather state.  The window's displaced coordinates are consecutive modulo the plane, so the byte offsets are
+// carried incrementally (+ one column / one row, reset at the plane's end: 3 operations) next to an unsigned counter for
+// the tap's validity (3 more) instead of being derived tap by tap.  Offsets of invalid taps may be anything: they are
+// replaced by kOob.  The arithmetic is modulo 2^32, which is what makes a start left of the plane (only reachable when the
+// first valid tap is further right) arrive at 0 on the right step.
 struct DmLevel {
   __amdgpu_buffer_rsrc_t rs;
   unsigned coff[8];
-  int iy0, by, hl, wl;
-  unsigned lane2;
+  unsigned r, uy;                 // running: byte offset of the next window row (+ 2 lane), its target row as unsigned
+  unsigned rstep, rend, lane2, hl;
   h2 w00, w01, w10, w11;
 };
 
@@ -222,31 +239,39 @@ __device__ __forceinline__ void dm_setup(const DmArgs& a, size_t slot_tile, int 
   const float xs = x0 * inv, ys = y0 * inv;
   const float fx = floorf(xs), fy = floorf(ys);
   const float fdx = xs - fx, fdy = ys - fy;
-  const int ix0 = static_cast<int>(fx) - 3;
-  st.iy0 = static_cast<int>(fy) - 3;
-  const int bx = ix0 - (sx >> L) + (wl >> 1);
-  st.by = st.iy0 - (sy >> L) + (hl >> 1);
-  st.hl = hl; st.wl = wl; st.lane2 = (unsigned)lane * 2u;
+  const int ix0 = static_cast<int>(fx) - 3, iy0 = static_cast<int>(fy) - 3;
+  int bx = ix0 - (sx >> L) + (wl >> 1), by = iy0 - (sy >> L) + (hl >> 1);
+  bx = bx < 0 ? bx + wl : (bx >= wl ? bx - wl : bx);
+  by = by < 0 ? by + hl : (by >= hl ? by - hl : by);
   const _Float16* base = a.lvl[L] + slot_tile * ((size_t)hl * wl * 64);
   st.rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, hl * wl * 128, 0x00020000);
+  const unsigned cend = (unsigned)wl * 128u;
+  unsigned c = (unsigned)bx * 128u, ux = (unsigned)ix0;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    const int tx = ix0 + i;
-    int d = bx + i;
-    d = d < 0 ? d + wl : (d >= wl ? d - wl : d);
-    st.coff[i] = (tx >= 0 && tx < wl) ? (unsigned)d * 128u : kOob;
+    st.coff[i] = ux < (unsigned)wl ? c : kOob;
+    ux += 1u;
+    c += 128u;
+    c = c == cend ? 0u : c;
   }
+  st.lane2 = (unsigned)lane * 2u;
+  st.rstep = cend;
+  st.rend = (unsigned)hl * cend + st.lane2;
+  st.r = (unsigned)by * cend + st.lane2;
+  st.uy = (unsigned)iy0;
+  st.hl = (unsigned)hl;
   st.w00 = splat(to_half_rn((1.0f - fdx) * (1.0f - fdy)));
   st.w01 = splat(to_half_rn((1.0f - fdx) * fdy));
   st.w10 = splat(to_half_rn(fdx * (1.0f - fdy)));
   st.w11 = splat(to_half_rn(fdx * fdy));
 }
 
-__device__ __forceinline__ void dm_load_row(const DmLevel& st, int j, unsigned (&row)[8]) {
-  const int ty = st.iy0 + j;
-  int d = st.by + j;
-  d = d < 0 ? d + st.hl : (d >= st.hl ? d - st.hl : d);
-  const unsigned roff = (ty >= 0 && ty < st.hl) ? (unsigned)(d * st.wl) * 128u + st.lane2 : kOob;
+// the next window row (rows are requested in order, 0..7)
+__device__ __forceinline__ void dm_load_row(DmLevel& st, unsigned short (&row)[8]) {
+  const unsigned roff = st.uy < st.hl ? st.r : kOob;
+  st.uy += 1u;
+  st.r += st.rstep;
+  st.r = st.r == st.rend ? st.lane2 : st.r;
 #pragma unroll
 #ifdef EXP_DM_NO_GATHER
   for (int i = 0; i < 8; ++i) row[i] = (roff + st.coff[i]) & 0x3c00u;          // ablation: arithmetic only, no memory
@@ -256,9 +281,9 @@ __device__ __forceinline__ void dm_load_row(const DmLevel& st, int j, unsigned (
 }
 
 // the 4 aligned tap pairs (2k, 2k+1) of a window row
-__device__ __forceinline__ void dm_pack_row(const unsigned (&row)[8], h2 (&p)[4]) {
+__device__ __forceinline__ void dm_pack_row(const unsigned short (&row)[8], h2 (&p)[4]) {
 #pragma unroll
-  for (int k = 0; k < 4; ++k) p[k] = pk(row[2 * k], row[2 * k + 1]);
+  for (int k = 0; k < 4; ++k) p[k] = perm16(row[2 * k + 1], row[2 * k], 0x05040100u);
 }
 // the odd pair (2k+1, 2k+2) from two aligned pairs: (a.hi, b.lo) in one v_perm_b32; beyond the window: (tap 7, 0)
 __device__ __forceinline__ h2 dm_odd(const h2 (&p)[4], int k) {
@@ -267,17 +292,22 @@ __device__ __forceinline__ h2 dm_odd(const h2 (&p)[4], int k) {
   return __builtin_bit_cast(h2, __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, p[k + 1]), a, 0x05040302u));
 }
 
+// EXACT: the reference's accumulator starts at +0 and channel 7 of every row is a zero.  Both only matter to a caller that
+// reads the lookup itself (0 + -0 = +0; the padding tap's blend is a finite sum of tap-7 values): the encoder-only form
+// starts from the first product and leaves the padding lane as it falls (its weight column is zero)
+template <bool EXACT>
 __device__ __forceinline__ u32x4 dm_blend_row(const DmLevel& st, const h2 (&p0)[4], const h2 (&p1)[4]) {
   u32x4 r;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    h2 acc = h2{(_Float16)0.0f, (_Float16)0.0f};
-    acc = acc_term(acc, p0[k], st.w00);
+    h2 acc;
+    if (EXACT) acc = acc_term(h2{(_Float16)0.0f, (_Float16)0.0f}, p0[k], st.w00);
+    else acc = acc_term0(p0[k], st.w00);
     acc = acc_term(acc, p1[k], st.w01);
     acc = acc_term(acc, dm_odd(p0, k), st.w10);
     acc = acc_term(acc, dm_odd(p1, k), st.w11);
     unsigned u = __builtin_bit_cast(unsigned, acc);
-    if (k == 3) u &= 0xffffu;
+    if (EXACT && k == 3) u &= 0xffffu;
     r[k] = u;
   }
   return r;
@@ -304,17 +334,21 @@ __device__ __forceinline__ void dm_kstep(int ks, u32x4 lo, u32x4 hi, const _Floa
 // retires (nothing follows level 3)
 template <int L, bool CORR>
 __device__ __forceinline__ void dm_level_pipelined(const DmArgs& a, bool live, size_t row, const _Float16* wlds, int lane,
-                                                   unsigned (&raw)[8][8], const DmLevel& cur, const DmLevel& nxt,
+                                                   unsigned short (&raw)[8][8], const DmLevel& cur, DmLevel& nxt,
                                                    u32x4& pending, f32x16 (&acc)[4][2]) {
   h2 P[2][4];
   dm_pack_row(raw[0], P[0]);
 #pragma unroll
   for (int j = 0; j < 7; ++j) {
     dm_pack_row(raw[j + 1], P[(j + 1) & 1]);
-    const u32x4 out = dm_blend_row(cur, P[j & 1], P[(j + 1) & 1]);
+    const u32x4 out = dm_blend_row<CORR>(cur, P[j & 1], P[(j + 1) & 1]);
     if (L < 3) {                                    // window row j is retired: its registers take row j of what follows
-      dm_load_row(nxt, j, raw[j]);
-      if (j == 6) dm_load_row(nxt, 7, raw[7]);
+      // (fenced: left alone, the scheduler gathers the requests of several rows into one clump behind a vmcnt(0), which
+      // drains the queue ten times per tile)
+      __builtin_amdgcn_sched_barrier(0);
+      dm_load_row(nxt, raw[j]);
+      if (j == 6) dm_load_row(nxt, raw[7]);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (CORR && live) *reinterpret_cast<u32x4*>(a.corr_cl + row * 256 + L * 64 + j * 8) = out;
     const int g = 7 * L + j;
@@ -356,6 +390,14 @@ __device__ __forceinline__ float2 dm_coords(const DmArgs& a, const DmUnit& u, co
   return c;
 }
 
+#ifdef EXP_DM_TIMESTAMPS
+// experiment (tools/exp_corr_timeline.py): shader-clock stamps of a wave's phases, written over the first 64 bytes of the
+// output row of the tile's first pixel
+#define DM_STAMP(k) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp[k]) : : "memory")
+#else
+#define DM_STAMP(k)
+#endif
+
 // One tile per wave, 4 waves (consecutive tiles) per workgroup.  A persistent form (2 workgroups per CU, waves walking
 // their units with the next tile's level 0 prefetched under the epilogue) was measured and is not faster: the launch is
 // bound by the per-SIMD instruction stream (~3200 vector instructions per tile at 2 waves per SIMD), not by how the tiles
@@ -369,16 +411,25 @@ __global__ __launch_bounds__(256, 2) void corr_dm_encode_kernel(DmArgs a) {
   const int HW = a.h * a.w;
   const int unit = blockIdx.x * 4 + wv;
   const bool has = unit < total;
+#ifdef EXP_DM_TIMESTAMPS
+  unsigned long long stamp[10];
+#endif
+  DM_STAMP(0);
 
   DmUnit u;
   dm_unit(a, has ? unit : total - 1, u);
   const DmPixel px = dm_pixel(a, u, lane);
   const float2 c = dm_coords(a, u, px, has);
-  unsigned raw[8][8];
+  unsigned short raw[8][8];
   DmLevel cur;
   dm_setup<0>(a, (size_t)u.slot_tile, px.sy, px.sx, lane, c.x, c.y, cur);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) dm_load_row(cur, j, raw[j]);
+  for (int j = 0; j < 8; ++j) dm_load_row(cur, raw[j]);
+  DM_STAMP(1);
+#ifdef EXP_DM_TIMESTAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // latency of the first 64 gathers, measured alone
+  DM_STAMP(8);
+#endif
   // encoder weights [128][224] -> LDS rows of kEnc2Lds halfs + the bias, behind the first 64 loads
   // (128 * 28 = 14 * 256 pieces of 16 bytes: all 14 loads of a thread are issued before the first LDS store)
   {
@@ -386,43 +437,68 @@ __global__ __launch_bounds__(256, 2) void corr_dm_encode_kernel(DmArgs a) {
 #pragma unroll
     for (int k = 0; k < 14; ++k)
       wreg[k] = *reinterpret_cast<const u32x4*>(a.enc_w + (size_t)(threadIdx.x + 256 * k) * 8);
-    const float bias_in = threadIdx.x < 128 ? a.enc_b[threadIdx.x] : 0.0f;
+    const float bias_in = a.enc_b[threadIdx.x & 127];
 #pragma unroll
     for (int k = 0; k < 14; ++k) {
       const int idx = threadIdx.x + 256 * k;
       const int r = idx / 28, cc = idx - r * 28;
       *reinterpret_cast<u32x4*>(wlds + r * kEnc2Lds + cc * 8) = wreg[k];
     }
-    if (threadIdx.x < 128) reinterpret_cast<float*>(wlds + 128 * kEnc2Lds)[threadIdx.x] = bias_in;
-  }
+    reinterpret_cast<float*>(wlds + 128 * kEnc2Lds)[threadIdx.x] = bias_in;      // (twice: no branch between the gathers
+  }                                                                              //  and their use, see perm16)
   __syncthreads();
-  if (!has) return;
+  DM_STAMP(2);
 
+  // the accumulators start at the bias: C/D of 32x32 puts channel 32 mb + 8 g + 4 (lane >> 5) + q in register 4 g + q.
+  // (A wave past the last unit runs on with every tap out of range and nothing stored.)
   f32x16 acc[4][2];
+  {
+    const float* bl = reinterpret_cast<const float*>(wlds + 128 * kEnc2Lds) + 4 * (lane >> 5);
 #pragma unroll
-  for (int mb = 0; mb < 4; ++mb)
+    for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(bl + 32 * mb + 8 * g);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.0f;
+        for (int q = 0; q < 4; ++q) acc[mb][0][4 * g + q] = acc[mb][1][4 * g + q] = b[q];
+      }
+  }
   u32x4 pending = u32x4{0u, 0u, 0u, 0u};
-  const bool live = px.live;
+  const bool live = px.live && has;
   const size_t row = (size_t)u.n * HW + px.pix;
   DmLevel nxt;
   dm_setup<1>(a, (size_t)u.slot_tile, px.sy, px.sx, lane, c.x, c.y, nxt);
   dm_level_pipelined<0, CORR>(a, live, row, wlds, lane, raw, cur, nxt, pending, acc);
+  DM_STAMP(3);
   cur = nxt;
   dm_setup<2>(a, (size_t)u.slot_tile, px.sy, px.sx, lane, c.x, c.y, nxt);
   dm_level_pipelined<1, CORR>(a, live, row, wlds, lane, raw, cur, nxt, pending, acc);
+  DM_STAMP(4);
   cur = nxt;
   dm_setup<3>(a, (size_t)u.slot_tile, px.sy, px.sx, lane, c.x, c.y, nxt);
   dm_level_pipelined<2, CORR>(a, live, row, wlds, lane, raw, cur, nxt, pending, acc);
+  DM_STAMP(5);
   dm_level_pipelined<3, CORR>(a, live, row, wlds, lane, raw, nxt, nxt, pending, acc);
+  DM_STAMP(6);
 
   // epilogue.  C/D of 32x32: a lane holds channel 32 mb + 8 (r >> 2) + 4 (lane >> 5) + (r & 3) of pixel 32 nb + (lane & 31);
   // swapping the upper half of block 0 with the lower half of block 1 leaves every lane with ITS pixel: 8 consecutive
-  // channels = one 16-byte store
-  _Float16* op = a.enc_out + row * (size_t)a.enc_stride;
+  // channels = 16 bytes.  Stored from there, one instruction would write 64 pieces of 16 bytes into 64 different lines
+  // (measured: ~380 clocks per store instruction, 6 k clocks per tile); instead the 64 bytes a pixel owns of each channel
+  // block go through a 4 KB LDS stage of the wave (16-byte slots XOR-swizzled by the pixel, conflict-free both ways) and
+  // leave with 4 lanes per pixel: 16 contiguous 64-byte runs per store.
+  _Float16* stage = wlds + (128 * kEnc2Lds + 512) + wv * 2048;
+  const int wslot = lane * 4, wsw = (lane >> 1) & 3;                   // own pixel: slots 4 lane + (g ^ wsw)
+  const int tyx = u.tile / a.ntx, txx = u.tile - tyx * a.ntx;
+  size_t orow[4];
+  bool olive[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {                                          // the pixel this lane stores in pass k
+    const int P = 16 * k + (lane >> 2);
+    const int sy = tyx * 8 + (P >> 3), sx = txx * 8 + (P & 7);
+    olive[k] = has && sy < a.h && sx < a.w;
+    orow[k] = ((size_t)u.n * HW + min(sy, a.h - 1) * a.w + min(sx, a.w - 1)) * (size_t)a.enc_stride + (lane & 3) * 8;
+  }
 #pragma unroll
   for (int mb = 0; mb < 4; ++mb) {
 #pragma unroll
@@ -435,14 +511,33 @@ __global__ __launch_bounds__(256, 2) void corr_dm_encode_kernel(DmArgs a) {
         v[r] = __uint_as_float(sw[0]);
         v[4 + r] = __uint_as_float(sw[1]);
       }
-      const int ch = 32 * mb + 8 * g;
-      const float* bl = reinterpret_cast<const float*>(wlds + 128 * kEnc2Lds) + ch;      // uniform address: LDS broadcast
-      f16x8 o;
+      u32x4 o;
 #pragma unroll
-      for (int cc = 0; cc < 8; ++cc) o[cc] = (_Float16)fmaxf(v[cc] + bl[cc], 0.0f);
-      if (live) *reinterpret_cast<f16x8*>(op + ch) = o;
+      for (int cc = 0; cc < 4; ++cc) {                  // ReLU after the rounding: one packed max per two channels
+        const h2 t = h2{(_Float16)v[2 * cc], (_Float16)v[2 * cc + 1]};
+        o[cc] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(t, h2{(_Float16)0.0f, (_Float16)0.0f}));
+      }
+      *reinterpret_cast<u32x4*>(stage + (wslot + (g ^ wsw)) * 8) = o;
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int P = 16 * k + (lane >> 2);
+      const u32x4 o = *reinterpret_cast<const u32x4*>(stage + (P * 4 + ((lane & 3) ^ ((P >> 1) & 3))) * 8);
+      if (olive[k]) *reinterpret_cast<u32x4*>(a.enc_out + orow[k] + 32 * mb) = o;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
+#ifdef EXP_DM_TIMESTAMPS
+  DM_STAMP(9);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  DM_STAMP(7);
+  if (lane == 0 && live)
+    for (int k = 0; k < 10; ++k) reinterpret_cast<unsigned long long*>(a.enc_out + row * (size_t)a.enc_stride)[k] = stamp[k];
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -650,7 +745,7 @@ extern "C" int glorie_corr_dm_lookup(const void* const* levels, const int* slots
     hipLaunchKernelGGL(corr_dm_lookup_kernel, dim3((a.ntx * a.nty + 3) / 4, N), dim3(256), 0, st, a);
     return check_launch();
   }
-  const size_t lds = sizeof(_Float16) * 128 * kEnc2Lds + 128 * sizeof(float);
+  const size_t lds = sizeof(_Float16) * 128 * kEnc2Lds + 256 * sizeof(float) + 4 * 4096;   // weights, bias, store stages
   static int cus = 0;
   if (!cus) {
     GLORIE_TRY(check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(corr_dm_encode_kernel<false>),
