@@ -31,6 +31,7 @@
 // that want the reference's tensor).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
 #include "common.hiph"
 
 namespace glorie {
@@ -43,7 +44,8 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 struct DmArgs {
   const _Float16* lvl[4];     // arena levels [capacity][ntiles][(h>>l)*(w>>l)][64]
-  const int* slots;           // slot of edge n (NULL: n itself)
+  const int* slots;           // slot of edge n (NULL: slot0 + n)
+  int slot0;
   const float* coords;        // [N][HW][2] (coords_xy) or [N][2][HW], UNscaled
   int coords_xy;
   int N, h, w, ntx, nty;
@@ -52,8 +54,10 @@ struct DmArgs {
   const float* enc_b;         // [128]
   _Float16* enc_out;          // rows of enc_stride halfs per edge-pixel
   int enc_stride;
+  unsigned enc_bytes;         // N * h * w * enc_stride * 2 (< 2^31: glorie_corr_dm_lookup splits larger calls)
 };
 
+constexpr unsigned kOobStore = 0xc0000000u;   // same for the encoder's output rows (one launch covers less than 2 GB of them)
 constexpr unsigned kOob = 0x40000000u;   // byte offset far beyond any plane: the buffer load returns 0 without a memory access
 
 __device__ __forceinline__ _Float16 to_half_rn(float prod) {
@@ -369,7 +373,7 @@ __device__ __forceinline__ void dm_unit(const DmArgs& a, int unit, DmUnit& u) {
   const int ntiles = a.ntx * a.nty;
   u.n = unit / ntiles;
   u.tile = unit - u.n * ntiles;
-  const int slot = a.slots ? a.slots[u.n] : u.n;
+  const int slot = a.slots ? a.slots[u.n] : a.slot0 + u.n;
   u.slot_tile = __builtin_amdgcn_readfirstlane(slot * ntiles + u.tile);
 }
 __device__ __forceinline__ DmPixel dm_pixel(const DmArgs& a, const DmUnit& u, int lane) {
@@ -412,17 +416,26 @@ __global__ __launch_bounds__(256, 2) void corr_dm_encode_kernel(DmArgs a) {
   const int unit = blockIdx.x * 4 + wv;
   const bool has = unit < total;
 #ifdef EXP_DM_TIMESTAMPS
-  unsigned long long stamp[10];
+  unsigned long long stamp[13];
 #endif
   DM_STAMP(0);
 
   DmUnit u;
   dm_unit(a, has ? unit : total - 1, u);
   const DmPixel px = dm_pixel(a, u, lane);
-  const float2 c = dm_coords(a, u, px, has);
+  DM_STAMP(10);
+  float2 c = dm_coords(a, u, px, has);
+#ifdef EXP_DM_TIMESTAMPS
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(c.x), "+v"(c.y) : : "memory");
+  DM_STAMP(11);
+#endif
   unsigned short raw[8][8];
   DmLevel cur;
   dm_setup<0>(a, (size_t)u.slot_tile, px.sy, px.sx, lane, c.x, c.y, cur);
+#ifdef EXP_DM_TIMESTAMPS
+  asm volatile("" : "+v"(cur.coff[7]), "+v"(cur.r) : : "memory");
+  DM_STAMP(12);
+#endif
 #pragma unroll
   for (int j = 0; j < 8; ++j) dm_load_row(cur, raw[j]);
   DM_STAMP(1);
@@ -430,22 +443,21 @@ __global__ __launch_bounds__(256, 2) void corr_dm_encode_kernel(DmArgs a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // latency of the first 64 gathers, measured alone
   DM_STAMP(8);
 #endif
-  // encoder weights [128][224] -> LDS rows of kEnc2Lds halfs + the bias, behind the first 64 loads
-  // (128 * 28 = 14 * 256 pieces of 16 bytes: all 14 loads of a thread are issued before the first LDS store)
-  {
-    u32x4 wreg[14];
+  // encoder weights [128][224] -> LDS rows of kEnc2Lds halfs + the bias, behind the first 64 gathers (128 * 28 = 14 * 256
+  // pieces of 16 bytes: all 14 loads of a thread are issued before the first LDS store).  Requesting them before the unit's
+  // coordinates was measured and is slower: vmcnt retires in order, so the coordinates then wait for the weights as well.
+  u32x4 wreg[14];
 #pragma unroll
-    for (int k = 0; k < 14; ++k)
-      wreg[k] = *reinterpret_cast<const u32x4*>(a.enc_w + (size_t)(threadIdx.x + 256 * k) * 8);
-    const float bias_in = a.enc_b[threadIdx.x & 127];
+  for (int k = 0; k < 14; ++k) wreg[k] = *reinterpret_cast<const u32x4*>(a.enc_w + (size_t)(threadIdx.x + 256 * k) * 8);
+  const float bias_in = a.enc_b[threadIdx.x & 127];
 #pragma unroll
-    for (int k = 0; k < 14; ++k) {
-      const int idx = threadIdx.x + 256 * k;
-      const int r = idx / 28, cc = idx - r * 28;
-      *reinterpret_cast<u32x4*>(wlds + r * kEnc2Lds + cc * 8) = wreg[k];
-    }
-    reinterpret_cast<float*>(wlds + 128 * kEnc2Lds)[threadIdx.x] = bias_in;      // (twice: no branch between the gathers
-  }                                                                              //  and their use, see perm16)
+  for (int k = 0; k < 14; ++k) {
+    const int idx = threadIdx.x + 256 * k;
+    const int r = idx / 28, cc = idx - r * 28;
+    *reinterpret_cast<u32x4*>(wlds + r * kEnc2Lds + cc * 8) = wreg[k];
+  }
+  reinterpret_cast<float*>(wlds + 128 * kEnc2Lds)[threadIdx.x] = bias_in;      // (twice: no branch between the gathers
+                                                                                 //  and their use, see perm16)
   __syncthreads();
   DM_STAMP(2);
 
@@ -490,14 +502,14 @@ __global__ __launch_bounds__(256, 2) void corr_dm_encode_kernel(DmArgs a) {
   _Float16* stage = wlds + (128 * kEnc2Lds + 512) + wv * 2048;
   const int wslot = lane * 4, wsw = (lane >> 1) & 3;                   // own pixel: slots 4 lane + (g ^ wsw)
   const int tyx = u.tile / a.ntx, txx = u.tile - tyx * a.ntx;
-  size_t orow[4];
-  bool olive[4];
+  const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void*)a.enc_out, 0, a.enc_bytes, 0x00020000);
+  unsigned ooff[4];                                                    // byte offset of the run this lane stores in pass k
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {                                          // the pixel this lane stores in pass k
+  for (int k = 0; k < 4; ++k) {
     const int P = 16 * k + (lane >> 2);
     const int sy = tyx * 8 + (P >> 3), sx = txx * 8 + (P & 7);
-    olive[k] = has && sy < a.h && sx < a.w;
-    orow[k] = ((size_t)u.n * HW + min(sy, a.h - 1) * a.w + min(sx, a.w - 1)) * (size_t)a.enc_stride + (lane & 3) * 8;
+    const unsigned off = ((unsigned)(u.n * HW + sy * a.w + sx) * (unsigned)a.enc_stride + (unsigned)(lane & 3) * 8u) * 2u;
+    ooff[k] = (has && sy < a.h && sx < a.w) ? off : kOobStore;         // outside the map: dropped by the range check
   }
 #pragma unroll
   for (int mb = 0; mb < 4; ++mb) {
@@ -522,12 +534,14 @@ __global__ __launch_bounds__(256, 2) void corr_dm_encode_kernel(DmArgs a) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    u32x4 o[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int P = 16 * k + (lane >> 2);
-      const u32x4 o = *reinterpret_cast<const u32x4*>(stage + (P * 4 + ((lane & 3) ^ ((P >> 1) & 3))) * 8);
-      if (olive[k]) *reinterpret_cast<u32x4*>(a.enc_out + orow[k] + 32 * mb) = o;
+      o[k] = *reinterpret_cast<const u32x4*>(stage + (P * 4 + ((lane & 3) ^ ((P >> 1) & 3))) * 8);
     }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) __builtin_amdgcn_raw_buffer_store_b128(o[k], ors, (int)(ooff[k] + 64u * mb), 0, 0);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
@@ -536,7 +550,7 @@ __global__ __launch_bounds__(256, 2) void corr_dm_encode_kernel(DmArgs a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   DM_STAMP(7);
   if (lane == 0 && live)
-    for (int k = 0; k < 10; ++k) reinterpret_cast<unsigned long long*>(a.enc_out + row * (size_t)a.enc_stride)[k] = stamp[k];
+    for (int k = 0; k < 13; ++k) reinterpret_cast<unsigned long long*>(a.enc_out + row * (size_t)a.enc_stride)[k] = stamp[k];
 #endif
 }
 
@@ -754,8 +768,23 @@ extern "C" int glorie_corr_dm_lookup(const void* const* levels, const int* slots
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)));
     cus = 1;
   }
-  const unsigned blocks = (unsigned)((units + 3) / 4);
-  if (corr_cl) hipLaunchKernelGGL((corr_dm_encode_kernel<true>), dim3(blocks), dim3(256), lds, st, a);
-  else hipLaunchKernelGGL((corr_dm_encode_kernel<false>), dim3(blocks), dim3(256), lds, st, a);
+  // the output rows are stored through a buffer descriptor (32-bit offsets, out-of-map lanes dropped by its range check):
+  // a call whose rows span 2 GB or more is issued in runs of edges
+  const size_t edge_bytes = (size_t)h * w * enc_stride * sizeof(_Float16);
+  if (edge_bytes >= 0x80000000ull) return GLORIE_EUNSUPPORTED;
+  const int per = (int)std::min<size_t>((size_t)N, std::max<size_t>(1, 0x7fffffffull / edge_bytes));
+  for (int n0 = 0; n0 < N; n0 += per) {
+    DmArgs c = a;
+    c.N = std::min(per, N - n0);
+    c.slots = slots ? slots + n0 : nullptr;
+    c.slot0 = n0;
+    c.coords = coords + (size_t)n0 * h * w * 2;
+    if (corr_cl) c.corr_cl = a.corr_cl + (size_t)n0 * h * w * 256;
+    c.enc_out = a.enc_out + (size_t)n0 * h * w * enc_stride;
+    c.enc_bytes = (unsigned)(edge_bytes * c.N);
+    const unsigned blocks = (unsigned)(((long)c.N * a.ntx * a.nty + 3) / 4);
+    if (corr_cl) hipLaunchKernelGGL((corr_dm_encode_kernel<true>), dim3(blocks), dim3(256), lds, st, c);
+    else hipLaunchKernelGGL((corr_dm_encode_kernel<false>), dim3(blocks), dim3(256), lds, st, c);
+  }
   return check_launch();
 }

@@ -32,17 +32,19 @@ for n in [int(v) for v in sys.argv[1:]] or (8, 24, 36):
                           enc_out=out.permute(0, 3, 1, 2))
     torch.cuda.synchronize()
     o = out.cpu().numpy()
-    st = np.stack([o[:, ty * 8, tx * 8, :40].copy().view(np.uint64).reshape(n, 10)
+    st = np.stack([o[:, ty * 8, tx * 8, :52].copy().view(np.uint64).reshape(n, 13)
                    for ty in range((h + 7) // 8) for tx in range((w + 7) // 8) if ty * 8 < h and tx * 8 < w], 1)
-    st = st.reshape(-1, 10).astype(np.int64)
+    st = st.reshape(-1, 13).astype(np.int64)
     lat = st[:, 8] - st[:, 1]
     drain = st[:, 7] - st[:, 9]
+    pre = np.stack([st[:, 10] - st[:, 0], st[:, 11] - st[:, 10], st[:, 12] - st[:, 11], st[:, 1] - st[:, 12]], 1)
     st = st[:, :8]
-    t0 = st[:, 0].min()
     d = np.diff(st, axis=1)
-    print(f"== {n} edges, {st.shape[0]} waves; launch span {(st[:, 7].max() - t0)} clocks; wave lifetime median "
-          f"{int(np.median(st[:, 7] - st[:, 0]))}  p90 {int(np.percentile(st[:, 7] - st[:, 0], 90))}; start spread p50 "
-          f"{int(np.median(st[:, 0] - t0))} p90 {int(np.percentile(st[:, 0] - t0, 90))} max {int((st[:, 0] - t0).max())}")
+    life = st[:, 7] - st[:, 0]                  # (stamps of different XCDs are not comparable: only differences within a wave)
+    print(f"== {n} edges, {st.shape[0]} waves; wave lifetime in shader clocks: median {int(np.median(life))}  p90 "
+          f"{int(np.percentile(life, 90))}")
+    print("   first phase: kernel arguments + unit + slot %d | coordinates fetched %d | level-0 state %d | 64 gathers issued %d"
+          % tuple(int(v) for v in np.median(pre, 0)))
     print(f"   latency of the first 64 gathers (issue done -> all landed): median {int(np.median(lat))}  p10 "
           f"{int(np.percentile(lat, 10))}  p90 {int(np.percentile(lat, 90))}")
     print(f"   of the last phase, waiting for the stores to land: median {int(np.median(drain))}  p90 {int(np.percentile(drain, 90))}")
