@@ -588,15 +588,27 @@ __global__ __launch_bounds__(64 * NW, (ST == 1 && MB * NB <= 16) ? 3 : 2) void c
         }
     }
   }
+#ifdef EXP_CONV_STAMPS
+  // experiment (tools/conv_timeline.sh): shader-clock stamps of K-tiles 10-13 of every 61st workgroup, [16][NW][4][8]
+  const int swg = lid / 61;
+#define CV_STAMP(k) do { if (a.stamps && lane == 0 && lid % 61 == 0 && swg < 16 && t >= 10 && t < 14) { unsigned long long ts_;   \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_) : : "memory");                                              \
+    a.stamps[((swg * NW + wv) * 4 + (t - 10)) * 8 + (k)] = ts_; } } while (0)
+#else
+#define CV_STAMP(k)
+#endif
   stage(0, 0);
   int cur = 0;                                 // LDS stage holding tile t
   for (int t = 0; t < T; ++t) {
+    CV_STAMP(0);
     // every DMA piece of tile t must have landed before anybody reads it.  The compiler's own wait in front of the barrier
     // counts register-spill traffic into vmcnt: a halo-staged experiment of the 256-channel variant (9 spilled VGPRs) got
     // `s_waitcnt vmcnt(5)` here, left its last weight pieces in flight and produced non-repeatable upper channels.  None
     // of the shipped variants spills, but the wait is explicit now.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    CV_STAMP(1);
     __syncthreads();                           // tile t landed (vmcnt(0) + barrier); ST = 2: the other stage is free
+    CV_STAMP(2);
     const char* base = smem + cur * (XBYTES + WBYTES);
     // all fragment reads of the step go out first (one exposed LDS latency per step, not per kk), the
     // DMA of the next tile is issued in their shadow, then the MFMAs run back to back
@@ -614,8 +626,11 @@ __global__ __launch_bounds__(64 * NW, (ST == 1 && MB * NB <= 16) ? 3 : 2) void c
       // single LDS stage, 3 workgroups per CU.  Every fragment of the step is in registers now, so
       // once all waves got theirs the buffer is free: tile t+1 streams into it under the MFMAs.
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      CV_STAMP(3);
       __builtin_amdgcn_s_barrier();
+      CV_STAMP(4);
       if (t + 1 < T) stage(t + 1, 0);
+      CV_STAMP(5);
     } else {
       if (t + 1 < T) stage(t + 1, cur ^ 1);
     }
@@ -626,6 +641,7 @@ __global__ __launch_bounds__(64 * NW, (ST == 1 && MB * NB <= 16) ? 3 : 2) void c
 #pragma unroll
         for (int ni = 0; ni < NB; ++ni)
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kk][mi], xf[kk][ni], acc[mi][ni], 0, 0, 0);
+    CV_STAMP(6);
     if (ST == 2) cur ^= 1;
   }
 
@@ -644,6 +660,213 @@ __global__ __launch_bounds__(64 * NW, (ST == 1 && MB * NB <= 16) ? 3 : 2) void c
         conv_epilogue_tile<EPI_BIAS_ACT, MB, NB>(a, acc, p0 + wn * (16 * NB) + col, n0 + wm * (16 * MB) + kg * 4,
                                                  a.tap_groups * 128);
     }
+  } else {
+    conv_epilogue_tile<EPI, MB, NB>(a, acc, p0 + wn * (16 * NB) + col, n0 + wm * (16 * MB) + kg * 4);
+  }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Producer / consumer form of the 128 x 128 tile (the default for 3x3 layers): 8 waves, 2 workgroups per CU.
+//
+// tools/conv_timeline.sh on conv_igemm_kernel: a wave spends its K-tile in series - wait for the DMA 420 cycles, barrier 174,
+// fragment reads 564, barrier 180, ISSUING the next tile's DMA pieces 980 (a piece waits ~80-120 cycles for the texture path
+// when every wave of the CU pushes its share at once, and a wave issues in order: dealing the pieces between the MFMAs gives
+// the same sum), MFMAs 660-1190 - so the matrix pipe sees 17-31 % of a wave's time.  Here waves 4-7 do nothing but stage
+// (DMA of tile t+1 into the other LDS stage, wait for it, barrier) and waves 0-3 do nothing but read fragments and issue
+// MFMAs: ONE barrier per K-tile - at barrier t tile t has landed and every consumer has finished reading tile t-1, whose
+// stage the producers refill next.  Registers are allocated per kernel, so the consumers are held to 128 VGPRs (the
+// fragments of the two 32-channel halves of a tile share their registers) and two workgroups (2 consumer + 2 producer waves
+// per SIMD) are resident; 6-wave workgroups would not do: the dispatcher books ceil(waves / 4) slots on every SIMD
+// (tools/probes/wave_placement.hip: one 5- or 6-wave workgroup per CU at 166 VGPRs).  Same tile mapping, K order, MFMA
+// and epilogues as conv_igemm_kernel<EPI, 4, 64, 4, 1, 4>: bit-identical results (tests/test_gpu_update_op.py).
+// ------------------------------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(512, 4) void conv_ps_kernel(ConvArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int MB = 4, NB = 4, NW = 4, TN = 128, PT = 128, RB = 128, SL = 8, RPI = 8, KK = 2;
+  constexpr int XI = PT / RPI / NW, WI = TN / RPI / NW;     // DMA instructions per producer wave per K-tile: 4 + 4
+  constexpr int XBYTES = PT * RB, WBYTES = TN * RB, STAGE = XBYTES + WBYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages x (pixel tile, weight tile)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wall = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool producer = wall >= NW;
+  const int wv = wall & 3;
+  const int col = lane & 15, kg = lane >> 4;
+  const int wm = wv & 1, wn = wv >> 1;
+  auto key = [](int row) { return row & 7; };
+
+  const int nwg = gridDim.x, ntn = (a.nout + TN - 1) / TN;
+  const int xcd = blockIdx.x & 7, q = nwg >> 3, r = nwg & 7;
+  const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+  const int pt = lid / ntn, nt = lid - pt * ntn;
+  const int tpm = (a.HW + PT - 1) / PT;
+  const long p0 = EPI == EPI_GLO ? (long)(pt / tpm) * a.HW + (long)(pt % tpm) * PT : a.pbeg + (long)pt * PT;
+  const int n0 = nt * TN;
+  const int nsteps_tap = a.cha + a.chb;
+  const int C = nsteps_tap * 64;
+  const int T = a.taps * nsteps_tap;
+
+  f32x4 acc[MB][NB];
+#pragma unroll
+  for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NB; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (EPI != EPI_BIAS_ACT && a.pre && !a.pre_late) {
+    // per-edge context term: seeds the accumulators through LDS exactly as in conv_igemm_kernel (the consumers stage and
+    // read it back; the producers only keep the barrier count)
+    constexpr int ROWB = TN * 2, SLOTS = ROWB / 16, RPP = 64 / SLOTS;
+    if (!producer) {
+      const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void*)a.pre, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+      for (int i = 0; i < PT / RPP / NW; ++i) {
+        const int piece = i * NW + wv;
+        const int row = piece * RPP + lane / SLOTS, sl = lane % SLOTS;
+        const long p = pre_pixel(a, min(p0 + row, a.P - 1));
+        const unsigned vo = (unsigned)((p * a.pre_stride + n0) * 2 + ((sl ^ (row & 15)) << 4));
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rP, (__attribute__((address_space(3))) void*)(smem + piece * 1024), 16, vo,
+                                                 0, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (!producer) {
+#pragma unroll
+      for (int ni = 0; ni < NB; ++ni) {
+        const int row = wn * (16 * NB) + ni * 16 + col;
+#pragma unroll
+        for (int mi = 0; mi < MB; ++mi) {
+          const int b = (wm * (16 * MB) + mi * 16 + kg * 4) * 2;
+          const f16x4 h = *reinterpret_cast<const f16x4*>(smem + row * ROWB + ((((b >> 4) ^ (row & 15))) << 4) + (b & 15));
+          acc[mi][ni] = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+        }
+      }
+    }
+    __syncthreads();                           // the stages are free for the first K tile
+  }
+
+  if (producer) {
+    // ---------------------------------------------------------------------------------------------------------------
+    // staging waves: see conv_igemm_kernel for the addressing (buffer descriptors, swizzled source slot, bit 31 = zero fill)
+    const int back = a.taps == 9 ? a.W + 1 : 0;
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.xa - (long)back * a.xa_stride), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.xb - (long)back * a.xb_stride), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, 0x7fffffff, 0x00020000);
+    const int srow = lane / SL, slot = lane % SL;
+    const int row0 = wv * RPI + srow;
+    const int sw0 = (slot ^ key(row0)) << 3;
+    const unsigned voffA0 = (unsigned)(((p0 + row0) * a.xa_stride + sw0) * 2);
+    const unsigned voffB0 = (unsigned)(((p0 + row0) * a.xb_stride + sw0) * 2);
+    const unsigned woff0 = (unsigned)(((size_t)row0 * C + sw0) * 2);
+    int vmask[XI];
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      const long p = p0 + (i * NW + wv) * RPI + srow;
+      int m = 0;
+      if (p < a.P) {
+        const int xw = (int)(p % a.W), yh = (int)((p / a.W) % a.H);
+        if (a.taps == 9) {
+#pragma unroll
+          for (int d = 0; d < 9; ++d) {
+            const int dy = d / 3 - 1, dx = d % 3 - 1;
+            if ((unsigned)(yh + dy) < (unsigned)a.H && (unsigned)(xw + dx) < (unsigned)a.W) m |= 1 << d;
+          }
+        } else {
+          m = 1;
+        }
+      }
+      vmask[i] = m;
+    }
+    auto stage = [&](int t, int buf) {
+      const int ch = t / a.taps, d = t - ch * a.taps;      // 64-channel chunk outermost, its taps inside (L2 reuse)
+      const int shift = (a.taps == 9 ? (d / 3 - 1) * a.W + (d % 3 - 1) : 0) + back;
+      const bool segA = ch < a.cha;
+      const int xs = segA ? a.xa_stride : a.xb_stride;
+      const unsigned xsoff = (unsigned)((shift * xs + (segA ? ch : ch - a.cha) * 64) * 2);
+      const unsigned wsoff = (unsigned)((((size_t)d * a.npad + n0) * C + ch * 64) * 2);
+      char* lx = smem + buf * STAGE;
+      char* lw = lx + XBYTES;
+      const unsigned xstep = (unsigned)(NW * RPI * xs * 2), wstep = (unsigned)(NW * RPI * C * 2);
+#ifdef EXP_PS_NO_PIXEL_DMA
+      if (d == 0)                               // ablation: the pixel tile is staged once per chunk (wrong results)
+#endif
+#pragma unroll
+      for (int i = 0; i < XI; ++i) {
+        const unsigned inv = ~((unsigned)vmask[i] >> d);
+        const unsigned vo = (inv << 31) | (segA ? voffA0 : voffB0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(segA ? rA : rB,
+            (__attribute__((address_space(3))) void*)(lx + (i * NW + wv) * RPI * RB), 16, vo, xsoff + i * xstep, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < WI; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rW,
+            (__attribute__((address_space(3))) void*)(lw + (i * NW + wv) * RPI * RB), 16, woff0, wsoff + i * wstep, 0, 0);
+    };
+#ifdef EXP_CONV_STAMPS
+    const int swg = lid / 61;
+#define PS_STAMP(k) do { if (a.stamps && lane == 0 && lid % 61 == 0 && swg < 16 && t >= 10 && t < 14) { unsigned long long ts_;   \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_) : : "memory");                                              \
+    a.stamps[((swg * 8 + wall) * 4 + (t - 10)) * 8 + (k)] = ts_; } } while (0)
+#else
+#define PS_STAMP(k)
+#endif
+    stage(0, 0);
+    for (int t = 0; t < T; ++t) {
+      PS_STAMP(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      PS_STAMP(1);
+      __builtin_amdgcn_s_barrier();            // barrier t: tile t is in LDS; nobody reads stage (t + 1) & 1 any more
+      PS_STAMP(2);
+      if (t + 1 < T) stage(t + 1, (t + 1) & 1);
+      PS_STAMP(3);
+    }
+    return;
+  }
+
+  // -----------------------------------------------------------------------------------------------------------------
+  // MFMA waves
+  int foff[KK];
+#pragma unroll
+  for (int kk = 0; kk < KK; ++kk) foff[kk] = col * RB + (((kk * 4 + kg) ^ key(col)) << 4);
+  const int wbase = XBYTES + wm * (16 * MB) * RB, xbase_l = wn * (16 * NB) * RB;
+#ifdef EXP_CONV_STAMPS
+  const int swg = lid / 61;
+#endif
+  for (int t = 0; t < T; ++t) {
+    PS_STAMP(0);
+    __builtin_amdgcn_s_barrier();              // barrier t
+    PS_STAMP(1);
+    const char* base = smem + (t & 1) * STAGE;
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      f16x8 wf[MB], xf[NB];
+#pragma unroll
+      for (int mi = 0; mi < MB; ++mi) wf[mi] = *reinterpret_cast<const f16x8*>(base + wbase + mi * 16 * RB + foff[kk]);
+#pragma unroll
+      for (int ni = 0; ni < NB; ++ni) xf[ni] = *reinterpret_cast<const f16x8*>(base + xbase_l + ni * 16 * RB + foff[kk]);
+#pragma unroll
+      for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NB; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[mi], xf[ni], acc[mi][ni], 0, 0, 0);
+      if (kk == 0) PS_STAMP(2); else PS_STAMP(3);
+    }
+    // every fragment read of tile t has returned (the MFMAs consumed them) before this wave reaches barrier t + 1
+  }
+
+  if constexpr (EPI == EPI_GLO) {
+    conv_epilogue_glo<MB, NB>(a, acc, p0, p0 + wn * (16 * NB) + col, wm, wn, kg, col, smem, pt);
+  } else if constexpr (EPI == EPI_UPSAMPLE) {
+    conv_epilogue_upsample<MB, NB>(a, acc, p0, n0, wm, wn, kg, col, smem);
+  } else if constexpr (EPI == EPI_HEADS) {
+    if (nt < a.tap_groups)                                                    // workgroup-uniform
+      conv_epilogue_heads<MB, NB>(a, acc, p0, n0, wm, wn, kg, col, lane, smem);
+    else
+      conv_epilogue_tile<EPI_BIAS_ACT, MB, NB>(a, acc, p0 + wn * (16 * NB) + col, n0 + wm * (16 * MB) + kg * 4,
+                                               a.tap_groups * 128);
   } else {
     conv_epilogue_tile<EPI, MB, NB>(a, acc, p0 + wn * (16 * NB) + col, n0 + wm * (16 * MB) + kg * 4);
   }
@@ -1101,6 +1324,30 @@ static void launch_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
   hipLaunchKernelGGL((conv_igemm_kernel<EPI, NB, BK, NW, ST, MB>), grid, dim3(64 * NW), lds, st, a);
 }
 
+template <int EPI>
+static void launch_ps_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
+  constexpr size_t lds = 2 * (128 * 128 + 128 * 128);          // two stages; the seeding / epilogue uses fit inside
+  hipLaunchKernelGGL((conv_ps_kernel<EPI>), grid, dim3(512), lds, st, a);
+}
+static int launch_conv_ps(const ConvArgs& a, int epilogue, hipStream_t st) {
+  constexpr int PT = 128;
+  long ptiles = (a.P - a.pbeg + PT - 1) / PT;
+  if (epilogue == EPI_GLO) ptiles = (a.P / a.HW) * ((a.HW + PT - 1) / PT);
+  if (ptiles <= 0) return GLORIE_OK;
+  const long nwg = ptiles * ((a.nout + 127) / 128);
+  if (nwg > 0x7fffffffL) return GLORIE_EINVAL;
+  const dim3 grid((unsigned)nwg);
+  switch (epilogue) {
+    case EPI_BIAS_ACT: launch_ps_one<EPI_BIAS_ACT>(a, grid, st); break;
+    case EPI_GRU_ZR: launch_ps_one<EPI_GRU_ZR>(a, grid, st); break;
+    case EPI_GLO: launch_ps_one<EPI_GLO>(a, grid, st); break;
+    case EPI_HEADS: launch_ps_one<EPI_HEADS>(a, grid, st); break;
+    case EPI_UPSAMPLE: launch_ps_one<EPI_UPSAMPLE>(a, grid, st); break;
+    default: launch_ps_one<EPI_GRU_Q>(a, grid, st); break;
+  }
+  return check_launch();
+}
+
 template <int NB, int BK, int NW, int ST, int MB = 4>
 static int launch_conv(const ConvArgs& a, int epilogue, hipStream_t st, long max_ptiles = -1) {
   constexpr int PT = (NW / 2) * 16 * NB;
@@ -1200,6 +1447,8 @@ static int conv_igemm_impl(const void* xa, int xa_stride, int ca, const void* xb
   // 385 vs 345 us.  It stays opt-in; tests/test_gpu_update_op.py pins it bit for bit against the 128 x 128 kernel.
   const char* c8 = getenv("GLORIE_CONV8");
   const bool conv8_on = c8 && c8[0] == '1';
+  const char* ps = getenv("GLORIE_CONV_PS");
+  if (ps && ps[0] == '1') return launch_conv_ps(a, epilogue, st);
   if (epilogue == EPI_HEADS || epilogue == EPI_UPSAMPLE) return launch_conv<4, 64, 4, 1>(a, epilogue, st);
   if (conv8_on && (nout & 255) == 0 && a.P >= 256) return launch_conv8(a, epilogue, st);
   // layers with <= 64 output channels (flow_encoder[2]) use a 64-channel tile instead of padding to 128

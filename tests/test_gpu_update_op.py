@@ -469,7 +469,7 @@ def test_conv8_equals_the_128_tile_kernel_bit_for_bit(gpu, n, h, w, ca, cb, nout
         torch.testing.assert_close(ref.float(), _conv_ref([xa, xb], weight), atol=4e-3, rtol=4e-3)
 
 
-@pytest.mark.parametrize("mode", ["128", "64", "split", "wide"])
+@pytest.mark.parametrize("mode", ["128", "64", "split", "wide", "ps"])
 def test_conv_tile_variants_are_bit_identical(gpu, mode, monkeypatch):
     """GLORIE_CONV_TILE only changes which pixels / channels a workgroup owns: every output element sums the same products in
     the same order, so the 64-pixel, split-launch and 128 x 256 variants must reproduce the default kernel bit for bit
@@ -494,7 +494,13 @@ def test_conv_tile_variants_are_bit_identical(gpu, mode, monkeypatch):
         return torch.cat([new, z, rnet], 1).clone()
 
     monkeypatch.delenv("GLORIE_CONV_TILE", raising=False)
+    monkeypatch.delenv("GLORIE_CONV_PS", raising=False)
     ref = run()
+    if mode == "ps":                  # producer / consumer form of the 128 x 128 tile (conv_ps_kernel), incl. the LDS seeding
+        monkeypatch.setenv("GLORIE_CONV_PS", "1")
+        for _ in range(3):
+            assert torch.equal(run(), ref)
+        return
     monkeypatch.setenv("GLORIE_CONV_TILE", mode)
     assert torch.equal(run(), ref)
 

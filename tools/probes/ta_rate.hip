@@ -39,7 +39,7 @@ template <int B> void run(const char* p, unsigned* o, unsigned span) {
 }
 int main() {
   char* p; unsigned* o; hipMalloc(&p, 16u << 20); hipMalloc(&o, 2048 * 256 * 4); hipMemset(p, 1, 16u << 20);
-  for (unsigned span : {16u << 10, 16u << 20}) {
+  for (unsigned span : {16u << 10, 512u << 10, 2u << 20, 4u << 20, 16u << 20}) {
     printf("span %u KB\n", span >> 10);
     run<2>(p, o, span); run<4>(p, o, span); run<8>(p, o, span); run<16>(p, o, span);
   }
