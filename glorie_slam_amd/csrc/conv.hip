@@ -666,6 +666,20 @@ __global__ __launch_bounds__(64 * NW, (ST == 1 && MB * NB <= 16) ? 3 : 2) void c
 #endif
 }
 
+// fragment reads as inline asm: the compiler neither waits for every outstanding LDS-DMA in front of them nor chooses the
+// lgkmcnt in front of their first use (it takes 0 at a loop header); the kernels below count their own waits
+__device__ __forceinline__ f16x8 lds_read16(unsigned addr) {
+  f16x8 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+template <int OFF>
+__device__ __forceinline__ f16x8 lds_read16_off(unsigned addr) {
+  f16x8 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // Producer / consumer form of the 128 x 128 tile (the default for 3x3 layers): 8 waves, 2 workgroups per CU.
 //
@@ -874,6 +888,210 @@ __global__ __launch_bounds__(512, 4) void conv_ps_kernel(ConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Producer / consumer form with the big wave tile: ONE workgroup of 8 waves per CU, three LDS stages of 48 KB.
+// Waves 0-3 (one per SIMD) own 128 x 64 (MB = 8, NB = 4: 256 channels x 128 pixels per workgroup) or 64 x 128 (MB = 4,
+// NB = 8: 128 channels x 256 pixels) of the tile and do nothing but fragment reads and MFMAs; waves 4-7 stage two K-tiles
+// ahead.  One barrier per K-tile, placed BETWEEN the two 32-channel halves of a tile's MFMAs: barrier t + 1 says tile t + 1
+// has landed, the consumer then requests the first-half fragments of tile t + 1 into the registers its first-half MFMAs of
+// tile t just released and issues the second half of tile t (whose fragments were requested beside the first half's MFMAs) -
+// every fragment is requested half a tile (>= 512 matrix-pipe cycles) before it is used and every read is issued beside MFMAs.  A consumer's reads of tile t have all returned
+// before it arrives at barrier t + 1 (explicit lgkmcnt(0)), after which the producers refill that stage with tile t + 3.
+// Same tile mapping and K order as conv_igemm_kernel; the per-edge context term is added in the epilogue.
+// ------------------------------------------------------------------------------------------------------------------
+template <int EPI, int MB, int NB>
+__global__ __launch_bounds__(512, 2) void conv_ps2_kernel(ConvArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int NW = 4, TN = 32 * MB, PT = 32 * NB, RB = 128, SL = 8, RPI = 8, KK = 2, NST = 3;
+  constexpr int XI = PT / RPI / NW, WI = TN / RPI / NW;     // DMA instructions per producer wave per K-tile
+  constexpr int XBYTES = PT * RB, WBYTES = TN * RB, STAGE = XBYTES + WBYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wall = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool producer = wall >= NW;
+  const int wv = wall & 3;
+  const int col = lane & 15, kg = lane >> 4;
+  const int wm = wv & 1, wn = wv >> 1;
+  auto key = [](int row) { return row & 7; };
+
+  const int nwg = gridDim.x, ntn = (a.nout + TN - 1) / TN;
+  const int xcd = blockIdx.x & 7, q = nwg >> 3, r = nwg & 7;
+  const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+  const int pt = lid / ntn, nt = lid - pt * ntn;
+  const long p0 = a.pbeg + (long)pt * PT;
+  const int n0 = nt * TN;
+  const int nsteps_tap = a.cha + a.chb;
+  const int C = nsteps_tap * 64;
+  const int T = a.taps * nsteps_tap;
+
+  if (producer) {
+    // staging waves: see conv_igemm_kernel for the addressing (buffer descriptors, swizzled source slot, bit 31 = zero fill)
+    const int back = a.taps == 9 ? a.W + 1 : 0;
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.xa - (long)back * a.xa_stride), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.xb - (long)back * a.xb_stride), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, 0x7fffffff, 0x00020000);
+    const int srow = lane / SL, slot = lane % SL;
+    const int row0 = wv * RPI + srow;
+    const int sw0 = (slot ^ key(row0)) << 3;
+    const unsigned voffA0 = (unsigned)(((p0 + row0) * a.xa_stride + sw0) * 2);
+    const unsigned voffB0 = (unsigned)(((p0 + row0) * a.xb_stride + sw0) * 2);
+    const unsigned woff0 = (unsigned)(((size_t)row0 * C + sw0) * 2);
+    int vmask[XI];
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      const long p = p0 + (i * NW + wv) * RPI + srow;
+      int m = 0;
+      if (p < a.P) {
+        const int xw = (int)(p % a.W), yh = (int)((p / a.W) % a.H);
+        if (a.taps == 9) {
+#pragma unroll
+          for (int d = 0; d < 9; ++d) {
+            const int dy = d / 3 - 1, dx = d % 3 - 1;
+            if ((unsigned)(yh + dy) < (unsigned)a.H && (unsigned)(xw + dx) < (unsigned)a.W) m |= 1 << d;
+          }
+        } else {
+          m = 1;
+        }
+      }
+      vmask[i] = m;
+    }
+    auto stage = [&](int t, int buf) {
+      const int ch = t / a.taps, d = t - ch * a.taps;      // 64-channel chunk outermost, its taps inside (L2 reuse)
+      const int shift = (a.taps == 9 ? (d / 3 - 1) * a.W + (d % 3 - 1) : 0) + back;
+      const bool segA = ch < a.cha;
+      const int xs = segA ? a.xa_stride : a.xb_stride;
+      const unsigned xsoff = (unsigned)((shift * xs + (segA ? ch : ch - a.cha) * 64) * 2);
+      const unsigned wsoff = (unsigned)((((size_t)d * a.npad + n0) * C + ch * 64) * 2);
+      char* lx = smem + buf * STAGE;
+      char* lw = lx + XBYTES;
+      const unsigned xstep = (unsigned)(NW * RPI * xs * 2), wstep = (unsigned)(NW * RPI * C * 2);
+#pragma unroll
+      for (int i = 0; i < XI; ++i) {
+        const unsigned inv = ~((unsigned)vmask[i] >> d);
+        const unsigned vo = (inv << 31) | (segA ? voffA0 : voffB0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(segA ? rA : rB,
+            (__attribute__((address_space(3))) void*)(lx + (i * NW + wv) * RPI * RB), 16, vo, xsoff + i * xstep, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < WI; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rW,
+            (__attribute__((address_space(3))) void*)(lw + (i * NW + wv) * RPI * RB), 16, woff0, wsoff + i * wstep, 0, 0);
+    };
+    stage(0, 0);
+    if (T > 1) stage(1, 1);
+    int nxt = 2;                                 // LDS stage of tile b + 2
+#ifdef EXP_CONV_STAMPS
+    const int swg = lid / 61;
+#define PS2_STAMP(k) do { if (a.stamps && lane == 0 && lid % 61 == 0 && swg < 16 && t >= 10 && t < 14) { unsigned long long ts_;  \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_) : : "memory");                                              \
+    a.stamps[((swg * 8 + wall) * 4 + (t - 10)) * 8 + (k)] = ts_; } } while (0)
+#else
+#define PS2_STAMP(k)
+#endif
+    for (int t = 0; t < T; ++t) {                // t: the barrier's (= the landed tile's) index
+      PS2_STAMP(0);
+      // tile t has landed (this wave's share): the pieces of tile t + 1 may still be on their way
+      if (t + 1 < T) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XI + WI) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      PS2_STAMP(1);
+      __builtin_amdgcn_s_barrier();              // barrier t
+      PS2_STAMP(2);
+      if (t + 2 < T) stage(t + 2, nxt);          // the stage of tile t - 1: every consumer's reads of it returned before barrier t
+      nxt = nxt == NST - 1 ? 0 : nxt + 1;
+      PS2_STAMP(3);
+    }
+    return;
+  }
+
+  // -----------------------------------------------------------------------------------------------------------------
+  // MFMA waves
+  f32x4 acc[MB][NB];
+#pragma unroll
+  for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NB; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int foff[KK];
+#pragma unroll
+  for (int kk = 0; kk < KK; ++kk) foff[kk] = col * RB + (((kk * 4 + kg) ^ key(col)) << 4);
+  const int wbase = XBYTES + wm * (16 * MB) * RB, xbase_l = wn * (16 * NB) * RB;
+  f16x8 wA[MB], xA[NB], wB[MB], xB[NB];
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
+  unsigned aw[KK], ax[KK];                       // + stage * STAGE; block mi / ni as the instruction offset
+#pragma unroll
+  for (int kk = 0; kk < KK; ++kk) { aw[kk] = lds0 + wbase + foff[kk]; ax[kk] = lds0 + xbase_l + foff[kk]; }
+  auto reads = [&](int buf, int kk, f16x8 (&wf)[MB], f16x8 (&xf)[NB]) {
+    const unsigned bo = (unsigned)buf * STAGE;
+    static_assert(MB == 4 || MB == 8, "wave tile");
+    wf[0] = lds_read16_off<0 * 16 * RB>(aw[kk] + bo); wf[1] = lds_read16_off<1 * 16 * RB>(aw[kk] + bo);
+    wf[2] = lds_read16_off<2 * 16 * RB>(aw[kk] + bo); wf[3] = lds_read16_off<3 * 16 * RB>(aw[kk] + bo);
+    if constexpr (MB == 8) {
+      wf[4] = lds_read16_off<4 * 16 * RB>(aw[kk] + bo); wf[5] = lds_read16_off<5 * 16 * RB>(aw[kk] + bo);
+      wf[6] = lds_read16_off<6 * 16 * RB>(aw[kk] + bo); wf[7] = lds_read16_off<7 * 16 * RB>(aw[kk] + bo);
+    }
+    xf[0] = lds_read16_off<0 * 16 * RB>(ax[kk] + bo); xf[1] = lds_read16_off<1 * 16 * RB>(ax[kk] + bo);
+    xf[2] = lds_read16_off<2 * 16 * RB>(ax[kk] + bo); xf[3] = lds_read16_off<3 * 16 * RB>(ax[kk] + bo);
+    if constexpr (NB == 8) {
+      xf[4] = lds_read16_off<4 * 16 * RB>(ax[kk] + bo); xf[5] = lds_read16_off<5 * 16 * RB>(ax[kk] + bo);
+      xf[6] = lds_read16_off<6 * 16 * RB>(ax[kk] + bo); xf[7] = lds_read16_off<7 * 16 * RB>(ax[kk] + bo);
+    }
+  };
+  // at most N reads still in flight; the fragments become valid here: tying them to the wait keeps their MFMAs behind it
+#define PS2_WAIT(N, wf, xf)                                                                                              \
+  do {                                                                                                                   \
+    if constexpr (MB == 8)                                                                                               \
+      asm volatile("s_waitcnt lgkmcnt(%12)" : "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2]), "+v"(wf[3]), "+v"(wf[4]),          \
+                   "+v"(wf[5]), "+v"(wf[6]), "+v"(wf[7]), "+v"(xf[0]), "+v"(xf[1]), "+v"(xf[2]), "+v"(xf[3]) : "n"(N) : "memory"); \
+    else                                                                                                                 \
+      asm volatile("s_waitcnt lgkmcnt(%12)" : "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2]), "+v"(wf[3]), "+v"(xf[0]),          \
+                   "+v"(xf[1]), "+v"(xf[2]), "+v"(xf[3]), "+v"(xf[4]), "+v"(xf[5]), "+v"(xf[6]), "+v"(xf[7]) : "n"(N) : "memory"); \
+  } while (0)
+  auto mma = [&](const f16x8 (&wf)[MB], const f16x8 (&xf)[NB]) {
+#pragma unroll
+    for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NB; ++ni)
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[mi], xf[ni], acc[mi][ni], 0, 0, 0);
+  };
+  constexpr int NF = MB + NB;                    // reads per half tile
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();                  // barrier 0
+  asm volatile("" ::: "memory");
+  reads(0, 0, wA, xA);
+  int cur = 0;
+#ifdef EXP_CONV_STAMPS
+  const int swg = lid / 61;
+#endif
+  for (int t = 0; t + 1 < T; ++t) {
+    const int nx = cur == NST - 1 ? 0 : cur + 1;
+    PS2_STAMP(0);
+    PS2_WAIT(0, wA, xA);                         // the first half of tile t is here
+    reads(cur, 1, wB, xB);                       // its second half: requested beside the first half's MFMAs
+    mma(wA, xA);
+    __builtin_amdgcn_sched_barrier(0);           // (the fences keep hipcc from sinking the MFMAs below the next wait)
+    PS2_STAMP(1);
+    PS2_WAIT(0, wB, xB);                         // every read of tile t has returned
+    __builtin_amdgcn_s_barrier();                // barrier t + 1: tile t + 1 is in LDS
+    __builtin_amdgcn_sched_barrier(0);
+    PS2_STAMP(2);
+    reads(nx, 0, wA, xA);                        // first half of tile t + 1, beside the second half's MFMAs
+    mma(wB, xB);
+    __builtin_amdgcn_sched_barrier(0);
+    PS2_STAMP(3);
+    cur = nx;
+  }
+  PS2_WAIT(0, wA, xA);
+  reads(cur, 1, wB, xB);
+  mma(wA, xA);
+  __builtin_amdgcn_sched_barrier(0);
+  PS2_WAIT(0, wB, xB);
+  mma(wB, xB);
+#undef PS2_WAIT
+  conv_epilogue_tile<EPI, MB, NB>(a, acc, p0 + wn * (16 * NB) + col, n0 + wm * (16 * MB) + kg * 4);
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // 256 output channels x 256 pixels per workgroup, 8 waves (2 channel halves x 4 pixel quarters, wave tile 128 x 64 =
 // 8 x 4 accumulator blocks), 128 KB of LDS (two K-tile buffers), one workgroup per CU = two waves per SIMD.
 //
@@ -893,17 +1111,6 @@ __global__ __launch_bounds__(512, 4) void conv_ps_kernel(ConvArgs a) {
 // reads fragments and issues DMA.  Fragment reads are inline `ds_read_b128` + explicit lgkmcnt: a compiler-visible LDS
 // load would be preceded by a wait for EVERY outstanding LDS-DMA (the waitcnt pass cannot tell the buffers apart).
 // ------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ f16x8 lds_read16(unsigned addr) {
-  f16x8 v;
-  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
-  return v;
-}
-template <int OFF>
-__device__ __forceinline__ f16x8 lds_read16_off(unsigned addr) {
-  f16x8 v;
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
-  return v;
-}
 __device__ __forceinline__ void wait_vm_units(int n) {      // at most n units (2 loads each) still in flight
   if (n >= 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   else if (n == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -1348,6 +1555,35 @@ static int launch_conv_ps(const ConvArgs& a, int epilogue, hipStream_t st) {
   return check_launch();
 }
 
+template <int EPI, int MB, int NB>
+static void launch_ps2_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
+  constexpr size_t lds = 3 * (size_t)(32 * NB + 32 * MB) * 128;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_ps2_kernel<EPI, MB, NB>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  hipLaunchKernelGGL((conv_ps2_kernel<EPI, MB, NB>), grid, dim3(512), lds, st, a);
+}
+template <int MB, int NB>
+static int launch_conv_ps2(ConvArgs a, int epilogue, hipStream_t st) {
+  constexpr int PT = 32 * NB, TN = 32 * MB;
+  const long ptiles = (a.P - a.pbeg + PT - 1) / PT;
+  if (ptiles <= 0) return GLORIE_OK;
+  const long nwg = ptiles * ((a.nout + TN - 1) / TN);
+  if (nwg > 0x7fffffffL) return GLORIE_EINVAL;
+  const dim3 grid((unsigned)nwg);
+  a.pre_late = 1;                                  // the context term rides with the epilogue's other loads
+  switch (epilogue) {
+    case EPI_BIAS_ACT: launch_ps2_one<EPI_BIAS_ACT, MB, NB>(a, grid, st); break;
+    case EPI_GRU_ZR: launch_ps2_one<EPI_GRU_ZR, MB, NB>(a, grid, st); break;
+    case EPI_GRU_Q: launch_ps2_one<EPI_GRU_Q, MB, NB>(a, grid, st); break;
+    default: return GLORIE_EUNSUPPORTED;
+  }
+  return check_launch();
+}
+
 template <int NB, int BK, int NW, int ST, int MB = 4>
 static int launch_conv(const ConvArgs& a, int epilogue, hipStream_t st, long max_ptiles = -1) {
   constexpr int PT = (NW / 2) * 16 * NB;
@@ -1449,6 +1685,8 @@ static int conv_igemm_impl(const void* xa, int xa_stride, int ca, const void* xb
   const bool conv8_on = c8 && c8[0] == '1';
   const char* ps = getenv("GLORIE_CONV_PS");
   if (ps && ps[0] == '1') return launch_conv_ps(a, epilogue, st);
+  if (ps && ps[0] == '2' && taps == 9 && epilogue <= EPI_GRU_Q && nout >= 128)
+    return (nout & 255) == 0 ? launch_conv_ps2<8, 4>(a, epilogue, st) : launch_conv_ps2<4, 8>(a, epilogue, st);
   if (epilogue == EPI_HEADS || epilogue == EPI_UPSAMPLE) return launch_conv<4, 64, 4, 1>(a, epilogue, st);
   if (conv8_on && (nout & 255) == 0 && a.P >= 256) return launch_conv8(a, epilogue, st);
   // layers with <= 64 output channels (flow_encoder[2]) use a 64-channel tile instead of padding to 128

@@ -469,7 +469,7 @@ def test_conv8_equals_the_128_tile_kernel_bit_for_bit(gpu, n, h, w, ca, cb, nout
         torch.testing.assert_close(ref.float(), _conv_ref([xa, xb], weight), atol=4e-3, rtol=4e-3)
 
 
-@pytest.mark.parametrize("mode", ["128", "64", "split", "wide", "ps"])
+@pytest.mark.parametrize("mode", ["128", "64", "split", "wide", "ps", "ps2"])
 def test_conv_tile_variants_are_bit_identical(gpu, mode, monkeypatch):
     """GLORIE_CONV_TILE only changes which pixels / channels a workgroup owns: every output element sums the same products in
     the same order, so the 64-pixel, split-launch and 128 x 256 variants must reproduce the default kernel bit for bit
@@ -500,6 +500,13 @@ def test_conv_tile_variants_are_bit_identical(gpu, mode, monkeypatch):
         monkeypatch.setenv("GLORIE_CONV_PS", "1")
         for _ in range(3):
             assert torch.equal(run(), ref)
+        return
+    if mode == "ps2":                 # 8 waves, one workgroup per CU, 3 LDS stages (conv_ps2_kernel): same products and K order,
+        monkeypatch.setenv("GLORIE_CONV_PS", "2")     # but the per-edge context term joins in the epilogue instead of seeding
+        first = run()
+        torch.testing.assert_close(first.float(), ref.float(), atol=2e-3, rtol=2e-3)
+        for _ in range(3):
+            assert torch.equal(run(), first)
         return
     monkeypatch.setenv("GLORIE_CONV_TILE", mode)
     assert torch.equal(run(), ref)
