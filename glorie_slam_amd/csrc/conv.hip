@@ -1698,7 +1698,9 @@ static int conv_igemm_impl(const void* xa, int xa_stride, int ca, const void* xb
   // 128 channels x 256 pixels for the 128-channel layers (q gate 174 -> 176 us); 64-pixel tiles
   // (4 per CU; z|r 329 us); whole rounds on 128-pixel tiles + the remainder as a second launch of 64-pixel tiles
   // (292 us: a 64-pixel workgroup costs 0.8 of a 128-pixel one and workgroups do not run in lockstep rounds, so the
-  // partly filled last round is cheaper than a round model says).  GLORIE_CONV_TILE = 128 | 64 | split | wide keeps the
+  // partly filled last round is cheaper than a round model says); two LDS stages with one barrier per K-tile and the next
+  // tile's DMA issued in the shadow of the fragment reads (round 3: 448 -> 256 at 32-channel K-tiles 320 -> 406 us, 448 -> 128
+  // 186 -> 197 us at 64-channel, 248 us at 32-channel K-tiles).  GLORIE_CONV_TILE = 128 | 64 | split | wide keeps the
   // variants reachable for tools/bench_conv.py.
   const int ntn = (nout + 127) / 128;
   const long slots128 = 3L * 256;
