@@ -74,6 +74,12 @@ SIGNATURES = {
     "glorie_ba_build_system": (_c_int, [_vp] * 10 + [_c_int] * 8 + [_vp, _vp]),
     "glorie_ba_solve_update": (_c_int, [_vp] * 5 + [_c_int] * 7 + [_c_f, _c_f, _c_int, _c_int] + [_vp] * 4),
     "glorie_ba_pack_system": (_c_int, [_vp, _vp, _c_int, _c_int, _vp]),
+    "glorie_comm_unique_id": (_c_int, [_vp]),
+    "glorie_comm_init": (_c_int, [_vp, _vp, _c_int, _c_int]),
+    "glorie_comm_destroy": (_c_int, [_vp]),
+    "glorie_comm_world": (_c_int, [_vp]),
+    "glorie_allreduce_normal_eq": (_c_int, [_vp, _vp, _sz, _vp]),
+    "glorie_allgather_rows": (_c_int, [_vp, _vp, _vp, _sz, _vp]),
     "glorie_dspo_scale_shift": (_c_int, [_vp] * 14 + [_c_int] * 6 + [_c_f, _c_f, _c_f, _vp, _vp]),
     "glorie_knn_build": (_c_int, [_vp, _vp, _c_int, _c_f, _c_int, _vp, _vp, _vp, _vp]),
     "glorie_knn_query": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_f, _vp, _vp, _vp, _vp, _vp]),

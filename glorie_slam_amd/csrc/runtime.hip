@@ -72,6 +72,7 @@ extern "C" int glorie_ctx_reserve(glorie_ctx* ctx, size_t scratch_bytes) {
 
 extern "C" int glorie_ctx_destroy(glorie_ctx* ctx) {
   if (!ctx) return GLORIE_EINVAL;
+  (void)glorie::comm_destroy(ctx);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->dstatus) (void)hipFree(ctx->dstatus);
   delete ctx;

@@ -12,6 +12,8 @@ Deliberate difference, documented in DESIGN.md: DSPO stage 2 updates `disps`, `d
 and `depth_shift` IN PLACE; the reference rebinds the attributes to new tensors
 (depth_video.py:278-282), which silently detaches the buffers shared with the mapper process.
 """
+import os
+
 import numpy as np
 import torch
 from torch.multiprocessing import Value
@@ -114,8 +116,14 @@ class DepthVideo:
         return ii, jj
 
     def enable_sharding(self, owner, rank, world, group=None):
-        """edges of this process' graphs are a source-keyframe shard (dist.shard_frames)"""
+        """edges of this process' graphs are a source-keyframe shard (dist.shard_frames).
+        GLORIE_NATIVE_COMM=1: the context gets its own RCCL communicator (dist.init_ctx_comm) and the BA's exchange step
+        runs as glorie_allreduce_normal_eq on the stream instead of a torch.distributed collective (opt-in: only its
+        one-rank form can be exercised on the single-GPU test box)."""
         self.shard = dict(owner=owner, rank=rank, world=world, group=group)
+        if os.environ.get("GLORIE_NATIVE_COMM") == "1" and self.poses.is_cuda and world > 1:
+            from . import dist as gdist
+            gdist.init_ctx_comm(self.ctx(), group)
 
     def sync_owned(self, *names):
         """all-gather the rows owned by each rank of the named per-keyframe buffers"""

@@ -9,6 +9,8 @@
 * Rendering: the cloud, its cell list and the decoder weights are replicated; rays are split in
   contiguous blocks (`shard_range`), no collective in the forward pass.
 """
+import ctypes
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -49,21 +51,58 @@ def _active(group=None):
     return dist.is_available() and dist.is_initialized()
 
 
-def allreduce_system(hv, group=None, n6=None, force=False):
+def init_ctx_comm(ctx, group=None, rank=None, world=None):
+    """give the context its own RCCL communicator (glorie_comm_init): rank 0 draws the id, torch.distributed's object
+    broadcast carries it (any backend), every rank joins.  With it the BA's exchange step is a C-ABI call on the stream
+    (glorie_allreduce_normal_eq) instead of a torch.distributed collective between two ctypes calls - and the sharded
+    iteration can be recorded into a hipGraph.  Without an initialised process group (one process) it forms a world of one."""
+    lib = L.load()
+    if _active(group):
+        rank = dist.get_rank(group) if rank is None else rank
+        world = dist.get_world_size(group) if world is None else world
+    else:
+        rank, world = 0, 1
+    box = [None]
+    if rank == 0:
+        buf = ctypes.create_string_buffer(128)
+        L.check(lib.glorie_comm_unique_id(buf), "glorie_comm_unique_id")
+        box[0] = bytes(buf.raw)
+    if world > 1:
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    L.check(lib.glorie_comm_init(ctx.handle, box[0], int(rank), int(world)), "glorie_comm_init")
+    return world
+
+
+def ctx_comm_world(ctx):
+    """ranks of the context's own communicator (0: none, the exchange goes through torch.distributed)"""
+    return int(L.load().glorie_comm_world(ctx.handle)) if ctx is not None else 0
+
+
+def allreduce_system(hv, group=None, n6=None, force=False, ctx=None):
     """sum the reduced system [H | v] over ranks (RCCL all-reduce; gloo in the CPU tests).  hv: n6*n6 + n6
     doubles.  On the device and for n6 >= PACK_MIN_N6 only the lower triangle + v travel
     (glorie_ba_pack_system): xGMI rings are per-link bound, half the bytes is half the time.
+    ctx with its own communicator (init_ctx_comm): the sum is glorie_allreduce_normal_eq on the current stream.
     force: run the collective even with one rank (exercises the RCCL path on a single GPU)."""
-    if not _active(group) or (dist.get_world_size(group) <= 1 and not force):
+    native = hv.is_cuda and ctx_comm_world(ctx) > 0
+    if not native and (not _active(group) or (dist.get_world_size(group) <= 1 and not force)):
         return hv
+    lib = L.load()
+
+    def reduce(buf):
+        if native:
+            L.check(lib.glorie_allreduce_normal_eq(ctx.handle, L.ptr(buf), int(buf.numel()), L.stream_ptr()),
+                    "glorie_allreduce_normal_eq")
+        else:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+
     if hv.is_cuda and n6 is not None and n6 >= PACK_MIN_N6:
         packed = torch.empty(n6 * (n6 + 1) // 2 + n6, dtype=torch.float64, device=hv.device)
-        lib = L.load()
         L.check(lib.glorie_ba_pack_system(L.ptr(hv), L.ptr(packed), int(n6), 0, L.stream_ptr()), "glorie_ba_pack_system")
-        dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+        reduce(packed)
         L.check(lib.glorie_ba_pack_system(L.ptr(hv), L.ptr(packed), int(n6), 1, L.stream_ptr()), "glorie_ba_pack_system")
         return hv
-    dist.all_reduce(hv, op=dist.ReduceOp.SUM, group=group)
+    reduce(hv)
     return hv
 
 
@@ -87,7 +126,7 @@ def ba_sharded(ctx, poses, disps, intrinsics, targets, weights, eta, ii, jj, t0,
                                            B, N, M, h, w, int(t0), int(t1),
                                            int(bool(motion_only)) | (L.BA_TARGETS_HWC if targets_hwc else 0),
                                            L.ptr(hv), L.stream_ptr()), "glorie_ba_build_system")
-        allreduce_system(hv, group, n6=n6, force=force_collective)
+        allreduce_system(hv, group, n6=n6, force=force_collective, ctx=ctx)
         L.check(lib.glorie_ba_solve_update(ctx.handle, L.ptr(poses), L.ptr(disps), L.ptr(ii), L.ptr(jj),
                                            B, N, M, h, w, int(t0), int(t1), float(lm), float(ep),
                                            int(bool(motion_only)), int(bool(depth_only)), L.ptr(hv),

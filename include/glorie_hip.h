@@ -424,6 +424,23 @@ int glorie_ba_solve_update(glorie_ctx* ctx, float* poses, float* disps, const in
                            float lm, float ep, int motion_only, int depth_only, const double* hv,
                            float* dx_out, float* dz_out, void* stream);
 
+/* The exchange step itself (glorie_allreduce_normal_eq(ctx, S_v_buf, n)).  The context owns an RCCL
+ * communicator: rank 0 draws an id (glorie_comm_unique_id, GLORIE_COMM_ID_BYTES bytes), hands it to every rank by whatever
+ * channel the host has (the Python side broadcasts it through torch.distributed's store), and every rank calls
+ * glorie_comm_init(ctx, id, rank, world) once - collective, like ncclCommInitRank.  glorie_allreduce_normal_eq sums `n`
+ * doubles in place over the ranks on `stream` (the packed or the full [H | v]); glorie_allgather_rows gathers
+ * bytes_per_rank bytes from every rank into recv (rank-major) - the owned disparity rows after an iteration.  Both are plain
+ * stream work: they may be recorded into a hipGraph together with the launches around them.  RCCL (librccl.so.1) is bound
+ * at first use; GLORIE_EUNSUPPORTED if it cannot be loaded, GLORIE_EINVAL if the context has no communicator.
+ * glorie_comm_world: ranks of the context's communicator, 0 without one.  The reference is single-GPU: no counterpart. */
+#define GLORIE_COMM_ID_BYTES 128
+int glorie_comm_unique_id(void* id_out);
+int glorie_comm_init(glorie_ctx* ctx, const void* id, int rank, int world);
+int glorie_comm_destroy(glorie_ctx* ctx);
+int glorie_comm_world(const glorie_ctx* ctx);
+int glorie_allreduce_normal_eq(glorie_ctx* ctx, double* hv, size_t n, void* stream);
+int glorie_allgather_rows(glorie_ctx* ctx, const void* send, void* recv, size_t bytes_per_rank, void* stream);
+
 /* Exchange format of the reduced system: the solve reads the lower triangle of H only, so ranks all-reduce
  * n6*(n6+1)/2 + n6 doubles (row r: columns 0..r, then v) instead of n6*n6 + n6 - 13 MB instead of 26 MB at
  * P = 300.  unpack = 0: hv -> packed; unpack = 1: packed -> the lower triangle and v of hv (the rest of hv is

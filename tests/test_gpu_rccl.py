@@ -70,3 +70,75 @@ def test_collectives_run_through_rccl(gpu, tmp_path):
         dp, dd, st = res[tag]
         assert st == 0 and dp < 2e-6 and dd < 2e-6, (tag, res[tag])
     assert res["pack_roundtrip"] and res["rows"]
+
+
+def _worker_native(rank, port, out_path):
+    """the context-owned communicator (glorie_comm_init / glorie_allreduce_normal_eq / glorie_allgather_rows): no
+    torch.distributed process group at all - the C ABI talks to RCCL itself"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    from glorie_slam_amd import _lib as L, dist as gdist, droid_backends as db
+    from test_gpu_ba import make_problem
+    lib = L.load()
+    res = {}
+    ctx = L.Context()
+    res["world_before"] = gdist.ctx_comm_world(ctx)
+    hv0 = torch.ones(8, dtype=torch.float64, device=dev)
+    res["rc_without_comm"] = int(lib.glorie_allreduce_normal_eq(ctx.handle, L.ptr(hv0), 8, L.stream_ptr()))
+    res["world"] = gdist.init_ctx_comm(ctx)
+    res["world_after"] = gdist.ctx_comm_world(ctx)
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    for K, tag in ((6, "small"), (20, "packed")):
+        g = make_problem(K, 12, 16, radius=3)
+        p0, d0 = t(g["poses"]), t(g["disps"])
+        db.ba(p0, d0, t(g["intrinsics"][0]), None, t(g["target"]), t(g["weight"]), t(g["eta"]), t(g["ii"]), t(g["jj"]), 1, K, 2,
+              1e-4, 0.1, False, False)
+        p1, d1 = t(g["poses"]), t(g["disps"])
+        args = (t(g["intrinsics"][0]), t(g["target"]), t(g["weight"]), t(g["eta"]), t(g["ii"]), t(g["jj"]))
+        gdist.ba_sharded(ctx, p1, d1, *args, 1, K, 2, 1e-4, 0.1)
+        torch.cuda.synchronize()
+        res[tag] = (float((p0 - p1).abs().max()), float((d0 - d1).abs().max()), ctx.ba_status()[0])
+        # the same two iterations recorded into a hipGraph (kernels + the RCCL all-reduce as stream work) and replayed
+        p2, d2 = t(g["poses"]), t(g["disps"])
+        ps, ds = p2.clone(), d2.clone()
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            gdist.ba_sharded(ctx, ps, ds, *args, 1, K, 2, 1e-4, 0.1)       # warm-up on the capture stream (arena sized)
+        side.synchronize()
+        ps.copy_(p2); ds.copy_(d2)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            gdist.ba_sharded(ctx, ps, ds, *args, 1, K, 2, 1e-4, 0.1)
+        graph.replay()
+        torch.cuda.synchronize()
+        res[tag + "_graph"] = (float((ps - p1).abs().max()), float((ds - d1).abs().max()))
+    # all-gather of owned rows through the C ABI (one rank: recv == send)
+    send = torch.arange(64, dtype=torch.float32, device=dev)
+    recv = torch.zeros_like(send)
+    L.check(lib.glorie_allgather_rows(ctx.handle, L.ptr(send), L.ptr(recv), send.numel() * 4, L.stream_ptr()), "allgather")
+    torch.cuda.synchronize()
+    res["rows"] = bool(torch.equal(send, recv))
+    L.check(lib.glorie_comm_destroy(ctx.handle), "glorie_comm_destroy")
+    res["world_destroyed"] = gdist.ctx_comm_world(ctx)
+    torch.save(res, out_path)
+
+
+def test_context_owned_communicator_and_graph_capture(gpu, tmp_path):
+    """glorie_allreduce_normal_eq on a ctx-owned RCCL communicator.  One rank here (two RCCL ranks cannot share
+    a device): the communicator is created without torch.distributed, the sharded BA with the native exchange equals the
+    single-call BA, and - what the torch.distributed form cannot do - build_system -> all-reduce -> solve_update replays
+    from a hipGraph with the same result."""
+    out = str(tmp_path / "native.pt")
+    mp.spawn(_worker_native, args=(0, out), nprocs=1, join=True)
+    res = torch.load(out)
+    assert res["world_before"] == 0 and res["rc_without_comm"] != 0          # no communicator: an error, not a silent skip
+    assert res["world"] == 1 and res["world_after"] == 1 and res["world_destroyed"] == 0
+    for tag in ("small", "packed"):
+        dp, dd, st = res[tag]
+        assert st == 0 and dp < 2e-6 and dd < 2e-6, (tag, res[tag])
+        gp, gd = res[tag + "_graph"]
+        assert gp == 0.0 and gd == 0.0, (tag, res[tag + "_graph"])
+    assert res["rows"]
