@@ -162,3 +162,51 @@ def test_trajectory_filler_interpolates_and_refines(gpu):
     assert video.counter.value == K and torch.equal(video.poses[:K], kf)
     assert torch.allclose(out.data[:, 3:].norm(dim=-1), torch.ones(6, device=gpu), atol=1e-4)
     assert out.inv().matrix().shape == (6, 4, 4)                          # what slam.py:176-180 does with the result
+
+
+@pytest.mark.parametrize("K", [256, 512])
+def test_backend_dense_ba_beyond_128_keyframes_is_a_fixed_point(gpu, K):
+    """BASELINE config 4 past the 128-keyframe test above: Backend.dense_ba (backend.py:27-62: proximity edges over the whole
+    buffer, volume-free correlation, update_lowmem, 6 P up to 3066 unknowns -> the multi-launch blocked Cholesky) on a
+    K-keyframe 30x40 loop trajectory.  No trained weights exist here, so the flow head's last layer is zeroed: the BA's
+    targets are then the reprojections of the current state and the generating trajectory must stay where it is through the
+    whole call - edge selection, 16-edge correlation batches, context terms per keyframe, the solver's size class."""
+    import types
+    from glorie_slam_amd.backend import Backend
+    from glorie_slam_amd.depth_video import DepthVideo
+    from glorie_slam_amd.droid_net import UpdateModule
+    h, w = 30, 40
+    cfg = {"cam": {"H_out": 8 * h, "W_out": 8 * w}, "device": str(gpu), "setting": "t", "scene": "s", "data": {"output": "/tmp"},
+           "tracking": {"buffer": K + 8, "beta": 0.75, "warmup": 8, "max_age": 50, "mono_thres": 0.1,
+                        "multiview_filter": {"thresh": 0.25, "visible_num": 2}, "store_images": False,
+                        "frontend": {"enable_loop": False, "keyframe_thresh": 0.0, "thresh": 16.0, "window": 25,
+                                     "radius": 1, "nms": 1, "max_factors": 75},
+                        "backend": {"BA_type": "DSPO", "thresh": 25.0, "radius": 1, "nms": 5, "normalize": False,
+                                    "loop_window": 25, "loop_thresh": 25.0, "loop_radius": 1, "loop_nms": 12}}}
+    g = synth.loop_graph(K=K, h=h, w=w)
+    fmaps, nets, inps = synth.feature_maps(K, h, w)
+    video = DepthVideo(cfg)
+    video.poses[:K] = _t(g["poses"][:K], gpu)
+    video.disps[:K] = _t(g["disps"][:K], gpu)
+    video.intrinsics[:] = _t(g["intrinsics"][0], gpu)
+    video.fmaps[:K] = _t(fmaps, gpu)
+    video.nets[:K] = _t(nets, gpu)
+    video.inps[:K] = _t(inps, gpu)
+    video.mono_disps[:K] = _t(g["disps"][:K], gpu)              # a prior that agrees with the state: stage 2 has nothing to pull
+    video.counter.value = K
+    torch.manual_seed(43)
+    upd = UpdateModule().to(gpu).eval()
+    with torch.no_grad():
+        upd.delta[2].weight.zero_()
+        upd.delta[2].bias.zero_()
+    be = Backend(types.SimpleNamespace(update=upd), video, cfg)
+    n, ne = be.dense_ba(steps=2)
+    torch.cuda.synchronize()
+    assert n == K and ne > 3 * K
+    assert video.ctx().ba_status()[0] == 0
+    p, p0 = video.poses[:K], _t(g["poses"][:K], gpu)
+    assert bool(torch.isfinite(p).all() and torch.isfinite(video.disps[:K]).all())
+    assert float((p[:, :3] - p0[:, :3]).norm(dim=-1).max()) < 2e-3
+    assert float((1.0 - (p[:, 3:] * p0[:, 3:]).sum(-1).abs()).max()) < 1e-5
+    rel = ((video.disps[:K] - _t(g["disps"][:K], gpu)).abs() / _t(g["disps"][:K], gpu)).mean()
+    assert float(rel) < 0.02, float(rel)
