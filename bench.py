@@ -374,12 +374,12 @@ def main():
         f"after {sustained_steps} sustained steps: BA status {ba_st2}, finite poses {bool(torch.isfinite(video.poses).all())}"
 
     # ---- strong scaling: ONE fixed long graph whatever the number of ranks (the case the sharding is for, BASELINE
-    # config 4: 30x40 maps, here 128 keyframes in a +-3 window = 756 edges, volume-free correlation), edges sharded by
+    # config 4: 30x40 maps, here 128 keyframes (GLORIE_STRONG_K) in a +-3 window = 756 edges, volume-free correlation), edges sharded by
     # source keyframe, one step = one BA-update of the whole graph.  Reported next to the weak figure above.
     strong = None
     if not args.no_strong:
         try:
-            KS = 128
+            KS = int(os.environ.get("GLORIE_STRONG_K", "128"))      # 512 = the long end of BASELINE config 4
             gS, videoS, graphS = build_graph(device, K=KS, h=30, w=40, rank=rank, world=world, corr_impl="otf",
                                              use_graphs=os.environ.get("GLORIE_NO_GRAPHS") is None)
 
