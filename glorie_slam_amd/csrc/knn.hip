@@ -225,10 +225,12 @@ struct TopK {
   }
   __device__ __forceinline__ float dist(int s) const { return __uint_as_float((unsigned)(key[s] >> 32)); }
   __device__ __forceinline__ int index(int s) const { return (int)(unsigned)key[s]; }
-  __device__ __forceinline__ void push(float dd, int ii) {
-    const unsigned long long x = ((unsigned long long)__float_as_uint(dd) << 32) | (unsigned)ii;
+  static __device__ __forceinline__ unsigned long long pack(float dd, int ii) {
+    return ((unsigned long long)__float_as_uint(dd) << 32) | (unsigned)ii;
+  }
+  // the insertion network, for every lane (a key that does not beat the list - e.g. the all-ones filler - changes nothing)
+  __device__ __forceinline__ void insert(unsigned long long x) {
     bool c = x < key[K - 1];
-    if (!c) return;
 #pragma unroll
     for (int s = K - 1; s > 0; --s) {            // new[s] = x < old[s-1] ? old[s-1] : (x < old[s] ? x : old[s])
       const bool cm = x < key[s - 1];
@@ -236,6 +238,59 @@ struct TopK {
       c = cm;
     }
     key[0] = c ? x : key[0];
+  }
+  __device__ __forceinline__ void push(float dd, int ii) {
+    const unsigned long long x = pack(dd, ii);
+    if (!(x < key[K - 1])) return;
+    insert(x);
+  }
+};
+
+// The list with a per-lane pending buffer in LDS.  push() runs its ~45-instruction network for the whole wave whenever ANY
+// lane improves its list - with 64 lanes that is at practically every one of the ~120 candidates a lane looks at, although
+// a single lane accepts only ~30-45 of them.  offer() instead appends an accepted key to the lane's own slots (one compare,
+// one LDS store) and the network runs in flush(): once any lane holds more than kPendFlush keys, for as many rounds as the
+// fullest lane needs - the wave executes max-over-lanes(accepted) networks instead of one per candidate.  Between flushes
+// the acceptance bound is stale (too generous): keys that no longer beat the list are dropped by the network itself, so the
+// final list is the same set in the same (distance, index) order.  Slot s of thread t is pend[s * 256 + t].
+constexpr int kPendSlots = 8, kPendFlush = 4;     // a scan step offers up to 4 candidates: 4 + 4 <= 8
+template <int K>
+struct TopKBuf {
+  TopK<K> top;
+  unsigned long long* pend;
+  int n;
+#ifdef EXP_KNN_STATS
+  int st_cand = 0, st_acc = 0, st_ins = 0, st_rows = 0, st_shells = 0;      // experiment: tools/knn_stats.py
+#endif
+  __device__ __forceinline__ void init(unsigned long long* lds_slot0) { top.init(); pend = lds_slot0; n = 0; }
+  __device__ __forceinline__ float dist(int s) const { return top.dist(s); }
+  __device__ __forceinline__ int index(int s) const { return top.index(s); }
+  // branch-free: the key is stored at the lane's next slot whether it is taken or not, the count only moves if it is
+  // (`valid` = false: a padding candidate of a scan step, never taken)
+  __device__ __forceinline__ void offer(float dd, int ii, bool valid = true) {
+    const unsigned long long x = TopK<K>::pack(dd, ii);
+    const bool take = valid && x < top.key[K - 1];
+#ifdef EXP_KNN_STATS
+    st_cand += valid;
+    st_acc += take;
+#endif
+    pend[n * 256] = x;
+    n += take ? 1 : 0;
+  }
+  // callable under divergence: the ballots see the active lanes only, idle lanes keep their keys for a later flush
+  __device__ __forceinline__ void flush() {
+#pragma unroll 1
+    for (int s = 0; s < kPendSlots; ++s) {
+      if (__builtin_amdgcn_ballot_w64(s < n) == 0ull) break;
+#ifdef EXP_KNN_STATS
+      ++st_ins;
+#endif
+      top.insert(s < n ? pend[s * 256] : ~0ull);
+    }
+    n = 0;
+  }
+  __device__ __forceinline__ void relieve() {
+    if (__builtin_amdgcn_ballot_w64(n > kPendFlush) != 0ull) flush();
   }
 };
 
@@ -257,8 +312,7 @@ __device__ __forceinline__ float dist2_exact(float qx, float qy, float qz, float
 template <int K>
 __device__ __forceinline__ void knn_search(const float4* __restrict__ sorted,
                                            const int* __restrict__ starts, const KnnGrid& g,
-                                           float qx, float qy, float qz, TopK<K>& top, float lim2 = FLT_MAX) {
-  top.init();
+                                           float qx, float qy, float qz, TopKBuf<K>& top, float lim2 = FLT_MAX) {
   if (g.npoints <= 0) return;
   const int cx = cell_coord(qx, g.ox, g.inv_cs, g.nx);
   const int cy = cell_coord(qy, g.oy, g.inv_cs, g.ny);
@@ -278,10 +332,11 @@ __device__ __forceinline__ void knn_search(const float4* __restrict__ sorted,
       for (int t = b; t < e; t += 4) {
         const int l = e - 1;
         const float4 p0 = sorted[t], p1 = sorted[min(t + 1, l)], p2 = sorted[min(t + 2, l)], p3 = sorted[min(t + 3, l)];
-        top.push(dist2_exact(qx, qy, qz, p0), __float_as_int(p0.w));
-        if (t + 1 < e) top.push(dist2_exact(qx, qy, qz, p1), __float_as_int(p1.w));
-        if (t + 2 < e) top.push(dist2_exact(qx, qy, qz, p2), __float_as_int(p2.w));
-        if (t + 3 < e) top.push(dist2_exact(qx, qy, qz, p3), __float_as_int(p3.w));
+        top.offer(dist2_exact(qx, qy, qz, p0), __float_as_int(p0.w));
+        top.offer(dist2_exact(qx, qy, qz, p1), __float_as_int(p1.w), t + 1 < e);
+        top.offer(dist2_exact(qx, qy, qz, p2), __float_as_int(p2.w), t + 2 < e);
+        top.offer(dist2_exact(qx, qy, qz, p3), __float_as_int(p3.w), t + 3 < e);
+        top.relieve();
       }
     };
     // Once the list is full, cells whose box lies farther from q than the current k-th best cannot contribute
@@ -297,6 +352,9 @@ __device__ __forceinline__ void knn_search(const float4* __restrict__ sorted,
 #pragma unroll 1
       for (int y = y0; y <= y1; ++y) {
         const bool face = (abs(z - cz) == m) || (abs(y - cy) == m);
+#ifdef EXP_KNN_STATS
+        ++top.st_rows;
+#endif
         const int row = (z * g.ny + y) * g.nx;
         const float ylo = g.oy + y * g.cs;
         const float by = fmaxf(fmaxf(ylo - qy, qy - (ylo + g.cs)) - slack, 0.0f);
@@ -329,6 +387,10 @@ __device__ __forceinline__ void knn_search(const float4* __restrict__ sorted,
         }
       }
     }
+    top.flush();                                     // the shell is complete: the stop test below needs the true k-th best
+#ifdef EXP_KNN_STATS
+    ++top.st_shells;
+#endif
     // distance from q to the faces of the scanned cube that still have cells behind them
     float rho = FLT_MAX;
     if (cx - m > 0) rho = fminf(rho, qx - (g.ox + (cx - m) * g.cs));
@@ -361,6 +423,7 @@ __global__ __launch_bounds__(256) void knn_query_kernel(
   // consecutive queries: ~25 rays x 10 depths straddle a 20 cm stretch of 6 cm cells, the patch at one depth is a
   // ~6 cm square - one or two cells, the coherence of a global sort by cell without the sort.
   __shared__ unsigned skey[256];
+  __shared__ unsigned long long pend[kPendSlots * 256];
   const int tid = threadIdx.x;
   const KnnGrid g = *gp;
   auto query_of = [&](int l) -> int {
@@ -402,13 +465,21 @@ __global__ __launch_bounds__(256) void knn_query_kernel(
   const unsigned mine = skey[tid];
   if (mine == 0xffffffffu) return;           // past the end of the query array
   const int t = query_of((int)(mine & 255u));
-  TopK<K> top;
+  TopKBuf<K> top;
+  top.init(pend + tid);
   const float r = radius_ptr ? radius_ptr[t] : radius;
   const float r2 = r * r;
   // ball_only: the caller only uses neighbours with d <= r^2 (the IDW weight of the others is zero): bound the search by
   // the ball, a little generously so that the comparison d <= r2 below sees every candidate
   knn_search<K>(sorted, starts, g, q[(size_t)t * 3 + 0], q[(size_t)t * 3 + 1], q[(size_t)t * 3 + 2], top,
                 ball_only ? r2 * 1.0001f + 1e-30f : FLT_MAX);
+#ifdef EXP_KNN_STATS
+  if (K == 8) {
+    const float v[5] = {(float)top.st_cand, (float)top.st_acc, (float)top.st_ins, (float)top.st_rows, (float)top.st_shells};
+    for (int s = 0; s < 5; ++s) D[(size_t)t * K + s] = v[s];
+    return;
+  }
+#endif
   int cnt = 0;
 #pragma unroll
   for (int s = 0; s < K; ++s) {
