@@ -383,6 +383,9 @@ class FusedUpdate:
         if self._ctx_key != key:
             self.precompute_shared_context(context)
             self._ctx_key = key
+            # the key holds addresses: keep the tensors alive, or a later edge set's unique(ii) / inverse tensors can land on
+            # the freed blocks with the same shape and version 0 and inherit a stale term
+            self._ctx_refs = (table, frames, index)
         return self._pre_kf[:int(frames.shape[0])], self._pre_map[:int(index.shape[0])]
 
     @torch.no_grad()

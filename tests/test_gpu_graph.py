@@ -345,3 +345,22 @@ def test_graph_replay_survives_a_moved_scratch_arena(gpu):
     for a, b in ((video_e.poses, video_g.poses), (video_e.disps, video_g.disps), (eager.target, graph.target)):
         assert torch.isfinite(b).all()
         torch.testing.assert_close(a, b, atol=2e-3, rtol=2e-3)
+
+
+def test_deferred_flag_resynchronises_after_a_missed_await(gpu):
+    """the stage-1 decision of a replayed depth_scale stage travels through a pinned word tagged with a launch count
+    (DepthVideo.publish_any_on / await_any_on).  If a replay's flag is never awaited the host's count falls behind the
+    device's: the next await must warn, follow the device and keep working - not spin and raise on every later step."""
+    _, video = make_video(gpu, 4, 12, 16)
+    one = torch.ones(1, dtype=torch.int32, device=gpu)
+    zero = torch.zeros(1, dtype=torch.int32, device=gpu)
+    video.publish_any_on(one)
+    assert video.await_any_on() == 1
+    video.publish_any_on(zero)                    # a replay whose flag nobody reads ...
+    video.publish_any_on(one)                     # ... and the next one
+    with pytest.warns(UserWarning, match="resynchronised"):
+        assert video.await_any_on(timeout=0.005) == 1
+    video.publish_any_on(zero)                    # in step again: no warning, the right decisions
+    assert video.await_any_on() == 0
+    video.publish_any_on(one)
+    assert video.await_any_on() == 1
