@@ -32,6 +32,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <algorithm>
+#include <stdlib.h>
 #include "common.hiph"
 
 namespace glorie {
@@ -772,7 +773,8 @@ extern "C" int glorie_corr_dm_lookup(const void* const* levels, const int* slots
   // a call whose rows span 2 GB or more is issued in runs of edges
   const size_t edge_bytes = (size_t)h * w * enc_stride * sizeof(_Float16);
   if (edge_bytes >= 0x80000000ull) return GLORIE_EUNSUPPORTED;
-  const int per = (int)std::min<size_t>((size_t)N, std::max<size_t>(1, 0x7fffffffull / edge_bytes));
+  int per = (int)std::min<size_t>((size_t)N, std::max<size_t>(1, 0x7fffffffull / edge_bytes));
+  if (const char* ce = getenv("GLORIE_CORR_DM_CHUNK")) per = std::max(1, std::min(per, atoi(ce)));   // tests: force the split
   for (int n0 = 0; n0 < N; n0 += per) {
     DmArgs c = a;
     c.N = std::min(per, N - n0);

@@ -382,6 +382,39 @@ def test_corr_dm_fused_encoder(gpu, N, h, w):
     torch.testing.assert_close(only.float(), old.float(), rtol=2e-3, atol=2e-3)
 
 
+def test_corr_dm_lookup_split_into_runs_of_edges(gpu, monkeypatch):
+    """the fused launch stores through a buffer descriptor with 32-bit offsets, so glorie_corr_dm_lookup issues calls whose
+    output rows span 2 GB or more in runs of edges (coords, slots, lookup and encoder rows advance per run); the run length is
+    forced down to 3 edges here (GLORIE_CORR_DM_CHUNK) and everything must equal the single launch bit for bit - with an
+    explicit slot list and with the implicit slot = edge"""
+    from glorie_slam_amd import droid_backends as db, update_ops as U
+    rng = np.random.default_rng(29)
+    N, h, w = 8, 16, 24
+    levels = [torch.from_numpy(rng.standard_normal((N, h, w, h >> l, w >> l)).astype(np.float16)).to(gpu) for l in range(4)]
+    dm = [db.dm_corr_level(v, l) for l, v in enumerate(levels)]
+    y, x = np.meshgrid(np.arange(h, dtype=np.float32), np.arange(w, dtype=np.float32), indexing="ij")
+    coords = np.stack([np.stack([x + 0.7 * n, y - 0.4 * n], -1) for n in range(N)]).astype(np.float32)
+    coords += rng.uniform(-2, 2, coords.shape).astype(np.float32)
+    ct = torch.from_numpy(coords).to(gpu)
+    g = torch.Generator().manual_seed(2)
+    ew = U.pack_corr_encoder_dm((torch.randn(128, 196, 1, 1, generator=g) / 14).to(gpu))
+    eb = torch.randn(128, generator=g).to(gpu)
+    slots = torch.tensor([3, 0, 7, 7, 1, 5, 2, 6], dtype=torch.int32, device=gpu)
+
+    def run(sl):
+        out = torch.zeros(N, 128, h, w, dtype=torch.float16, device=gpu).contiguous(memory_format=torch.channels_last)
+        corr = db.corr_dm_lookup(dm, ct, h, w, slots=sl, interleaved=True, enc_w=ew, enc_b=eb, enc_out=out)
+        return corr.clone(), out
+
+    for sl in (None, slots):
+        monkeypatch.delenv("GLORIE_CORR_DM_CHUNK", raising=False)
+        c0, e0 = run(sl)
+        monkeypatch.setenv("GLORIE_CORR_DM_CHUNK", "3")
+        c1, e1 = run(sl)
+        assert torch.equal(c0.view(torch.int16), c1.view(torch.int16)) and torch.equal(e0, e1)
+        assert float(e0.abs().max()) > 0
+
+
 def test_corr_arena_layouts_agree(gpu):
     """the two arena layouts hold the same pyramid: identical lookups (planar and channels-last), and the fused
     lookup + encoder of the displacement-major arena matches the two-launch form of the tiled one"""
