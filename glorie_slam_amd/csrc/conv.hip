@@ -1700,7 +1700,8 @@ static int conv_igemm_impl(const void* xa, int xa_stride, int ca, const void* xb
   // (292 us: a 64-pixel workgroup costs 0.8 of a 128-pixel one and workgroups do not run in lockstep rounds, so the
   // partly filled last round is cheaper than a round model says); two LDS stages with one barrier per K-tile and the next
   // tile's DMA issued in the shadow of the fragment reads (round 3: 448 -> 256 at 32-channel K-tiles 320 -> 406 us, 448 -> 128
-  // 186 -> 197 us at 64-channel, 248 us at 32-channel K-tiles).  GLORIE_CONV_TILE = 128 | 64 | split | wide keeps the
+  // 186 -> 197 us at 64-channel, 248 us at 32-channel K-tiles); the single stage with 32-channel K-tiles at FOUR workgroups
+  // per CU (113-128 VGPRs: 448 -> 128 186 -> 271 us).  GLORIE_CONV_TILE = 128 | 64 | split | wide keeps the
   // variants reachable for tools/bench_conv.py.
   const int ntn = (nout + 127) / 128;
   const long slots128 = 3L * 256;
