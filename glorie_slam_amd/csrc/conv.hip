@@ -512,6 +512,9 @@ __global__ __launch_bounds__(64 * NW, (ST == 1 && MB * NB <= 16) ? 3 : 2) void c
     char* lx = smem + buf * (XBYTES + WBYTES);
     char* lw = lx + XBYTES;
     const unsigned xstep = (unsigned)(NW * RPI * xs * 2), wstep = (unsigned)(NW * RPI * C * 2);
+#ifdef EXP_NO_PIXEL_DMA
+    if (d == 0)                                  // ablation: the pixel tile is staged once per chunk (wrong results)
+#endif
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
       const unsigned inv = ~((unsigned)vmask[i] >> d);
@@ -654,6 +657,240 @@ __global__ __launch_bounds__(64 * NW, (ST == 1 && MB * NB <= 16) ? 3 : 2) void c
       conv_epilogue_upsample<MB, NB>(a, acc, p0, n0, wm, wn, kg, col, smem);
   } else if constexpr (EPI == EPI_HEADS) {
     if constexpr (MB == 4 && NB == 4 && NW == 4 && ST == 1) {
+      if (nt < a.tap_groups)                                                    // workgroup-uniform
+        conv_epilogue_heads<MB, NB>(a, acc, p0, n0, wm, wn, kg, col, lane, smem);
+      else
+        conv_epilogue_tile<EPI_BIAS_ACT, MB, NB>(a, acc, p0 + wn * (16 * NB) + col, n0 + wm * (16 * MB) + kg * 4,
+                                                 a.tap_groups * 128);
+    }
+  } else {
+    conv_epilogue_tile<EPI, MB, NB>(a, acc, p0 + wn * (16 * NB) + col, n0 + wm * (16 * MB) + kg * 4);
+  }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// conv_igemm_kernel for 3x3 layers with the PIXEL tile shared by the nine taps of a 64-channel chunk.
+//
+// The nine taps of a chunk read the same pixel rows shifted by (dy W + dx): instead of staging 128 rows per tap, the
+// workgroup stages the 128 + 2 (W + 1) rows its taps touch ONCE per chunk (a haloed tile: 290 rows at W = 80, 37 KB) and
+// every tap reads its fragments from there at its own row offset - 181 KB of DMA per chunk instead of 288 KB for a
+// 128-channel tile.  tools/exp_conv.sh measured the ceiling of that first (pixel tile staged at tap 0 only, wrong results):
+// 128-channel layers -13...-27 %, the z|r gates -5 %.  The real kernel keeps a fraction of it, because the haloed tile arrives
+// as one burst of 37 pieces at every chunk boundary with nothing to compute beside it (a second tile buffer would cost the
+// third resident workgroup): q gate 170.7 -> 164.4 us, heads 160.7 -> 156.4 us, 448 -> 128 -3...5 %, the 128 -> 128 layer
+// unchanged; +0.9 % on the BA-update step in an interleaved A/B (950-956 -> 960-962 it/s).  The 256-channel tile (448 -> 256
+// 324 -> 363 us: 256 VGPRs with spills, the weights are two thirds of its staging anyway) and the 64-channel tile (43.7 ->
+// 47.8 us) lose and stay on conv_igemm_kernel; the dispatch takes this kernel for the 128-channel tile only.
+// Everything else is conv_igemm_kernel<EPI, 4, 64, 4, 1, MB>: same tile mapping, K order (chunk outermost, taps inside),
+// single LDS stage for the weights (wait, barrier, fragment reads, barrier, DMA of the next tile, MFMAs), same MFMA sequence
+// and epilogues - results are bit-identical (tests/test_gpu_update_op.py).  What differs:
+//   * zero padding moves from the DMA (bit 31 of a lane's offset) to the fragment: a lane whose pixel has no neighbour for
+//     this tap replaces what it read by zeros (32 selects per K-tile, placed behind the barrier that frees the stage);
+//     rows of the halo outside [0, P) are zero-filled by the DMA's range check as before;
+//   * a fragment row starts anywhere, so its swizzle key (row & 7) is computed per tap (28 vector instructions per K-tile);
+//     ds_read_b128 of 16 consecutive rows is conflict-free for every start row with that key (brute-force checked against
+//     the lane groups of MI355X_MICROARCH.md);
+//   * the halo tile is re-staged after the barrier that follows the fragment reads of a chunk's last tap - the same point
+//     where the weights of the next tile are staged.
+// LDS: weights 32 MB rows + 128 + 2 W + 2 pixel rows (the last DMA piece overlaps its predecessor so that the tile takes no
+// more than that: 53.5 KB at W = 80, three workgroups per CU; with whole 8-row pieces it was two and 4 % slower than the
+// plain kernel); up to W = 83 for the 128-channel tile.
+// ------------------------------------------------------------------------------------------------------------------
+template <int EPI, int MB>
+__global__ __launch_bounds__(256, MB <= 4 ? 3 : 2) void conv_halo_kernel(ConvArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int NB = 4, NW = 4, TN = 32 * MB, PT = 128, RB = 128, SL = 8, RPI = 8, KK = 2;
+  constexpr int WI = TN / RPI / NW;                    // weight DMA instructions per wave per K-tile
+  constexpr int WBYTES = TN * RB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [weights][halo pixel rows]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int col = lane & 15, kg = lane >> 4;
+  const int wm = wv & 1, wn = wv >> 1;
+  const int halo = a.W + 1;                            // rows in front of (and behind) the tile
+  const int hrows = PT + 2 * halo;
+  const int npieces = (hrows + RPI - 1) / RPI;         // DMA pieces of 8 rows
+  char* const lx = smem + WBYTES;
+
+  const int nwg = gridDim.x, ntn = (a.nout + TN - 1) / TN;
+  const int xcd = blockIdx.x & 7, q = nwg >> 3, r = nwg & 7;
+  const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+  const int pt = lid / ntn, nt = lid - pt * ntn;
+  const int tpm = (a.HW + PT - 1) / PT;
+  const long p0 = EPI == EPI_GLO ? (long)(pt / tpm) * a.HW + (long)(pt % tpm) * PT : a.pbeg + (long)pt * PT;
+  const int n0 = nt * TN;
+  const int nchunks = a.cha + a.chb;
+  const int C = nchunks * 64;
+  const int T = 9 * nchunks;
+
+  // descriptors `halo` rows in front of the tensors: halo row h of the tile is pixel p0 - halo + h
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(a.xa - (long)halo * a.xa_stride), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(a.xb - (long)halo * a.xb_stride), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, 0x7fffffff, 0x00020000);
+  const int srow = lane / SL, slot = lane % SL;
+  const int row0 = wv * RPI + srow;
+  const int sw0 = (slot ^ (row0 & 7)) << 3;            // swizzled 16-byte slot, in halfs (key = row & 7 = srow)
+  const unsigned voffA0 = (unsigned)(((p0 + row0) * a.xa_stride + sw0) * 2);
+  const unsigned voffB0 = (unsigned)(((p0 + row0) * a.xb_stride + sw0) * 2);
+  const unsigned woff0 = (unsigned)(((size_t)row0 * C + sw0) * 2);
+  constexpr int XIMAX = 12;                            // pieces per wave: ceil(ceil((128 + 2 W + 2) / 8) / 4), W <= 127
+  unsigned hmask = 0;                                  // bit i: the row of piece i * 4 + wv this lane stages lies inside [0, P)
+#pragma unroll
+  for (int i = 0; i < XIMAX; ++i) {
+    const long p = p0 - halo + (long)((i * NW + wv) * RPI + srow);
+    hmask |= (p >= 0 && p < a.P) ? (1u << i) : 0u;
+  }
+  auto stage_pixels = [&](int ch) {
+    const bool segA = ch < a.cha;
+    const int xs = segA ? a.xa_stride : a.xb_stride;
+    const unsigned xsoff = (unsigned)(((segA ? ch : ch - a.cha) * 64) * 2);
+    const unsigned xstep = (unsigned)(NW * RPI * xs * 2);
+    unsigned hm = hmask;
+    asm volatile("" : "+v"(hm));                       // keeps the twelve masked offsets from being hoisted out of the K loop
+#pragma unroll
+    for (int i = 0; i < XIMAX; ++i) {
+      const int piece = i * NW + wv;                   // wave-uniform
+      if (piece < npieces - 1 || (piece == npieces - 1 && (hrows & 7) == 0)) {
+        const unsigned inv = ~(hm >> i);
+        const unsigned vo = (inv << 31) | (segA ? voffA0 : voffB0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(segA ? rA : rB,
+            (__attribute__((address_space(3))) void*)(lx + piece * RPI * RB), 16, vo, xsoff + i * xstep, 0, 0);
+      } else if (piece == npieces - 1) {
+        // the last piece ends with the tile's last row (it re-writes up to 7 rows of its predecessor with the same bytes):
+        // the tile then takes exactly 128 + 2 W + 2 rows of LDS, which is what lets three workgroups share a CU at W = 80
+        const int rowL = hrows - RPI + srow;
+        const long pL = p0 - halo + rowL;
+        const unsigned invL = (pL >= 0 && pL < a.P) ? 0u : 0x80000000u;
+        const unsigned voL = invL | (unsigned)(((p0 + rowL) * xs + ((slot ^ (rowL & 7)) << 3)) * 2);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(segA ? rA : rB,
+            (__attribute__((address_space(3))) void*)(lx + (hrows - RPI) * RB), 16, voL, xsoff, 0, 0);
+      }
+    }
+  };
+  auto stage_weights = [&](int ch, int d) {
+    const unsigned wsoff = (unsigned)((((size_t)d * a.npad + n0) * C + ch * 64) * 2);
+    const unsigned wstep = (unsigned)(NW * RPI * C * 2);
+#pragma unroll
+    for (int i = 0; i < WI; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rW,
+          (__attribute__((address_space(3))) void*)(smem + (i * NW + wv) * RPI * RB), 16, woff0, wsoff + i * wstep, 0, 0);
+  };
+
+  f32x4 acc[MB][NB];
+#pragma unroll
+  for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NB; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // tap validity of this lane's four pixels (blocks ni): bit 9 ni + d
+  unsigned long long pmask = 0ull;
+#pragma unroll
+  for (int ni = 0; ni < NB; ++ni) {
+    const long p = p0 + wn * (16 * NB) + ni * 16 + col;
+    if (p < a.P) {
+      const int xw = (int)(p % a.W), yh = (int)((p / a.W) % a.H);
+#pragma unroll
+      for (int d = 0; d < 9; ++d) {
+        const int dy = d / 3 - 1, dx = d % 3 - 1;
+        if ((unsigned)(yh + dy) < (unsigned)a.H && (unsigned)(xw + dx) < (unsigned)a.W) pmask |= 1ull << (9 * ni + d);
+      }
+    }
+  }
+  int woffr[KK];                                       // weight fragments: row = 16 blk + col, slot kk * 4 + kg, key = col & 7
+#pragma unroll
+  for (int kk = 0; kk < KK; ++kk) woffr[kk] = col * RB + (((kk * 4 + kg) ^ (col & 7)) << 4);
+  const int wbase = wm * (16 * MB) * RB;
+  const int rb0 = wn * (16 * NB) + col + halo;         // halo row of this lane's pixel of block 0 for the centre tap
+
+  if (EPI != EPI_BIAS_ACT && a.pre && !a.pre_late) {
+    // per-edge context term: seeds the accumulators through LDS as in conv_igemm_kernel
+    constexpr int ROWB = TN * 2, SLOTS = ROWB / 16, RPP = 64 / SLOTS;
+    const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void*)a.pre, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < PT / RPP / NW; ++i) {
+      const int piece = i * NW + wv;
+      const int row = piece * RPP + lane / SLOTS, sl = lane % SLOTS;
+      const long p = pre_pixel(a, min(p0 + row, a.P - 1));
+      const unsigned vo = (unsigned)((p * a.pre_stride + n0) * 2 + ((sl ^ (row & 15)) << 4));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rP, (__attribute__((address_space(3))) void*)(smem + piece * 1024), 16, vo,
+                                               0, 0, 0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ni = 0; ni < NB; ++ni) {
+      const int row = wn * (16 * NB) + ni * 16 + col;
+#pragma unroll
+      for (int mi = 0; mi < MB; ++mi) {
+        const int b = (wm * (16 * MB) + mi * 16 + kg * 4) * 2;
+        const f16x4 h = *reinterpret_cast<const f16x4*>(smem + row * ROWB + ((((b >> 4) ^ (row & 15))) << 4) + (b & 15));
+        acc[mi][ni] = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+      }
+    }
+    __syncthreads();
+  }
+  stage_pixels(0);
+  stage_weights(0, 0);
+  int ch = 0, d = 0;                                   // chunk and tap of tile t
+  for (int t = 0; t < T; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                   // tile t (and at d == 0 the chunk's pixel rows) landed
+    const int shift = (d / 3 - 1) * a.W + (d % 3 - 1);
+    f16x8 wf[KK][MB], xf[KK][NB];
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+      for (int mi = 0; mi < MB; ++mi)
+        wf[kk][mi] = *reinterpret_cast<const f16x8*>(smem + wbase + mi * 16 * RB + woffr[kk]);
+    {
+      // the four pixel blocks of a lane are 16 rows apart: same swizzle key, one address + immediate offsets
+      const int rr = rb0 + shift;
+      const unsigned o0 = (unsigned)WBYTES + (unsigned)rr * RB + (unsigned)((kg ^ (rr & 7)) << 4);
+      const char* b0 = smem + o0;
+      const char* b1 = smem + (o0 ^ 64u);
+#pragma unroll
+      for (int ni = 0; ni < NB; ++ni) {
+        xf[0][ni] = *reinterpret_cast<const f16x8*>(b0 + ni * 16 * RB);
+        xf[1][ni] = *reinterpret_cast<const f16x8*>(b1 + ni * 16 * RB);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                      // every wave holds its fragments
+    {
+      // zero padding: a pixel without a neighbour for this tap contributes a zero fragment
+      const unsigned pm = (unsigned)(pmask >> d);      // bit 9 ni
+      const f16x8 zf = {};
+#pragma unroll
+      for (int ni = 0; ni < NB; ++ni) {
+        const bool ok = (pm >> (9 * ni)) & 1u;
+        xf[0][ni] = ok ? xf[0][ni] : zf;
+        xf[1][ni] = ok ? xf[1][ni] : zf;
+      }
+    }
+    int ch1 = ch, d1 = d + 1;
+    if (d1 == 9) { d1 = 0; ch1 = ch + 1; }
+    if (t + 1 < T) {
+      if (d1 == 0) stage_pixels(ch1);                  // the chunk's last tap has been read: its pixel rows are free
+      stage_weights(ch1, d1);
+    }
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+      for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NB; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kk][mi], xf[kk][ni], acc[mi][ni], 0, 0, 0);
+    ch = ch1;
+    d = d1;
+  }
+
+  if constexpr (EPI == EPI_GLO) {
+    if constexpr (MB == 4) conv_epilogue_glo<MB, NB>(a, acc, p0, p0 + wn * (16 * NB) + col, wm, wn, kg, col, smem, pt);
+  } else if constexpr (EPI == EPI_UPSAMPLE) {
+    if constexpr (MB == 4) conv_epilogue_upsample<MB, NB>(a, acc, p0, n0, wm, wn, kg, col, smem);
+  } else if constexpr (EPI == EPI_HEADS) {
+    if constexpr (MB == 4) {
       if (nt < a.tap_groups)                                                    // workgroup-uniform
         conv_epilogue_heads<MB, NB>(a, acc, p0, n0, wm, wn, kg, col, lane, smem);
       else
@@ -1531,6 +1768,48 @@ static void launch_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
   hipLaunchKernelGGL((conv_igemm_kernel<EPI, NB, BK, NW, ST, MB>), grid, dim3(64 * NW), lds, st, a);
 }
 
+template <int EPI, int MB>
+static void launch_halo_one(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+  static size_t granted = 64 * 1024;          // more dynamic LDS than 64 KB needs the opt-in (once per kernel and size)
+  if (lds > granted) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<EPI, MB>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    granted = lds;
+  }
+  hipLaunchKernelGGL((conv_halo_kernel<EPI, MB>), grid, dim3(256), lds, st, a);
+}
+// LDS of conv_halo_kernel: weight stage + haloed pixel rows, and never less than the
+// [pixel][channel] tile its seeding prologue / epilogues lay out
+static size_t halo_lds_bytes(int W, int MB) {
+  const size_t need = (size_t)32 * MB * 128 + (size_t)(128 + 2 * (W + 1)) * 128;
+  const size_t seed = (size_t)128 * 32 * MB * 2;
+  return need > seed ? need : seed;
+}
+template <int MB>
+static int launch_conv_halo(const ConvArgs& a, int epilogue, hipStream_t st) {
+  constexpr int PT = 128, TN = 32 * MB;
+  const long ptiles = (a.P - a.pbeg + PT - 1) / PT;
+  if (ptiles <= 0) return GLORIE_OK;
+  const long nwg = ptiles * ((a.nout + TN - 1) / TN);
+  if (nwg > 0x7fffffffL) return GLORIE_EINVAL;
+  const dim3 grid((unsigned)nwg);
+  const size_t lds = halo_lds_bytes(a.W, MB);
+  switch (epilogue) {
+    case EPI_BIAS_ACT: launch_halo_one<EPI_BIAS_ACT, MB>(a, grid, lds, st); break;
+    case EPI_GRU_ZR: launch_halo_one<EPI_GRU_ZR, MB>(a, grid, lds, st); break;
+    case EPI_GRU_Q:
+      if constexpr (MB == 4) launch_halo_one<EPI_GRU_Q, MB>(a, grid, lds, st);
+      else return GLORIE_EUNSUPPORTED;
+      break;
+    case EPI_HEADS:
+      if constexpr (MB == 4) launch_halo_one<EPI_HEADS, MB>(a, grid, lds, st);
+      else return GLORIE_EUNSUPPORTED;
+      break;
+    default: return GLORIE_EUNSUPPORTED;
+  }
+  return check_launch();
+}
+
 template <int EPI>
 static void launch_ps_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
   constexpr size_t lds = 2 * (128 * 128 + 128 * 128);          // two stages; the seeding / epilogue uses fit inside
@@ -1687,6 +1966,21 @@ static int conv_igemm_impl(const void* xa, int xa_stride, int ca, const void* xb
   if (ps && ps[0] == '1') return launch_conv_ps(a, epilogue, st);
   if (ps && ps[0] == '2' && taps == 9 && epilogue <= EPI_GRU_Q && nout >= 128)
     return (nout & 255) == 0 ? launch_conv_ps2<8, 4>(a, epilogue, st) : launch_conv_ps2<4, 8>(a, epilogue, st);
+  // 3x3 layers on the 128-channel tile: the pixel tile is shared by the nine taps of a chunk (conv_halo_kernel) while its haloed
+  // tile leaves three workgroups per CU (image width <= 83); small launches keep their 64-pixel tiles, the 256- and 64-channel
+  // tiles their per-tap staging (measured slower with the shared tile).  GLORIE_CONV_HALO=0: per-tap staging everywhere.
+  {
+    const char* hl = getenv("GLORIE_CONV_HALO");
+    const char* tmv = getenv("GLORIE_CONV_TILE");
+    const char* c8v = getenv("GLORIE_CONV8");
+    const bool plain_env = (tmv && tmv[0]) || (c8v && c8v[0] == '1');
+    if (!(hl && hl[0] == '0') && !plain_env && taps == 9 && a.pbeg == 0) {
+      const long tiles128 = (a.P + 127) / 128 * ((nout + 127) / 128);
+      if (nout > 64 && (nout & 255) != 0 && W <= 83 && (epilogue <= EPI_GRU_Q || epilogue == EPI_HEADS) &&
+          !(epilogue == EPI_BIAS_ACT && tiles128 <= 384))
+        return launch_conv_halo<4>(a, epilogue, st);
+    }
+  }
   if (epilogue == EPI_HEADS || epilogue == EPI_UPSAMPLE) return launch_conv<4, 64, 4, 1>(a, epilogue, st);
   if (conv8_on && (nout & 255) == 0 && a.P >= 256) return launch_conv8(a, epilogue, st);
   // layers with <= 64 output channels (flow_encoder[2]) use a 64-channel tile instead of padding to 128

@@ -465,7 +465,7 @@ def test_conv8_equals_the_128_tile_kernel_bit_for_bit(gpu, n, h, w, ca, cb, nout
         torch.testing.assert_close(ref.float(), _conv_ref([xa, xb], weight), atol=4e-3, rtol=4e-3)
 
 
-@pytest.mark.parametrize("mode", ["128", "64", "split", "wide", "ps", "ps2"])
+@pytest.mark.parametrize("mode", ["128", "64", "split", "wide", "nohalo", "ps", "ps2"])
 def test_conv_tile_variants_are_bit_identical(gpu, mode, monkeypatch):
     """GLORIE_CONV_TILE only changes which pixels / channels a workgroup owns: every output element sums the same products in
     the same order, so the 64-pixel, split-launch and 128 x 256 variants must reproduce the default kernel bit for bit
@@ -491,7 +491,12 @@ def test_conv_tile_variants_are_bit_identical(gpu, mode, monkeypatch):
 
     monkeypatch.delenv("GLORIE_CONV_TILE", raising=False)
     monkeypatch.delenv("GLORIE_CONV_PS", raising=False)
+    monkeypatch.delenv("GLORIE_CONV_HALO", raising=False)
     ref = run()
+    if mode == "nohalo":              # per-tap pixel staging (rounds 1-2) against the shared haloed tile (conv_halo_kernel, default)
+        monkeypatch.setenv("GLORIE_CONV_HALO", "0")
+        assert torch.equal(run(), ref)
+        return
     if mode == "ps":                  # producer / consumer form of the 128 x 128 tile (conv_ps_kernel), incl. the LDS seeding
         monkeypatch.setenv("GLORIE_CONV_PS", "1")
         for _ in range(3):
