@@ -692,7 +692,9 @@ __global__ __launch_bounds__(64 * NW, (ST == 1 && MB * NB <= 16) ? 3 : 2) void c
 //     ds_read_b128 of 16 consecutive rows is conflict-free for every start row with that key (brute-force checked against
 //     the lane groups of MI355X_MICROARCH.md);
 //   * the halo tile is re-staged after the barrier that follows the fragment reads of a chunk's last tap - the same point
-//     where the weights of the next tile are staged.
+//     where the weights of the next tile are staged.  (Re-staging it in three parts as its rows go dead - the first W rows
+//     behind tap 2, the next W behind tap 5, the rest at the boundary - was measured: the step LOSES 2.6 %, 931-935 -> 907-910
+//     it/s; K-tiles that carry 14 pieces instead of 4 cost more than the one burst saves.)
 // LDS: weights 32 MB rows + 128 + 2 W + 2 pixel rows (the last DMA piece overlaps its predecessor so that the tile takes no
 // more than that: 53.5 KB at W = 80, three workgroups per CU; with whole 8-row pieces it was two and 4 % slower than the
 // plain kernel); up to W = 83 for the 128-channel tile.
