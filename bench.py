@@ -479,12 +479,16 @@ def main():
         g3.update(t0=1, t1=8, itrs=2, use_inactive=False, opt_type="pose_depth" if i % 2 == 0 else "depth_scale")
     g3.fast_update.gate_events = []
     g3.fast_update.q_events, g3.fast_update.heads_events = [], []
+    g3.fast_update.corr_events = []
     for i in range(30):
         g3.update(t0=1, t1=8, itrs=2, use_inactive=False, opt_type="pose_depth" if i % 2 == 0 else "depth_scale")
     torch.cuda.synchronize()
     ev = g3.fast_update.gate_events
     evq, evh = g3.fast_update.q_events, g3.fast_update.heads_events
+    evc = g3.fast_update.corr_events
     g3.fast_update.gate_events = g3.fast_update.q_events = g3.fast_update.heads_events = None
+    g3.fast_update.corr_events = None
+    corr_step_ms = (sum(a.elapsed_time(b) for a, b in evc) / len(evc)) if evc else None
     n3, hw3 = int(g3.ii.shape[0]), g3.ht * g3.wd
     q_ms = sum(a.elapsed_time(b) for a, b in evq) / max(len(evq), 1)
     heads_ms = sum(a.elapsed_time(b) for a, b in evh) / max(len(evh), 1)
@@ -543,7 +547,13 @@ def main():
     HW = graph.ht * graph.wd
     alg_bytes = 936.0 * N * HW  # 936 B per edge-pixel
     # the python wrapper adds a coords permute/copy (small); kernel time is reported by rocprof
-    corr_ms = ev0.elapsed_time(ev1) / reps
+    # Twenty back-to-back replays of the one launch read the same 89 MB again and again (it stays in the 256 MB Infinity
+    # Cache) at boost clocks: kept as `back_to_back_ms`.  `ms_per_launch` / `frac` are the launch inside real BA-update steps
+    # (events around it in the 30 eager iterations above: cold pyramid, the step's clocks) - the duration
+    # `rocprofv3 --kernel-trace --stats` averages over the steps.
+    corr_b2b_ms = ev0.elapsed_time(ev1) / reps
+    corr_ms = corr_step_ms if (corr_step_ms and graph.corr_impl != "otf" and graph.fast_update is not None
+                               and getattr(graph.corr, "layout", None) == "dm") else corr_b2b_ms
     achieved = alg_bytes / (corr_ms * 1e-3) / 1e9
 
     # ---- M2: rendered rays/sec (full 640x480 frame, rays sharded over ranks) ----------
@@ -757,7 +767,8 @@ def main():
         "roofline_corr": {"bound": "hbm", "kernel": corr_kernel,
                           "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": achieved / HBM_PEAK_GBS, "traffic": corr_traffic if full else None,
-                          "alg_bytes_per_launch": alg_bytes, "ms_per_launch": corr_ms,
+                          "alg_bytes_per_launch": alg_bytes, "ms_per_launch": corr_ms, "back_to_back_ms": corr_b2b_ms,
+                          "back_to_back_frac": alg_bytes / (corr_b2b_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                           # bytes the hardware really moved (PMC) over the same time: the rocprof HBM GB/s
                           "measured_hbm_gbs": (corr_traffic / (corr_ms * 1e-3) / 1e9) if (full and corr_traffic) else None,
                           "measured_hbm_frac": (corr_traffic / (corr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)

@@ -281,6 +281,7 @@ class FusedUpdate:
         self.gate_events = None   # a list: (start, end) events of every z|r gate launch are appended (eager steps only)
         self.q_events = None      # the same for the q gate launch and for the heads' hidden convolution (bench.py)
         self.heads_events = None
+        self.corr_events = None   # the same for the correlation lookup (+ corr_encoder[0]) launch
 
     # -- weight packing ----------------------------------------------------------------
     def _sync(self):
@@ -450,7 +451,14 @@ class FusedUpdate:
             # volume-free lookup with corr_encoder[0] fused behind it (csrc/corr_otf.hip): the 196-channel map
             # never exists in HBM
             c1 = cl_map(128)
+            evc = self.corr_events
+            if evc is not None:
+                c0e, c1e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                c0e.record()
             corr.encode_into(W, c1)
+            if evc is not None:
+                c1e.record()
+                evc.append((c0e, c1e))
         else:
             if callable(corr):
                 corr = corr()                          # the lookup itself, issued behind the forks
