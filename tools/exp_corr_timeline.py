@@ -27,7 +27,10 @@ for n in [int(v) for v in sys.argv[1:]] or (8, 24, 36):
     cn, sl = c[:n].contiguous(), arena.slots[:n].contiguous()
     if same_slot:
         sl = torch.zeros_like(sl)
-    for _ in range(5):
+    cold = os.environ.get("EXP_COLD") == "1"                 # flush L2 / Infinity Cache in front of the stamped launch
+    for rep in range(5):
+        if cold and rep == 4:
+            torch.empty(1 << 28, dtype=torch.float32, device=dev).fill_(1.0)
         db.corr_dm_lookup(arena.views(), cn, h, w, slots=sl, interleaved=True, want_corr=False, enc_w=w_dm, enc_b=bias,
                           enc_out=out.permute(0, 3, 1, 2))
     torch.cuda.synchronize()
