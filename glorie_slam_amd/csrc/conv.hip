@@ -483,7 +483,7 @@ __global__ __launch_bounds__(64 * NW, (ST == 1 && MB * NB <= 16) ? 3 : 2) void c
     const long p = p0 + (i * NW + wv) * RPI + srow;
     int m = 0;
     if (p < a.P) {
-      const int xw = (int)(p % a.W), yh = (int)((p / a.W) % a.H);
+      const int pi_ = (int)p, xw = pi_ % a.W, yh = (pi_ / a.W) % a.H;      // p < P < 2^31 (the 31-bit offset check of the launch)
       if (a.taps == 9) {
 #pragma unroll
         for (int d = 0; d < 9; ++d) {
@@ -792,7 +792,7 @@ __global__ __launch_bounds__(256, MB <= 4 ? 3 : 2) void conv_halo_kernel(ConvArg
   for (int ni = 0; ni < NB; ++ni) {
     const long p = p0 + wn * (16 * NB) + ni * 16 + col;
     if (p < a.P) {
-      const int xw = (int)(p % a.W), yh = (int)((p / a.W) % a.H);
+      const int pi_ = (int)p, xw = pi_ % a.W, yh = (pi_ / a.W) % a.H;      // p < P < 2^31 (the 31-bit offset check of the launch)
 #pragma unroll
       for (int d = 0; d < 9; ++d) {
         const int dy = d / 3 - 1, dx = d % 3 - 1;
@@ -1020,7 +1020,7 @@ __global__ __launch_bounds__(512, 4) void conv_ps_kernel(ConvArgs a) {
       const long p = p0 + (i * NW + wv) * RPI + srow;
       int m = 0;
       if (p < a.P) {
-        const int xw = (int)(p % a.W), yh = (int)((p / a.W) % a.H);
+        const int pi_ = (int)p, xw = pi_ % a.W, yh = (pi_ / a.W) % a.H;      // p < P < 2^31 (the 31-bit offset check of the launch)
         if (a.taps == 9) {
 #pragma unroll
           for (int d = 0; d < 9; ++d) {
@@ -1182,7 +1182,7 @@ __global__ __launch_bounds__(512, 2) void conv_ps2_kernel(ConvArgs a) {
       const long p = p0 + (i * NW + wv) * RPI + srow;
       int m = 0;
       if (p < a.P) {
-        const int xw = (int)(p % a.W), yh = (int)((p / a.W) % a.H);
+        const int pi_ = (int)p, xw = pi_ % a.W, yh = (pi_ / a.W) % a.H;      // p < P < 2^31 (the 31-bit offset check of the launch)
         if (a.taps == 9) {
 #pragma unroll
           for (int d = 0; d < 9; ++d) {
