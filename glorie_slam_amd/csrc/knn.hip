@@ -328,6 +328,8 @@ __device__ __forceinline__ void knn_search(const float4* __restrict__ sorted,
     // (a lane's search is a chain of dependent loads: this is what bounds the kernel).
     // ONE scan site (the insertion is ~60 VALU instructions, inlined once per load slot): ranges are walked 4 points
     // at a time, the tail re-reads the last point with the insertion masked off.
+    // (Requesting the next four points before looking at the current four - always legal, the indices are clamped into the
+    // range - was measured: 111 instead of 96 VGPRs, 0.180 -> 0.197 ms; the ranges are too short for the extra loads to pay.)
     auto scan = [&](int b, int e) {
       for (int t = b; t < e; t += 4) {
         const int l = e - 1;
