@@ -242,7 +242,7 @@ def altcorr_forward(fmap1, fmap2, coords, radius):
     return [out]
 
 
-def altcorr_backward(*args):
+def altcorr_backward(fmap1, fmap2, coords, corr_grad, radius):
     raise NotImplementedError("altcorr_backward: training-only, not on the SLAM hot path")
 
 
@@ -263,7 +263,7 @@ def frame_distance(poses, disps, intrinsics, ii, jj, beta):
     return dist
 
 
-def projmap(*args):
+def projmap(poses, disps, intrinsics, ii, jj):
     raise NotImplementedError("projmap is exported by the reference but never called "
                               "(SURVEY.md section 2.1)")
 

@@ -22,6 +22,28 @@ def _conv(cin, cout, k):
     return nn.Conv2d(cin, cout, kernel_size=(k, k), padding=(k // 2, k // 2))
 
 
+def cvx_upsample(data, mask):
+    """droid_net.py:9-23: 8x convex upsampling of a per-pixel field, data [N,h,w,dim], mask [N,576,h,w] (logits of the
+    9 taps per 8x8 sub-pixel) -> [N,8h,8w,dim].  One glorie_cvx_upsample launch per channel (softmax in fp32, like the
+    reference outside autocast); DepthVideo.upsample calls the kernel directly on its buffers."""
+    batch, ht, wd, dim = data.shape
+    mask = mask.reshape(batch, 576, ht, wd)
+    ix = torch.arange(batch, device=data.device)
+    out = torch.empty(batch, 8 * ht, 8 * wd, dim, dtype=torch.float32, device=data.device)
+    for c in range(dim):
+        up = torch.empty(batch, 8 * ht, 8 * wd, dtype=torch.float32, device=data.device)
+        droid_backends.cvx_upsample(data[..., c].float().contiguous(), ix, mask.contiguous(), up, softmax_f32=True)
+        out[..., c] = up
+    return out
+
+
+def upsample_disp(disp, mask):
+    """droid_net.py:26-31"""
+    batch, num, ht, wd = disp.shape
+    return cvx_upsample(disp.reshape(batch * num, ht, wd, 1), mask.reshape(batch * num, -1, ht, wd)) \
+        .view(batch, num, 8 * ht, 8 * wd)
+
+
 class GradientClip(nn.Module):
     """identity in the forward pass (clipping.py:7-26 only alters gradients)"""
 

@@ -53,7 +53,26 @@ class SE3:
         qi = _qconj(self.data[..., 3:])
         return SE3(torch.cat([-_qrot(qi, self.data[..., :3]), qi], -1))
 
+    manifold_dim = 6
+
+    def act(self, X):
+        """homogeneous points [..., 4]: (R X[:3] + t X[3], X[3])  (droid_kernels.cu:72-79)"""
+        Y = _qrot(self.data[..., 3:], X[..., :3]) + self.data[..., :3] * X[..., 3:4]
+        return torch.cat([Y, X[..., 3:4]], -1)
+
+    def adjT(self, a):
+        """dual adjoint on covectors [..., 6] = [tau, phi] (droid_kernels.cu:81-97): Ad(T)^T a"""
+        t, qi = self.data[..., :3], _qconj(self.data[..., 3:])
+        u = torch.cross(a[..., :3], t.expand_as(a[..., :3]), dim=-1)
+        return torch.cat([_qrot(qi, a[..., :3]), _qrot(qi, a[..., 3:]) + _qrot(qi, u)], -1)
+
+    def retr(self, a):
+        """left retraction exp(a) * T (droid_kernels.cu:877-896)"""
+        return SE3.exp(a) * self
+
     def __mul__(self, other):
+        if isinstance(other, torch.Tensor):
+            return self.act(other)
         q = _qmul(self.data[..., 3:], other.data[..., 3:])
         t = _qrot(self.data[..., 3:], other.data[..., :3]) + self.data[..., :3]
         return SE3(torch.cat([t, q], -1))

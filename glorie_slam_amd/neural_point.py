@@ -20,6 +20,11 @@ from . import _lib as L
 from . import point_ops
 
 
+def get_scale(depth_prev, depth_curr):
+    """neural_point.py:11-16: least-squares s with depth_prev * s = depth_curr"""
+    return torch.sum(depth_prev * depth_curr) / torch.sum(depth_prev * depth_prev)
+
+
 def se3_inv(poses):
     """inverse of [tx ty tz qx qy qz qw] rigid transforms (lietorch SE3(poses).inv().data)"""
     t, q = poses[..., :3], poses[..., 3:]
@@ -143,13 +148,14 @@ class NeuralPointCloud(object):
             self.col_feats = feats.detach().clone()
 
     # ---- store ------------------------------------------------------------------------
-    def add_points(self, pts, geo_feats=None, col_feats=None):
+    def add_points(self, video_idxs, geo_feats=None, col_feats=None):
         """Two call forms.
         add_points(video_idxs: int | int64 tensor) -- the reference's method (neural_point.py:145-162):
             unproject the full-resolution depth of those keyframes of `self.video` into
             `_full_pcl` / `_full_mask`; returns the number of valid pixels.
         add_points(pts [n,3] float, geo_feats=None, col_feats=None) -- plain append (+ features,
             default N(0,0.1) as neural_point.py:243-246) and rebuild of the search structure."""
+        pts = video_idxs                                   # the parameter keeps the reference's name (keyword callers)
         if isinstance(pts, int) or (torch.is_tensor(pts) and not pts.is_floating_point()):
             return self._add_video_points(pts)
         pts = pts.detach().to(self.device, torch.float32).reshape(-1, 3)

@@ -364,3 +364,42 @@ def test_deferred_flag_resynchronises_after_a_missed_await(gpu):
     assert video.await_any_on() == 0
     video.publish_any_on(one)
     assert video.await_any_on() == 1
+
+
+def _load_topology_fixture():
+    import json
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "topology.npz"))
+    meta = json.loads(str(z["meta"]))
+    return {k: (z["d_" + k], v) for k, v in meta.items()}
+
+
+@pytest.mark.parametrize("name", sorted(_load_topology_fixture()))
+def test_topology_matches_reference_fixture(gpu, name):
+    """bit-exact graph topology against the REFERENCE: the scripts of tests/golden/recording.py replayed on the real
+    DepthVideo + FactorGraph (HIP reproject, correlation arena with slot recycling for `volume`), `video.distance`
+    answered from the stored matrix; edge lists, ages, inactive / bad lists, weight rows and proposal return values
+    after every operation equal what /root/reference/src/factor_graph.py held (tests/golden/make_pins.py).  The CPU
+    twin (fake buffers, also target / net rows) is tests/test_pins.py."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import recording as R
+    d, meta = _load_topology_fixture()[name]
+    K = d.shape[0]
+    g, video = make_video(gpu, K, 16, 16, buffer=K + 2)
+    dm = torch.from_numpy(d).to(gpu)
+    video.distance = lambda ii=None, jj=None, beta=0.3, bidirectional=True: dm[
+        torch.as_tensor(ii).long().reshape(-1).to(gpu), torch.as_tensor(jj).long().reshape(-1).to(gpu)].clone()
+    graph = make_graph(gpu, video, corr_impl=meta["corr_impl"], max_factors=meta["max_factors"])
+    states = R.run_topology_script(graph, video, meta["script"])
+    keys = ("ii", "jj", "age", "ii_inac", "jj_inac", "ii_bad", "jj_bad", "weight_mean", "weight_inac_mean", "net_rows",
+            "counter", "ret")
+    for k, (got, want, op) in enumerate(zip(states, meta["states"], meta["script"])):
+        if "cleared" in want:
+            assert got == want
+            continue
+        for key in keys:
+            assert got[key] == want[key], (name, k, op, key)
+    if meta["corr_impl"] == "volume":
+        assert len(graph.corr) == len(states[-1]["ii"])            # the arena holds exactly the live edges
