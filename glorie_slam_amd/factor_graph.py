@@ -127,7 +127,8 @@ class FactorGraph:
             return
         if self.max_factors > 0 and self.ii.shape[0] + ii.shape[0] > self.max_factors \
                 and self.corr is not None and remove:
-            ix = torch.arange(len(self.age))[torch.argsort(self.age).cpu()]
+            # equal ages keep their index order (what the reference's CUDA radix sort does; torch's CPU sort does not)
+            ix = torch.arange(len(self.age))[torch.argsort(self.age, stable=True).cpu()]
             self.rm_factors(ix >= self.max_factors - ii.shape[0], store=True)
         net = self.video.nets[ii].to(self.device).unsqueeze(0)
         if self.corr_impl == "volume":
@@ -622,7 +623,7 @@ class FactorGraph:
                 es.append((i, j))
                 es.append((j, i))
                 d[(i - t0) * wj + (j - t1)] = np.inf
-        # torch.argsort on the device is not stable; ties are broken by index here
+        # equal distances keep their index order: the order of the reference's device sort (cub radix sort)
         for k in np.argsort(d, kind="stable"):
             if d[k] > thresh:
                 continue

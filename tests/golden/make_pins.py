@@ -9,7 +9,7 @@ tracker.py / mapper.py rely on.
                     bad lists, target / weight row tags after EVERY operation (add_neighborhood_factors :312-320,
                     add_proximity_factors :323-383, add_backend_proximity_factors :386-462, add_factors incl. the
                     factor limit :95-143, rm_factors :146-170, rm_keyframe :173-209, filter_edges :68-75,
-                    __filter_repeated_edges :42-53).  Tie rule pinned here = torch.argsort / torch.sort on CPU.
+                    __filter_repeated_edges :42-53).  Equal sort keys: see mint_topology.
   driver_traces.json  Frontend (src/frontend.py:40-117), Backend (src/backend.py:27-97) and PoseTrajectoryFiller
                     (src/trajectory_filler.py:34-107) run over `RecordingGraph` / `DriverVideo`: every call they make,
                     in order, with its arguments.
@@ -59,8 +59,23 @@ def install_more_stubs():
 
 
 def mint_topology():
+    """Equal keys: the reference calls torch.argsort / torch.sort without `stable=` (factor_graph.py:114,360,416) on CUDA
+    tensors, where the sort is cub's radix sort and equal keys stay in index order; torch's CPU sort (this container) is
+    NOT stable beyond 16 elements.  The sorts are therefore forced stable while minting, so that the fixture holds the
+    order the reference produces on its own device (edge ages are integers: ties are the rule, not the exception)."""
     from src.factor_graph import FactorGraph
     arrays, meta = {}, {}
+    real_argsort, real_sort = torch.argsort, torch.sort
+    torch.argsort = lambda x, *a, **k: real_argsort(x, *a, **{**k, "stable": True})
+    torch.sort = lambda x, *a, **k: real_sort(x, *a, **{**k, "stable": True})
+    try:
+        _mint_topology_cases(FactorGraph, arrays, meta)
+    finally:
+        torch.argsort, torch.sort = real_argsort, real_sort
+    np.savez_compressed(os.path.join(OUT, "topology.npz"), meta=np.array(json.dumps(meta)), **arrays)
+
+
+def _mint_topology_cases(FactorGraph, arrays, meta):
     for name, (kind, K, seed, max_factors, corr_impl, script) in R.topology_cases().items():
         d = R.distance_matrix(kind, K, seed)
         video = R.MatrixVideo(d)
@@ -72,7 +87,6 @@ def mint_topology():
         last = [s for s in states if "ii" in s][-1]
         print(f"  {name}: {len(script)} operations, final edges {len(last['ii'])}, inactive {len(last['ii_inac'])}, "
               f"bad {len(last['ii_bad'])}, returns {[s['ret'] for s in states if s.get('ret') is not None]}")
-    np.savez_compressed(os.path.join(OUT, "topology.npz"), meta=np.array(json.dumps(meta)), **arrays)
 
 
 def _patch(module_names):
