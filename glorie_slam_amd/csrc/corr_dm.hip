@@ -68,8 +68,12 @@ __device__ __forceinline__ _Float16 to_half_rn(float prod) {
   return (_Float16)prod;
 }
 __device__ __forceinline__ h2 splat(_Float16 v) { return h2{v, v}; }
-// (hi.lo16 << 16) | lo.lo16 in one v_perm_b32
-__device__ __forceinline__ h2 pk(unsigned lo, unsigned hi) { return __builtin_bit_cast(h2, __builtin_amdgcn_perm(hi, lo, 0x05040100u)); }
+// A lane's tap is half of a dword it shares with its neighbour lane (lanes 2m, 2m + 1 own the halves of dword m of the line):
+// the gathers fetch that aligned DWORD (buffer_load_dword: measured much cheaper per instruction than buffer_load_ushort on
+// gfx950 - the fused lookup 32.9 -> 27 us at G8 for the same lines) and the pair-forming v_perm_b32 picks the lane's half:
+// selector 0x05040100 = (hi.lo16 << 16) | lo.lo16 for even lanes, 0x07060302 = (hi.hi16 << 16) | lo.hi16 for odd lanes
+__device__ __forceinline__ unsigned half_sel(int lane) { return (lane & 1) ? 0x07060302u : 0x05040100u; }
+__device__ __forceinline__ h2 pk(unsigned lo, unsigned hi, unsigned sel) { return __builtin_bit_cast(h2, __builtin_amdgcn_perm(hi, lo, sel)); }
 
 // one term of the reference's accumulation: products and sums individually rounded to fp16 (no contraction)
 __device__ __forceinline__ h2 acc_term(h2 acc, h2 s, h2 w) {
@@ -109,19 +113,19 @@ __device__ __forceinline__ void dm_gather(const DmArgs& a, size_t slot_tile, int
     const int ty = iy0 + j;
     int d = by + j;
     d = d < 0 ? d + hl : (d >= hl ? d - hl : d);
-    roff[j] = (ty >= 0 && ty < hl) ? (unsigned)(d * wl) * 128u + (unsigned)lane * 2u : kOob;
+    roff[j] = (ty >= 0 && ty < hl) ? (unsigned)(d * wl) * 128u + (unsigned)(lane >> 1) * 4u : kOob;
   }
 #pragma unroll
   for (int j = 0; j < 8; ++j)
 #pragma unroll
     for (int i = 0; i < 8; ++i)
-      raw[j][i] = __builtin_amdgcn_raw_buffer_load_b16(rs, (int)(roff[j] + coff[i]), 0, 0);
+      raw[j][i] = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(roff[j] + coff[i]), 0, 0);
 }
 
 // ---- bilinear blend of one level: 7 window rows of 8 packed taps (tap 7 zero) ---------------------------------------
 // out(i, j) = (((0 + s(i,j) w00) + s(i,j+1) w01) + s(i+1,j) w10) + s(i+1,j+1) w11   (correlation_kernels.cu:52-64: the four
 // contributions reach corr[i][j] in exactly this order), evaluated for taps (2k, 2k+1) at once on the packed fp16 pipes
-__device__ __forceinline__ void dm_blend(const unsigned (&raw)[8][8], float fdx, float fdy, u32x4 (&rows)[7]) {
+__device__ __forceinline__ void dm_blend(const unsigned (&raw)[8][8], float fdx, float fdy, unsigned sel, u32x4 (&rows)[7]) {
   const h2 w00 = splat(to_half_rn((1.0f - fdx) * (1.0f - fdy)));
   const h2 w01 = splat(to_half_rn((1.0f - fdx) * fdy));
   const h2 w10 = splat(to_half_rn(fdx * (1.0f - fdy)));
@@ -129,10 +133,10 @@ __device__ __forceinline__ void dm_blend(const unsigned (&raw)[8][8], float fdx,
   h2 P[2][4], Q[2][4];            // window rows j, j + 1: pairs (2k, 2k+1) and (2k+1, 2k+2)
   auto pack_row = [&](int j, h2 (&p)[4], h2 (&q)[4]) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) p[k] = pk(raw[j][2 * k], raw[j][2 * k + 1]);
+    for (int k = 0; k < 4; ++k) p[k] = pk(raw[j][2 * k], raw[j][2 * k + 1], sel);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) q[k] = pk(raw[j][2 * k + 1], raw[j][2 * k + 2]);
-    q[3] = pk(raw[j][7], 0u);
+    for (int k = 0; k < 3; ++k) q[k] = pk(raw[j][2 * k + 1], raw[j][2 * k + 2], sel);
+    q[3] = pk(raw[j][7], 0u, sel);
   };
   pack_row(0, P[0], Q[0]);
 #pragma unroll
@@ -163,7 +167,7 @@ __device__ __forceinline__ void dm_level(const DmArgs& a, size_t slot_tile, int 
   float fdx, fdy;
   dm_gather<L>(a, slot_tile, sy, sx, lane, x0, y0, raw, fdx, fdy);
   u32x4 rows[7];
-  dm_blend(raw, fdx, fdy, rows);
+  dm_blend(raw, fdx, fdy, half_sel(lane), rows);
   if (live) {
     u32x4* op = reinterpret_cast<u32x4*>(a.corr_cl + row * 256 + L * 64);
 #pragma unroll
@@ -215,12 +219,9 @@ __global__ __launch_bounds__(256) void corr_dm_lookup_kernel(DmArgs a) {
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kEnc2Lds = 232;   // halfs per weight row in LDS (224 + 8)
 
-// v_perm_b32 on 16-bit loads: hipcc zero-extends a buffer_load_ushort result before __builtin_amdgcn_perm (one v_and per
-// tap) although the selector never reads the upper half; the asm form takes the registers as they are
-__device__ __forceinline__ h2 perm16(unsigned short s0, unsigned short s1, unsigned sel) {
-  unsigned r;
-  asm("v_perm_b32 %0, %1, %2, %3" : "=v"(r) : "v"(s0), "v"(s1), "s"(sel));
-  return __builtin_bit_cast(h2, r);
+// the lane's halves of two gathered dwords as one packed pair (selector: half_sel of the lane)
+__device__ __forceinline__ h2 perm16(unsigned s0, unsigned s1, unsigned sel) {
+  return __builtin_bit_cast(h2, __builtin_amdgcn_perm(s0, s1, sel));
 }
 
 // Per-level gather state.  The window's displaced coordinates are consecutive modulo the plane, so the byte offsets are
@@ -231,8 +232,8 @@ __device__ __forceinline__ h2 perm16(unsigned short s0, unsigned short s1, unsig
 struct DmLevel {
   __amdgpu_buffer_rsrc_t rs;
   unsigned coff[8];
-  unsigned r, uy;                 // running: byte offset of the next window row (+ 2 lane), its target row as unsigned
-  unsigned rstep, rend, lane2, hl;
+  unsigned r, uy;                 // running: byte offset of the next window row (+ the lane's dword), its target row as unsigned
+  unsigned rstep, rend, lane2, hl, sel;
   h2 w00, w01, w10, w11;
 };
 
@@ -259,7 +260,8 @@ __device__ __forceinline__ void dm_setup(const DmArgs& a, size_t slot_tile, int 
     c += 128u;
     c = c == cend ? 0u : c;
   }
-  st.lane2 = (unsigned)lane * 2u;
+  st.lane2 = (unsigned)(lane >> 1) * 4u;
+  st.sel = half_sel(lane);
   st.rstep = cend;
   st.rend = (unsigned)hl * cend + st.lane2;
   st.r = (unsigned)by * cend + st.lane2;
@@ -272,7 +274,7 @@ __device__ __forceinline__ void dm_setup(const DmArgs& a, size_t slot_tile, int 
 }
 
 // the next window row (rows are requested in order, 0..7)
-__device__ __forceinline__ void dm_load_row(DmLevel& st, unsigned short (&row)[8]) {
+__device__ __forceinline__ void dm_load_row(DmLevel& st, unsigned (&row)[8]) {
   const unsigned roff = st.uy < st.hl ? st.r : kOob;
   st.uy += 1u;
   st.r += st.rstep;
@@ -281,14 +283,14 @@ __device__ __forceinline__ void dm_load_row(DmLevel& st, unsigned short (&row)[8
 #ifdef EXP_DM_NO_GATHER
   for (int i = 0; i < 8; ++i) row[i] = (roff + st.coff[i]) & 0x3c00u;          // ablation: arithmetic only, no memory
 #else
-  for (int i = 0; i < 8; ++i) row[i] = __builtin_amdgcn_raw_buffer_load_b16(st.rs, (int)(roff + st.coff[i]), 0, 0);
+  for (int i = 0; i < 8; ++i) row[i] = __builtin_amdgcn_raw_buffer_load_b32(st.rs, (int)(roff + st.coff[i]), 0, 0);
 #endif
 }
 
 // the 4 aligned tap pairs (2k, 2k+1) of a window row
-__device__ __forceinline__ void dm_pack_row(const unsigned short (&row)[8], h2 (&p)[4]) {
+__device__ __forceinline__ void dm_pack_row(const unsigned (&row)[8], unsigned sel, h2 (&p)[4]) {
 #pragma unroll
-  for (int k = 0; k < 4; ++k) p[k] = perm16(row[2 * k + 1], row[2 * k], 0x05040100u);
+  for (int k = 0; k < 4; ++k) p[k] = perm16(row[2 * k + 1], row[2 * k], sel);
 }
 // the odd pair (2k+1, 2k+2) from two aligned pairs: (a.hi, b.lo) in one v_perm_b32; beyond the window: (tap 7, 0)
 __device__ __forceinline__ h2 dm_odd(const h2 (&p)[4], int k) {
@@ -339,13 +341,13 @@ __device__ __forceinline__ void dm_kstep(int ks, u32x4 lo, u32x4 hi, const _Floa
 // retires (nothing follows level 3)
 template <int L, bool CORR>
 __device__ __forceinline__ void dm_level_pipelined(const DmArgs& a, bool live, size_t row, const _Float16* wlds, int lane,
-                                                   unsigned short (&raw)[8][8], const DmLevel& cur, DmLevel& nxt,
+                                                   unsigned (&raw)[8][8], const DmLevel& cur, DmLevel& nxt,
                                                    u32x4& pending, f32x16 (&acc)[4][2]) {
   h2 P[2][4];
-  dm_pack_row(raw[0], P[0]);
+  dm_pack_row(raw[0], cur.sel, P[0]);
 #pragma unroll
   for (int j = 0; j < 7; ++j) {
-    dm_pack_row(raw[j + 1], P[(j + 1) & 1]);
+    dm_pack_row(raw[j + 1], cur.sel, P[(j + 1) & 1]);
     const u32x4 out = dm_blend_row<CORR>(cur, P[j & 1], P[(j + 1) & 1]);
     if (L < 3) {                                    // window row j is retired: its registers take row j of what follows
       // (fenced: left alone, the scheduler gathers the requests of several rows into one clump behind a vmcnt(0), which
@@ -430,7 +432,7 @@ __global__ __launch_bounds__(256, 2) void corr_dm_encode_kernel(DmArgs a) {
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(c.x), "+v"(c.y) : : "memory");
   DM_STAMP(11);
 #endif
-  unsigned short raw[8][8];
+  unsigned raw[8][8];
   DmLevel cur;
   dm_setup<0>(a, (size_t)u.slot_tile, px.sy, px.sx, lane, c.x, c.y, cur);
 #ifdef EXP_DM_TIMESTAMPS
@@ -555,6 +557,11 @@ __global__ __launch_bounds__(256, 2) void corr_dm_encode_kernel(DmArgs a) {
 #endif
 }
 
+// (Round 4, measured and removed: a warm-up kernel on a side stream that touched the lookup's lines - per tile and level the
+// bounding box of the 64 windows, one dword per line - as soon as the reprojection had produced the coordinates.  In the steps
+// the lookup runs on a cold pyramid: 50 us against 40 us when launched a second time, tools/exp_corr_warm.py.  The warm-up
+// took the lookup from 48.4 to 44.5 us but the step from 969 to 940 it/s: its 89 MB of HBM reads and the fork / join compete
+// with the flow encoder's convolutions for more than they save.)
 // ---------------------------------------------------------------------------------------------------------------------
 // Builder: all-pairs <f1/4, f2/4> (fp16 GEMM, fp32 accumulate, rounded to fp16) + three avg_pool2d levels, written in the
 // displacement-major layout.  Workgroup = half a source tile (4 x 8 pixels) x 8 aligned target rows: level 0 on the matrix

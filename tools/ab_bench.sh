@@ -6,6 +6,6 @@ for r in $(seq $R); do
     env $cfg timeout 600 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-sequence --no-strong 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
-print('$cfg', 'it/s %.1f sustained %.1f conv frac %.3f (%.1f us) rays/s %.2fM' % (d['value'], d['sustained_value'], d['roofline']['frac'], 1e3*d['roofline']['ms_per_launch'], d['rays_per_sec']/1e6))"
+print('$cfg', 'it/s %.1f sustained %.1f conv frac %.3f (%.1f us) rays/s %.2fM corr %.1f us (%.3f)' % (d['value'], d['sustained_value'], d['roofline']['frac'], 1e3*d['roofline']['ms_per_launch'], d['rays_per_sec']/1e6, 1e3*d['roofline_corr']['ms_per_launch'], d['roofline_corr']['frac']))"
   done
 done
