@@ -817,3 +817,45 @@ def test_full_frame_render_is_order_independent(gpu):
     assert valid.float().mean() > 0.99 and torch.isfinite(depth).all() and torch.isfinite(color).all()
     true_depth = rays["depth"]
     assert float(((depth - true_depth).abs() / true_depth)[valid].max()) < 0.06      # samples span 0.95 .. 1.05 d
+
+
+def test_knn_bit_exact_on_the_baseline_cloud(gpu):
+    """BASELINE size: the 524,288-point cloud of the bench (cell size derived from its bounding box, the max_cells clamp,
+    multi-shell walks) searched the way the renderer searches it - the samples of 48 image rows in patch order, per-query
+    radii, weights and mask from the same launch, stopping at the query ball - and 4,608 of those queries, spread over the
+    strips, checked against brute force over all points: indices and squared distances bit for bit (inside the ball for the
+    bounded search, all 8 slots for the plain one), neighbour counts, weights."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from glorie_slam_amd import point_ops
+    npc, dec, ren, rays = bench.build_renderer(gpu)
+    pts_host = npc.cloud_pos().cpu().numpy()
+    assert pts_host.shape[0] == 524286                           # 174,762 hits x 3 (SURVEY 8(d): Np = 524,288 nominal)
+    S, W = ren.N_surface, 640
+    rng = np.random.default_rng(11)
+    checked = 0
+    for row0 in (0, 232, 464):                                   # top strip (image border), middle, bottom
+        sl = slice(row0 * W, (row0 + 16) * W)
+        z, q, views, rq, nz = point_ops.ray_samples(rays["o"][sl], rays["d"][sl], rays["depth"][sl], rays["radius"][sl], S,
+                                                    ren.near_end_surface, ren.far_end_surface)
+        D, I, nn, w, has = npc.index.search(q, 8, radius_per_query=rq, image_layout=(S, W), weights=(2, False, True))
+        D2, I2, nn2 = npc.index.search(q, 8, radius_per_query=rq)                      # plain exact search, any order
+        pick = np.sort(rng.choice(q.shape[0], 1536, replace=False))
+        qh, rh = q[pick].cpu().numpy(), rq[pick].cpu().numpy()
+        rD, rI = oknn.knn_bruteforce(pts_host, qh, 8, chunk=256)
+        assert np.array_equal(I2[pick].cpu().numpy(), rI) and np.array_equal(D2[pick].cpu().numpy(), rD)
+        rnn = oknn.neighbor_count(rD, rh)
+        assert np.array_equal(nn2[pick].cpu().numpy(), rnn) and np.array_equal(nn[pick].cpu().numpy(), rnn)
+        inside = rD < (rh * rh)[:, None]
+        Db, Ib = D[pick].cpu().numpy(), I[pick].cpu().numpy()
+        assert np.array_equal(Ib[inside], rI[inside]) and np.array_equal(Db[inside], rD[inside])
+        # the weights of the same launch: 1 / (D + 1e-10) inside the ball, L1-normalised, zero outside; mask = at least 2 inside
+        wr = np.where(inside, 1.0 / (rD.astype(np.float32) + np.float32(1e-10)), 0.0).astype(np.float32)
+        wr = wr / np.maximum(wr.sum(1, keepdims=True), np.float32(1e-30))
+        ok = rnn >= 2
+        np.testing.assert_allclose(w[pick].cpu().numpy()[ok], wr[ok], rtol=2e-6, atol=1e-7)
+        assert np.array_equal(has[pick].cpu().numpy().astype(bool), ok)
+        assert 3.0 < rnn.mean() <= 8.0                            # the radii of the bench give partially filled balls
+        checked += len(pick)
+    assert checked == 4608
