@@ -24,7 +24,12 @@ struct Rccl {
 static Rccl& rccl() {
   static Rccl r = [] {
     Rccl t;
-    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    // the copy that is already in the process (torch bundles one) before any other: two RCCL instances in one process
+    // do not share their bootstrap state
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
+    if (!h && dlsym(RTLD_DEFAULT, "ncclAllReduce")) h = dlopen(nullptr, RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!h) return t;
     t.get_unique_id = reinterpret_cast<decltype(t.get_unique_id)>(dlsym(h, "ncclGetUniqueId"));

@@ -87,6 +87,9 @@ constexpr int kTM2 = 128;
 // exactly x like torch's threshold.  On this chip VALU work does not hide behind fp32 MFMAs of the same
 // SIMD (tools/probes/mfma_valu_overlap.hip: the two add up), and expf / logf cost 3.7x these two instructions.
 __device__ __forceinline__ float softplus100_fast(float x) {
+#ifdef EXP_MLP_NO_SOFTPLUS
+  return fmaxf(x, 0.0f);                                    // ablation (tools/exp_mlp_ablate.sh): what do the transcendentals cost?
+#endif
   const float e = __builtin_amdgcn_exp2f(-144.26950408889634f * __builtin_fabsf(x));
   return fmaf(0.006931471805599453f, __builtin_amdgcn_logf(1.0f + e), fmaxf(x, 0.0f));
 }
@@ -459,7 +462,11 @@ __device__ __forceinline__ void split2(const f32x4 a, const f32x4 b, h16x8& hi, 
 #pragma unroll
   for (int s = 0; s < 8; ++s) {
     hi[s] = (_Float16)v[s];
+#ifdef EXP_MLP_NO_SPLIT
+    lo[s] = (_Float16)0.0f;                                 // ablation: the cost of forming the low halves
+#else
     lo[s] = (_Float16)(v[s] - (float)hi[s]);
+#endif
   }
 }
 // Range guard of the split kernels.  The split holds |x| <= 65504 (fp16 max).  A larger operand becomes hi = inf,

@@ -257,9 +257,12 @@ class POINT(nn.Module):
 
     def range_guard(self, device):
         """point_ops.RangeGuard of the fused kernels on `device` (include/glorie_hip.h: glorie_render_mlp range_flag)"""
+        dev = torch.device(device)
+        if dev.type == "cuda" and dev.index is None:           # 'cuda' names the current device: cuda:0 != cuda otherwise
+            dev = torch.device("cuda", torch.cuda.current_device())
         g = getattr(self, "_guard", None)
-        if g is None or g.flag.device != torch.device(device):
-            g = self._guard = point_ops.RangeGuard(device)
+        if g is None or g.flag.device != dev:
+            g = self._guard = point_ops.RangeGuard(dev)
         return g
 
     def _fused_ok(self, p, npc_geo_feats, npc_col_feats, is_tracker, stage):

@@ -254,15 +254,20 @@ class DepthVideo:
             if time.perf_counter() > t_end:
                 torch.cuda.current_stream().synchronize()
                 word = int(self._flag_np[0])
-                if (word >> 1) != want:
-                    # the host's count and the device's went apart (a replay whose flag was never awaited, e.g. an
-                    # exception between graph.replay() and this call): after the stream synchronisation the word holds
-                    # the decision of the last publish launch, which is this replay's - follow the device count from here
-                    # on instead of failing every later step
+                if (word >> 1) > want:
+                    # the device is AHEAD: an earlier replay's flag was never awaited (e.g. an exception between
+                    # graph.replay() and this call).  After the stream synchronisation the word holds the decision of the
+                    # last publish launch, which is this replay's - follow the device count from here on instead of
+                    # failing every later step
                     import warnings
                     warnings.warn("deferred depth_scale decision: launch count %d, expected %d - resynchronised"
                                   % (word >> 1, want))
                     self._flag_expected = word >> 1
+                elif (word >> 1) < want:
+                    # the device is BEHIND: this replay contained no publish launch, the word is an older step's decision
+                    self._flag_expected = word >> 1
+                    raise RuntimeError("deferred depth_scale decision: the replay published nothing (launch count %d, "
+                                       "expected %d)" % (word >> 1, want))
                 return word & 1
 
     def dspo(self, target, weight, eta, ii, jj, t0=1, t1=None, itrs=2, lm=1e-4, ep=0.1,

@@ -70,6 +70,7 @@ def init_ctx_comm(ctx, group=None, rank=None, world=None):
     if world > 1:
         dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
     L.check(lib.glorie_comm_init(ctx.handle, box[0], int(rank), int(world)), "glorie_comm_init")
+    ctx._comm_group = (group, int(rank), int(world))        # allreduce_system checks its `group` against this
     return world
 
 
@@ -85,6 +86,13 @@ def allreduce_system(hv, group=None, n6=None, force=False, ctx=None):
     ctx with its own communicator (init_ctx_comm): the sum is glorie_allreduce_normal_eq on the current stream.
     force: run the collective even with one rank (exercises the RCCL path on a single GPU)."""
     native = hv.is_cuda and ctx_comm_world(ctx) > 0
+    if native:
+        # the communicator sums over the ranks it was built for: a caller that names another group (or a process group
+        # that appeared after a world-of-one communicator was made) goes through torch.distributed instead
+        made = getattr(ctx, "_comm_group", None)
+        want_world = dist.get_world_size(group) if _active(group) else 1
+        if made is None or made[2] != want_world or (made[0] is not group and not (made[0] is None and group is None)):
+            native = False
     if not native and (not _active(group) or (dist.get_world_size(group) <= 1 and not force)):
         return hv
     lib = L.load()

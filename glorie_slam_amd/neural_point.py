@@ -266,7 +266,11 @@ class NeuralPointCloud(object):
                              image_layout=None, weights=None):
         """neural_point.py:264-313 -> (D [Q,nn] squared distances, I [Q,nn] int64, neighbor_num [Q] int32).
         image_layout: see KnnIndex.search (an ordering hint for image-shaped query batches, same result);
-        weights = (min_nn, expo): the IDW weights and neighbour mask of the decoders from the same launch (two more returns)"""
+        weights = (min_nn, expo[, ball_only]): the IDW weights and neighbour mask of the decoders from the same launch (two more
+        returns).  With ball_only (what both render paths pass) the search stops at the query radius: D / I are then the
+        EXACT nearest neighbours only for the slots inside the ball (d <= r^2, the ones with a non-zero weight, counted by
+        neighbor_num); slots beyond it may hold farther points, or I = -1 / D = FLT_MAX - a relaxed contract compared with
+        the reference's faiss result, whose consumers (decoder.py:130-173) never read those slots either."""
         assert step in ['add', 'query']
         if retrain:
             self.index.set_points(self._cloud_pos)

@@ -98,18 +98,12 @@ class Renderer(object):
         ev = torch.cuda.Event()
         ev.record()
         # neighbours + IDW weights + mask from ONE launch (the geometry kernel interpolates its feature itself: no [Q,32] round
-        # trip); a fixed query radius that differs from the cloud's falls back to the separate weights launch
-        radius = 0.0 if g.use_dynamic_radius else npc.get_radius_query()
+        # trip).  The search is bounded by the query radius (per sample, or the cloud's fixed one): I / D are exact inside
+        # the ball - the only slots with a non-zero weight - and unspecified beyond it (NeuralPointCloud.find_neighbors_faiss)
         expo = getattr(g, "weighting", "distance") != "distance"
-        if g.use_dynamic_radius or radius == npc.radius_query:
-            D, I, nn_num, w, has = npc.find_neighbors_faiss(pts, step='query', dynamic_radius=rq,
-                                                            image_layout=(S, image_w) if image_w else None,
-                                                            weights=(g.min_nn_num, expo, True))
-        else:
-            D, I, nn_num = npc.find_neighbors_faiss(pts, step='query', dynamic_radius=rq,
-                                                    image_layout=(S, image_w) if image_w else None)
-            _, has, w = point_ops.idw_gather(D, I, nn_num, None, radius=radius, radius_per_query=None,
-                                             min_nn=g.min_nn_num, return_weights=True, raw_mask=True)
+        D, I, nn_num, w, has = npc.find_neighbors_faiss(pts, step='query', dynamic_radius=rq,
+                                                        image_layout=(S, image_w) if image_w else None,
+                                                        weights=(g.min_nn_num, expo, True))
         cp = cloud_pos if cloud_pos is not None else npc.cloud_pos()
         # (precise: exact-fp32 decoder kernels - the caller's answer to a tripped range guard of the fp16-split ones)
         raw = point_ops.render_mlp(decoders._packed(), pts, views, cp, npc_col_feats, None, I, w, has,
