@@ -61,8 +61,8 @@ struct ConvArgs {
   const int* pre_map;                           // map (edge) -> map of `pre` it reads (null: its own)
   long pbeg;                                    // first pixel of this launch (a layer may be split into two launches)
   int pre_late;                                 // add `pre` in the epilogue instead of seeding the accumulators with it
-  int dbg;                                      // ablation bits of conv8_kernel (GLORIE_CONV8_DBG; timing experiments only)
-  unsigned long long* stamps;                   // dbg & 128: s_memtime checkpoints of workgroup 0, tiles 10-12, [8 waves][128]
+  int pair;                                     // weight rows packed so that a lane owns 8 consecutive channels (conv_epilogue_tile)
+  unsigned long long* stamps;                   // EXP_CONV_STAMPS builds: s_memtime checkpoints (tools/conv_timeline.py)
   // EPI_HEADS: the first tap_groups 128-channel tiles feed the tap GEMM of a 3x3 head instead of being stored
   const f16x8* tap_w; float* tap_out; int tap_groups, tap_ncols;
   // EPI_UPSAMPLE: convex upsampling of the disparity maps with the tile's logits as the mask
@@ -141,9 +141,111 @@ typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 // pbase + 16*ni.  Every load is issued with a clamped (always valid) address and every store goes through a buffer
 // descriptor with bit 31 of its offset set for pixels / channels past the end (the range check drops it) - a guarded
 // load + store per block is a chain of MB * NB dependent memory round trips at the tail of every workgroup.
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4e;
+
+// The same epilogue for PAIRED weight rows (round 4; ConvArgs.pair, update_ops.pack_conv_igemm(pair=True)).  The ablation
+// of the z|r gate launch (tools/bench_gate_epilogue.py: 263 us, of which loads 26, stores 21, sigmoid 15 - 211 us without the
+// three) showed the epilogue's cost to be its vector-memory INSTRUCTIONS: a lane owns 4 channels per 16-row MFMA block, so
+// every load / store moves 8 bytes per lane and the wave needs MB * NB of each.  With the rows of every 32-channel group
+// packed as  row 16 blk + r  <->  channel 8 (r / 4) + 4 blk + r % 4,  the lane's 4 rows of blocks 2b and 2b + 1 are 8
+// CONSECUTIVE channels: 16-byte loads and stores, half as many.  The per-map gate terms (float, identical for every pixel
+// of a map) are loaded once per wave instead of once per pixel block and re-loaded only where a tile straddles two maps.
+// Same products, same sums, same rounding: the outputs are bit-identical to the unpaired kernel's.
+template <int EPI, int MB, int NB>
+__device__ __forceinline__ void conv_epilogue_pair(const ConvArgs& a, f32x4 (&acc)[MB][NB], long pbase, int nwave) {
+  static_assert(MB % 2 == 0, "pairs of 16-row blocks");
+  constexpr int PB = MB / 2;
+  const int kg = (threadIdx.x & 63) >> 4;
+  const __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rO2 = __builtin_amdgcn_make_buffer_rsrc((void*)(EPI == EPI_GRU_ZR ? a.out2 : a.out), 0,
+                                                                      0x7fffffff, 0x00020000);
+  const bool upper = EPI == EPI_GRU_ZR && nwave >= 128;          // wave-uniform: this wave holds r (channels 128..255)
+  const bool late = EPI != EPI_BIAS_ACT && a.pre;                // paired launches always add the context term here
+  int nch[PB];
+#pragma unroll
+  for (int b = 0; b < PB; ++b) nch[b] = min(nwave + 32 * b + 8 * kg, a.nout - 8);
+  float4 g[PB][2];
+  int e_cur = -1;
+  if (EPI == EPI_BIAS_ACT) {
+#pragma unroll
+    for (int b = 0; b < PB; ++b) {
+      g[b][0] = a.terms ? *reinterpret_cast<const float4*>(a.terms + nch[b]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      g[b][1] = a.terms ? *reinterpret_cast<const float4*>(a.terms + nch[b] + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+#pragma unroll
+  for (int ni = 0; ni < NB; ++ni) {
+    const long p = pbase + ni * 16;
+    const bool okp = p < a.P;
+    const long pc = okp ? p : a.P - 1;
+    const int e = (int)(pc / a.HW);
+    if (EPI != EPI_BIAS_ACT && __builtin_amdgcn_ballot_w64(e != e_cur) != 0ull) {      // first block, or the tile crosses into the next map
+#pragma unroll
+      for (int b = 0; b < PB; ++b) {
+        g[b][0] = *reinterpret_cast<const float4*>(a.terms + (size_t)e * a.terms_stride + nch[b]);
+        g[b][1] = *reinterpret_cast<const float4*>(a.terms + (size_t)e * a.terms_stride + nch[b] + 4);
+      }
+      e_cur = e;
+    }
+    const long pp = late ? pre_pixel(a, pc) : 0;
+    f16x8 nv[PB], zv[PB], pl[PB];
+#pragma unroll
+    for (int b = 0; b < PB; ++b) {
+      if (late) pl[b] = *reinterpret_cast<const f16x8*>(a.pre + pp * a.pre_stride + nch[b]);
+      if (EPI == EPI_GRU_Q) {
+        nv[b] = *reinterpret_cast<const f16x8*>(a.net + pc * a.net_stride + nch[b]);
+        zv[b] = *reinterpret_cast<const f16x8*>(a.z + pc * a.z_stride + nch[b]);
+      } else if (upper) {
+        nv[b] = *reinterpret_cast<const f16x8*>(a.net + pc * a.net_stride + (nch[b] - 128));
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < PB; ++b) {
+      const int n = nwave + 32 * b + 8 * kg;
+      f16x8 o;
+#pragma unroll
+      for (int hb = 0; hb < 2; ++hb) {
+        f32x4 v = acc[2 * b + hb][ni];
+        const float4 gg = g[b][hb];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int s = 4 * hb + k;
+          float f = v[k];
+          if (late) f += (float)pl[b][s];
+          f += (k == 0 ? gg.x : k == 1 ? gg.y : k == 2 ? gg.z : gg.w);
+          if (EPI == EPI_BIAS_ACT) {
+            if (a.act == CACT_RELU) f = fmaxf(f, 0.0f);
+            else if (a.act == CACT_SIGMOID) f = csigmoid(f);
+            o[s] = (_Float16)f;
+          } else if (EPI == EPI_GRU_ZR) {
+            o[s] = (_Float16)(upper ? csigmoid(f) * (float)nv[b][s] : csigmoid(f));
+          } else {
+            const float zz = (float)zv[b][s];
+            o[s] = (_Float16)((1.0f - zz) * (float)nv[b][s] + zz * ctanh(f));
+          }
+        }
+      }
+      const bool ok = okp && n + 8 <= a.nout;
+      if (upper) {
+        const unsigned vo = ok ? (unsigned)((pc * a.out2_stride + (n - 128)) * 2) : 0x80000000u;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4e, o), rO2, vo, 0, 0);
+      } else {
+        const unsigned vo = ok ? (unsigned)((pc * a.out_stride + n) * 2) : 0x80000000u;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4e, o), rO, vo, 0, 0);
+      }
+    }
+  }
+}
+
 template <int EPI, int MB, int NB>
 __device__ __forceinline__ void conv_epilogue_tile(const ConvArgs& a, f32x4 (&acc)[MB][NB], long pbase, int nbase,
                                                    int out_ch0 = 0) {
+  if constexpr (MB % 2 == 0 && (EPI == EPI_BIAS_ACT || EPI == EPI_GRU_ZR || EPI == EPI_GRU_Q)) {
+    if (a.pair) {                                                  // launch-uniform
+      conv_epilogue_pair<EPI, MB, NB>(a, acc, pbase, nbase - 4 * (int)((threadIdx.x & 63) >> 4));
+      return;
+    }
+  }
   const __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rO2 = __builtin_amdgcn_make_buffer_rsrc((void*)(EPI == EPI_GRU_ZR ? a.out2 : a.out), 0,
                                                                       0x7fffffff, 0x00020000);
@@ -161,6 +263,12 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvArgs& a, f32x4 (&ac
 #pragma unroll
     for (int mi = 0; mi < MB; ++mi) {
       const int nc = min(nbase + mi * 16, a.nout - 4);
+#ifdef EXP_EPI_NO_LOADS
+      // ablation (tools/exp_conv_wreg.py): what do the epilogue's scattered 8-byte loads cost?
+      pl[mi] = f16x4{1, 1, 1, 1}; nv[mi] = f16x4{1, 1, 1, 1}; zv[mi] = f16x4{1, 1, 1, 1};
+      g[mi] = make_float4(0.f, 0.f, 0.f, 0.f);
+      continue;
+#endif
       if (late) pl[mi] = *reinterpret_cast<const f16x4*>(a.pre + pp * a.pre_stride + nc);
       if (EPI == EPI_BIAS_ACT) {
         g[mi] = a.terms ? *reinterpret_cast<const float4*>(a.terms + nc) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -201,6 +309,15 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvArgs& a, f32x4 (&ac
           o[k] = (_Float16)((1.0f - zz) * (float)nv[mi][k] + zz * ctanh(f[k]));
         }
       }
+#ifdef EXP_EPI_NO_SIGMOID
+      if (EPI != EPI_BIAS_ACT) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = (_Float16)f[k];
+      }
+#endif
+#ifdef EXP_EPI_NO_STORE
+      if (o[0] != (_Float16)12345.0f) continue;
+#endif
       const bool ok = okp && n < a.nout;
       if (upper) {
         const unsigned vo = ok ? (unsigned)((pc * a.out2_stride + (n - 128)) * 2) : 0x80000000u;
@@ -905,854 +1022,6 @@ __global__ __launch_bounds__(256, MB <= 4 ? 3 : 2) void conv_halo_kernel(ConvArg
 #endif
 }
 
-// fragment reads as inline asm: the compiler neither waits for every outstanding LDS-DMA in front of them nor chooses the
-// lgkmcnt in front of their first use (it takes 0 at a loop header); the kernels below count their own waits
-__device__ __forceinline__ f16x8 lds_read16(unsigned addr) {
-  f16x8 v;
-  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
-  return v;
-}
-template <int OFF>
-__device__ __forceinline__ f16x8 lds_read16_off(unsigned addr) {
-  f16x8 v;
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
-  return v;
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// Producer / consumer form of the 128 x 128 tile (the default for 3x3 layers): 8 waves, 2 workgroups per CU.
-//
-// tools/conv_timeline.sh on conv_igemm_kernel: a wave spends its K-tile in series - wait for the DMA 420 cycles, barrier 174,
-// fragment reads 564, barrier 180, ISSUING the next tile's DMA pieces 980 (a piece waits ~80-120 cycles for the texture path
-// when every wave of the CU pushes its share at once, and a wave issues in order: dealing the pieces between the MFMAs gives
-// the same sum), MFMAs 660-1190 - so the matrix pipe sees 17-31 % of a wave's time.  Here waves 4-7 do nothing but stage
-// (DMA of tile t+1 into the other LDS stage, wait for it, barrier) and waves 0-3 do nothing but read fragments and issue
-// MFMAs: ONE barrier per K-tile - at barrier t tile t has landed and every consumer has finished reading tile t-1, whose
-// stage the producers refill next.  Registers are allocated per kernel, so the consumers are held to 128 VGPRs (the
-// fragments of the two 32-channel halves of a tile share their registers) and two workgroups (2 consumer + 2 producer waves
-// per SIMD) are resident; 6-wave workgroups would not do: the dispatcher books ceil(waves / 4) slots on every SIMD
-// (tools/probes/wave_placement.hip: one 5- or 6-wave workgroup per CU at 166 VGPRs).  Same tile mapping, K order, MFMA
-// and epilogues as conv_igemm_kernel<EPI, 4, 64, 4, 1, 4>: bit-identical results (tests/test_gpu_update_op.py).
-// ------------------------------------------------------------------------------------------------------------------
-template <int EPI>
-__global__ __launch_bounds__(512, 4) void conv_ps_kernel(ConvArgs a) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int MB = 4, NB = 4, NW = 4, TN = 128, PT = 128, RB = 128, SL = 8, RPI = 8, KK = 2;
-  constexpr int XI = PT / RPI / NW, WI = TN / RPI / NW;     // DMA instructions per producer wave per K-tile: 4 + 4
-  constexpr int XBYTES = PT * RB, WBYTES = TN * RB, STAGE = XBYTES + WBYTES;
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages x (pixel tile, weight tile)
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wall = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool producer = wall >= NW;
-  const int wv = wall & 3;
-  const int col = lane & 15, kg = lane >> 4;
-  const int wm = wv & 1, wn = wv >> 1;
-  auto key = [](int row) { return row & 7; };
-
-  const int nwg = gridDim.x, ntn = (a.nout + TN - 1) / TN;
-  const int xcd = blockIdx.x & 7, q = nwg >> 3, r = nwg & 7;
-  const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
-  const int pt = lid / ntn, nt = lid - pt * ntn;
-  const int tpm = (a.HW + PT - 1) / PT;
-  const long p0 = EPI == EPI_GLO ? (long)(pt / tpm) * a.HW + (long)(pt % tpm) * PT : a.pbeg + (long)pt * PT;
-  const int n0 = nt * TN;
-  const int nsteps_tap = a.cha + a.chb;
-  const int C = nsteps_tap * 64;
-  const int T = a.taps * nsteps_tap;
-
-  f32x4 acc[MB][NB];
-#pragma unroll
-  for (int mi = 0; mi < MB; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < NB; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  if (EPI != EPI_BIAS_ACT && a.pre && !a.pre_late) {
-    // per-edge context term: seeds the accumulators through LDS exactly as in conv_igemm_kernel (the consumers stage and
-    // read it back; the producers only keep the barrier count)
-    constexpr int ROWB = TN * 2, SLOTS = ROWB / 16, RPP = 64 / SLOTS;
-    if (!producer) {
-      const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void*)a.pre, 0, 0x7fffffff, 0x00020000);
-#pragma unroll
-      for (int i = 0; i < PT / RPP / NW; ++i) {
-        const int piece = i * NW + wv;
-        const int row = piece * RPP + lane / SLOTS, sl = lane % SLOTS;
-        const long p = pre_pixel(a, min(p0 + row, a.P - 1));
-        const unsigned vo = (unsigned)((p * a.pre_stride + n0) * 2 + ((sl ^ (row & 15)) << 4));
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rP, (__attribute__((address_space(3))) void*)(smem + piece * 1024), 16, vo,
-                                                 0, 0, 0);
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
-    if (!producer) {
-#pragma unroll
-      for (int ni = 0; ni < NB; ++ni) {
-        const int row = wn * (16 * NB) + ni * 16 + col;
-#pragma unroll
-        for (int mi = 0; mi < MB; ++mi) {
-          const int b = (wm * (16 * MB) + mi * 16 + kg * 4) * 2;
-          const f16x4 h = *reinterpret_cast<const f16x4*>(smem + row * ROWB + ((((b >> 4) ^ (row & 15))) << 4) + (b & 15));
-          acc[mi][ni] = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
-        }
-      }
-    }
-    __syncthreads();                           // the stages are free for the first K tile
-  }
-
-  if (producer) {
-    // ---------------------------------------------------------------------------------------------------------------
-    // staging waves: see conv_igemm_kernel for the addressing (buffer descriptors, swizzled source slot, bit 31 = zero fill)
-    const int back = a.taps == 9 ? a.W + 1 : 0;
-    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(a.xa - (long)back * a.xa_stride), 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(a.xb - (long)back * a.xb_stride), 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, 0x7fffffff, 0x00020000);
-    const int srow = lane / SL, slot = lane % SL;
-    const int row0 = wv * RPI + srow;
-    const int sw0 = (slot ^ key(row0)) << 3;
-    const unsigned voffA0 = (unsigned)(((p0 + row0) * a.xa_stride + sw0) * 2);
-    const unsigned voffB0 = (unsigned)(((p0 + row0) * a.xb_stride + sw0) * 2);
-    const unsigned woff0 = (unsigned)(((size_t)row0 * C + sw0) * 2);
-    int vmask[XI];
-#pragma unroll
-    for (int i = 0; i < XI; ++i) {
-      const long p = p0 + (i * NW + wv) * RPI + srow;
-      int m = 0;
-      if (p < a.P) {
-        const int pi_ = (int)p, xw = pi_ % a.W, yh = (pi_ / a.W) % a.H;      // p < P < 2^31 (the 31-bit offset check of the launch)
-        if (a.taps == 9) {
-#pragma unroll
-          for (int d = 0; d < 9; ++d) {
-            const int dy = d / 3 - 1, dx = d % 3 - 1;
-            if ((unsigned)(yh + dy) < (unsigned)a.H && (unsigned)(xw + dx) < (unsigned)a.W) m |= 1 << d;
-          }
-        } else {
-          m = 1;
-        }
-      }
-      vmask[i] = m;
-    }
-    auto stage = [&](int t, int buf) {
-      const int ch = t / a.taps, d = t - ch * a.taps;      // 64-channel chunk outermost, its taps inside (L2 reuse)
-      const int shift = (a.taps == 9 ? (d / 3 - 1) * a.W + (d % 3 - 1) : 0) + back;
-      const bool segA = ch < a.cha;
-      const int xs = segA ? a.xa_stride : a.xb_stride;
-      const unsigned xsoff = (unsigned)((shift * xs + (segA ? ch : ch - a.cha) * 64) * 2);
-      const unsigned wsoff = (unsigned)((((size_t)d * a.npad + n0) * C + ch * 64) * 2);
-      char* lx = smem + buf * STAGE;
-      char* lw = lx + XBYTES;
-      const unsigned xstep = (unsigned)(NW * RPI * xs * 2), wstep = (unsigned)(NW * RPI * C * 2);
-#ifdef EXP_PS_NO_PIXEL_DMA
-      if (d == 0)                               // ablation: the pixel tile is staged once per chunk (wrong results)
-#endif
-#pragma unroll
-      for (int i = 0; i < XI; ++i) {
-        const unsigned inv = ~((unsigned)vmask[i] >> d);
-        const unsigned vo = (inv << 31) | (segA ? voffA0 : voffB0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(segA ? rA : rB,
-            (__attribute__((address_space(3))) void*)(lx + (i * NW + wv) * RPI * RB), 16, vo, xsoff + i * xstep, 0, 0);
-      }
-#pragma unroll
-      for (int i = 0; i < WI; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rW,
-            (__attribute__((address_space(3))) void*)(lw + (i * NW + wv) * RPI * RB), 16, woff0, wsoff + i * wstep, 0, 0);
-    };
-#ifdef EXP_CONV_STAMPS
-    const int swg = lid / 61;
-#define PS_STAMP(k) do { if (a.stamps && lane == 0 && lid % 61 == 0 && swg < 16 && t >= 10 && t < 14) { unsigned long long ts_;   \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_) : : "memory");                                              \
-    a.stamps[((swg * 8 + wall) * 4 + (t - 10)) * 8 + (k)] = ts_; } } while (0)
-#else
-#define PS_STAMP(k)
-#endif
-    stage(0, 0);
-    for (int t = 0; t < T; ++t) {
-      PS_STAMP(0);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      PS_STAMP(1);
-      __builtin_amdgcn_s_barrier();            // barrier t: tile t is in LDS; nobody reads stage (t + 1) & 1 any more
-      PS_STAMP(2);
-      if (t + 1 < T) stage(t + 1, (t + 1) & 1);
-      PS_STAMP(3);
-    }
-    return;
-  }
-
-  // -----------------------------------------------------------------------------------------------------------------
-  // MFMA waves
-  int foff[KK];
-#pragma unroll
-  for (int kk = 0; kk < KK; ++kk) foff[kk] = col * RB + (((kk * 4 + kg) ^ key(col)) << 4);
-  const int wbase = XBYTES + wm * (16 * MB) * RB, xbase_l = wn * (16 * NB) * RB;
-#ifdef EXP_CONV_STAMPS
-  const int swg = lid / 61;
-#endif
-  for (int t = 0; t < T; ++t) {
-    PS_STAMP(0);
-    __builtin_amdgcn_s_barrier();              // barrier t
-    PS_STAMP(1);
-    const char* base = smem + (t & 1) * STAGE;
-#pragma unroll
-    for (int kk = 0; kk < KK; ++kk) {
-      f16x8 wf[MB], xf[NB];
-#pragma unroll
-      for (int mi = 0; mi < MB; ++mi) wf[mi] = *reinterpret_cast<const f16x8*>(base + wbase + mi * 16 * RB + foff[kk]);
-#pragma unroll
-      for (int ni = 0; ni < NB; ++ni) xf[ni] = *reinterpret_cast<const f16x8*>(base + xbase_l + ni * 16 * RB + foff[kk]);
-#pragma unroll
-      for (int mi = 0; mi < MB; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NB; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[mi], xf[ni], acc[mi][ni], 0, 0, 0);
-      if (kk == 0) PS_STAMP(2); else PS_STAMP(3);
-    }
-    // every fragment read of tile t has returned (the MFMAs consumed them) before this wave reaches barrier t + 1
-  }
-
-  if constexpr (EPI == EPI_GLO) {
-    conv_epilogue_glo<MB, NB>(a, acc, p0, p0 + wn * (16 * NB) + col, wm, wn, kg, col, smem, pt);
-  } else if constexpr (EPI == EPI_UPSAMPLE) {
-    conv_epilogue_upsample<MB, NB>(a, acc, p0, n0, wm, wn, kg, col, smem);
-  } else if constexpr (EPI == EPI_HEADS) {
-    if (nt < a.tap_groups)                                                    // workgroup-uniform
-      conv_epilogue_heads<MB, NB>(a, acc, p0, n0, wm, wn, kg, col, lane, smem);
-    else
-      conv_epilogue_tile<EPI_BIAS_ACT, MB, NB>(a, acc, p0 + wn * (16 * NB) + col, n0 + wm * (16 * MB) + kg * 4,
-                                               a.tap_groups * 128);
-  } else {
-    conv_epilogue_tile<EPI, MB, NB>(a, acc, p0 + wn * (16 * NB) + col, n0 + wm * (16 * MB) + kg * 4);
-  }
-#endif
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// Producer / consumer form with the big wave tile: ONE workgroup of 8 waves per CU, three LDS stages of 48 KB.
-// Waves 0-3 (one per SIMD) own 128 x 64 (MB = 8, NB = 4: 256 channels x 128 pixels per workgroup) or 64 x 128 (MB = 4,
-// NB = 8: 128 channels x 256 pixels) of the tile and do nothing but fragment reads and MFMAs; waves 4-7 stage two K-tiles
-// ahead.  One barrier per K-tile, placed BETWEEN the two 32-channel halves of a tile's MFMAs: barrier t + 1 says tile t + 1
-// has landed, the consumer then requests the first-half fragments of tile t + 1 into the registers its first-half MFMAs of
-// tile t just released and issues the second half of tile t (whose fragments were requested beside the first half's MFMAs) -
-// every fragment is requested half a tile (>= 512 matrix-pipe cycles) before it is used and every read is issued beside MFMAs.  A consumer's reads of tile t have all returned
-// before it arrives at barrier t + 1 (explicit lgkmcnt(0)), after which the producers refill that stage with tile t + 3.
-// Same tile mapping and K order as conv_igemm_kernel; the per-edge context term is added in the epilogue.
-// ------------------------------------------------------------------------------------------------------------------
-template <int EPI, int MB, int NB>
-__global__ __launch_bounds__(512, 2) void conv_ps2_kernel(ConvArgs a) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int NW = 4, TN = 32 * MB, PT = 32 * NB, RB = 128, SL = 8, RPI = 8, KK = 2, NST = 3;
-  constexpr int XI = PT / RPI / NW, WI = TN / RPI / NW;     // DMA instructions per producer wave per K-tile
-  constexpr int XBYTES = PT * RB, WBYTES = TN * RB, STAGE = XBYTES + WBYTES;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wall = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool producer = wall >= NW;
-  const int wv = wall & 3;
-  const int col = lane & 15, kg = lane >> 4;
-  const int wm = wv & 1, wn = wv >> 1;
-  auto key = [](int row) { return row & 7; };
-
-  const int nwg = gridDim.x, ntn = (a.nout + TN - 1) / TN;
-  const int xcd = blockIdx.x & 7, q = nwg >> 3, r = nwg & 7;
-  const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
-  const int pt = lid / ntn, nt = lid - pt * ntn;
-  const long p0 = a.pbeg + (long)pt * PT;
-  const int n0 = nt * TN;
-  const int nsteps_tap = a.cha + a.chb;
-  const int C = nsteps_tap * 64;
-  const int T = a.taps * nsteps_tap;
-
-  if (producer) {
-    // staging waves: see conv_igemm_kernel for the addressing (buffer descriptors, swizzled source slot, bit 31 = zero fill)
-    const int back = a.taps == 9 ? a.W + 1 : 0;
-    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(a.xa - (long)back * a.xa_stride), 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(a.xb - (long)back * a.xb_stride), 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, 0x7fffffff, 0x00020000);
-    const int srow = lane / SL, slot = lane % SL;
-    const int row0 = wv * RPI + srow;
-    const int sw0 = (slot ^ key(row0)) << 3;
-    const unsigned voffA0 = (unsigned)(((p0 + row0) * a.xa_stride + sw0) * 2);
-    const unsigned voffB0 = (unsigned)(((p0 + row0) * a.xb_stride + sw0) * 2);
-    const unsigned woff0 = (unsigned)(((size_t)row0 * C + sw0) * 2);
-    int vmask[XI];
-#pragma unroll
-    for (int i = 0; i < XI; ++i) {
-      const long p = p0 + (i * NW + wv) * RPI + srow;
-      int m = 0;
-      if (p < a.P) {
-        const int pi_ = (int)p, xw = pi_ % a.W, yh = (pi_ / a.W) % a.H;      // p < P < 2^31 (the 31-bit offset check of the launch)
-        if (a.taps == 9) {
-#pragma unroll
-          for (int d = 0; d < 9; ++d) {
-            const int dy = d / 3 - 1, dx = d % 3 - 1;
-            if ((unsigned)(yh + dy) < (unsigned)a.H && (unsigned)(xw + dx) < (unsigned)a.W) m |= 1 << d;
-          }
-        } else {
-          m = 1;
-        }
-      }
-      vmask[i] = m;
-    }
-    auto stage = [&](int t, int buf) {
-      const int ch = t / a.taps, d = t - ch * a.taps;      // 64-channel chunk outermost, its taps inside (L2 reuse)
-      const int shift = (a.taps == 9 ? (d / 3 - 1) * a.W + (d % 3 - 1) : 0) + back;
-      const bool segA = ch < a.cha;
-      const int xs = segA ? a.xa_stride : a.xb_stride;
-      const unsigned xsoff = (unsigned)((shift * xs + (segA ? ch : ch - a.cha) * 64) * 2);
-      const unsigned wsoff = (unsigned)((((size_t)d * a.npad + n0) * C + ch * 64) * 2);
-      char* lx = smem + buf * STAGE;
-      char* lw = lx + XBYTES;
-      const unsigned xstep = (unsigned)(NW * RPI * xs * 2), wstep = (unsigned)(NW * RPI * C * 2);
-#pragma unroll
-      for (int i = 0; i < XI; ++i) {
-        const unsigned inv = ~((unsigned)vmask[i] >> d);
-        const unsigned vo = (inv << 31) | (segA ? voffA0 : voffB0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(segA ? rA : rB,
-            (__attribute__((address_space(3))) void*)(lx + (i * NW + wv) * RPI * RB), 16, vo, xsoff + i * xstep, 0, 0);
-      }
-#pragma unroll
-      for (int i = 0; i < WI; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rW,
-            (__attribute__((address_space(3))) void*)(lw + (i * NW + wv) * RPI * RB), 16, woff0, wsoff + i * wstep, 0, 0);
-    };
-    stage(0, 0);
-    if (T > 1) stage(1, 1);
-    int nxt = 2;                                 // LDS stage of tile b + 2
-#ifdef EXP_CONV_STAMPS
-    const int swg = lid / 61;
-#define PS2_STAMP(k) do { if (a.stamps && lane == 0 && lid % 61 == 0 && swg < 16 && t >= 10 && t < 14) { unsigned long long ts_;  \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_) : : "memory");                                              \
-    a.stamps[((swg * 8 + wall) * 4 + (t - 10)) * 8 + (k)] = ts_; } } while (0)
-#else
-#define PS2_STAMP(k)
-#endif
-    for (int t = 0; t < T; ++t) {                // t: the barrier's (= the landed tile's) index
-      PS2_STAMP(0);
-      // tile t has landed (this wave's share): the pieces of tile t + 1 may still be on their way
-      if (t + 1 < T) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XI + WI) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      PS2_STAMP(1);
-      __builtin_amdgcn_s_barrier();              // barrier t
-      PS2_STAMP(2);
-      if (t + 2 < T) stage(t + 2, nxt);          // the stage of tile t - 1: every consumer's reads of it returned before barrier t
-      nxt = nxt == NST - 1 ? 0 : nxt + 1;
-      PS2_STAMP(3);
-    }
-    return;
-  }
-
-  // -----------------------------------------------------------------------------------------------------------------
-  // MFMA waves
-  f32x4 acc[MB][NB];
-#pragma unroll
-  for (int mi = 0; mi < MB; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < NB; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-  int foff[KK];
-#pragma unroll
-  for (int kk = 0; kk < KK; ++kk) foff[kk] = col * RB + (((kk * 4 + kg) ^ key(col)) << 4);
-  const int wbase = XBYTES + wm * (16 * MB) * RB, xbase_l = wn * (16 * NB) * RB;
-  f16x8 wA[MB], xA[NB], wB[MB], xB[NB];
-  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
-  unsigned aw[KK], ax[KK];                       // + stage * STAGE; block mi / ni as the instruction offset
-#pragma unroll
-  for (int kk = 0; kk < KK; ++kk) { aw[kk] = lds0 + wbase + foff[kk]; ax[kk] = lds0 + xbase_l + foff[kk]; }
-  auto reads = [&](int buf, int kk, f16x8 (&wf)[MB], f16x8 (&xf)[NB]) {
-    const unsigned bo = (unsigned)buf * STAGE;
-    static_assert(MB == 4 || MB == 8, "wave tile");
-    wf[0] = lds_read16_off<0 * 16 * RB>(aw[kk] + bo); wf[1] = lds_read16_off<1 * 16 * RB>(aw[kk] + bo);
-    wf[2] = lds_read16_off<2 * 16 * RB>(aw[kk] + bo); wf[3] = lds_read16_off<3 * 16 * RB>(aw[kk] + bo);
-    if constexpr (MB == 8) {
-      wf[4] = lds_read16_off<4 * 16 * RB>(aw[kk] + bo); wf[5] = lds_read16_off<5 * 16 * RB>(aw[kk] + bo);
-      wf[6] = lds_read16_off<6 * 16 * RB>(aw[kk] + bo); wf[7] = lds_read16_off<7 * 16 * RB>(aw[kk] + bo);
-    }
-    xf[0] = lds_read16_off<0 * 16 * RB>(ax[kk] + bo); xf[1] = lds_read16_off<1 * 16 * RB>(ax[kk] + bo);
-    xf[2] = lds_read16_off<2 * 16 * RB>(ax[kk] + bo); xf[3] = lds_read16_off<3 * 16 * RB>(ax[kk] + bo);
-    if constexpr (NB == 8) {
-      xf[4] = lds_read16_off<4 * 16 * RB>(ax[kk] + bo); xf[5] = lds_read16_off<5 * 16 * RB>(ax[kk] + bo);
-      xf[6] = lds_read16_off<6 * 16 * RB>(ax[kk] + bo); xf[7] = lds_read16_off<7 * 16 * RB>(ax[kk] + bo);
-    }
-  };
-  // at most N reads still in flight; the fragments become valid here: tying them to the wait keeps their MFMAs behind it
-#define PS2_WAIT(N, wf, xf)                                                                                              \
-  do {                                                                                                                   \
-    if constexpr (MB == 8)                                                                                               \
-      asm volatile("s_waitcnt lgkmcnt(%12)" : "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2]), "+v"(wf[3]), "+v"(wf[4]),          \
-                   "+v"(wf[5]), "+v"(wf[6]), "+v"(wf[7]), "+v"(xf[0]), "+v"(xf[1]), "+v"(xf[2]), "+v"(xf[3]) : "n"(N) : "memory"); \
-    else                                                                                                                 \
-      asm volatile("s_waitcnt lgkmcnt(%12)" : "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2]), "+v"(wf[3]), "+v"(xf[0]),          \
-                   "+v"(xf[1]), "+v"(xf[2]), "+v"(xf[3]), "+v"(xf[4]), "+v"(xf[5]), "+v"(xf[6]), "+v"(xf[7]) : "n"(N) : "memory"); \
-  } while (0)
-  auto mma = [&](const f16x8 (&wf)[MB], const f16x8 (&xf)[NB]) {
-#pragma unroll
-    for (int mi = 0; mi < MB; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < NB; ++ni)
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[mi], xf[ni], acc[mi][ni], 0, 0, 0);
-  };
-  constexpr int NF = MB + NB;                    // reads per half tile
-  asm volatile("" ::: "memory");
-  __builtin_amdgcn_s_barrier();                  // barrier 0
-  asm volatile("" ::: "memory");
-  reads(0, 0, wA, xA);
-  int cur = 0;
-#ifdef EXP_CONV_STAMPS
-  const int swg = lid / 61;
-#endif
-  for (int t = 0; t + 1 < T; ++t) {
-    const int nx = cur == NST - 1 ? 0 : cur + 1;
-    PS2_STAMP(0);
-    PS2_WAIT(0, wA, xA);                         // the first half of tile t is here
-    reads(cur, 1, wB, xB);                       // its second half: requested beside the first half's MFMAs
-    mma(wA, xA);
-    __builtin_amdgcn_sched_barrier(0);           // (the fences keep hipcc from sinking the MFMAs below the next wait)
-    PS2_STAMP(1);
-    PS2_WAIT(0, wB, xB);                         // every read of tile t has returned
-    __builtin_amdgcn_s_barrier();                // barrier t + 1: tile t + 1 is in LDS
-    __builtin_amdgcn_sched_barrier(0);
-    PS2_STAMP(2);
-    reads(nx, 0, wA, xA);                        // first half of tile t + 1, beside the second half's MFMAs
-    mma(wB, xB);
-    __builtin_amdgcn_sched_barrier(0);
-    PS2_STAMP(3);
-    cur = nx;
-  }
-  PS2_WAIT(0, wA, xA);
-  reads(cur, 1, wB, xB);
-  mma(wA, xA);
-  __builtin_amdgcn_sched_barrier(0);
-  PS2_WAIT(0, wB, xB);
-  mma(wB, xB);
-#undef PS2_WAIT
-  conv_epilogue_tile<EPI, MB, NB>(a, acc, p0 + wn * (16 * NB) + col, n0 + wm * (16 * MB) + kg * 4);
-#endif
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// 256 output channels x 256 pixels per workgroup, 8 waves (2 channel halves x 4 pixel quarters, wave tile 128 x 64 =
-// 8 x 4 accumulator blocks), 128 KB of LDS (two K-tile buffers), one workgroup per CU = two waves per SIMD.
-//
-// A K-tile (one tap of one 64-channel chunk: 256 + 256 rows of 128 B) is staged as FOUR 16 KB units, the row sets one
-// phase of the wave tile reads:   U0 = weights of the waves' channel blocks 0-3,  U1 = pixels of their blocks 0-1,
-//                                 U2 = pixel blocks 2-3,                          U3 = channel blocks 4-7.
-// Per K-tile four phases, each {fragment reads, DMA of ONE unit of a later tile, counted vmcnt, barrier,
-// 16 MFMAs = one quadrant of the wave tile x 64 channels, barrier}:
-//      p1 reads U0 U1, computes (c0-3, p0-1), stages U0(t+1)        p3 reads U3,  computes (c4-7, p2-3), stages U3(t+1)
-//      p2 reads U2,    computes (c0-3, p2-3), stages U2(t+1)        p4 reads -,   computes (c4-7, p0-1), stages U1(t+2)
-// Units are issued 4-5 phases before they are read and never waited for with vmcnt(0): after its issue each phase
-// waits until the unit issued three phases earlier has landed (6 loads may stay in flight across the barriers); the
-// barrier that follows publishes it, it is read from the next phase on.  A region is re-staged no earlier than two
-// phases after its last read (the pixel fragments of blocks 0-1 stay in registers for p4).
-// The two channel halves (waves 0-3 / 4-7 = the two waves of every SIMD) run half a phase apart (waves 4-7 take one
-// extra barrier before the loop, waves 0-3 one after it): while one wave of a SIMD is in its MFMA cluster the other
-// reads fragments and issues DMA.  Fragment reads are inline `ds_read_b128` + explicit lgkmcnt: a compiler-visible LDS
-// load would be preceded by a wait for EVERY outstanding LDS-DMA (the waitcnt pass cannot tell the buffers apart).
-// ------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void wait_vm_units(int n) {      // at most n units (2 loads each) still in flight
-  if (n >= 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  else if (n == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else if (n == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-template <int EPI, int SCHED, bool DBG>
-__global__ __launch_bounds__(512) void conv8_kernel(ConvArgs a) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int RB = 128;                     // bytes per staged row (64 halfs)
-  const int dbg = DBG ? a.dbg : 0;            // ablation / timing bits: a second instantiation, never the product kernel
-  constexpr int UNIT = 128 * RB;              // 16 KB
-  constexpr int BUF = 4 * UNIT;               // one K-tile: [U0 | U1 | U2 | U3]
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: LDS-DMA destinations stay in SGPRs
-  const int col = lane & 15, kg = lane >> 4;
-  const int wr = wv >> 2, wc = wv & 3;
-
-  const int nwg = gridDim.x, ntn = a.nout >> 8;
-  const int xcd = blockIdx.x & 7, q = nwg >> 3, r = nwg & 7;
-  const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
-  const int pt = lid / ntn, nt = lid - pt * ntn;
-  const long p0 = a.pbeg + (long)pt * 256;
-  const int n0 = nt * 256;
-
-  const int nch = a.cha + a.chb;
-  const int C = nch * 64;
-  const int T = a.taps * nch;                 // K-tiles
-  const int G = 4 * T;                        // units, in issue order U1(0) U0(0) U2(0) U3(0) U1(1) U0(1) ...
-
-  const int back = a.taps == 9 ? a.W + 1 : 0;
-  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(a.xa - (long)back * a.xa_stride), 0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(a.xb - (long)back * a.xb_stride), 0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, 0x7fffffff, 0x00020000);
-
-  // staging roles: a unit is 16 one-KB pieces (8 rows of 128 B, lane -> row lane/8, 16-byte slot lane%8, the slot
-  // XOR-swizzled with the row on the SOURCE side); wave wv moves pieces wv and wv + 8
-  const int srow = lane >> 3, slot = lane & 7;
-  unsigned woff[2][2];                        // [channel unit 0: U0 / 1: U3][piece]
-  unsigned xoffA[2][2], xoffB[2][2];          // [pixel unit 0: U1 / 1: U2][piece]
-  int xmask[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int r0 = (wv + 8 * i) * 8 + srow;   // row of the unit
-    const int sw = (slot ^ (r0 & 7)) << 3;    // halfs
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int chn = n0 + (r0 >> 6) * 128 + u * 64 + (r0 & 63);
-      woff[u][i] = (unsigned)(((size_t)chn * C + sw) * 2);
-      const long pp = p0 + (r0 >> 5) * 64 + u * 32 + (r0 & 31);
-      int m = 0;
-      if (pp < a.P) {
-        const int xw = (int)(pp % a.W), yh = (int)((pp / a.W) % a.H);
-        if (a.taps == 9) {
-#pragma unroll
-          for (int d = 0; d < 9; ++d) {
-            const int dy = d / 3 - 1, dx = d % 3 - 1;
-            if ((unsigned)(yh + dy) < (unsigned)a.H && (unsigned)(xw + dx) < (unsigned)a.W) m |= 1 << d;
-          }
-        } else {
-          m = 1;
-        }
-      }
-      xmask[u][i] = m;
-      const long pc = pp < a.P ? pp : 0;
-      xoffA[u][i] = (unsigned)((pc * a.xa_stride + sw) * 2);
-      xoffB[u][i] = (unsigned)((pc * a.xb_stride + sw) * 2);
-    }
-  }
-
-  // K-tile cursor: chunk-major, the taps of a chunk back to back (the 9 shifted reads of a chunk hit L2); advanced
-  // incrementally - no division in the loop
-  struct Cursor { int tile, ch, d, dy, dx; };
-  const bool taps9 = a.taps == 9;
-  auto advance = [&](Cursor& c) {
-    ++c.tile; ++c.d; ++c.dx;
-    const bool wx = c.dx > 1;
-    c.dx = wx ? -1 : c.dx; c.dy += wx ? 1 : 0;
-    const bool wc_ = c.d == a.taps;
-    c.d = wc_ ? 0 : c.d; c.ch += wc_ ? 1 : 0; c.dy = wc_ ? -1 : c.dy; c.dx = wc_ ? -1 : c.dx;
-  };
-  // what a unit's two DMA instructions need: computed ahead of the issue, beside the MFMAs (an LDS-DMA issue stalls its
-  // wave for 60-200 cycles; ~60 scalar instructions of address arithmetic in front of it doubled that).  The values are
-  // wave-uniform; readfirstlane keeps the loop-carried ones in SGPRs (a VGPR copy would turn every DMA into a waterfall loop)
-  auto sgpr = [](unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
-  struct UnitW { unsigned soff; bool on; };
-  struct UnitX { unsigned soff, vo0, vo1; bool segA, on; };
-  auto prep_w = [&](const Cursor& c) {
-    UnitW u;
-    u.on = c.tile < T && !((dbg & 1) && c.tile > 1) && !(dbg & 64);
-    u.soff = sgpr((unsigned)((((size_t)c.d * a.npad) * C + c.ch * 64) * 2));
-    return u;
-  };
-  auto prep_x = [&](const Cursor& c, int which) {            // which: 0 = U1, 1 = U2
-    UnitX u;
-    u.on = c.tile < T && !((dbg & 1) && c.tile > 1) && !(dbg & 32);
-    const int shift = (taps9 ? c.dy * a.W + c.dx : 0) + back;
-    u.segA = c.ch < a.cha;
-    const int xs = u.segA ? a.xa_stride : a.xb_stride;
-    u.soff = sgpr((unsigned)((shift * xs + (u.segA ? c.ch : c.ch - a.cha) * 64) * 2));
-    const unsigned i0 = ~((unsigned)xmask[which][0] >> c.d), i1 = ~((unsigned)xmask[which][1] >> c.d);
-    u.vo0 = (i0 << 31) | (u.segA ? xoffA[which][0] : xoffB[which][0]);
-    u.vo1 = (i1 << 31) | (u.segA ? xoffA[which][1] : xoffB[which][1]);
-    return u;
-  };
-  // region: position of the unit in its K-tile buffer (U0 | U1 | U2 | U3)
-  auto issue_w = [&](const UnitW& u, int tile, int region, int which) {
-    if (!u.on) return;
-    char* dst = smem + (tile & 1) * BUF + region * UNIT + wv * 1024;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (__attribute__((address_space(3))) void*)dst, 16, woff[which][0], u.soff, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (__attribute__((address_space(3))) void*)(dst + 8192), 16, woff[which][1],
-                                             u.soff, 0, 0);
-  };
-  auto issue_x = [&](const UnitX& u, int tile, int region) {
-    if (!u.on) return;
-    char* dst = smem + (tile & 1) * BUF + region * UNIT + wv * 1024;
-    if (u.segA) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)dst, 16, u.vo0, u.soff, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(dst + 8192), 16, u.vo1, u.soff, 0, 0);
-    } else {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (__attribute__((address_space(3))) void*)dst, 16, u.vo0, u.soff, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (__attribute__((address_space(3))) void*)(dst + 8192), 16, u.vo1, u.soff, 0, 0);
-    }
-  };
-  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
-  using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
-
-  f32x4 acc[8][4];                            // [channel block 4*quadrant + i][pixel block 2*quadrant + i]
-  const bool seeded = EPI != EPI_BIAS_ACT && a.pre && !a.pre_late;
-  f16x4 pv[2][4][2][2];
-  if (seeded) {
-    // the hoisted per-pixel term seeds the accumulators: 32 independent 8-byte loads (rows past the end re-read the
-    // last pixel; they are never stored), issued ahead of the first units and consumed behind them
-#pragma unroll
-    for (int nq = 0; nq < 2; ++nq)
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        const long p = pre_pixel(a, min(p0 + wc * 64 + nq * 32 + ni * 16 + col, a.P - 1));
-#pragma unroll
-        for (int mq = 0; mq < 2; ++mq)
-#pragma unroll
-          for (int mi = 0; mi < 4; ++mi)
-            pv[mq][mi][nq][ni] = *reinterpret_cast<const f16x4*>(a.pre + p * a.pre_stride + n0 + wr * 128 + mq * 64 +
-                                                                 mi * 16 + kg * 4);
-      }
-  }
-
-  // prologue: the first five units; U1(0) and U0(0) must have landed before the first reads
-  if ((dbg & 256) && a.stamps && lane == 0 && wv == 0 && lid < 64) a.stamps[1024 + lid * 2] = __builtin_readcyclecounter();
-  Cursor c1{0, 0, 0, -1, -1}, c2{0, 0, 0, -1, -1};   // c1: the tile whose U0/U2/U3 the coming phases stage, c2: the one after it
-  {
-    const UnitW w0 = prep_w(c1);
-    issue_x(prep_x(c1, 0), 0, 1); issue_w(w0, 0, 0, 0); issue_x(prep_x(c1, 1), 0, 2); issue_w(w0, 0, 3, 1);
-    advance(c1);
-    if (SCHED == 0) issue_x(prep_x(c1, 0), 1, 1);
-    c2 = c1; advance(c2);
-  }
-  UnitW pw = prep_w(c1);                      // weights of tile t+1
-  UnitX px, px2;                              // the pixel unit(s) the next load half issues
-  if (SCHED == 1) { px = prep_x(c1, 0); px2 = prep_x(c1, 1); }
-#pragma unroll
-  for (int mq = 0; mq < 2; ++mq)
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-      for (int nq = 0; nq < 2; ++nq)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-          const f16x4 h = pv[mq][mi][nq][ni];
-          acc[mq * 4 + mi][nq * 2 + ni] = seeded ? f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]}
-                                       : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-  wait_vm_units(SCHED == 1 ? 0 : min(G, 5) - 2);
-  __builtin_amdgcn_s_barrier();
-  if (SCHED == 0 && wr == 1) __builtin_amdgcn_s_barrier();  // the second channel half runs half a phase behind
-
-  // fragment addresses (LDS byte offsets): row = 16*blk + col, logical 16-byte slot kk*4 + kg, swizzle key col & 7
-  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
-  unsigned fa[2], fb[2];
-#pragma unroll
-  for (int kk = 0; kk < 2; ++kk) {
-    const unsigned f = (unsigned)(col * RB + (((kk * 4 + kg) ^ (col & 7)) << 4));
-    fa[kk] = lds0 + wr * 64 * RB + f;         // + region * UNIT + mi * 16 * RB as the instruction offset
-    fb[kk] = lds0 + wc * 32 * RB + f;
-  }
-
-  f16x8 wf[4][2] = {}, x0[2][2] = {}, x1[2][2] = {};
-  auto mfma_quadrant = [&](auto MQ, auto NQ, f16x8 (&wf)[4][2], f16x8 (&xf)[2][2]) {
-    constexpr int mq = decltype(MQ)::value, nq = decltype(NQ)::value;
-    if ((dbg & 4) || ((dbg & 512) && wr == 1)) return;
-    if (SCHED == 0) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-          acc[mq * 4 + mi][nq * 2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[mi][kk], xf[ni][kk], acc[mq * 4 + mi][nq * 2 + ni], 0, 0, 0);
-    if (SCHED == 0) __builtin_amdgcn_s_setprio(0);
-  };
-#define C8_READ_W(REGION)                                                                              \
-  if (!(dbg & 2)) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                                   \
-    wf[0][kk] = lds_read16_off<(REGION) * UNIT + 0 * 16 * RB>(fa[kk] + bufo);                          \
-    wf[1][kk] = lds_read16_off<(REGION) * UNIT + 1 * 16 * RB>(fa[kk] + bufo);                          \
-    wf[2][kk] = lds_read16_off<(REGION) * UNIT + 2 * 16 * RB>(fa[kk] + bufo);                          \
-    wf[3][kk] = lds_read16_off<(REGION) * UNIT + 3 * 16 * RB>(fa[kk] + bufo);                          \
-  }
-#define C8_READ_X(XF, REGION)                                                                          \
-  if (!(dbg & 2)) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                                   \
-    XF[0][kk] = lds_read16_off<(REGION) * UNIT + 0 * 16 * RB>(fb[kk] + bufo);                          \
-    XF[1][kk] = lds_read16_off<(REGION) * UNIT + 1 * 16 * RB>(fb[kk] + bufo);                          \
-  }
-  // the fragments become valid at the lgkmcnt(0): tying them to the wait keeps the MFMAs behind it
-#define C8_WAIT_W() asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wf[0][0]), "+v"(wf[0][1]), "+v"(wf[1][0]), "+v"(wf[1][1]), \
-                                 "+v"(wf[2][0]), "+v"(wf[2][1]), "+v"(wf[3][0]), "+v"(wf[3][1]) :: "memory")
-#define C8_WAIT_X(XF) asm volatile("" : "+v"(XF[0][0]), "+v"(XF[0][1]), "+v"(XF[1][0]), "+v"(XF[1][1]) :: "memory")
-#define C8_PHASE_SYNC(PH)                         \
-  __builtin_amdgcn_sched_barrier(0);              \
-  __builtin_amdgcn_s_barrier();                   \
-  __builtin_amdgcn_sched_barrier(0)
-#define C8_PHASE_END()                            \
-  __builtin_amdgcn_sched_barrier(0);              \
-  __builtin_amdgcn_s_barrier();                   \
-  __builtin_amdgcn_sched_barrier(0)
-
-  if constexpr (SCHED == 1) {
-    // ONE barrier per K-tile.  After barrier t every wave's pieces of tile t have landed and nobody reads the other buffer
-    // any more, so tile t+1 streams into it while tile t is computed; a wave waits for its own pieces (issued 1-2 k cycles
-    // earlier) only at the end of the tile.  An LDS-DMA issue blocks its wave for 60-200 cycles per piece: the two waves of a
-    // SIMD (channel halves 0 / 1) issue their 8 pieces at different points of the tile - at its start / between the second
-    // and the third quadrant - so one of them is in an MFMA cluster while the other is stuck in the texture queue.  Within the
-    // tile a wave is free-running: all 24 fragment reads go out ahead of the quadrant that needs them (counted lgkmcnt).
-    f16x8 wg[4][2] = {};                       // second weight set: channels 4-7 are read while 0-3 are still in use
-    auto issue_tile = [&](int tile) {
-      issue_x(px, tile, 1); issue_w(pw, tile, 0, 0); issue_x(px2, tile, 2); issue_w(pw, tile, 3, 1);
-    };
-    for (int t = 0; t < T; ++t) {
-      const unsigned bufo = (unsigned)((t & 1) * BUF);
-      if (wr == 0) issue_tile(t + 1);
-      C8_READ_X(x0, 1)
-      C8_READ_W(0)
-      C8_READ_X(x1, 2)
-      asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(wf[0][0]), "+v"(wf[0][1]), "+v"(wf[1][0]), "+v"(wf[1][1]), "+v"(wf[2][0]),
-                   "+v"(wf[2][1]), "+v"(wf[3][0]), "+v"(wf[3][1]), "+v"(x0[0][0]), "+v"(x0[0][1]), "+v"(x0[1][0]),
-                   "+v"(x0[1][1]) :: "memory");
-      mfma_quadrant(I0{}, I0{}, wf, x0);
-      if (!(dbg & 2)) {
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-          wg[0][kk] = lds_read16_off<3 * UNIT + 0 * 16 * RB>(fa[kk] + bufo);
-          wg[1][kk] = lds_read16_off<3 * UNIT + 1 * 16 * RB>(fa[kk] + bufo);
-          wg[2][kk] = lds_read16_off<3 * UNIT + 2 * 16 * RB>(fa[kk] + bufo);
-          wg[3][kk] = lds_read16_off<3 * UNIT + 3 * 16 * RB>(fa[kk] + bufo);
-        }
-      }
-      asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(x1[0][0]), "+v"(x1[0][1]), "+v"(x1[1][0]), "+v"(x1[1][1]) :: "memory");
-      mfma_quadrant(I0{}, I1{}, wf, x1);
-      if (wr == 1) issue_tile(t + 1);
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wg[0][0]), "+v"(wg[0][1]), "+v"(wg[1][0]), "+v"(wg[1][1]), "+v"(wg[2][0]),
-                   "+v"(wg[2][1]), "+v"(wg[3][0]), "+v"(wg[3][1]) :: "memory");
-      // operands of the tile after next: scalar work that hides in the MFMA gaps
-      advance(c1);
-      pw = prep_w(c1); px = prep_x(c1, 0); px2 = prep_x(c1, 1);
-      mfma_quadrant(I1{}, I1{}, wg, x1);
-      mfma_quadrant(I1{}, I0{}, wg, x0);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  } else {
-#ifdef GLORIE_CONV8_TIMELINE        // per-phase checkpoints (tools/conv8_timeline.py); they cost ~100 cycles each: off in the product
-#define C8_STAMP(k) do { if ((dbg & 128) && lid == 0 && lane == 0 && t >= 10 && t < 13)                  \
-    a.stamps[wv * 128 + (t - 10) * 32 + (k)] = __builtin_readcyclecounter(); } while (0)
-#else
-#define C8_STAMP(k) do { } while (0)
-#endif
-  for (int t = 0; t < T; ++t) {
-    const unsigned bufo = (unsigned)((t & 1) * BUF);
-    const int ph = 4 * t;
-    C8_STAMP(0);
-    // ---- p1: (channels 0-3, pixels 0-1)
-    C8_READ_X(x0, 1)
-    C8_READ_W(0)
-    C8_STAMP(1);
-    issue_w(pw, t + 1, 0, 0);
-    C8_STAMP(2);
-    wait_vm_units((dbg & 8) ? 0 : min(3, G - 3 - ph));
-    C8_STAMP(3);
-    C8_PHASE_SYNC(ph);
-    C8_STAMP(4);
-    C8_WAIT_W(); C8_WAIT_X(x0);
-    C8_STAMP(5);
-    px = prep_x(c1, 1);
-    mfma_quadrant(I0{}, I0{}, wf, x0);
-    C8_STAMP(6);
-    C8_PHASE_END();
-    C8_STAMP(7);
-    // ---- p2: (channels 0-3, pixels 2-3)
-    C8_READ_X(x1, 2)
-    C8_STAMP(8 + 1);
-    issue_x(px, t + 1, 2);
-    C8_STAMP(8 + 2);
-    wait_vm_units((dbg & 8) ? 0 : min(3, G - 3 - (ph + 1)));
-    C8_STAMP(8 + 3);
-    C8_PHASE_SYNC(ph + 1);
-    C8_STAMP(8 + 4);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); C8_WAIT_X(x1);
-    C8_STAMP(8 + 5);
-    mfma_quadrant(I0{}, I1{}, wf, x1);
-    C8_STAMP(8 + 6);
-    C8_PHASE_END();
-    C8_STAMP(8 + 7);
-    // ---- p3: (channels 4-7, pixels 2-3)
-    C8_READ_W(3)
-    C8_STAMP(16 + 1);
-    issue_w(pw, t + 1, 3, 1);
-    C8_STAMP(16 + 2);
-    wait_vm_units((dbg & 8) ? 0 : min(3, G - 3 - (ph + 2)));
-    C8_STAMP(16 + 3);
-    C8_PHASE_SYNC(ph + 2);
-    C8_STAMP(16 + 4);
-    C8_WAIT_W();
-    C8_STAMP(16 + 5);
-    px = prep_x(c2, 0);
-    mfma_quadrant(I1{}, I1{}, wf, x1);
-    C8_STAMP(16 + 6);
-    C8_PHASE_END();
-    C8_STAMP(16 + 7);
-    // ---- p4: (channels 4-7, pixels 0-1), fragments already in registers
-    C8_STAMP(24 + 1);
-    issue_x(px, t + 2, 1);
-    C8_STAMP(24 + 2);
-    wait_vm_units((dbg & 8) ? 0 : min(3, G - 3 - (ph + 3)));
-    C8_STAMP(24 + 3);
-    C8_PHASE_SYNC(ph + 3);
-    C8_STAMP(24 + 4);
-    C8_STAMP(24 + 5);
-    c1 = c2; advance(c2);
-    pw = prep_w(c1);
-    mfma_quadrant(I1{}, I0{}, wf, x0);
-    C8_STAMP(24 + 6);
-    C8_PHASE_END();
-    C8_STAMP(24 + 7);
-  }
-#undef C8_STAMP
-  if (wr == 0) __builtin_amdgcn_s_barrier();
-  }
-  if ((dbg & 256) && a.stamps && lane == 0 && wv == 0 && lid < 64) a.stamps[1024 + lid * 2 + 1] = __builtin_readcyclecounter();
-#undef C8_READ_W
-#undef C8_READ_X
-#undef C8_WAIT_W
-#undef C8_WAIT_X
-#undef C8_PHASE_SYNC
-#undef C8_PHASE_END
-
-  // ---- epilogue: lane owns channels n0 + wr*128 + 16*mi + kg*4 .. +3 of pixels p0 + wc*64 + 16*ni + col
-  conv_epilogue_tile<EPI, 8, 4>(a, acc, p0 + wc * 64 + col, n0 + wr * 128 + kg * 4);
-#endif
-}
-
-template <int EPI>
-static void launch_conv8_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
-  constexpr size_t lds = 2 * 4 * 128 * 128;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv8_kernel<EPI, 0, false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv8_kernel<EPI, 1, false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv8_kernel<EPI, 0, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv8_kernel<EPI, 1, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr = true;
-  }
-  const char* sc = getenv("GLORIE_CONV8_SCHED");
-  const bool phases8 = sc && sc[0] == '0';
-  if (a.dbg) {
-    if (phases8) hipLaunchKernelGGL((conv8_kernel<EPI, 0, true>), grid, dim3(512), lds, st, a);
-    else hipLaunchKernelGGL((conv8_kernel<EPI, 1, true>), grid, dim3(512), lds, st, a);
-  } else {
-    if (phases8) hipLaunchKernelGGL((conv8_kernel<EPI, 0, false>), grid, dim3(512), lds, st, a);
-    else hipLaunchKernelGGL((conv8_kernel<EPI, 1, false>), grid, dim3(512), lds, st, a);
-  }
-}
-
-static int launch_conv8(const ConvArgs& a, int epilogue, hipStream_t st) {
-  const long nwg = ((a.P - a.pbeg + 255) / 256) * (a.nout / 256);
-  if (nwg > 0x7fffffffL) return GLORIE_EINVAL;
-  const dim3 grid((unsigned)nwg);
-  switch (epilogue) {
-    case EPI_BIAS_ACT: launch_conv8_one<EPI_BIAS_ACT>(a, grid, st); break;
-    case EPI_GRU_ZR: launch_conv8_one<EPI_GRU_ZR>(a, grid, st); break;
-    default: launch_conv8_one<EPI_GRU_Q>(a, grid, st); break;
-  }
-  return check_launch();
-}
-
 template <int EPI, int NB, int BK, int NW, int ST, int MB>
 static void launch_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
   constexpr int RB = BK * 2, PT = (NW / 2) * 16 * NB;
@@ -1812,59 +1081,6 @@ static int launch_conv_halo(const ConvArgs& a, int epilogue, hipStream_t st) {
   return check_launch();
 }
 
-template <int EPI>
-static void launch_ps_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
-  constexpr size_t lds = 2 * (128 * 128 + 128 * 128);          // two stages; the seeding / epilogue uses fit inside
-  hipLaunchKernelGGL((conv_ps_kernel<EPI>), grid, dim3(512), lds, st, a);
-}
-static int launch_conv_ps(const ConvArgs& a, int epilogue, hipStream_t st) {
-  constexpr int PT = 128;
-  long ptiles = (a.P - a.pbeg + PT - 1) / PT;
-  if (epilogue == EPI_GLO) ptiles = (a.P / a.HW) * ((a.HW + PT - 1) / PT);
-  if (ptiles <= 0) return GLORIE_OK;
-  const long nwg = ptiles * ((a.nout + 127) / 128);
-  if (nwg > 0x7fffffffL) return GLORIE_EINVAL;
-  const dim3 grid((unsigned)nwg);
-  switch (epilogue) {
-    case EPI_BIAS_ACT: launch_ps_one<EPI_BIAS_ACT>(a, grid, st); break;
-    case EPI_GRU_ZR: launch_ps_one<EPI_GRU_ZR>(a, grid, st); break;
-    case EPI_GLO: launch_ps_one<EPI_GLO>(a, grid, st); break;
-    case EPI_HEADS: launch_ps_one<EPI_HEADS>(a, grid, st); break;
-    case EPI_UPSAMPLE: launch_ps_one<EPI_UPSAMPLE>(a, grid, st); break;
-    default: launch_ps_one<EPI_GRU_Q>(a, grid, st); break;
-  }
-  return check_launch();
-}
-
-template <int EPI, int MB, int NB>
-static void launch_ps2_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
-  constexpr size_t lds = 3 * (size_t)(32 * NB + 32 * MB) * 128;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_ps2_kernel<EPI, MB, NB>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr = true;
-  }
-  hipLaunchKernelGGL((conv_ps2_kernel<EPI, MB, NB>), grid, dim3(512), lds, st, a);
-}
-template <int MB, int NB>
-static int launch_conv_ps2(ConvArgs a, int epilogue, hipStream_t st) {
-  constexpr int PT = 32 * NB, TN = 32 * MB;
-  const long ptiles = (a.P - a.pbeg + PT - 1) / PT;
-  if (ptiles <= 0) return GLORIE_OK;
-  const long nwg = ptiles * ((a.nout + TN - 1) / TN);
-  if (nwg > 0x7fffffffL) return GLORIE_EINVAL;
-  const dim3 grid((unsigned)nwg);
-  a.pre_late = 1;                                  // the context term rides with the epilogue's other loads
-  switch (epilogue) {
-    case EPI_BIAS_ACT: launch_ps2_one<EPI_BIAS_ACT, MB, NB>(a, grid, st); break;
-    case EPI_GRU_ZR: launch_ps2_one<EPI_GRU_ZR, MB, NB>(a, grid, st); break;
-    case EPI_GRU_Q: launch_ps2_one<EPI_GRU_Q, MB, NB>(a, grid, st); break;
-    default: return GLORIE_EUNSUPPORTED;
-  }
-  return check_launch();
-}
-
 template <int NB, int BK, int NW, int ST, int MB = 4>
 static int launch_conv(const ConvArgs& a, int epilogue, hipStream_t st, long max_ptiles = -1) {
   constexpr int PT = (NW / 2) * 16 * NB;
@@ -1909,7 +1125,10 @@ static int conv_igemm_impl(const void* xa, int xa_stride, int ca, const void* xb
                            float* up_out = nullptr, int up_f32 = 0) {
   if (N < 0 || H <= 0 || W <= 0 || (taps != 1 && taps != 9) || nout <= 0 || (nout & 3)) return GLORIE_EINVAL;
   if (ca < 0 || cb < 0 || (ca % 64) || (cb % 64) || ca + cb == 0) return GLORIE_EINVAL;
+  const int pair = (epilogue >> 8) & 1;                 // GLORIE_CONV_PAIR16: the weights come from a paired packing
+  epilogue &= 0xff;
   if (epilogue < 0 || epilogue > 5) return GLORIE_EINVAL;
+  if (pair && (epilogue > EPI_GRU_Q || (nout & 31))) return GLORIE_EINVAL;
   if (epilogue == EPI_UPSAMPLE && (!up_disps || !up_ix || !up_out || !terms || nout != 1024 || taps != 1 || pre))
     return GLORIE_EINVAL;
   if (epilogue == EPI_HEADS && (!tap_w || !tap_out || !terms || tap_groups < 1 || tap_ncols < 1 || tap_ncols > 32 ||
@@ -1942,9 +1161,9 @@ static int conv_igemm_impl(const void* xa, int xa_stride, int ca, const void* xb
   // every iteration, L2 resident - its loads ride with the epilogue's other loads, 277 -> 274 us in the steps) and seeds the
   // accumulators through LDS when it is a per-edge tensor streamed from HBM; GLORIE_CONV_PRE=e|s forces either
   { const char* pl_ = getenv("GLORIE_CONV_PRE"); a.pre_late = pl_ ? (pl_[0] == 'e') : (a.pre_map != nullptr); }
-  { const char* d = getenv("GLORIE_CONV8_DBG"); a.dbg = d ? atoi(d) : 0; }
-  a.stamps = getenv("GLORIE_CONV8_STAMPS") ? (unsigned long long*)strtoull(getenv("GLORIE_CONV8_STAMPS"), nullptr, 0) : nullptr;
-  if (!a.stamps) a.dbg &= ~(128 | 256);
+  a.pair = pair;
+  if (pair) a.pre_late = 1;                  // the accumulator seeding reads `pre` in the unpaired channel order
+  a.stamps = getenv("GLORIE_CONV_STAMPS") ? (unsigned long long*)strtoull(getenv("GLORIE_CONV_STAMPS"), nullptr, 0) : nullptr;
   // buffer-descriptor addressing: 31-bit byte offsets per input segment and for the weights
   const long lim = 0x7fffffffL;
   if (((a.P + W + 2) * (long)xa_stride + 64) * 2 > lim || ((a.P + W + 2) * (long)xb_stride + 64) * 2 > lim ||
@@ -1958,24 +1177,13 @@ static int conv_igemm_impl(const void* xa, int xa_stride, int ca, const void* xb
   // (loads two steps ahead, ST = 4) 915, 8 waves with a 3-stage ring and counted vmcnt 830, 256-pixel
   // tiles 850, 32-channel steps at 4 workgroups per CU 824; the same wave tile on v_mfma_f32_32x32x16_f16
   // (16 instead of 32 MFMAs per step) 945.
-  // 256-channel multiples (the z|r gates) can run on 256 x 256 tiles (conv8_kernel, GLORIE_CONV8=1).  Measured on the
-  // 36-edge gate launch it needs 3107 cycles per 256 x 256 x 64 block against 4 x 807 = 3230 for the 128 x 128 kernel,
-  // but its 675 workgroups fill 2.64 rounds of 256 CUs (one workgroup per CU) where 2700 fill 3.52 rounds of 768 slots:
-  // 385 vs 345 us.  It stays opt-in; tests/test_gpu_update_op.py pins it bit for bit against the 128 x 128 kernel.
-  const char* c8 = getenv("GLORIE_CONV8");
-  const bool conv8_on = c8 && c8[0] == '1';
-  const char* ps = getenv("GLORIE_CONV_PS");
-  if (ps && ps[0] == '1') return launch_conv_ps(a, epilogue, st);
-  if (ps && ps[0] == '2' && taps == 9 && epilogue <= EPI_GRU_Q && nout >= 128)
-    return (nout & 255) == 0 ? launch_conv_ps2<8, 4>(a, epilogue, st) : launch_conv_ps2<4, 8>(a, epilogue, st);
   // 3x3 layers on the 128-channel tile: the pixel tile is shared by the nine taps of a chunk (conv_halo_kernel) while its haloed
   // tile leaves three workgroups per CU (image width <= 83); small launches keep their 64-pixel tiles, the 256- and 64-channel
   // tiles their per-tap staging (measured slower with the shared tile).  GLORIE_CONV_HALO=0: per-tap staging everywhere.
   {
     const char* hl = getenv("GLORIE_CONV_HALO");
     const char* tmv = getenv("GLORIE_CONV_TILE");
-    const char* c8v = getenv("GLORIE_CONV8");
-    const bool plain_env = (tmv && tmv[0]) || (c8v && c8v[0] == '1');
+    const bool plain_env = tmv && tmv[0];
     if (!(hl && hl[0] == '0') && !plain_env && taps == 9 && a.pbeg == 0) {
       const long tiles128 = (a.P + 127) / 128 * ((nout + 127) / 128);
       if (nout > 64 && (nout & 255) != 0 && W <= 83 && (epilogue <= EPI_GRU_Q || epilogue == EPI_HEADS) &&
@@ -1984,7 +1192,6 @@ static int conv_igemm_impl(const void* xa, int xa_stride, int ca, const void* xb
     }
   }
   if (epilogue == EPI_HEADS || epilogue == EPI_UPSAMPLE) return launch_conv<4, 64, 4, 1>(a, epilogue, st);
-  if (conv8_on && (nout & 255) == 0 && a.P >= 256) return launch_conv8(a, epilogue, st);
   // layers with <= 64 output channels (flow_encoder[2]) use a 64-channel tile instead of padding to 128
   if (nout <= 64 && epilogue == EPI_BIAS_ACT) return launch_conv<4, 64, 4, 1, 2>(a, epilogue, st);
   // Tile choice.  Default: 128 x 128 (3 workgroups per CU); layers whose output channels are a multiple of 256 (the z|r
@@ -2029,7 +1236,7 @@ extern "C" int glorie_conv_igemm(const void* xa, int xa_stride, int ca, const vo
                                  int net_stride, const void* z, int z_stride, void* out, int out_stride,
                                  void* out2, int out2_stride, const void* pre, int pre_stride, const int* pre_map,
                                  int N, int H, int W, void* stream) {
-  if (epilogue == EPI_HEADS || epilogue == EPI_UPSAMPLE) return GLORIE_EINVAL;          // have their own entry points
+  if ((epilogue & 0xff) == EPI_HEADS || (epilogue & 0xff) == EPI_UPSAMPLE) return GLORIE_EINVAL;   // have their own entry points
   return conv_igemm_impl(xa, xa_stride, ca, xb, xb_stride, cb, w_packed, taps, nout, epilogue, terms, terms_stride, act,
                          net, net_stride, z, z_stride, out, out_stride, out2, out2_stride, pre, pre_stride, pre_map, N, H,
                          W, stream, nullptr, nullptr, 0, 0);

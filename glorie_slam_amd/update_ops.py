@@ -172,16 +172,31 @@ def conv3x3_small(x, w_packed, out_bias, K, acts, scale=1.0, in_bias=None, in_re
 EPI_BIAS_ACT, EPI_GRU_ZR, EPI_GRU_Q, EPI_GLO = 0, 1, 2, 3
 
 
-def pack_conv_igemm(weight):
+EPI_PAIR16 = 0x100          # flag on glorie_conv_igemm's `epilogue`: the weights come from pack_conv_igemm(pair=True)
+
+
+def pack_conv_igemm(weight, pair=False):
     """conv weight [Nout, C, k, k] (k = 1 or 3) -> the fp16 operand of glorie_conv_igemm:
-    [taps][npad][C] (npad = Nout rounded up to 128, zero rows) followed by 64 zero halfs"""
+    [taps][npad][C] (npad = Nout rounded up to 128, zero rows) followed by 64 zero halfs.
+    pair: within every group of 32 output channels, row 16 blk + r holds channel 8 (r // 4) + 4 blk + r % 4, so that a lane of
+    the kernel owns 8 consecutive channels of its pixel (16-byte epilogue loads / stores, csrc/conv.hip: conv_epilogue_pair);
+    the tensor remembers it (conv_igemm passes EPI_PAIR16).  Bias / gate epilogues only, Nout % 32 == 0."""
     nout, C, kh, kw = weight.shape
     if kh != kw or kh not in (1, 3) or C % 64:
         raise RuntimeError("pack_conv_igemm: need 1x1 or 3x3 weights with C % 64 == 0")
     taps, npad = kh * kw, (nout + 127) // 128 * 128
     w = torch.zeros(taps, npad, C, dtype=torch.float16, device=weight.device)
     w[:, :nout] = weight.detach().permute(2, 3, 0, 1).reshape(taps, nout, C).half()
-    return torch.cat([w.reshape(-1), torch.zeros(64, dtype=torch.float16, device=weight.device)])
+    if pair:
+        if nout % 32:
+            raise RuntimeError("pack_conv_igemm: pair needs Nout % 32 == 0")
+        R = torch.arange(npad, device=weight.device)
+        r = R % 16
+        chan = 32 * (R // 32) + 8 * (r // 4) + 4 * ((R % 32) // 16) + r % 4
+        w = w[:, chan]
+    out = torch.cat([w.reshape(-1), torch.zeros(64, dtype=torch.float16, device=weight.device)])
+    out._glorie_pair = bool(pair)
+    return out
 
 
 def pack_corr_encoder(weight):
@@ -242,8 +257,10 @@ def conv_igemm(xa, xb, w_packed, taps, nout, out, epilogue=EPI_BIAS_ACT, terms=N
     if pre_map is not None and (pre is None or pre_map.dtype != torch.int32 or pre_map.numel() != n or
                                 not pre_map.is_contiguous() or pre_map.device != ref.device):
         raise RuntimeError("conv_igemm: pre_map must be a contiguous int32 [N] on the device, next to pre")
-    if out.shape[1] != (128 if epilogue != EPI_BIAS_ACT else nout) or out.shape[0] != n:
+    if out.shape[1] != (128 if (epilogue & 0xff) != EPI_BIAS_ACT else nout) or out.shape[0] != n:
         raise RuntimeError("conv_igemm: bad output shape")
+    if getattr(w_packed, "_glorie_pair", False):
+        epilogue |= EPI_PAIR16
     L.check(L.load().glorie_conv_igemm(pa, sa, ca, pb, sb, cb, L.ptr(w_packed), taps, nout, epilogue,
                                        L.ptr(terms), ts, act, pn, sn, pz, sz, L.ptr(out), _rows(out, "out"),
                                        po2, so2, pp, sp, L.ptr(pre_map), n, h, w, L.stream_ptr()), "glorie_conv_igemm")

@@ -9,7 +9,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 stamps = torch.zeros(16 * 4 * 4 * 8, dtype=torch.int64, device="cuda")
-os.environ["GLORIE_CONV8_STAMPS"] = str(stamps.data_ptr())
+os.environ["GLORIE_CONV_STAMPS"] = str(stamps.data_ptr())
 import bench  # noqa: E402
 
 dev = torch.device("cuda:0")
