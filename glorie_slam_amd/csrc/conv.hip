@@ -71,10 +71,12 @@ struct ConvArgs {
 
 constexpr int kTileN = 128;       // output channels per workgroup
 
-__device__ __forceinline__ float csigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// v_rcp_f32 (1 ulp) instead of the IEEE division sequence (v_div_scale / v_rcp / four FMAs / v_div_fmas / v_div_fixup per
+// element): the gates are rounded to fp16 right after, and the epilogues evaluate 128 of these per lane
+__device__ __forceinline__ float csigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float ctanh(float x) {
   const float e = __expf(-2.0f * fabsf(x));
-  return copysignf((1.0f - e) / (1.0f + e), x);
+  return copysignf((1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e), x);
 }
 
 __device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
