@@ -25,7 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
-PMC_SUMMARY = "r02_pmc_kernels.json"   # refreshed per round by tools/pmc_passes.sh
+PMC_SUMMARY = "r04_pmc_kernels.json"   # refreshed per round by tools/pmc_passes.sh
 PMC_CORR_SUMMARY = "r03_pmc_corr.json"  # tools/pmc_corr.sh
 MFMA_F16_PEAK_TF = 2500.0  # same guide: ~2.5 PFLOP/s dense f16/bf16 (not the 2:1-sparsity figure)
 
@@ -310,21 +310,25 @@ def main():
         step_no[0] = 0
         graph.target, graph.weight, graph.net = target0.clone(), weight0.clone(), net0.clone()
 
-    def step():
-        # DSPO schedule of the frontend (frontend.py:50-53): stages alternate
-        opt = "pose_depth" if step_no[0] % 2 == 0 else "depth_scale"
-        fu = graph.fast_update
-        if step_no[0] % 12 == 0 and fu is not None and (fu._pre is not None or fu._pre_kf is not None):
-            # The gate convolutions over the context features are evaluated once per edge set, not per
-            # iteration (FusedUpdate.precompute_shared_context: one map per source keyframe).  The frontend adds
-            # one keyframe and a few edges every 12 iterations (frontend.py:23-24); the bench graph never changes,
-            # so that cost is charged here explicitly, conservatively for ALL keyframes, every 12 timed steps.
-            if fu._pre_kf is not None:
-                fu.precompute_shared_context((video.inps, graph._unique_ii(), graph._groups()[0]))
-            else:
-                fu.precompute_context()
-        step_no[0] += 1
-        graph.update(t0=1, t1=K, itrs=2, use_inactive=False, opt_type=opt)
+    def make_step(graph_, video_, K_, counter):
+        def step_():
+            # DSPO schedule of the frontend (frontend.py:50-53): stages alternate
+            opt = "pose_depth" if counter[0] % 2 == 0 else "depth_scale"
+            fu = graph_.fast_update
+            if counter[0] % 12 == 0 and fu is not None and (fu._pre is not None or fu._pre_kf is not None):
+                # The gate convolutions over the context features are evaluated once per edge set, not per
+                # iteration (FusedUpdate.precompute_shared_context: one map per source keyframe).  The frontend adds
+                # one keyframe and a few edges every 12 iterations (frontend.py:23-24); the bench graph never changes,
+                # so that cost is charged here explicitly, conservatively for ALL keyframes, every 12 timed steps.
+                if fu._pre_kf is not None:
+                    fu.precompute_shared_context((video_.inps, graph_._unique_ii(), graph_._groups()[0]))
+                else:
+                    fu.precompute_context()
+            counter[0] += 1
+            graph_.update(t0=1, t1=K_, itrs=2, use_inactive=False, opt_type=opt)
+        return step_
+
+    step = make_step(graph, video, K, step_no)
 
     def barrier():
         if world > 1:
@@ -338,16 +342,28 @@ def main():
     for _ in range(args.warmup):
         step()
     reset()
-    barrier()
-    t_start = time.perf_counter()
-    for _ in range(args.steps):
+
+    def timed_steps(n):
+        barrier()
+        t0_ = time.perf_counter()
+        for _ in range(n):
+            step()
+        barrier()
+        dt = time.perf_counter() - t0_
+        if world > 1:
+            tmax = torch.tensor([dt], device=device)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt
+
+    # `value` is measured on a WARM chip: K steps straight after the warm-up run on boost clocks (a 20-step burst is 20 ms),
+    # which no tracking session sustains.  The burst figure is kept as `burst_value`; then `soak` untimed steps bring the
+    # part to the clocks it holds under this load and the K timed steps of the contract follow.
+    burst_elapsed = timed_steps(args.steps)
+    soak_steps = int(os.environ.get("GLORIE_BENCH_SOAK", "300"))
+    for _ in range(soak_steps):
         step()
-    barrier()
-    elapsed = time.perf_counter() - t_start
-    if world > 1:
-        tmax = torch.tensor([elapsed], device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed = timed_steps(args.steps)
     # ---- the timed steps did the work they claim: solver status, finite state, stage-2 fallbacks ----
     ba_st = video.ctx().ba_status()
     assert ba_st[0] == 0, f"BA status word after the timed loop: {ba_st} (bit 0 eta/M mismatch, bit 2 Cholesky failed)"
@@ -372,6 +388,65 @@ def main():
     ba_st2 = video.ctx().ba_status()
     assert ba_st2[0] == 0 and bool(torch.isfinite(video.poses).all()), \
         f"after {sustained_steps} sustained steps: BA status {ba_st2}, finite poses {bool(torch.isfinite(video.poses).all())}"
+
+    # ---- the same graph at the size of the SHIPPED Replica config (configs/Replica/replica.yaml:55-56: 320 x 640 output ->
+    # 40 x 80 maps, HW = 3200; SURVEY 8: "report both"), same schedule, soak + 100 timed steps
+    replica_yaml = None
+    if world == 1:
+        gR, videoR, graphR = build_graph(device, K=8, h=40, w=80, use_graphs=os.environ.get("GLORIE_NO_GRAPHS") is None)
+        stepR = make_step(graphR, videoR, 8, [0])
+        for _ in range(4 + 150):
+            stepR()
+        torch.cuda.synchronize()
+        t_r0 = time.perf_counter()
+        for _ in range(100):
+            stepR()
+        torch.cuda.synchronize()
+        ms_r = 1e3 * (time.perf_counter() - t_r0) / 100
+        okR = videoR.ctx().ba_status()[0] == 0 and bool(torch.isfinite(videoR.poses).all())
+        replica_yaml = {"workload": "G8 topology (8 keyframes, 36 edges) at 40x80 maps = 320x640 / 8", "hw": 3200, "steps": 100,
+                        "ms_per_step": ms_r, "iters_per_sec": 1e3 / ms_r, "state_ok": bool(okR)}
+        del graphR, videoR, gR, stepR
+        torch.cuda.empty_cache()
+
+    # ---- the exchange step by itself (self-verification of a multi-GPU record): who took part, how many bytes, how long
+    exchange = None
+    try:
+        from glorie_slam_amd import dist as gdist
+        P_ = K - 1
+        n6 = 6 * P_
+        hv_ = torch.zeros(n6 * n6 + n6, dtype=torch.float64, device=device)
+        ctx_ = video.ctx()
+        native_world = gdist.ctx_comm_world(ctx_)
+        grp = video.shard["group"] if getattr(video, "shard", None) else None
+        packed = n6 >= gdist.PACK_MIN_N6
+        nbytes = 8 * ((n6 * (n6 + 1) // 2 + n6) if packed else (n6 * n6 + n6))
+        ar_ms = None
+        if world > 1 or native_world > 0:
+            for _ in range(3):
+                gdist.allreduce_system(hv_, grp, n6=n6, force=True, ctx=ctx_)
+            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            barrier()
+            a0.record()
+            for _ in range(20):
+                gdist.allreduce_system(hv_, grp, n6=n6, force=True, ctx=ctx_)
+            a1.record()
+            torch.cuda.synchronize()
+            ar_ms = a0.elapsed_time(a1) / 20
+        edges_by_rank = [int(graph.ii.numel())]
+        if world > 1:
+            tl = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+            dist.all_gather(tl, torch.tensor([int(graph.ii.numel())], dtype=torch.int64, device=device))
+            edges_by_rank = [int(t_.item()) for t_ in tl]
+        exchange = {"torch_distributed_world": int(dist.get_world_size()) if (dist.is_available() and dist.is_initialized()) else 1,
+                    "backend": (dist.get_backend() if (dist.is_available() and dist.is_initialized()) else None),
+                    "rccl_ranks_ctx_communicator": int(native_world),
+                    "path": "glorie_allreduce_normal_eq (ctx-owned RCCL communicator)" if native_world > 0 else
+                            ("torch.distributed all_reduce" if world > 1 else "none (one rank)"),
+                    "pose_unknowns": int(n6), "allreduce_bytes": int(nbytes), "packed_lower_triangle": bool(packed),
+                    "allreduce_ms": ar_ms, "allreduces_per_step": 2, "edges_local_by_rank": edges_by_rank}
+    except Exception as exc:
+        exchange = {"error": repr(exc)[:300]}
 
     # ---- strong scaling: ONE fixed long graph whatever the number of ranks (the case the sharding is for, BASELINE
     # config 4: 30x40 maps, here 128 keyframes (GLORIE_STRONG_K) in a +-3 window = 756 edges, volume-free correlation), edges sharded by
@@ -669,6 +744,56 @@ def main():
                     "ms_per_global_ba_2steps": float(np.median(srun.timing["ba_ms"])), "cloud_points": ssum["points"],
                     "note": "untrained networks, flow head zeroed (fixed point at the generating trajectory): costs, not accuracy"}
         del srun, sc, simgs
+    # ---- config 3 at length: 220 frames (glorie_slam_amd.pipeline.synthetic_long_runner: culled repeats, loop closure into
+    # revisits, global BA every 20 keyframes, 20 mapping iterations per kept keyframe, 512-frame buffer)
+    sequence_long = None
+    if rank == 0 and world == 1 and not args.no_sequence:
+        try:
+            from glorie_slam_amd.pipeline import synthetic_long_runner
+            torch.cuda.empty_cache()
+            torch.cuda.reset_peak_memory_stats()
+            lrun, lc, lframes = synthetic_long_runner(device, n_frames=220, map_iters=20)
+            n_loop = [0, 0]
+            real_loop = lrun.frontend.loop_closing.loop_ba
+
+            def counted_loop(*a, **k):
+                o_ = real_loop(*a, **k)
+                n_loop[0] += 1
+                n_loop[1] += int(o_[1] > 0)
+                return o_
+            lrun.frontend.loop_closing.loop_ba = counted_loop
+            torch.cuda.synchronize()
+            t_l = time.perf_counter()
+            lsum = lrun.run(lframes(), lc["intrinsics"], final_ba_steps=4)
+            torch.cuda.synchronize()
+            t_l = time.perf_counter() - t_l
+            tr = np.array(lrun.timing["track_ms"])
+            kp = np.array(lrun.timing["kept"])
+            after_boot = np.arange(len(tr)) > 8
+            kept_ms = tr[kp & after_boot]
+            fgl = lrun.frontend.graph
+            Kl = int(lsum["keyframes"])
+            sequence_long = {
+                "frames": 220, "kept_keyframes": Kl, "culled": int(220 - Kl), "resolution": "640x480 (60x80 BA)", "video_buffer": 512,
+                "wall_s": t_l, "ms_per_kept_keyframe_p50": float(np.percentile(kept_ms, 50)),
+                "ms_per_kept_keyframe_p95": float(np.percentile(kept_ms, 95)),
+                "ms_per_culled_frame_p50": float(np.percentile(tr[~kp & after_boot], 50)) if (~kp & after_boot).any() else None,
+                "loop_ba_calls": n_loop[0], "loop_ba_with_edges": n_loop[1],
+                "global_ba_calls": len(lrun.timing["ba_ms"]), "ms_per_global_ba_last": float(lrun.timing["ba_ms"][-1]),
+                "ms_per_mapping_iteration": float(np.mean(lrun.timing["map_iter_ms"][2:])),
+                "hipgraph_captures_per_keyframe": fgl.stats["captures"] / max(Kl, 1),
+                "hipgraph_replays_per_keyframe": fgl.stats["replays"] / max(Kl, 1),
+                "eager_updates_per_keyframe": fgl.stats["eager"] / max(Kl, 1),
+                "corr_arena_slots_high_water": int(fgl.corr.capacity), "frontend_max_factors": int(fgl.max_factors),
+                "cloud_points": int(lsum["points"]),
+                "max_memory_allocated_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
+                "state_ok": bool(lc["video"].ctx().ba_status()[0] == 0 and torch.isfinite(lc["video"].poses[:Kl]).all()),
+                "mapping_loss_decreased": int(sum(1 for a_, b_ in lsum["losses"] if b_ < a_)),
+                "note": "untrained networks, flow head zeroed (fixed point at the generating trajectory): costs, not accuracy"}
+            del lrun, lc, lframes
+            torch.cuda.empty_cache()
+        except Exception as exc:
+            sequence_long = {"error": repr(exc)[:300]}
     # KNN + feature gather alone (HIP events), 2156 B per sample
     S = ren.N_surface
     nq = min(rays["o"].shape[0], 61440)            # 96 image rows: the batch render_img evaluates
@@ -729,6 +854,7 @@ def main():
         "unit": "BA-update iters/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
+        "soak_steps": soak_steps, "burst_value": world * args.steps / burst_elapsed,
         "sustained_ms_per_step": sustained_ms, "sustained_steps": sustained_steps,
         "sustained_value": world * 1e3 / sustained_ms,
         "checks": {"ba_status": ba_st, "stage2_fallbacks": fallbacks, "stage2_steps": stage2_steps,
@@ -780,6 +906,9 @@ def main():
         "rays_per_sec_batch5000": 5000.0 / (batch_ms * 1e-3), "ms_per_batch5000": batch_ms,
         "train_batch5000": train,
         "sequence": sequence,
+        "sequence_long": sequence_long,
+        "replica_yaml_40x80": replica_yaml,
+        "exchange_step": exchange,
         "strong_scaling_graph": strong,
         "render": {"rays_local": int(n_r // render_reps), "samples_per_ray": int(S), "cloud_points": int(npc.pts_num()),
                    "ms_per_frame_shard": 1e3 * t_r / render_reps},

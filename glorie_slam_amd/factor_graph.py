@@ -49,6 +49,7 @@ class FactorGraph:
         self.target_inac, self.weight_inac = zero_tw(), zero_tw()
         self._uniq_cache = None
         self.use_graphs = bool(use_graphs) and str(device).startswith("cuda")
+        self.stats = {"captures": 0, "replays": 0, "eager": 0}     # hipGraph bookkeeping of update() (pipeline / bench)
         self._topo = 0                      # bumped whenever the edge set changes
         self._graphs = {}                   # (topology, arguments) -> captured update
         self._lowmem_update = None
@@ -286,6 +287,7 @@ class FactorGraph:
         if ent == "seen":
             try:
                 ent = self._capture(key, (t0, t1, itrs, use_inactive, EP, motion_only, opt_type, not sharded))
+                self.stats["captures"] += 1
             except Exception as exc:        # a failed capture must not take the step down: stay eager
                 import warnings
                 warnings.warn(f"hipGraph capture of FactorGraph.update failed ({exc!r}); running eagerly")
@@ -305,6 +307,7 @@ class FactorGraph:
             if src is not dst:
                 dst.copy_(src)
         graph.replay()
+        self.stats["replays"] += 1
         self.net, self.target, self.weight = s_net, s_target, s_weight
         self._ba_args = ba_args
         self._eta_fb = eta_fb
@@ -364,6 +367,8 @@ class FactorGraph:
     @torch.no_grad()
     def _update_eager(self, t0=None, t1=None, itrs=2, use_inactive=False, EP=1e-7, motion_only=False,
                       opt_type="pose_depth", run_ba=True):
+        if run_ba and not torch.cuda.is_current_stream_capturing():
+            self.stats["eager"] += 1
         if self.fast_update is not None and self.poses_on_device() and self.target.is_contiguous() \
                 and self.target.dtype == torch.float32:
             # reprojection + motion features of the flow encoder (padded fp16 map) in one launch

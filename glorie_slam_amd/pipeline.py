@@ -57,8 +57,8 @@ class SequenceRunner:
         self.mapped = 0                       # keyframes [0, mapped) are in the cloud
         self.last_ba = 0
         self.losses = []                      # per mapped keyframe: (first, last) loss of its mapping iterations
-        self.timing = {"track_ms": [], "map_iter_ms": [], "ba_ms": []}
-        self.init_state = None                # callable(k): the tracker's initial guess for a new keyframe (tests)
+        self.timing = {"track_ms": [], "map_iter_ms": [], "ba_ms": [], "kept": []}
+        self.init_state = None                # callable(k, tstamp): the tracker's initial guess for a new keyframe (tests)
 
     # ---- tracker.py:33-77 ------------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -71,12 +71,13 @@ class SequenceRunner:
         if appended:
             self.images[n_before] = image[0].to(self.device)
             if self.init_state is not None:
-                self.init_state(n_before)
+                self.init_state(n_before, tstamp)
         self.frontend()
         kept = appended and self.video.counter.value > n_before
         cur = self.video.counter.value
         torch.cuda.synchronize()
         self.timing["track_ms"].append(1e3 * (time.perf_counter() - t0))      # motion filter + frontend of this frame
+        self.timing["kept"].append(bool(kept))
         if self.frontend.is_initialized and cur - self.last_ba >= self.ba_every and self.ba_every > 0:
             tb = time.perf_counter()
             self.backend.dense_ba(self.ba_steps)
@@ -156,7 +157,8 @@ class SequenceRunner:
         return self.losses[-1]
 
     def map_pending(self):
-        """map every keyframe the frontend has finished with (all but the newest, which is still the initial guess slot)"""
+        """map every keyframe the frontend has finished with (its redundancy test culls a frame inside the same call that
+        appended it, tracker.py:56-69: what is below the window's end afterwards is final)"""
         done = self.frontend.t1 if self.frontend.is_initialized else 0
         while self.mapped < done:
             self.map_keyframe(self.mapped)
@@ -247,10 +249,73 @@ def synthetic_runner(device, K, zero_flow_head=True, map_iters=20, map_rays=1000
                          map_iters=map_iters, map_rays=map_rays, add_stride=8)
     poses = t(g["poses"])
 
-    def init_state(k):
+    def init_state(k, tstamp=None):
         video.poses[k] = poses[k]
         video.disps[k] = disps[k]
         video.disps_up[k] = 1.0 / full[k]
     run.init_state = init_state
     intr = torch.tensor([cam.fx, cam.fy, cam.cx, cam.cy])
     return run, dict(poses=poses, disps=disps, cfg=cfg, video=video, npc=npc, intrinsics=intr)
+
+
+def synthetic_long_runner(device, n_frames=220, leg=60, repeat_every=9, map_iters=20, map_rays=1000, buffer=512, ba_every=20,
+                          H=480, W=640):
+    """Config 3 beyond the 13-frame miniature: a stream of `n_frames` 640x480 frames whose camera walks the arc of
+    synth.keyframe_graph forth and back (a triangle wave of period 2 * leg: frame 2 * leg stands where frame 0 stood, so the
+    loop-closure search finds pairs more than 20 keyframes apart), with every `repeat_every`-th frame a repeat of its
+    predecessor (zero induced flow: the frontend's redundancy test culls it, rm_keyframe shifts the buffers), loop closure
+    enabled, a global BA every `ba_every` keyframes, `map_iters` mapping iterations per kept keyframe, a 512-frame buffer.
+    Flow head zeroed: the generating trajectory is a fixed point.  -> (runner, dict(...), frames iterator factory)"""
+    import types
+
+    import numpy as np
+
+    from . import synth
+    from .decoder import POINT
+    from .depth_video import DepthVideo
+    from .droid_net import DroidNet
+    from .neural_point import NeuralPointCloud
+    from .renderer import Renderer
+    h, w = H // 8, W // 8
+    cfg = synthetic_cfg(device, buffer, H, W)
+    cfg["tracking"]["frontend"].update({"enable_loop": True, "keyframe_thresh": 0.5})
+    g = synth.keyframe_graph(K=leg + 1, h=h, w=w, radius=3)
+    # arc position of stream frame f: triangle wave; every repeat_every-th frame repeats its predecessor
+    pos, u = [], 0
+    for f in range(n_frames):
+        if f and f % repeat_every == 0:
+            pos.append(pos[-1])
+            continue
+        k = u % (2 * leg)
+        pos.append(k if k <= leg else 2 * leg - k)
+        u += 1
+    torch.manual_seed(43)
+    net = DroidNet().to(device).eval()
+    with torch.no_grad():
+        net.update.delta[2].weight.zero_()
+        net.update.delta[2].bias.zero_()
+    video = DepthVideo(cfg)
+    npc = NeuralPointCloud(cfg)
+    torch.manual_seed(43)
+    dec = POINT(cfg, use_view_direction=True).eval().to(device)
+    cam = types.SimpleNamespace(H=H, W=W, fx=320.0 * W / 640.0, fy=320.0 * H / 480.0, cx=319.5 * W / 640.0, cy=239.5 * H / 480.0)
+    ren = Renderer(cfg, cam)
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(device)
+    disps, poses = t(g["disps"]), t(g["poses"])
+    full = torch.nn.functional.interpolate(1.0 / disps[:, None], size=(H, W), mode="bilinear", align_corners=False)[:, 0]
+    run = SequenceRunner(net, video, cfg, npc, dec, ren, lambda ts, im: (full[pos[int(ts)]] * 1.25 + 0.1), use_graphs=True,
+                         ba_every=ba_every, ba_steps=2, map_iters=map_iters, map_rays=map_rays, add_stride=8)
+
+    def init_state(k, tstamp):
+        a = pos[int(tstamp)]
+        video.poses[k] = poses[a]
+        video.disps[k] = disps[a]
+        video.disps_up[k] = 1.0 / full[a]
+    run.init_state = init_state
+    bank = synthetic_images(leg + 1, H, W)                                  # one texture per arc position
+
+    def frames():
+        for f in range(n_frames):
+            yield f, bank[pos[f]:pos[f] + 1]
+    intr = torch.tensor([cam.fx, cam.fy, cam.cx, cam.cy])
+    return run, dict(poses=poses, disps=disps, cfg=cfg, video=video, npc=npc, intrinsics=intr, pos=pos), frames
