@@ -1175,7 +1175,11 @@ __global__ __launch_bounds__(512, 4) void mlp_nb_v4_kernel(NbParams P, const flo
   const h16x8* wl = W1f + lane;
 #pragma unroll 1
   for (int k = 0; k < 8; ++k) {
+#ifdef EXP_NB_NO_GATHER
+    const int pt = (q0 + srow) & 0xffff;                    // ablation: consecutive rows instead of the neighbours'
+#else
     const int pt = ibuf[srow * 8 + k];
+#endif
     const float w = wbuf[srow * 8 + k];
     const float4 c0 = *reinterpret_cast<const float4*>(col_feats + (size_t)pt * 32 + 4 * g);
     const float4 c1 = *reinterpret_cast<const float4*>(col_feats + (size_t)pt * 32 + 16 + 4 * g);
@@ -1190,17 +1194,29 @@ __global__ __launch_bounds__(512, 4) void mlp_nb_v4_kernel(NbParams P, const flo
       for (int sidx = 0; sidx < 5; ++sidx) {
         const float4 bf = *reinterpret_cast<const float4*>(bsl + 16 * sidx);
         const float a = fmaf(rz, bf.z, fmaf(ry, bf.y, rx * bf.x));
+#ifdef EXP_NB_NO_SINCOS
+        ev[sidx] = a;
+#else
         ev[sidx] = (4 * sidx + g >= 10) ? cos_rev(a) : sin_rev(a);
+#endif
       }
       ev[5] = ev[6] = ev[7] = 0.0f;
       h16x8 bhi, blo;
       split2(f32x4{ev[0], ev[1], ev[2], ev[3]}, f32x4{ev[4], ev[5], ev[6], ev[7]}, bhi, blo);
 #pragma unroll
       for (int to = 0; to < 8; ++to) {
+#ifdef EXP_NB_NO_LDSW
+        const h16x8 ahi = bhi, alo = blo;                     // ablation: no fragment reads
+#else
         const h16x8 ahi = wl[to * 64], alo = wl[(8 + to) * 64];
+#endif
+#ifdef EXP_NB_NO_MFMA
+        acc[to][0] += (float)ahi[0] * (float)bhi[to & 7] + (float)alo[1] * (float)blo[to & 7];      // ablation: no matrix work
+#else
         acc[to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, bhi, acc[to], 0, 0, 0);
         acc[to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, blo, acc[to], 0, 0, 0);
         acc[to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, bhi, acc[to], 0, 0, 0);
+#endif
         __builtin_amdgcn_sched_barrier(0);     // keeps the compiler from hoisting all 32 fragment reads (128 registers)
       }
     }
@@ -1210,10 +1226,18 @@ __global__ __launch_bounds__(512, 4) void mlp_nb_v4_kernel(NbParams P, const flo
       split2(f32x4{c0.x, c0.y, c0.z, c0.w}, f32x4{c1.x, c1.y, c1.z, c1.w}, bhi, blo);
 #pragma unroll
       for (int to = 0; to < 8; ++to) {
+#ifdef EXP_NB_NO_LDSW
+        const h16x8 ahi = bhi, alo = blo;
+#else
         const h16x8 ahi = wl[(16 + to) * 64], alo = wl[(24 + to) * 64];
+#endif
+#ifdef EXP_NB_NO_MFMA
+        acc[to][1] += (float)ahi[0] * (float)bhi[to & 7] + (float)alo[1] * (float)blo[to & 7];
+#else
         acc[to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, bhi, acc[to], 0, 0, 0);
         acc[to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, blo, acc[to], 0, 0, 0);
         acc[to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, bhi, acc[to], 0, 0, 0);
+#endif
         __builtin_amdgcn_sched_barrier(0);     // keeps the compiler from hoisting all 32 fragment reads (128 registers)
       }
     }
@@ -1264,6 +1288,18 @@ __global__ __launch_bounds__(512, 4) void mlp_nb_v4_kernel(NbParams P, const flo
 // the kernel sits on its vector floor (8 x 128 softplus per sample, two quarter-rate transcendentals each: ~340 us).  A
 // degree-6 polynomial for log2(1 + e) on packed fp32 FMAs instead of v_log_f32 was slower too (405 us: v_pk_fma_f32 beside
 // MFMAs is no faster than two v_fma_f32, MI355X_MICROARCH.md), as was the colour kernel with it (450 vs 427 us).
+//
+// Round 4: what the kernel's 397 us are made of (tools/exp_mlp_ablate.sh, builds with -DEXP_NB_* / -DEXP_MLP_*; every line is
+// the kernel with ONE thing removed): fragment reads from LDS 268 (-129), MFMAs 303 (-94), softplus 304 (-91), neighbour
+// gather made sequential 366 (-31), low halves of the split 375 (-20), sin / cos 394; without MFMAs, fragment reads and
+// softplus 170.  The transcendentals are NOT the floor the round-3 note took them for (v_exp_f32 / v_log_f32 issue at
+// ~5/3 of a plain VALU slot on this part, MI355X_MICROARCH.md; a packed-fp16 polynomial for the correction term needs
+// degree 8 on [0, 8] and its monomial coefficients ~8^k / k! cancel catastrophically in fp16) - the A operand is: the same
+// 32 KB of W1 fragments are read from LDS in front of every MFMA, 1 KB per read, 1024 clocks of the CU's one LDS pipe per
+// 816 clocks of MFMA on its four SIMDs.  Keeping the 16 high fragments in 64 VGPRs (a third of the reads, 198 VGPRs, 2
+// waves per SIMD, a wave walking 16-sample blocks with the next neighbour's row prefetched; bit-identical) measured 432 us:
+// what the reads save, the lost occupancy costs (4 -> 2 waves per SIMD hide the gather and interleave MFMA with VALU
+// worse).  Not kept.
 }  // namespace glorie
 
 using namespace glorie;
