@@ -26,7 +26,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 PMC_SUMMARY = "r04_pmc_kernels.json"   # refreshed per round by tools/pmc_passes.sh
-PMC_CORR_SUMMARY = "r03_pmc_corr.json"  # tools/pmc_corr.sh
+PMC_CORR_SUMMARY = "r04_pmc_corr.json"  # tools/pmc_corr.sh
+KNN_GATHER_PHASE = "r04_knn_gather_phase.json"   # tools/knn_gather_phase.sh
 MFMA_F16_PEAK_TF = 2500.0  # same guide: ~2.5 PFLOP/s dense f16/bf16 (not the 2:1-sparsity figure)
 
 
@@ -149,9 +150,12 @@ def _pmc_traffic():
         return None, None, None
     get = lambda k: d[k]["hbm_bytes"] if k in d and d[k].get("hbm_bytes") is not None else None
     knn = None
-    if get("knn_query") is not None and get("idw_gather") is not None:
-        # round 1 profiled two single-table gather launches per batch, round 2 the two-table launch
-        knn = get("knn_query") + (2 if PMC_SUMMARY.startswith("r01") else 1) * get("idw_gather")
+    if get("knn_query") is not None and get("mlp_geo") is not None and get("mlp_nb") is not None:
+        # round 4: the product's R1 + R2 = the search launch + the two decoder kernels that pull the feature rows (their
+        # counters include the kernels' other traffic: positions, masks, the 32-float colour feature they hand on)
+        knn = get("knn_query") + get("mlp_geo") + get("mlp_nb")
+    elif get("knn_query") is not None and get("idw_gather") is not None:
+        knn = get("knn_query") + get("idw_gather")
     return get("conv_igemm_gru_zr"), get("corr_lookup"), knn
 
 
@@ -824,7 +828,18 @@ def main():
     knn_search_ms = timed(knn_product)
     Dk, Ik, nnk, _, _ = knn_product()
     gather_ms = timed(lambda: point_ops.idw_gather2(Dk, Ik, nnk, npc.geo_feats, npc.col_feats, radius_per_query=rq))
-    knn_ms = knn_search_ms + gather_ms
+    # R2 as the product performs it: the feature rows are pulled inside mlp_geo_v4 / mlp_nb_v4.  Their gather phases were
+    # isolated with an instrumentation build that removes the networks (tools/knn_gather_phase.sh, -DEXP_GATHER_ONLY: ids,
+    # weights, rows, positions and the interpolation stay) and are read from the round's profile; the search is timed live
+    gp = None
+    try:
+        with open(os.path.join(ROOT, "profiles", KNN_GATHER_PHASE)) as f:
+            gp = json.load(f)
+    except Exception:
+        gp = None
+    scale = pq.shape[0] / 614400.0
+    product_gather_ms = (gp["geo_gather_ms"] + gp["nb_gather_ms"]) * scale if gp else None
+    knn_ms = knn_search_ms + (product_gather_ms if product_gather_ms is not None else gather_ms)
     knn_bytes = 2156.0 * pq.shape[0]
     knn_gbs = knn_bytes / (knn_ms * 1e-3) / 1e9
     # fused decoders alone: executed FLOPs (post-sum F_theta form, 358,848 FLOP per sample)
@@ -913,9 +928,14 @@ def main():
         "render": {"rays_local": int(n_r // render_reps), "samples_per_ray": int(S), "cloud_points": int(npc.pts_num()),
                    "ms_per_frame_shard": 1e3 * t_r / render_reps},
         "roofline_knn": {"bound": "hbm", "kernel": "knn_query_kernel<8> as the renderer launches it (image-patch order, bounded by the "
-                                                   "query radius, + IDW weights and mask) + stand-alone idw_gather2_kernel (both feature "
-                                                   "tables; the product gathers the rows inside mlp_geo_v4 / mlp_nb_v4)",
-                         "search_ms": knn_search_ms, "gather_ms": gather_ms,
+                                                   "query radius, + IDW weights and mask; timed live) + the gather phases of mlp_geo_v4 and "
+                                                   "mlp_nb_v4 (feature rows, positions, interpolation; isolated by the -DEXP_GATHER_ONLY "
+                                                   "build of tools/knn_gather_phase.sh, profiles/" + KNN_GATHER_PHASE + ")",
+                         "search_ms": knn_search_ms, "product_gather_ms": product_gather_ms,
+                         "product_gather_parts_ms": ({"mlp_geo_v4": gp["geo_gather_ms"] * scale, "mlp_nb_v4": gp["nb_gather_ms"] * scale}
+                                                     if gp else None),
+                         "standalone_gather2_ms": gather_ms,
+                         "standalone_composite_frac": knn_bytes / ((knn_search_ms + gather_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "achieved": knn_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": knn_gbs / HBM_PEAK_GBS, "traffic": knn_traffic if world == 1 else None,
                          "alg_bytes_per_launch": knn_bytes, "ms_per_launch": knn_ms,

@@ -1059,6 +1059,13 @@ __global__ __launch_bounds__(512, 4) void mlp_geo_v4_kernel(GeoParams P, const f
       }
     }
     split2(c[0], c[1], chi, clo);
+#ifdef EXP_GATHER_ONLY
+    // measurement build (tools/knn_gather_phase.sh): the kernel's R2 phase alone - ids, weights, the 8 feature rows and their
+    // interpolation - with the decoder removed; the interpolated feature's sum stands in for the occupancy
+    if (g == 0 && qs < Q) raw[(size_t)qs * 4 + 3] = (c[0][0] + c[0][1]) + (c[1][2] + c[1][3]);
+    cur = nxt;
+    continue;
+#endif
   }
   auto act = [&](int li) {   // ReLU(acc + bias) + fc_c bias
 #pragma unroll
@@ -1185,6 +1192,13 @@ __global__ __launch_bounds__(512, 4) void mlp_nb_v4_kernel(NbParams P, const flo
     const float4 c1 = *reinterpret_cast<const float4*>(col_feats + (size_t)pt * 32 + 16 + 4 * g);
     const float rx = cloud[(size_t)pt * 3 + 0] - qx, ry = cloud[(size_t)pt * 3 + 1] - qy,
                 rz = cloud[(size_t)pt * 3 + 2] - qz;
+#ifdef EXP_GATHER_ONLY
+    // measurement build: the neighbour's feature row and position, weighted - no embedding, no layers
+    ysum[0][0] += w * (c0.x + c1.x + rx); ysum[0][1] += w * (c0.y + c1.y + ry);
+    ysum[0][2] += w * (c0.z + c1.z + rz); ysum[0][3] += w * (c0.w + c1.w);
+    sw += w;
+    continue;
+#endif
     f32x4 acc[8];
     zero<8>(acc);
     // chunk 0: embedding features 4s + g (sin for feature < 10), phases in revolutions

@@ -31,8 +31,12 @@ pq = (rays["o"][:nq, None] + rays["d"][:nq, None] * z[..., None]).reshape(-1, 3)
 rq = rays["radius"][:nq].repeat_interleave(S)
 from glorie_slam_amd import point_ops  # noqa: E402
 for _ in range(3):
-    D, I, nn = npc.index.search(pq, 8, radius_per_query=rq, image_layout=(S, rays["W"]))
+    # the search as the renderer launches it (weights + mask from the same launch, bounded by the query radius)
+    D, I, nn, w_, has_ = npc.index.search(pq, 8, radius_per_query=rq, image_layout=(S, rays["W"]), weights=(2, False, True))
     point_ops.idw_gather2(D, I, nn, npc.geo_feats, npc.col_feats, radius_per_query=rq)
+# one full-frame render pass: the decoder kernels (the product's R2 gathers happen inside mlp_geo_v4 / mlp_nb_v4)
+for _ in range(2):
+    bench.render_pass(npc, dec, ren, rays, dev)
 # calibration: a 1 GiB float4 streaming copy (reads 1 GiB, writes 1 GiB)
 src = torch.empty(1 << 28, dtype=torch.float32, device=dev).normal_()
 for _ in range(3):
