@@ -389,3 +389,19 @@ def test_oracle_stage1_agrees_with_reference_python_BA():
     assert np.abs(poses[:, :3] - f["poses"][:, :3]).max() < 2e-3 * step_t
     assert np.abs(poses[:, 3:] - f["poses"][:, 3:]).max() < 2e-3 * np.abs(f["poses"][:, 3:] - POPS["poses"][:, 3:]).max()
     assert np.abs(disps - f["disps"]).max() < 3e-2 * step_d
+
+
+def test_oracle_frame_distance_equals_reference_induced_flow():
+    """oracle/geom.py:frame_distance (frame_distance_kernel restated, droid_kernels.cu:518-657) at beta = 1 is the mean
+    magnitude of the flow induced by the full relative motion - which the reference also has in Python
+    (projective_ops.induced_flow :127-139 = projective_transform - grid): the coords of pops.npz are that transform's
+    output.  Pins the rotation + translation half of the distance the graph topology is thresholded on (the
+    translation-only half, beta < 1, has no Python counterpart)."""
+    from oracle import geom as ogeom
+    keep = POPS["ii"] != POPS["jj"]
+    N, h, w = POPS["coords"].shape[1:4]
+    y, x = np.meshgrid(np.arange(h, dtype=np.float32), np.arange(w, dtype=np.float32), indexing="ij")
+    flow = POPS["coords"][0] - np.stack([x, y], -1)[None]
+    want = np.sqrt((flow.astype(np.float64) ** 2).sum(-1)).reshape(N, -1).mean(1)
+    d = ogeom.frame_distance(POPS["poses"], POPS["disps"], POPS["intr"][0], POPS["ii"][keep], POPS["jj"][keep], 1.0)
+    np.testing.assert_allclose(d, want[keep], rtol=2e-5)
