@@ -28,6 +28,7 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (s
 PMC_SUMMARY = "r04_pmc_kernels.json"   # refreshed per round by tools/pmc_passes.sh
 PMC_CORR_SUMMARY = "r04_pmc_corr.json"  # tools/pmc_corr.sh
 KNN_GATHER_PHASE = "r04_knn_gather_phase.json"   # tools/knn_gather_phase.sh
+KNN_LAYOUT = "image"                             # --knn-layout
 MFMA_F16_PEAK_TF = 2500.0  # same guide: ~2.5 PFLOP/s dense f16/bf16 (not the 2:1-sparsity figure)
 
 
@@ -125,7 +126,7 @@ def render_pass(npc, dec, ren, rays, device):
     # the batching of Renderer.render_img: whole 16-row strips, so the neighbour search can walk image patches
     bs = ren.ray_batch_size
     W = rays["W"]
-    image_w = W if os.environ.get("GLORIE_BENCH_KNN_LAYOUT", "image") == "image" else None
+    image_w = W if KNN_LAYOUT == "image" else None
     if image_w:
         bs -= bs % (16 * W)
     n = rays["o"].shape[0]
@@ -275,7 +276,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sequence", action="store_true", help="skip the 13-frame tracking + mapping sequence (config 3)")
     ap.add_argument("--no-strong", action="store_true", help="skip the fixed 128-keyframe graph (strong-scaling figure)")
+    ap.add_argument("--soak", type=int, default=300, help="untimed steps between the burst figure and the timed steps")
+    ap.add_argument("--strong-k", type=int, default=128, help="keyframes of the strong-scaling graph (512 = long end of config 4)")
+    ap.add_argument("--corr-impl", default="volume", choices=["volume", "otf"], help="correlation operator of the timed graph")
+    ap.add_argument("--knn-layout", default="image", choices=["image", "linear"], help="query order of the renderer's search")
     args = ap.parse_args()
+    global KNN_LAYOUT
+    KNN_LAYOUT = args.knn_layout
 
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
@@ -301,7 +308,7 @@ def main():
     # the launches of a step are replayed as a hipGraph per (edge set, stage); when sharded the replay stops
     # before the BA, whose all-reduce and row exchange are issued eagerly (FactorGraph.update)
     g, video, graph = build_graph(device, K=K_graph, rank=rank, world=world,
-                                  corr_impl=os.environ.get("GLORIE_BENCH_CORR", "volume"),
+                                  corr_impl=args.corr_impl,
                                   use_graphs=os.environ.get("GLORIE_NO_GRAPHS") is None)
     K = g["K"]
     poses0, disps0 = video.poses.clone(), video.disps.clone()
@@ -364,7 +371,7 @@ def main():
     # which no tracking session sustains.  The burst figure is kept as `burst_value`; then `soak` untimed steps bring the
     # part to the clocks it holds under this load and the K timed steps of the contract follow.
     burst_elapsed = timed_steps(args.steps)
-    soak_steps = int(os.environ.get("GLORIE_BENCH_SOAK", "300"))
+    soak_steps = int(args.soak)
     for _ in range(soak_steps):
         step()
     elapsed = timed_steps(args.steps)
@@ -458,7 +465,7 @@ def main():
     strong = None
     if not args.no_strong:
         try:
-            KS = int(os.environ.get("GLORIE_STRONG_K", "128"))      # 512 = the long end of BASELINE config 4
+            KS = int(args.strong_k)
             gS, videoS, graphS = build_graph(device, K=KS, h=30, w=40, rank=rank, world=world, corr_impl="otf",
                                              use_graphs=os.environ.get("GLORIE_NO_GRAPHS") is None)
 
@@ -807,7 +814,7 @@ def main():
     from glorie_slam_amd import point_ops
 
     img_w = int(rays["W"]) if "W" in rays else None
-    layout = (S, img_w) if (img_w and os.environ.get("GLORIE_BENCH_KNN_LAYOUT", "image") == "image") else None
+    layout = (S, img_w) if (img_w and args.knn_layout == "image") else None
 
     # R1 as the renderer launches it: ONE launch = exact search bounded by the query radius + IDW weights + neighbour mask
     # (glorie_knn_query_weights).  R2 (the 128-byte feature rows) is gathered inside the decoder kernels in the product;

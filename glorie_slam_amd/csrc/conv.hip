@@ -60,7 +60,6 @@ struct ConvArgs {
   const _Float16* pre; int pre_stride;          // per-pixel term added before the gate non-linearity (or null)
   const int* pre_map;                           // map (edge) -> map of `pre` it reads (null: its own)
   long pbeg;                                    // first pixel of this launch (a layer may be split into two launches)
-  int pre_late;                                 // add `pre` in the epilogue instead of seeding the accumulators with it
   int pair;                                     // weight rows packed so that a lane owns 8 consecutive channels (conv_epilogue_tile)
   unsigned long long* stamps;                   // EXP_CONV_STAMPS builds: s_memtime checkpoints (tools/conv_timeline.py)
   // EPI_HEADS: the first tap_groups 128-channel tiles feed the tap GEMM of a 3x3 head instead of being stored
@@ -260,7 +259,7 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvArgs& a, f32x4 (&ac
     const int e = (int)(pc / a.HW);
     float4 g[MB];
     f16x4 nv[MB], zv[MB], pl[MB];
-    const bool late = EPI != EPI_BIAS_ACT && a.pre && a.pre_late;       // wave-uniform
+    const bool late = EPI != EPI_BIAS_ACT && a.pre;                     // launch-uniform
     const long pp = late ? pre_pixel(a, pc) : 0;
 #pragma unroll
     for (int mi = 0; mi < MB; ++mi) {
@@ -659,57 +658,6 @@ __global__ __launch_bounds__(64 * NW, (ST == 1 && MB * NB <= 16) ? 3 : 2) void c
   for (int kk = 0; kk < KK; ++kk) foff[kk] = col * RB + (((kk * 4 + kg) ^ key(col)) << 4);
   const int wbase = XBYTES + wm * (16 * MB) * RB, xbase_l = wn * (16 * NB) * RB;
 
-  if (EPI != EPI_BIAS_ACT && a.pre && !a.pre_late) {
-    // The hoisted per-pixel term seeds the accumulators (an add in the epilogue would be an exposed round trip at the tail
-    // of every workgroup).  A lane owns 4 channels of 16 pixels per block: fetched directly that is 8-byte pieces of 16
-    // different rows per instruction, every 128-byte line requested by 8 instructions - measured +47 us on the 36-edge z|r
-    // launch.  With a 128 x 128 tile the [pixel][channel] fp16 tile is exactly the 32 KB LDS stage: it comes in as 32
-    // row-contiguous DMA pieces (16-byte slot XOR-swizzled with the row on the source side) and is read back per lane.
-    if constexpr ((PT == 128 || PT == 64) && (TN == 128 || TN == 256) && ST == 1 && BK == 64) {
-      // (the launch reserves max(stage, PT * TN * 2) bytes of LDS: 64 KB for the 256-channel tile)
-      constexpr int ROWB = TN * 2, SLOTS = ROWB / 16, RPP = 64 / SLOTS;      // bytes / 16-byte slots per row, rows per piece
-      const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void*)a.pre, 0, 0x7fffffff, 0x00020000);
-#pragma unroll
-      for (int i = 0; i < PT / RPP / NW; ++i) {
-        const int piece = i * NW + wv;
-        const int row = piece * RPP + lane / SLOTS, sl = lane % SLOTS;
-        const long p = pre_pixel(a, min(p0 + row, a.P - 1));
-        const unsigned vo = (unsigned)((p * a.pre_stride + n0) * 2 + ((sl ^ (row & 15)) << 4));
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rP, (__attribute__((address_space(3))) void*)(smem + piece * 1024), 16, vo,
-                                                 0, 0, 0);
-      }
-      __syncthreads();
-#pragma unroll
-      for (int ni = 0; ni < NB; ++ni) {
-        const int row = wn * (16 * NB) + ni * 16 + col;
-#pragma unroll
-        for (int mi = 0; mi < MB; ++mi) {
-          const int b = (wm * (16 * MB) + mi * 16 + kg * 4) * 2;
-          const f16x4 h = *reinterpret_cast<const f16x4*>(smem + row * ROWB + ((((b >> 4) ^ (row & 15))) << 4) + (b & 15));
-          acc[mi][ni] = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
-        }
-      }
-      __syncthreads();                         // the stage is free for the first K tile
-    } else {
-      f16x4 pv[MB][NB];
-#pragma unroll
-      for (int ni = 0; ni < NB; ++ni) {
-        const long p = pre_pixel(a, min(p0 + wn * (16 * NB) + ni * 16 + col, a.P - 1));
-#pragma unroll
-        for (int mi = 0; mi < MB; ++mi) {
-          const int n = min(n0 + wm * (16 * MB) + mi * 16 + kg * 4, a.nout - 4);
-          pv[mi][ni] = *reinterpret_cast<const f16x4*>(a.pre + p * a.pre_stride + n);
-        }
-      }
-#pragma unroll
-      for (int ni = 0; ni < NB; ++ni)
-#pragma unroll
-        for (int mi = 0; mi < MB; ++mi) {
-          const f16x4 h = pv[mi][ni];
-          acc[mi][ni] = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
-        }
-    }
-  }
 #ifdef EXP_CONV_STAMPS
   // experiment (tools/conv_timeline.sh): shader-clock stamps of K-tiles 10-13 of every 61st workgroup, [16][NW][4][8]
   const int swg = lid / 61;
@@ -925,32 +873,6 @@ __global__ __launch_bounds__(256, MB <= 4 ? 3 : 2) void conv_halo_kernel(ConvArg
   const int wbase = wm * (16 * MB) * RB;
   const int rb0 = wn * (16 * NB) + col + halo;         // halo row of this lane's pixel of block 0 for the centre tap
 
-  if (EPI != EPI_BIAS_ACT && a.pre && !a.pre_late) {
-    // per-edge context term: seeds the accumulators through LDS as in conv_igemm_kernel
-    constexpr int ROWB = TN * 2, SLOTS = ROWB / 16, RPP = 64 / SLOTS;
-    const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void*)a.pre, 0, 0x7fffffff, 0x00020000);
-#pragma unroll
-    for (int i = 0; i < PT / RPP / NW; ++i) {
-      const int piece = i * NW + wv;
-      const int row = piece * RPP + lane / SLOTS, sl = lane % SLOTS;
-      const long p = pre_pixel(a, min(p0 + row, a.P - 1));
-      const unsigned vo = (unsigned)((p * a.pre_stride + n0) * 2 + ((sl ^ (row & 15)) << 4));
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rP, (__attribute__((address_space(3))) void*)(smem + piece * 1024), 16, vo,
-                                               0, 0, 0);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int ni = 0; ni < NB; ++ni) {
-      const int row = wn * (16 * NB) + ni * 16 + col;
-#pragma unroll
-      for (int mi = 0; mi < MB; ++mi) {
-        const int b = (wm * (16 * MB) + mi * 16 + kg * 4) * 2;
-        const f16x4 h = *reinterpret_cast<const f16x4*>(smem + row * ROWB + ((((b >> 4) ^ (row & 15))) << 4) + (b & 15));
-        acc[mi][ni] = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
-      }
-    }
-    __syncthreads();
-  }
   stage_pixels(0);
   stage_weights(0, 0);
   int ch = 0, d = 0;                                   // chunk and tap of tile t
@@ -1028,10 +950,7 @@ template <int EPI, int NB, int BK, int NW, int ST, int MB>
 static void launch_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
   constexpr int RB = BK * 2, PT = (NW / 2) * 16 * NB;
   constexpr size_t stage_bytes = (size_t)ST * (PT * RB + 32 * MB * RB);
-  // gate epilogues seed their accumulators through LDS: the [pixel][channel] fp16 tile of the context term must fit
-  constexpr size_t seed_bytes = (EPI != EPI_BIAS_ACT && ST == 1 && BK == 64 && (PT == 128 || PT == 64) && MB * 32 <= 256)
-                                    ? (size_t)PT * 32 * MB * 2 : 0;
-  constexpr size_t lds = stage_bytes > seed_bytes ? stage_bytes : seed_bytes;
+  constexpr size_t lds = stage_bytes;
   static bool attr = false;            // > 64 KB of dynamic LDS needs the opt-in once per kernel
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<EPI, NB, BK, NW, ST, MB>),
@@ -1128,7 +1047,9 @@ static int conv_igemm_impl(const void* xa, int xa_stride, int ca, const void* xb
   if (N < 0 || H <= 0 || W <= 0 || (taps != 1 && taps != 9) || nout <= 0 || (nout & 3)) return GLORIE_EINVAL;
   if (ca < 0 || cb < 0 || (ca % 64) || (cb % 64) || ca + cb == 0) return GLORIE_EINVAL;
   const int pair = (epilogue >> 8) & 1;                 // GLORIE_CONV_PAIR16: the weights come from a paired packing
+  const int policy = (epilogue >> 12) & 15;             // GLORIE_CONV_POLICY_*: tile choice forced by the caller (tests, bench_conv)
   epilogue &= 0xff;
+  if (policy > 5) return GLORIE_EINVAL;
   if (epilogue < 0 || epilogue > 5) return GLORIE_EINVAL;
   if (pair && (epilogue > EPI_GRU_Q || (nout & 31))) return GLORIE_EINVAL;
   if (epilogue == EPI_UPSAMPLE && (!up_disps || !up_ix || !up_out || !terms || nout != 1024 || taps != 1 || pre))
@@ -1159,13 +1080,14 @@ static int conv_igemm_impl(const void* xa, int xa_stride, int ca, const void* xb
   a.tap_w = reinterpret_cast<const f16x8*>(tap_w); a.tap_out = tap_out; a.tap_groups = tap_groups;
   a.tap_ncols = tap_ncols;
   a.up_disps = up_disps; a.up_ix = up_ix; a.up_out = up_out; a.up_f32 = up_f32;
-  // the context term is added in the epilogue when it is the shared per-keyframe map (pre_map: 8 maps read by 36 edges in
-  // every iteration, L2 resident - its loads ride with the epilogue's other loads, 277 -> 274 us in the steps) and seeds the
-  // accumulators through LDS when it is a per-edge tensor streamed from HBM; GLORIE_CONV_PRE=e|s forces either
-  { const char* pl_ = getenv("GLORIE_CONV_PRE"); a.pre_late = pl_ ? (pl_[0] == 'e') : (a.pre_map != nullptr); }
+  // the context term joins in the epilogue (16-byte pieces with paired weights; rounds 2-3 seeded the accumulators with it
+  // through an LDS image of the [pixel][channel] tile, which the paired channel order made obsolete)
   a.pair = pair;
-  if (pair) a.pre_late = 1;                  // the accumulator seeding reads `pre` in the unpaired channel order
+#ifdef EXP_CONV_STAMPS
   a.stamps = getenv("GLORIE_CONV_STAMPS") ? (unsigned long long*)strtoull(getenv("GLORIE_CONV_STAMPS"), nullptr, 0) : nullptr;
+#else
+  a.stamps = nullptr;
+#endif
   // buffer-descriptor addressing: 31-bit byte offsets per input segment and for the weights
   const long lim = 0x7fffffffL;
   if (((a.P + W + 2) * (long)xa_stride + 64) * 2 > lim || ((a.P + W + 2) * (long)xb_stride + 64) * 2 > lim ||
@@ -1181,12 +1103,9 @@ static int conv_igemm_impl(const void* xa, int xa_stride, int ca, const void* xb
   // (16 instead of 32 MFMAs per step) 945.
   // 3x3 layers on the 128-channel tile: the pixel tile is shared by the nine taps of a chunk (conv_halo_kernel) while its haloed
   // tile leaves three workgroups per CU (image width <= 83); small launches keep their 64-pixel tiles, the 256- and 64-channel
-  // tiles their per-tap staging (measured slower with the shared tile).  GLORIE_CONV_HALO=0: per-tap staging everywhere.
+  // tiles their per-tap staging (measured slower with the shared tile).  Policy 5 (nohalo): per-tap staging everywhere.
   {
-    const char* hl = getenv("GLORIE_CONV_HALO");
-    const char* tmv = getenv("GLORIE_CONV_TILE");
-    const bool plain_env = tmv && tmv[0];
-    if (!(hl && hl[0] == '0') && !plain_env && taps == 9 && a.pbeg == 0) {
+    if (policy == 0 && taps == 9 && a.pbeg == 0) {
       const long tiles128 = (a.P + 127) / 128 * ((nout + 127) / 128);
       if (nout > 64 && (nout & 255) != 0 && W <= 83 && (epilogue <= EPI_GRU_Q || epilogue == EPI_HEADS) &&
           !(epilogue == EPI_BIAS_ACT && tiles128 <= 384))
@@ -1206,14 +1125,15 @@ static int conv_igemm_impl(const void* xa, int xa_stride, int ca, const void* xb
   // partly filled last round is cheaper than a round model says); two LDS stages with one barrier per K-tile and the next
   // tile's DMA issued in the shadow of the fragment reads (round 3: 448 -> 256 at 32-channel K-tiles 320 -> 406 us, 448 -> 128
   // 186 -> 197 us at 64-channel, 248 us at 32-channel K-tiles); the single stage with 32-channel K-tiles at FOUR workgroups
-  // per CU (113-128 VGPRs: 448 -> 128 186 -> 271 us).  GLORIE_CONV_TILE = 128 | 64 | split | wide keeps the
-  // variants reachable for tools/bench_conv.py.
+  // per CU (113-128 VGPRs: 448 -> 128 186 -> 271 us).  The policy bits keep the variants reachable for tests and
+  // tools/bench_conv.py.
   const int ntn = (nout + 127) / 128;
   const long slots128 = 3L * 256;
   const long full_rounds = ((a.P + 127) / 128 * ntn) / slots128;
   const long pt_a = full_rounds * slots128 / ntn;               // pixel tiles of the whole rounds
-  const char* tm = getenv("GLORIE_CONV_TILE");
-  const char t0c = tm ? tm[0] : 0;
+  // policy (bits 12-15 of `epilogue`, include/glorie_hip.h): 0 auto, 1 = 128 x 128, 2 = 64-pixel tiles, 3 = whole rounds +
+  // remainder, 4 = 128 x 256, 5 = auto without the haloed tile
+  const char t0c = policy == 1 ? '1' : policy == 2 ? '6' : policy == 3 ? 's' : policy == 4 ? 'w' : 0;
   if (t0c == 0 && (nout & 255) == 0) return launch_conv<4, 64, 4, 1, 8>(a, epilogue, st);
   // small launches (GraphAgg's convolutions run on the 8 keyframe maps, 300 pixel tiles): 128-pixel tiles would leave most
   // of the 768 workgroup slots empty and every CU with one latency-bound workgroup - 64-pixel tiles double the workgroups

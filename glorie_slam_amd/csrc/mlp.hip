@@ -481,162 +481,10 @@ __device__ __forceinline__ float relu_keep_nan(float x) { return x < 0.0f ? 0.0f
 __device__ __forceinline__ void report_range(bool bad, int* __restrict__ range_flag) {
   if (range_flag && __builtin_amdgcn_ballot_w64(bad) != 0 && (threadIdx.x & 63) == 0) atomicOr(range_flag, 1);
 }
-// acc[to] += W_chunk[:, 16 to ..] . b   with b given as split halfs
-__device__ __forceinline__ void mma_h3(f32x4 (&acc)[8], const h16x8 bhi, const h16x8 blo, const float* Wb) {
-  const int lane = threadIdx.x & 63;
-  const h16x8* wp = reinterpret_cast<const h16x8*>(Wb) + lane;
-#pragma unroll
-  for (int to = 0; to < 8; ++to) {
-    const h16x8 ahi = wp[to * 64], alo = wp[(8 + to) * 64];
-    acc[to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, bhi, acc[to], 0, 0, 0);
-    acc[to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, blo, acc[to], 0, 0, 0);
-    acc[to] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, bhi, acc[to], 0, 0, 0);
-  }
-}
 
-__global__ __launch_bounds__(512, 4) void mlp_col_v4_kernel(ColParams P, const float* __restrict__ W16,
-                                                            const float* __restrict__ pts,
-                                                            const float* __restrict__ views,
-                                                            const float* __restrict__ c_col, int Q,
-                                                            float* __restrict__ raw, int* __restrict__ range_flag) {
-  bool bad = false;
-  extern __shared__ float smem[];
-  float* Wbuf = smem;                         // [2][4096]
-  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-  const int r = lane & 15, g = lane >> 4;
-  const int q0 = blockIdx.x * kTM2;
-  const int qs = q0 + wv * 16 + r;            // this lane's sample (all four k-slots of a column share it)
-  const int q = min(qs, Q - 1);
-
-  // ---- B operands: embedding (80 channels = blocks 0..4 -> chunks {0,1}, {2,3}, {4,-}) and colour feature (32, read
-  // and split once: the fp32 kernel re-read it before each of its five uses for lack of registers) ----
-  h16x8 ehi[3], elo[3], chi, clo;
-  auto load_c = [&]() {
-    const float4 v0 = *reinterpret_cast<const float4*>(c_col + (size_t)q * 32 + 4 * g);
-    const float4 v1 = *reinterpret_cast<const float4*>(c_col + (size_t)q * 32 + 16 + 4 * g);
-    split2(f32x4{v0.x, v0.y, v0.z, v0.w}, f32x4{v1.x, v1.y, v1.z, v1.w}, chi, clo);
-  };
-  {
-    // phases in revolutions: the 2 pi of the reference's embedding is the period of v_sin / v_cos
-    const float px = pts[(size_t)q * 3 + 0], py = pts[(size_t)q * 3 + 1], pz = pts[(size_t)q * 3 + 2];
-    float vx = views[(size_t)q * 3 + 0], vy = views[(size_t)q * 3 + 1], vz = views[(size_t)q * 3 + 2];
-    const float nrm = fmaxf(sqrtf(vx * vx + vy * vy + vz * vz), 1e-12f);
-    vx = vx / nrm; vy = vy / nrm; vz = vz / nrm;
-    f32x4 e[6];
-#pragma unroll
-    for (int t = 0; t < 5; ++t)
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        const int f = 16 * t + 4 * g + rr;   // feature index 0..79: [sin p | cos p | sin v | cos v] x 20
-        const int blk = f / 20, ff = f - blk * 20;
-        const float* Bm = blk < 2 ? P.Bp : P.Bv;
-        const float x = blk < 2 ? px : vx, y = blk < 2 ? py : vy, z = blk < 2 ? pz : vz;
-        const float a = fmaf(z, Bm[40 + ff], fmaf(y, Bm[20 + ff], x * Bm[ff]));
-        e[t][rr] = (blk & 1) ? cos_rev(a) : sin_rev(a);
-      }
-    e[5] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int c = 0; c < 3; ++c) split2(e[2 * c], e[2 * c + 1], ehi[c], elo[c]);
-  }
-
-  f32x4 acc[8];
-  h16x8 hhi[4], hlo[4];
-  constexpr int NC = 27;
-  ChunkRegs nxt = chunk_load16(W16, 0);
-  chunk_store16(Wbuf, nxt);
-  __syncthreads();
-
-  auto act = [&](int li) {
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      const float4 bb = *reinterpret_cast<const float4*>(P.bias + li * 128 + 16 * t + 4 * g);
-      const float4 fb = *reinterpret_cast<const float4*>(P.fcb + li * 128 + 16 * t + 4 * g);
-      acc[t][0] = softplus100_fast(acc[t][0] + bb.x) + fb.x;
-      acc[t][1] = softplus100_fast(acc[t][1] + bb.y) + fb.y;
-      acc[t][2] = softplus100_fast(acc[t][2] + bb.z) + fb.z;
-      acc[t][3] = softplus100_fast(acc[t][3] + bb.w) + fb.w;
-    }
-  };
-  auto next_layer = [&]() {
-#pragma unroll
-    for (int c = 0; c < 4; ++c) split2(acc[2 * c], acc[2 * c + 1], hhi[c], hlo[c]);
-    zero<8>(acc);
-  };
-
-#define GL_CHUNK(cidx, BHI, BLO)                                    \
-  {                                                                 \
-    if ((cidx) + 1 < NC) nxt = chunk_load16(W16, (cidx) + 1);       \
-    mma_h3(acc, BHI, BLO, Wbuf + ((cidx) & 1) * kChunkFloats16);    \
-    if ((cidx) + 1 < NC) chunk_store16(Wbuf + (((cidx) + 1) & 1) * kChunkFloats16, nxt); \
-    __syncthreads();                                                \
-  }
-
-  // layer 0: W0 (80 rows -> chunks 0..2), Fc0 (chunk 3)
-  zero<8>(acc);
-  GL_CHUNK(0, ehi[0], elo[0])
-  GL_CHUNK(1, ehi[1], elo[1])
-  GL_CHUNK(2, ehi[2], elo[2])
-  load_c();
-  act(0);
-  GL_CHUNK(3, chi, clo)
-  // layer 1
-  next_layer();
-  GL_CHUNK(4, hhi[0], hlo[0])
-  GL_CHUNK(5, hhi[1], hlo[1])
-  GL_CHUNK(6, hhi[2], hlo[2])
-  GL_CHUNK(7, hhi[3], hlo[3])
-  act(1);
-  GL_CHUNK(8, chi, clo)
-  // layer 2
-  next_layer();
-  GL_CHUNK(9, hhi[0], hlo[0])
-  GL_CHUNK(10, hhi[1], hlo[1])
-  GL_CHUNK(11, hhi[2], hlo[2])
-  GL_CHUNK(12, hhi[3], hlo[3])
-  act(2);
-  GL_CHUNK(13, chi, clo)
-  // layer 3 (skip): W3e on the embedding, W3h on the hidden state
-  next_layer();
-  GL_CHUNK(14, ehi[0], elo[0])
-  GL_CHUNK(15, ehi[1], elo[1])
-  GL_CHUNK(16, ehi[2], elo[2])
-  GL_CHUNK(17, hhi[0], hlo[0])
-  GL_CHUNK(18, hhi[1], hlo[1])
-  GL_CHUNK(19, hhi[2], hlo[2])
-  GL_CHUNK(20, hhi[3], hlo[3])
-  act(3);
-  GL_CHUNK(21, chi, clo)
-  // layer 4
-  next_layer();
-  GL_CHUNK(22, hhi[0], hlo[0])
-  GL_CHUNK(23, hhi[1], hlo[1])
-  GL_CHUNK(24, hhi[2], hlo[2])
-  GL_CHUNK(25, hhi[3], hlo[3])
-  act(4);
-  GL_CHUNK(26, chi, clo)
-#undef GL_CHUNK
-  // output layer 128 -> 3 in fp32 as in mlp_col_v3_kernel
-  f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
-  {
-    const float* wp = P.Wout + (4 * g) * 16 + r;
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr)
-        o = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[(16 * t + rr) * 16], acc[t][rr], o, 0, 0, 0);
-  }
-  if (g == 0 && qs < Q) {
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-      bad = bad | not_finite(o[ch]);
-      raw[(size_t)qs * 4 + ch] = 1.0f / (1.0f + __expf(-(o[ch] + P.bout[ch])));
-    }
-  }
-  report_range(bad, range_flag);
-}
 
 // ---- colour decoder, round 3: NB column blocks (16 NB samples) per wave ------------------------------------------------
-// mlp_col_v4_kernel gives a wave 16 samples: every A fragment (weights) read from LDS feeds 3 MFMAs, and the 442 KB weight
+// Round 2's colour kernel (mlp_col_v4_kernel, removed in round 4) gave a wave 16 samples: every A fragment (weights) read from LDS feeds 3 MFMAs, and the 442 KB weight
 // stream is re-staged for every 128 samples - LDS reads (1 KB per 3 x 16 MFMA cycles and wave: 1024 LDS cycles against 768
 // matrix cycles per chunk and CU) and the L2 -> LDS stream (2.1 GB per 614k-sample batch) bound it, not the matrix pipe
 // (MfmaUtil 41 %).  Here a wave owns NB = 2 blocks of 16 samples: an A fragment feeds 6 MFMAs, a workgroup of WAVES waves
@@ -955,7 +803,7 @@ __global__ __launch_bounds__(512, 4) void mlp_nb_v3_kernel(NbParams P, const flo
   }
 }
 
-// geometry decoder on the fp16 matrix cores with the 3-term split (see mlp_col_v4_kernel): the 480 K-rows are 15 chunks
+// geometry decoder on the fp16 matrix cores with the 3-term split (see mlp_col_v5_kernel): the 480 K-rows are 15 chunks
 // of 32, packed by point_ops.pack_decoders as A fragments [chunk][hi|lo][out block 2][lane 64][8 halfs] (1024 floats per
 // chunk) and staged once per workgroup; the 32 -> 1 output layer stays fp32.  The 96-channel embedding is evaluated where
 // it is consumed (layer 0 and again at the skip layer) instead of being kept: 24 v_sin per sample against 24 registers
@@ -1133,7 +981,7 @@ __global__ __launch_bounds__(512, 4) void mlp_geo_v4_kernel(GeoParams P, const f
   report_range(bad, range_flag);
 }
 
-// per-neighbour F_theta on the fp16 matrix cores with the 3-term split (see mlp_col_v4_kernel).  The 52 input channels of a
+// per-neighbour F_theta on the fp16 matrix cores with the 3-term split (see mlp_col_v5_kernel).  The 52 input channels of a
 // neighbour are two 32-slot chunks: chunk 0 = the 20 embedding features (lane slot s < 5 <-> feature 4s + g, slots 5..7
 // zero), chunk 1 = the 32 colour-feature channels (slot s <-> channel 16 (s >> 2) + 4 g + (s & 3), the two 16-byte loads of
 // the feature row).  W1 is packed split, as A fragments [chunk][hi|lo][out block][lane][8] (point_ops.pack_decoders), and copied
@@ -1413,14 +1261,8 @@ extern "C" int glorie_render_mlp(const float* packed, const float* pts, const fl
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)nb4_lds);
       attr4 = true;
     }
-    // GLORIE_MLP_COL_VARIANT: "v4" = 16 samples per wave (round 2), "n2w8" / "n2w4" = 32 samples per wave, 8 / 4 waves per
-    // workgroup.  Measured per 614k-sample batch: 495 / 485 / 427 us -> default n2w4
-    auto pick = [](const char* name, int dflt) {
-      const char* v = getenv(name);
-      if (!v || !v[0]) return dflt;
-      return v[0] == 'v' ? 0 : ((v[0] == 'n' && v[1] == '2' && v[2] == 'w' && v[3] == '8') ? 1 : 2);
-    };
-    const int variant_col = pick("GLORIE_MLP_COL_VARIANT", 2);
+    // colour decoder: 32 samples per wave, 4 waves per workgroup (measured per 614k-sample batch against 16 samples per wave
+    // and against 8-wave workgroups: 427 vs 495 / 485 us; the other two forms were removed in round 4)
     if (f32 && f32[0] == '1')
       hipLaunchKernelGGL(mlp_nb_v3_kernel, dim3(blocks2), dim3(512), nb_lds, st, n, pts, cloud_pos, col_feats,
                          I, weights, has, Q, c_col_scratch);
@@ -1431,15 +1273,9 @@ extern "C" int glorie_render_mlp(const float* packed, const float* pts, const fl
     if (f32 && f32[0] == '1')
       hipLaunchKernelGGL(mlp_col_v3_kernel, dim3(blocks2), dim3(512), col_lds, st, k, col_chunks, pts, views,
                          c_col_scratch, Q, raw);
-    else if (variant_col == 1)
-      hipLaunchKernelGGL((mlp_col_v5_kernel<2, 8>), dim3((Q + 255) / 256), dim3(512), col16_lds, st, k, col_chunks16, pts,
-                         views, c_col_scratch, Q, raw, range_flag);
-    else if (variant_col == 2)
+    else
       hipLaunchKernelGGL((mlp_col_v5_kernel<2, 4>), dim3((Q + 127) / 128), dim3(256), col16_lds, st, k, col_chunks16, pts,
                          views, c_col_scratch, Q, raw, range_flag);
-    else
-      hipLaunchKernelGGL(mlp_col_v4_kernel, dim3(blocks2), dim3(512), col16_lds, st, k,
-                         col_chunks16, pts, views, c_col_scratch, Q, raw, range_flag);
   }
   return check_launch();
 }

@@ -17,8 +17,6 @@ import torch.nn.functional as F
 
 from . import droid_backends
 
-_PAIR = os.environ.get("GLORIE_CONV_PAIR", "1") != "0"      # A/B switch of the paired-channel epilogue (round 4)
-
 
 def _conv(cin, cout, k):
     return nn.Conv2d(cin, cout, kernel_size=(k, k), padding=(k // 2, k // 2))
@@ -322,18 +320,18 @@ class FusedUpdate:
         W["ce1_p"] = OtfCorrBlock.pack_encoder(m.corr_encoder[0].weight)
         W["ce1_cl"] = U.pack_corr_encoder(m.corr_encoder[0].weight)
         W["ce1_dm"] = U.pack_corr_encoder_dm(m.corr_encoder[0].weight)
-        W["ce2"], W["ce2_b"] = U.pack_conv_igemm(m.corr_encoder[2].weight, pair=_PAIR), f32(m.corr_encoder[2].bias)
+        W["ce2"], W["ce2_b"] = U.pack_conv_igemm(m.corr_encoder[2].weight, pair=True), f32(m.corr_encoder[2].bias)
         W["fe1"], W["fe1_b"] = U.pack_flow_conv7(m.flow_encoder[0].weight), f32(m.flow_encoder[0].bias)
-        W["fe2"], W["fe2_b"] = U.pack_conv_igemm(m.flow_encoder[2].weight, pair=_PAIR), f32(m.flow_encoder[2].bias)
-        W["zr"] = U.pack_conv_igemm(torch.cat([g.convz.weight, g.convr.weight], 0), pair=_PAIR)
-        W["q"] = U.pack_conv_igemm(g.convq.weight, pair=_PAIR)
+        W["fe2"], W["fe2_b"] = U.pack_conv_igemm(m.flow_encoder[2].weight, pair=True), f32(m.flow_encoder[2].bias)
+        W["zr"] = U.pack_conv_igemm(torch.cat([g.convz.weight, g.convr.weight], 0), pair=True)
+        W["q"] = U.pack_conv_igemm(g.convq.weight, pair=True)
         # the same gates split by input channels [net | inp | corr | flow] (gru.py:20-24): the part over the
         # context features inp is evaluated once per edge (`pre`), the rest every iteration
         dyn = lambda wt: torch.cat([wt[:, 0:128], wt[:, 256:448]], 1)
-        W["zr_dyn"] = U.pack_conv_igemm(torch.cat([dyn(g.convz.weight), dyn(g.convr.weight)], 0), pair=_PAIR)
-        W["q_dyn"] = U.pack_conv_igemm(dyn(g.convq.weight), pair=_PAIR)
+        W["zr_dyn"] = U.pack_conv_igemm(torch.cat([dyn(g.convz.weight), dyn(g.convr.weight)], 0), pair=True)
+        W["q_dyn"] = U.pack_conv_igemm(dyn(g.convq.weight), pair=True)
         W["pre"] = U.pack_conv_igemm(torch.cat([g.convz.weight[:, 128:256], g.convr.weight[:, 128:256],
-                                                g.convq.weight[:, 128:256]], 0), pair=_PAIR)
+                                                g.convq.weight[:, 128:256]], 0), pair=True)
         W["w"], W["w_b"] = U.pack_conv_igemm(g.w.weight), f32(g.w.bias)
         # glo terms: g[n] = glo[n] @ G + (bias of the 1x1 glo conv + bias of the 3x3 gate conv)
         W["G"] = f32(torch.cat([g.convz_glo.weight.view(128, 128), g.convr_glo.weight.view(128, 128),
@@ -345,7 +343,7 @@ class FusedUpdate:
         W["h2"] = U.pack_conv3x3_small([m.delta[2].weight, m.weight[2].weight])
         W["h2_taps"] = U.pack_head_taps([m.delta[2].weight, m.weight[2].weight])
         W["h2_b"] = f32(torch.cat([m.delta[2].bias, m.weight[2].bias]))
-        W["a2"], W["a2_b"] = U.pack_conv_igemm(m.agg.conv2.weight, pair=_PAIR), f32(m.agg.conv2.bias)
+        W["a2"], W["a2_b"] = U.pack_conv_igemm(m.agg.conv2.weight, pair=True), f32(m.agg.conv2.bias)
         W["eta"], W["eta_b"] = U.pack_conv3x3_small([m.agg.eta[0].weight]), f32(m.agg.eta[0].bias)
         W["up"], W["up_b"] = U.pack_conv_igemm(m.agg.upmask[0].weight), f32(m.agg.upmask[0].bias)
         W["up_cvx"], W["up_cvx_b"] = U.pack_upmask_conv(m.agg.upmask[0].weight, m.agg.upmask[0].bias)
@@ -666,14 +664,15 @@ class CorrArena:
 
     layout "dm" (default for 4 levels): displacement-major, source-tiled lines (csrc/corr_dm.hip) - neighbouring source
     pixels share the 128-byte lines their windows read, and corr_encoder[0] can run inside the lookup launch
-    (`lookup_encode`).  layout "tiled": per-pixel planes in 4x8 blocks (csrc/corr.hip, rounds 1-2; GLORIE_CORR_LAYOUT=tiled)."""
+    (`lookup_encode`).  layout "tiled": per-pixel planes in 4x8 blocks (csrc/corr.hip, rounds 1-2; what other pyramid shapes
+    fall back to, and what the layout-agreement tests pass explicitly)."""
 
     def __init__(self, h, w, device, num_levels=4, radius=3, capacity=16, layout=None):
         assert radius == 3
         self.h, self.w, self.num_levels, self.radius = h, w, num_levels, radius
         self.device = torch.device(device)
         if layout is None:
-            layout = os.environ.get("GLORIE_CORR_LAYOUT", "dm")
+            layout = "dm"
         if num_levels != 4 or (h >> 3) < 1 or (w >> 3) < 1 or w > 112:
             layout = "tiled"                 # the displacement-major lookup is the 4-level, radius-3 form only
         if layout not in ("dm", "tiled"):

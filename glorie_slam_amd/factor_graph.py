@@ -56,8 +56,8 @@ class FactorGraph:
         # fp16 channels-last form of the update operator with fused element-wise stages
         # (droid_net.FusedUpdate, csrc/gru.hip)
         self.fast_update = FusedUpdate(update_op, inplace=self.use_graphs) if str(device).startswith("cuda") else None
-        # gate term of the context features per keyframe instead of per edge (GLORIE_SHARE_CONTEXT=0: per edge, for A/B runs)
-        self.share_context = os.environ.get("GLORIE_SHARE_CONTEXT", "1") != "0"
+        # gate term of the context features per source keyframe instead of per edge (an attribute: tests compare both)
+        self.share_context = True
 
     def _use_arena(self):
         """the HIP pyramid builder + slot arena (widths that are multiples of 8, fp16 maps on the GPU)"""

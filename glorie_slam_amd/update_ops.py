@@ -224,13 +224,17 @@ def pack_corr_encoder_dm(weight):
     return wp.reshape(128, 224).contiguous()
 
 
+CONV_POLICY = {None: 0, "auto": 0, "128": 1, "64": 2, "split": 3, "wide": 4, "nohalo": 5}   # bits 12-15 of `epilogue`
+
+
 def conv_igemm(xa, xb, w_packed, taps, nout, out, epilogue=EPI_BIAS_ACT, terms=None, act=ACT_NONE,
-               net=None, z=None, out2=None, pre=None, pre_map=None):
+               net=None, z=None, out2=None, pre=None, pre_map=None, policy=None):
     """Implicit-GEMM convolution with fused epilogue (csrc/conv.hip, include/glorie_hip.h).
     xa / xb: channels-last fp16 maps [N,Ca,h,w] / [N,Cb,h,w] (either may be None); writes `out`
     (and `out2` for the GRU gates) and returns `out`.  pre: fp16 channels-last [N,nout,h,w] added before the
     gate non-linearity (the hoisted convolution over the context features); with pre_map (int32 [N]) map e reads map
-    pre_map[e] of `pre`, which then holds one map per distinct context (source keyframe) instead of one per edge."""
+    pre_map[e] of `pre`, which then holds one map per distinct context (source keyframe) instead of one per edge.
+    policy: tile choice forced by the caller (CONV_POLICY; tests and tools/bench_conv.py - the product passes None = auto)."""
     ref = xa if xa is not None else xb
     L.need_cuda(ref, w_packed, out)
     n, _, h, w = ref.shape
@@ -261,6 +265,7 @@ def conv_igemm(xa, xb, w_packed, taps, nout, out, epilogue=EPI_BIAS_ACT, terms=N
         raise RuntimeError("conv_igemm: bad output shape")
     if getattr(w_packed, "_glorie_pair", False):
         epilogue |= EPI_PAIR16
+    epilogue |= CONV_POLICY[policy] << 12
     L.check(L.load().glorie_conv_igemm(pa, sa, ca, pb, sb, cb, L.ptr(w_packed), taps, nout, epilogue,
                                        L.ptr(terms), ts, act, pn, sn, pz, sz, L.ptr(out), _rows(out, "out"),
                                        po2, so2, pp, sp, L.ptr(pre_map), n, h, w, L.stream_ptr()), "glorie_conv_igemm")

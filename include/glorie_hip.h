@@ -265,7 +265,16 @@ int glorie_conv3x3_small(const void* x, int x_stride, const float* in_bias, int 
  * is therefore evaluated once per edge instead of once per iteration (a convolution is linear in its input
  * channels: conv([net|inp|corr|flow]) = conv_dyn([net|corr|flow]) + conv_inp(inp)).
  * pre_map (may be NULL): int32 [N], map e reads the rows of map pre_map[e] of `pre` - edges with the same source
- * keyframe have the same context features (inp = video.inps[ii]), so the term is stored once per keyframe. */
+ * keyframe have the same context features (inp = video.inps[ii]), so the term is stored once per keyframe.
+ * `epilogue` carries two more fields above its low byte (round 4):
+ *   bit 8  (GLORIE_CONV_PAIR16): the rows of w_packed are PAIRED - within every group of 32 output channels, row 16 blk + r
+ *          holds channel 8 (r / 4) + 4 blk + r % 4 - so that a lane of the kernel owns 8 consecutive channels of its pixel and
+ *          the epilogue moves 16-byte pieces (epilogues 0-2, nout % 32 == 0; update_ops.pack_conv_igemm(pair=True)).  Same
+ *          products and sums: the output is bit-identical to the unpaired packing's.
+ *   bits 12-15: tile policy forced by the caller, 0 = automatic (what every product call passes); 1 = 128 x 128 tiles,
+ *          2 = 64-pixel tiles, 3 = whole rounds of 128-pixel tiles + the remainder as 64-pixel tiles, 4 = 128 x 256,
+ *          5 = automatic without the haloed pixel tile.  Tests (bit-identity of the variants) and tools/bench_conv.py. */
+#define GLORIE_CONV_PAIR16 0x100
 int glorie_conv_igemm(const void* xa, int xa_stride, int ca, const void* xb, int xb_stride, int cb,
                       const void* w_packed, int taps, int nout, int epilogue, const float* terms,
                       int terms_stride, int act, const void* net, int net_stride, const void* z,

@@ -336,9 +336,7 @@ def test_fused_update_on_the_channels_last_lookup(gpu):
 
 def test_shared_context_term_equals_per_edge_term(gpu, monkeypatch):
     """Edges with the same source keyframe have the same context features: the hoisted gate term kept once per
-    keyframe and read through pre_map gives the bits of the per-edge term (with both forms seeding the accumulators;
-    by default the shared form is added in the epilogue instead - same sum, one fp32 rounding in a different place)."""
-    monkeypatch.setenv("GLORIE_CONV_PRE", "s")
+    keyframe and read through pre_map gives the bits of the per-edge term (both forms add it in the epilogue)."""
     from glorie_slam_amd.droid_net import FusedUpdate, UpdateModule
     torch.manual_seed(5)
     mod = UpdateModule().to(gpu).eval()
@@ -367,11 +365,7 @@ def test_shared_context_term_equals_per_edge_term(gpu, monkeypatch):
     assert b._ctx_key != key
     for x, y in zip(rc, rd):
         assert torch.equal(x, y)
-    # default placement of the shared term (epilogue): equal up to the rounding of one fp32 addition
-    monkeypatch.delenv("GLORIE_CONV_PRE")
-    re_ = b(net, table[ii][None], corr, flow, ii, jj, context=(table, frames, ix))
-    for x, y in zip(re_, rd):
-        torch.testing.assert_close(x.float(), y.float(), atol=2e-3, rtol=2e-3)
+
 
 
 # ---- implicit-GEMM convolution (csrc/conv.hip) -------------------------------------------------
@@ -428,9 +422,10 @@ def test_conv_igemm_gru_epilogues(gpu):
 
 
 @pytest.mark.parametrize("mode", ["128", "64", "split", "wide", "nohalo"])
-def test_conv_tile_variants_are_bit_identical(gpu, mode, monkeypatch):
-    """GLORIE_CONV_TILE only changes which pixels / channels a workgroup owns: every output element sums the same products in
-    the same order, so the 64-pixel, split-launch and 128 x 256 variants must reproduce the default kernel bit for bit
+def test_conv_tile_variants_are_bit_identical(gpu, mode):
+    """The tile policy only changes which pixels / channels a workgroup owns: every output element sums the same products in
+    the same order, so the 64-pixel, split-launch, 128 x 256 and per-tap-staging variants must reproduce the default kernel
+    bit for bit - and so must the PAIRED weight packing (a lane owning 8 consecutive channels) against the unpaired one
     (13 maps of 24 x 32 = 9984 pixels: 78 tiles of 128, enough for one whole round + a remainder in the split form)"""
     from glorie_slam_amd import update_ops as U
     n, h, w = 13, 24, 32
@@ -438,28 +433,25 @@ def test_conv_tile_variants_are_bit_identical(gpu, mode, monkeypatch):
     wide_t = _cl_half(n, 256, h, w, gpu, 52)
     xb = wide_t[:, 64:256]
     g = torch.Generator(device="cpu").manual_seed(53)
-    wq = U.pack_conv_igemm((torch.randn(128, 320, 3, 3, generator=g) / 54).to(gpu))
-    wzr = U.pack_conv_igemm((torch.randn(256, 320, 3, 3, generator=g) / 54).to(gpu))
+    wq_t = (torch.randn(128, 320, 3, 3, generator=g) / 54).to(gpu)
+    wzr_t = (torch.randn(256, 320, 3, 3, generator=g) / 54).to(gpu)
     terms = torch.randn(n, 384, generator=g).to(gpu)
     pre = _cl_half(n, 384, h, w, gpu, 54)
     z0 = _cl_half(n, 128, h, w, gpu, 55).abs().clamp(max=1.0)
     cl = lambda c: torch.empty((n, c, h, w), dtype=torch.float16, device=gpu, memory_format=torch.channels_last)
 
-    def run():
+    def run(policy, pair):
+        wq, wzr = U.pack_conv_igemm(wq_t, pair=pair), U.pack_conv_igemm(wzr_t, pair=pair)
         new, z, rnet = cl(128), cl(128), cl(128)
-        U.conv_igemm(net, xb, wq, 9, 128, new, epilogue=U.EPI_GRU_Q, terms=terms[:, 256:], net=net, z=z0, pre=pre[:, 256:384])
-        U.conv_igemm(net, xb, wzr, 9, 256, z, epilogue=U.EPI_GRU_ZR, terms=terms[:, :256], net=net, out2=rnet, pre=pre[:, 0:256])
+        U.conv_igemm(net, xb, wq, 9, 128, new, epilogue=U.EPI_GRU_Q, terms=terms[:, 256:], net=net, z=z0, pre=pre[:, 256:384],
+                     policy=policy)
+        U.conv_igemm(net, xb, wzr, 9, 256, z, epilogue=U.EPI_GRU_ZR, terms=terms[:, :256], net=net, out2=rnet, pre=pre[:, 0:256],
+                     policy=policy)
         return torch.cat([new, z, rnet], 1).clone()
 
-    monkeypatch.delenv("GLORIE_CONV_TILE", raising=False)
-    monkeypatch.delenv("GLORIE_CONV_HALO", raising=False)
-    ref = run()
-    if mode == "nohalo":              # per-tap pixel staging (rounds 1-2) against the shared haloed tile (conv_halo_kernel, default)
-        monkeypatch.setenv("GLORIE_CONV_HALO", "0")
-        assert torch.equal(run(), ref)
-        return
-    monkeypatch.setenv("GLORIE_CONV_TILE", mode)
-    assert torch.equal(run(), ref)
+    ref = run(None, False)
+    assert torch.equal(run(mode, False), ref)
+    assert torch.equal(run(mode, True), ref) and torch.equal(run(None, True), ref)
 
 
 def test_flow_conv7_matches_conv2d(gpu):

@@ -86,20 +86,16 @@ def tile_modes():
     terms = torch.randn(n, 384, device=dev)
     z, rnet, new, h1 = cl(128), cl(128), cl(128), cl(384)
     cases = {
-        "z|r gate 320->256": lambda: U.conv_igemm(net, dynx, wzr, 9, 256, z, epilogue=U.EPI_GRU_ZR, terms=terms[:, 0:256],
-                                                  net=net, out2=rnet, pre=pre[:, 0:256]),
-        "q gate 320->128": lambda: U.conv_igemm(rnet, dynx, wq, 9, 128, new, epilogue=U.EPI_GRU_Q, terms=terms[:, 256:384],
-                                                net=net, z=z, pre=pre[:, 256:384]),
-        "heads 128->384": lambda: U.conv_igemm(net, None, wh, 9, 384, h1),
+        "z|r gate 320->256": lambda pol: U.conv_igemm(net, dynx, wzr, 9, 256, z, epilogue=U.EPI_GRU_ZR, terms=terms[:, 0:256],
+                                                      net=net, out2=rnet, pre=pre[:, 0:256], policy=pol),
+        "q gate 320->128": lambda pol: U.conv_igemm(rnet, dynx, wq, 9, 128, new, epilogue=U.EPI_GRU_Q, terms=terms[:, 256:384],
+                                                    net=net, z=z, pre=pre[:, 256:384], policy=pol),
+        "heads 128->384": lambda pol: U.conv_igemm(net, None, wh, 9, 384, h1, policy=pol),
     }
     for name, fn in cases.items():
         res = []
-        for mode in ("128", "wide", "64", "split", None):
-            if mode is None:
-                os.environ.pop("GLORIE_CONV_TILE", None)
-            else:
-                os.environ["GLORIE_CONV_TILE"] = mode
-            res.append(f"{mode or 'auto'} {timed(fn):6.1f} us")
+        for mode in ("128", "wide", "64", "split", "nohalo", None):
+            res.append(f"{mode or 'auto'} {timed(lambda: fn(mode)):6.1f} us")
         print(f"{name:20s} " + "   ".join(res), flush=True)
 
 

@@ -16,16 +16,12 @@ w_ce1 = U.pack_conv_igemm(torch.randn(128, 256, 1, 1, device=dev) / 16)
 w_ce2 = U.pack_conv_igemm(torch.randn(128, 128, 3, 3, device=dev) / 34)
 w_fe2 = U.pack_conv_igemm(torch.randn(64, 128, 3, 3, device=dev) / 34)
 cases = {
-    "ce1 1x1 256->128": lambda: U.conv_igemm(x256, None, w_ce1, 1, 128, o128, terms=b128, act=U.ACT_RELU),
-    "ce2 3x3 128->128": lambda: U.conv_igemm(x128, None, w_ce2, 9, 128, o128, terms=b128, act=U.ACT_RELU),
-    "fe2 3x3 128->64": lambda: U.conv_igemm(x128, None, w_fe2, 9, 64, o64, terms=b64, act=U.ACT_RELU),
+    "ce1 1x1 256->128": lambda pol: U.conv_igemm(x256, None, w_ce1, 1, 128, o128, terms=b128, act=U.ACT_RELU, policy=pol),
+    "ce2 3x3 128->128": lambda pol: U.conv_igemm(x128, None, w_ce2, 9, 128, o128, terms=b128, act=U.ACT_RELU, policy=pol),
+    "fe2 3x3 128->64": lambda pol: U.conv_igemm(x128, None, w_fe2, 9, 64, o64, terms=b64, act=U.ACT_RELU, policy=pol),
 }
 for name, fn in cases.items():
     res = []
     for mode in ("128", "wide", "64", None):
-        if mode is None:
-            os.environ.pop("GLORIE_CONV_TILE", None)
-        else:
-            os.environ["GLORIE_CONV_TILE"] = mode
-        res.append(f"{mode or 'auto'} {timed(fn):6.1f} us")
+        res.append(f"{mode or 'auto'} {timed(lambda: fn(mode)):6.1f} us")
     print(f"{name:20s} " + "   ".join(res), flush=True)
