@@ -39,6 +39,31 @@ def test_pack_conv_igemm_layout():
     assert U.pack_conv_igemm(w1).numel() == 640 * 128 + 64               # 576 -> 5 tiles of 128
 
 
+def test_pack_conv_igemm_paired_rows():
+    """pair=True (include/glorie_hip.h: GLORIE_CONV_PAIR16): within every group of 32 output channels, packed row
+    16 blk + r holds channel 8 (r // 4) + 4 blk + r % 4 - the MFMA hands lane group kg rows 4 kg .. 4 kg + 3 of a 16-row
+    block, so the lane's rows of blocks 2b and 2b + 1 are the 8 consecutive channels 32 b + 8 kg .. + 7"""
+    import pytest
+    g = torch.Generator().manual_seed(2)
+    w = torch.randn(96, 64, 3, 3, generator=g)
+    pk = U.pack_conv_igemm(w, pair=True)
+    assert pk._glorie_pair and not U.pack_conv_igemm(w)._glorie_pair
+    body = pk[:-64].view(9, 128, 64)
+    plain = U.pack_conv_igemm(w)[:-64].view(9, 128, 64)
+    for R in range(128):
+        r = R % 16
+        chan = 32 * (R // 32) + 8 * (r // 4) + 4 * ((R % 32) // 16) + r % 4
+        assert torch.equal(body[:, R], plain[:, chan])
+    for b in range(4):                                           # what a lane (kg) owns across a pair of blocks
+        for kg in range(4):
+            rows = [32 * b + 16 * blk + 4 * kg + k for blk in (0, 1) for k in range(4)]
+            chans = [32 * b + 8 * (r % 16 // 4) + 4 * ((r % 32) // 16) + r % 4 for r in rows]
+            assert chans == list(range(32 * b + 8 * kg, 32 * b + 8 * kg + 8))
+    with pytest.raises(RuntimeError):
+        U.pack_conv_igemm(torch.randn(70, 64, 3, 3), pair=True)          # Nout % 32 != 0
+    assert U.CONV_POLICY[None] == 0 and sorted(U.CONV_POLICY.values())[-1] == 5 and U.EPI_PAIR16 == 0x100
+
+
 def test_pack_conv3x3_small_and_flow_layouts():
     g = torch.Generator().manual_seed(2)
     ws = [torch.randn(2, 128, 3, 3, generator=g), torch.randn(2, 128, 3, 3, generator=g)]
