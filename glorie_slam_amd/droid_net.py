@@ -473,6 +473,11 @@ class FusedUpdate:
             else:
                 wn = U.conv_igemm(net0, None, W["w"], 1, 128, cl_map(128))
                 g = U.gru_glo_terms(wn, W["w_b"], net0, W["G"], W["G_b"])
+        if self.glo_stream and not self.parallel:
+            # joined in front of the lookup: the branch is through by then (it started beside the 68 us flow encoder), and the
+            # lookup keeps the chip to itself - with the join behind corr_encoder[2] its tail still overlapped the lookup:
+            # step +0.4 %, lookup 48 -> 57 us
+            main.wait_stream(side[1])
         # corr_encoder (droid_net.py:73-77): 1x1 as a transposed GEMM on the NCHW lookup output
         if hasattr(corr, "encode_into"):
             # volume-free lookup with corr_encoder[0] fused behind it (csrc/corr_otf.hip): the 196-channel map
