@@ -1,5 +1,5 @@
 """Correlation lookups on graph G8 (36 edges, 60x80) in isolation: the tiled volume gather, the volume-free MFMA
-lookup (legacy 4x4-per-wave kernel with GLORIE_OTF_LEGACY=1) and the lookup with the fused corr_encoder[0].
+lookup and the lookup with the fused corr_encoder[0].
     python tools/bench_corr.py"""
 import os
 import sys

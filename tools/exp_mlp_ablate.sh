@@ -7,7 +7,7 @@ if [ $# -eq 0 ]; then set -- "" "-DEXP_MLP_NO_SOFTPLUS" "-DEXP_MLP_NO_SPLIT" "-D
 for fl in "$@"; do
   GLORIE_EXTRA_HIPFLAGS="$fl" python glorie_slam_amd/build.py > /dev/null 2>&1 || exit 1
   echo "== flags: [$fl]" >> gpurun_out/exp_mlp_ablate.txt
-  (cd /tmp && rm -rf /tmp/prof && GLORIE_MLP_NB=${NBV:-5} rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o r -- python $R/tools/prof_render.py > /tmp/log 2>&1
+  (cd /tmp && rm -rf /tmp/prof && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o r -- python $R/tools/prof_render.py > /tmp/log 2>&1
    f=$(find /tmp/prof -name "*kernel_stats.csv" | head -1); python $R/tools/show_stats.py $f 5 | grep "nb_v\|col_v" >> $R/gpurun_out/exp_mlp_ablate.txt)
 done
 GLORIE_EXTRA_HIPFLAGS="" python glorie_slam_amd/build.py > /dev/null 2>&1

@@ -1,4 +1,4 @@
-"""s_memtime checkpoints of one workgroup of the otf8 lookup (GLORIE_OTF_DBG=32): where a workgroup's 40k cycles go"""
+"""s_memtime checkpoints of one workgroup of the otf8 lookup (GLORIE_OTF_DBG=32 in a -DEXP_OTF_DBG build of corr_otf.hip): where a workgroup's 40k cycles go"""
 import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
