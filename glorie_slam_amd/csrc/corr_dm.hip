@@ -12,15 +12,18 @@
 // fetches ~3.5 128-byte lines per (pixel, level) for 128 useful bytes (profiles/r02_pmc_kernels.json: 311 MB read for 88.5 MB).
 // Here the SAME values are stored so that neighbouring source pixels that look at the same displacement share a line:
 //
-//   D_l[slot][tile][dy][dx][lane]      fp16, one 128-byte line per (tile, dy, dx)
+//   D_l[slot][tile][dy][dx >> 1][lane][dx & 1]   fp16, one 256-byte line per (tile, dy, displacement-column PAIR): a lane's
+//                                                two neighbouring displacement columns are one dword (round 4)
 //     tile = 8 x 8 block of source pixels (row-major over ceil(h/8) x ceil(w/8)),  lane = (sy & 7) * 8 + (sx & 7)
 //     dy   = (ty - (sy >> l) + ((h>>l) >> 1)) mod (h>>l)          (ty, tx) = target pixel of level l
-//     dx   = (tx - (sx >> l) + ((w>>l) >> 1)) mod (w>>l)
+//     dx   = (tx - (sx >> l) + ((w>>l) >> 1)) mod Wp,  Wp = (w>>l) rounded up to even (odd widths: one zero column)
 //
 // which is a bijection of every source pixel's plane (a cyclic shift by the pixel's own level-l position, centred so that
-// zero flow sits mid-plane and the wrap is at +-half an image of displacement).  A wave owns one tile; for window tap
-// (i, j) lane s reads D_l[tile][by(s) + j][bx(s) + i][s] with a 2-byte buffer load: wherever the flow is locally constant
-// all 64 lanes hit ONE line, and the union over the 8 x 8 window is ~(8 + spread)^2 lines per 64 pixels instead of 64 x 3.5.
+// zero flow sits mid-plane and the wrap is at +-half an image of displacement).  A wave owns one tile; for window row j
+// lane s reads the FIVE dwords D_l[tile][by(s) + j][(bx(s) >> 1) + c][s] that hold its 8 window columns (the launch's cost is
+// its number of gather instructions - 32.0 / 26.8 / 24.5 us with 256 / 128 / 0 per tile - so two taps travel per load: 160
+// instead of 256 gathers, +12 % bytes for windows that start on an odd column): wherever the flow is locally constant all
+// 64 lanes hit ONE line, and the union over the 8 x 8 window is ~(8 + spread)^2 / 2 lines per 64 pixels instead of 64 x 3.5.
 // Same footprint (planes are padded to whole tiles: +6.7 % at 60 x 80), same values, so the arithmetic of the lookup
 // (c10::Half products and sums, see corr.hip) is reproduced bit for bit.
 //
@@ -44,7 +47,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 struct DmArgs {
-  const _Float16* lvl[4];     // arena levels [capacity][ntiles][(h>>l)*(w>>l)][64]
+  const _Float16* lvl[4];     // arena levels [capacity][ntiles][(h>>l) * Wp][64], Wp = even(w>>l)
   const int* slots;           // slot of edge n (NULL: slot0 + n)
   int slot0;
   const float* coords;        // [N][HW][2] (coords_xy) or [N][2][HW], UNscaled
@@ -68,12 +71,25 @@ __device__ __forceinline__ _Float16 to_half_rn(float prod) {
   return (_Float16)prod;
 }
 __device__ __forceinline__ h2 splat(_Float16 v) { return h2{v, v}; }
-// A lane's tap is half of a dword it shares with its neighbour lane (lanes 2m, 2m + 1 own the halves of dword m of the line):
-// the gathers fetch that aligned DWORD (buffer_load_dword: measured much cheaper per instruction than buffer_load_ushort on
-// gfx950 - the fused lookup 32.9 -> 27 us at G8 for the same lines) and the pair-forming v_perm_b32 picks the lane's half:
-// selector 0x05040100 = (hi.lo16 << 16) | lo.lo16 for even lanes, 0x07060302 = (hi.hi16 << 16) | lo.hi16 for odd lanes
-__device__ __forceinline__ unsigned half_sel(int lane) { return (lane & 1) ? 0x07060302u : 0x05040100u; }
-__device__ __forceinline__ h2 pk(unsigned lo, unsigned hi, unsigned sel) { return __builtin_bit_cast(h2, __builtin_amdgcn_perm(hi, lo, sel)); }
+// Window columns i = 0..7 of a lane start at displaced column bx; the five dwords D[0..4] of a window row hold the displaced
+// columns e .. e + 9, e = bx - (bx & 1).  A packed pair of taps is ONE v_perm_b32 of two neighbouring dwords with a per-lane
+// selector (perm(D[k+1], D[k], sel): selector bytes 0-3 name D[k], 4-7 D[k+1], 0x0c yields zero):
+//   aligned pair (2k, 2k+1):  bx even: D[k] as it is (0x03020100);  bx odd: (D[k].hi, D[k+1].lo) (0x05040302)
+//   odd pair (2k+1, 2k+2):    bx even: (D[k].hi, D[k+1].lo);        bx odd: D[k+1] as it is (0x07060504)
+// and a tap whose target column lies outside the level's map gets 0x0c0c for its half - zero padding costs no instruction.
+__device__ __forceinline__ void dm_selectors(int px, unsigned ux0, unsigned wl, unsigned (&selp)[4], unsigned (&selq)[4]) {
+  const unsigned lo_a = px ? 0x0302u : 0x0100u, hi_a = px ? 0x0504u : 0x0302u;      // aligned pair: halves (2k, 2k+1)
+  const unsigned lo_o = px ? 0x0504u : 0x0302u, hi_o = px ? 0x0706u : 0x0504u;      // odd pair: halves (2k+1, 2k+2)
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const bool v0 = ux0 + (unsigned)(2 * k) < wl, v1 = ux0 + (unsigned)(2 * k + 1) < wl, v2 = ux0 + (unsigned)(2 * k + 2) < wl;
+    selp[k] = (v0 ? lo_a : 0x0c0cu) | ((v1 ? hi_a : 0x0c0cu) << 16);
+    selq[k] = (v1 ? lo_o : 0x0c0cu) | (((k < 3 && v2) ? hi_o : 0x0c0cu) << 16);      // beyond the window: (tap 7, 0)
+  }
+}
+__device__ __forceinline__ h2 perm2(unsigned d1, unsigned d0, unsigned sel) {
+  return __builtin_bit_cast(h2, __builtin_amdgcn_perm(d1, d0, sel));
+}
 
 // one term of the reference's accumulation: products and sums individually rounded to fp16 (no contraction)
 __device__ __forceinline__ h2 acc_term(h2 acc, h2 s, h2 w) {
@@ -89,43 +105,51 @@ __device__ __forceinline__ h2 acc_term0(h2 s, h2 w) {
 // ---- one level of one tile: gather the 8 x 8 window of every lane's pixel ------------------------------------------
 template <int L>
 __device__ __forceinline__ void dm_gather(const DmArgs& a, size_t slot_tile, int sy, int sx, int lane, float x0, float y0,
-                                          unsigned (&raw)[8][8], float& fdx, float& fdy) {
-  const int hl = a.h >> L, wl = a.w >> L;
+                                          unsigned (&raw)[8][5], unsigned (&selp)[4], unsigned (&selq)[4], float& fdx, float& fdy) {
+  const int hl = a.h >> L, wl = a.w >> L, wp = (wl + 1) & ~1;
   const float inv = 1.0f / (float)(1 << L);
   const float xs = x0 * inv, ys = y0 * inv;
   const float fx = floorf(xs), fy = floorf(ys);
   fdx = xs - fx;
   fdy = ys - fy;
   const int ix0 = static_cast<int>(fx) - 3, iy0 = static_cast<int>(fy) - 3;
-  const int bx = ix0 - (sx >> L) + (wl >> 1), by = iy0 - (sy >> L) + (hl >> 1);
-  const _Float16* base = a.lvl[L] + slot_tile * ((size_t)hl * wl * 64);
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, hl * wl * 128, 0x00020000);
-  unsigned coff[8], roff[8];
+  int bx = ix0 - (sx >> L) + (wl >> 1);
+  bx %= wp;
+  bx = bx < 0 ? bx + wp : bx;
+  const int by = iy0 - (sy >> L) + (hl >> 1);
+  const int px = bx & 1;
+  dm_selectors(px, (unsigned)ix0, (unsigned)wl, selp, selq);
+  const _Float16* base = a.lvl[L] + slot_tile * ((size_t)hl * wp * 64);
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, hl * wp * 128, 0x00020000);
+  unsigned coff[5], roff[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int tx = ix0 + i;
-    int d = bx + i;
-    d = d < 0 ? d + wl : (d >= wl ? d - wl : d);
-    coff[i] = (tx >= 0 && tx < wl) ? (unsigned)d * 128u : kOob;
+  for (int c = 0; c < 5; ++c) {
+    // dword c holds window columns 2c - px and 2c + 1 - px
+    const int i0 = 2 * c - px, i1 = i0 + 1;
+    const bool need = (i0 >= 0 && i0 < 8 && (unsigned)(ix0 + i0) < (unsigned)wl) ||
+                      (i1 >= 0 && i1 < 8 && (unsigned)(ix0 + i1) < (unsigned)wl);
+    const int d = ((bx >> 1) + c) % (wp >> 1);          // small levels wrap more than once (wp / 2 may be < 5)
+    coff[c] = need ? (unsigned)d * 256u : kOob;
   }
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int ty = iy0 + j;
-    int d = by + j;
-    d = d < 0 ? d + hl : (d >= hl ? d - hl : d);
-    roff[j] = (ty >= 0 && ty < hl) ? (unsigned)(d * wl) * 128u + (unsigned)(lane >> 1) * 4u : kOob;
+    int d = (by + j) % hl;
+    d = d < 0 ? d + hl : d;
+    roff[j] = (ty >= 0 && ty < hl) ? (unsigned)(d * (wp >> 1)) * 256u + (unsigned)lane * 4u : kOob;
   }
 #pragma unroll
   for (int j = 0; j < 8; ++j)
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-      raw[j][i] = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(roff[j] + coff[i]), 0, 0);
+    for (int c = 0; c < 5; ++c)
+      raw[j][c] = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(roff[j] + coff[c]), 0, 0);
 }
 
 // ---- bilinear blend of one level: 7 window rows of 8 packed taps (tap 7 zero) ---------------------------------------
 // out(i, j) = (((0 + s(i,j) w00) + s(i,j+1) w01) + s(i+1,j) w10) + s(i+1,j+1) w11   (correlation_kernels.cu:52-64: the four
 // contributions reach corr[i][j] in exactly this order), evaluated for taps (2k, 2k+1) at once on the packed fp16 pipes
-__device__ __forceinline__ void dm_blend(const unsigned (&raw)[8][8], float fdx, float fdy, unsigned sel, u32x4 (&rows)[7]) {
+__device__ __forceinline__ void dm_blend(const unsigned (&raw)[8][5], float fdx, float fdy, const unsigned (&selp)[4],
+                                         const unsigned (&selq)[4], u32x4 (&rows)[7]) {
   const h2 w00 = splat(to_half_rn((1.0f - fdx) * (1.0f - fdy)));
   const h2 w01 = splat(to_half_rn((1.0f - fdx) * fdy));
   const h2 w10 = splat(to_half_rn(fdx * (1.0f - fdy)));
@@ -133,10 +157,10 @@ __device__ __forceinline__ void dm_blend(const unsigned (&raw)[8][8], float fdx,
   h2 P[2][4], Q[2][4];            // window rows j, j + 1: pairs (2k, 2k+1) and (2k+1, 2k+2)
   auto pack_row = [&](int j, h2 (&p)[4], h2 (&q)[4]) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) p[k] = pk(raw[j][2 * k], raw[j][2 * k + 1], sel);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) q[k] = pk(raw[j][2 * k + 1], raw[j][2 * k + 2], sel);
-    q[3] = pk(raw[j][7], 0u, sel);
+    for (int k = 0; k < 4; ++k) {
+      p[k] = perm2(raw[j][k + 1], raw[j][k], selp[k]);
+      q[k] = perm2(raw[j][k + 1], raw[j][k], selq[k]);
+    }
   };
   pack_row(0, P[0], Q[0]);
 #pragma unroll
@@ -163,11 +187,11 @@ __device__ __forceinline__ void dm_blend(const unsigned (&raw)[8][8], float fdx,
 template <int L>
 __device__ __forceinline__ void dm_level(const DmArgs& a, size_t slot_tile, int sy, int sx, int lane, float x0, float y0,
                                          bool live, size_t row) {
-  unsigned raw[8][8];
+  unsigned raw[8][5], selp[4], selq[4];
   float fdx, fdy;
-  dm_gather<L>(a, slot_tile, sy, sx, lane, x0, y0, raw, fdx, fdy);
+  dm_gather<L>(a, slot_tile, sy, sx, lane, x0, y0, raw, selp, selq, fdx, fdy);
   u32x4 rows[7];
-  dm_blend(raw, fdx, fdy, half_sel(lane), rows);
+  dm_blend(raw, fdx, fdy, selp, selq, rows);
   if (live) {
     u32x4* op = reinterpret_cast<u32x4*>(a.corr_cl + row * 256 + L * 64);
 #pragma unroll
@@ -219,52 +243,52 @@ __global__ __launch_bounds__(256) void corr_dm_lookup_kernel(DmArgs a) {
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kEnc2Lds = 232;   // halfs per weight row in LDS (224 + 8)
 
-// the lane's halves of two gathered dwords as one packed pair (selector: half_sel of the lane)
-__device__ __forceinline__ h2 perm16(unsigned s0, unsigned s1, unsigned sel) {
-  return __builtin_bit_cast(h2, __builtin_amdgcn_perm(s0, s1, sel));
-}
-
-// Per-level gather state.  The window's displaced coordinates are consecutive modulo the plane, so the byte offsets are
-// carried incrementally (+ one column / one row, reset at the plane's end: 3 operations) next to an unsigned counter for
-// the tap's validity (3 more) instead of being derived tap by tap.  Offsets of invalid taps may be anything: they are
-// replaced by kOob.  The arithmetic is modulo 2^32, which is what makes a start left of the plane (only reachable when the
-// first valid tap is further right) arrive at 0 on the right step.
+// Per-level gather state.  The window's displaced rows are consecutive modulo the plane, so the row's byte offset is carried
+// incrementally (+ one row, reset at the plane's end: 3 operations) next to an unsigned counter for the row's validity (3
+// more) instead of being derived row by row; the five column offsets and the eight pair selectors are fixed per level.
+// Offsets of invalid rows / unneeded dwords are replaced by kOob (the load returns 0 without a memory access).
 struct DmLevel {
   __amdgpu_buffer_rsrc_t rs;
-  unsigned coff[8];
+  unsigned coff[5];
+  unsigned selp[4], selq[4];
   unsigned r, uy;                 // running: byte offset of the next window row (+ the lane's dword), its target row as unsigned
-  unsigned rstep, rend, lane2, hl, sel;
+  unsigned rstep, rend, lane4, hl;
   h2 w00, w01, w10, w11;
 };
 
 template <int L>
 __device__ __forceinline__ void dm_setup(const DmArgs& a, size_t slot_tile, int sy, int sx, int lane, float x0, float y0,
                                          DmLevel& st) {
-  const int hl = a.h >> L, wl = a.w >> L;
+  const int hl = a.h >> L, wl = a.w >> L, wp = (wl + 1) & ~1, wp2 = wp >> 1;
   const float inv = 1.0f / (float)(1 << L);
   const float xs = x0 * inv, ys = y0 * inv;
   const float fx = floorf(xs), fy = floorf(ys);
   const float fdx = xs - fx, fdy = ys - fy;
   const int ix0 = static_cast<int>(fx) - 3, iy0 = static_cast<int>(fy) - 3;
+  // |displacement| < 2 planes for every coordinate that has a valid tap at all; others only need SOME in-range value
   int bx = ix0 - (sx >> L) + (wl >> 1), by = iy0 - (sy >> L) + (hl >> 1);
-  bx = bx < 0 ? bx + wl : (bx >= wl ? bx - wl : bx);
+  bx = bx < 0 ? bx + wp : (bx >= wp ? bx - wp : bx);
   by = by < 0 ? by + hl : (by >= hl ? by - hl : by);
-  const _Float16* base = a.lvl[L] + slot_tile * ((size_t)hl * wl * 64);
-  st.rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, hl * wl * 128, 0x00020000);
-  const unsigned cend = (unsigned)wl * 128u;
-  unsigned c = (unsigned)bx * 128u, ux = (unsigned)ix0;
+  const int px = bx & 1;
+  dm_selectors(px, (unsigned)ix0, (unsigned)wl, st.selp, st.selq);
+  const _Float16* base = a.lvl[L] + slot_tile * ((size_t)hl * wp * 64);
+  st.rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, hl * wp * 128, 0x00020000);
+  const unsigned cend = (unsigned)wp2 * 256u;
+  unsigned c = (unsigned)(bx >> 1) * 256u;
+  // dword cc holds window columns 2 cc - px and 2 cc + 1 - px: needed if either has its target inside the map
+  const unsigned ux = (unsigned)(ix0 - px);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    st.coff[i] = ux < (unsigned)wl ? c : kOob;
-    ux += 1u;
-    c += 128u;
+  for (int cc = 0; cc < 5; ++cc) {
+    const bool n0 = (cc > 0 || px == 0) && (cc < 4 || px == 1) && ux + (unsigned)(2 * cc) < (unsigned)wl;
+    const bool n1 = cc < 4 && ux + (unsigned)(2 * cc + 1) < (unsigned)wl;
+    st.coff[cc] = (n0 || n1) ? c : kOob;
+    c += 256u;
     c = c == cend ? 0u : c;
   }
-  st.lane2 = (unsigned)(lane >> 1) * 4u;
-  st.sel = half_sel(lane);
+  st.lane4 = (unsigned)lane * 4u;
   st.rstep = cend;
-  st.rend = (unsigned)hl * cend + st.lane2;
-  st.r = (unsigned)by * cend + st.lane2;
+  st.rend = (unsigned)hl * cend + st.lane4;
+  st.r = (unsigned)by * cend + st.lane4;
   st.uy = (unsigned)iy0;
   st.hl = (unsigned)hl;
   st.w00 = splat(to_half_rn((1.0f - fdx) * (1.0f - fdy)));
@@ -273,37 +297,35 @@ __device__ __forceinline__ void dm_setup(const DmArgs& a, size_t slot_tile, int 
   st.w11 = splat(to_half_rn(fdx * fdy));
 }
 
-// the next window row (rows are requested in order, 0..7)
-__device__ __forceinline__ void dm_load_row(DmLevel& st, unsigned (&row)[8]) {
+// the next window row (rows are requested in order, 0..7): five dwords = ten displaced columns
+__device__ __forceinline__ void dm_load_row(DmLevel& st, unsigned (&row)[5]) {
   const unsigned roff = st.uy < st.hl ? st.r : kOob;
   st.uy += 1u;
   st.r += st.rstep;
-  st.r = st.r == st.rend ? st.lane2 : st.r;
+  st.r = st.r == st.rend ? st.lane4 : st.r;
 #pragma unroll
 #ifdef EXP_DM_NO_GATHER
-  for (int i = 0; i < 8; ++i) row[i] = (roff + st.coff[i]) & 0x3c00u;          // ablation: arithmetic only, no memory
+  for (int i = 0; i < 5; ++i) row[i] = (roff + st.coff[i]) & 0x3c003c00u;          // ablation: arithmetic only, no memory
 #else
-  for (int i = 0; i < 8; ++i) row[i] = __builtin_amdgcn_raw_buffer_load_b32(st.rs, (int)(roff + st.coff[i]), 0, 0);
+  for (int i = 0; i < 5; ++i) row[i] = __builtin_amdgcn_raw_buffer_load_b32(st.rs, (int)(roff + st.coff[i]), 0, 0);
 #endif
 }
 
-// the 4 aligned tap pairs (2k, 2k+1) of a window row
-__device__ __forceinline__ void dm_pack_row(const unsigned (&row)[8], unsigned sel, h2 (&p)[4]) {
+// the 4 aligned tap pairs (2k, 2k+1) and the 4 odd pairs (2k+1, 2k+2) of a window row
+__device__ __forceinline__ void dm_pack_row(const unsigned (&row)[5], const DmLevel& st, h2 (&p)[4], h2 (&q)[4]) {
 #pragma unroll
-  for (int k = 0; k < 4; ++k) p[k] = perm16(row[2 * k + 1], row[2 * k], sel);
-}
-// the odd pair (2k+1, 2k+2) from two aligned pairs: (a.hi, b.lo) in one v_perm_b32; beyond the window: (tap 7, 0)
-__device__ __forceinline__ h2 dm_odd(const h2 (&p)[4], int k) {
-  const unsigned a = __builtin_bit_cast(unsigned, p[k]);
-  if (k == 3) return __builtin_bit_cast(h2, a >> 16);
-  return __builtin_bit_cast(h2, __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, p[k + 1]), a, 0x05040302u));
+  for (int k = 0; k < 4; ++k) {
+    p[k] = perm2(row[k + 1], row[k], st.selp[k]);
+    q[k] = perm2(row[k + 1], row[k], st.selq[k]);
+  }
 }
 
 // EXACT: the reference's accumulator starts at +0 and channel 7 of every row is a zero.  Both only matter to a caller that
 // reads the lookup itself (0 + -0 = +0; the padding tap's blend is a finite sum of tap-7 values): the encoder-only form
 // starts from the first product and leaves the padding lane as it falls (its weight column is zero)
 template <bool EXACT>
-__device__ __forceinline__ u32x4 dm_blend_row(const DmLevel& st, const h2 (&p0)[4], const h2 (&p1)[4]) {
+__device__ __forceinline__ u32x4 dm_blend_row(const DmLevel& st, const h2 (&p0)[4], const h2 (&q0)[4], const h2 (&p1)[4],
+                                              const h2 (&q1)[4]) {
   u32x4 r;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -311,8 +333,8 @@ __device__ __forceinline__ u32x4 dm_blend_row(const DmLevel& st, const h2 (&p0)[
     if (EXACT) acc = acc_term(h2{(_Float16)0.0f, (_Float16)0.0f}, p0[k], st.w00);
     else acc = acc_term0(p0[k], st.w00);
     acc = acc_term(acc, p1[k], st.w01);
-    acc = acc_term(acc, dm_odd(p0, k), st.w10);
-    acc = acc_term(acc, dm_odd(p1, k), st.w11);
+    acc = acc_term(acc, q0[k], st.w10);
+    acc = acc_term(acc, q1[k], st.w11);
     unsigned u = __builtin_bit_cast(unsigned, acc);
     if (EXACT && k == 3) u &= 0xffffu;
     r[k] = u;
@@ -341,14 +363,14 @@ __device__ __forceinline__ void dm_kstep(int ks, u32x4 lo, u32x4 hi, const _Floa
 // retires (nothing follows level 3)
 template <int L, bool CORR>
 __device__ __forceinline__ void dm_level_pipelined(const DmArgs& a, bool live, size_t row, const _Float16* wlds, int lane,
-                                                   unsigned (&raw)[8][8], const DmLevel& cur, DmLevel& nxt,
+                                                   unsigned (&raw)[8][5], const DmLevel& cur, DmLevel& nxt,
                                                    u32x4& pending, f32x16 (&acc)[4][2]) {
-  h2 P[2][4];
-  dm_pack_row(raw[0], cur.sel, P[0]);
+  h2 P[2][4], Q[2][4];
+  dm_pack_row(raw[0], cur, P[0], Q[0]);
 #pragma unroll
   for (int j = 0; j < 7; ++j) {
-    dm_pack_row(raw[j + 1], cur.sel, P[(j + 1) & 1]);
-    const u32x4 out = dm_blend_row<CORR>(cur, P[j & 1], P[(j + 1) & 1]);
+    dm_pack_row(raw[j + 1], cur, P[(j + 1) & 1], Q[(j + 1) & 1]);
+    const u32x4 out = dm_blend_row<CORR>(cur, P[j & 1], Q[j & 1], P[(j + 1) & 1], Q[(j + 1) & 1]);
     if (L < 3) {                                    // window row j is retired: its registers take row j of what follows
       // (fenced: left alone, the scheduler gathers the requests of several rows into one clump behind a vmcnt(0), which
       // drains the queue ten times per tile)
@@ -432,7 +454,7 @@ __global__ __launch_bounds__(256, 2) void corr_dm_encode_kernel(DmArgs a) {
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(c.x), "+v"(c.y) : : "memory");
   DM_STAMP(11);
 #endif
-  unsigned raw[8][8];
+  unsigned raw[8][5];
   DmLevel cur;
   dm_setup<0>(a, (size_t)u.slot_tile, px.sy, px.sx, lane, c.x, c.y, cur);
 #ifdef EXP_DM_TIMESTAMPS
@@ -460,7 +482,7 @@ __global__ __launch_bounds__(256, 2) void corr_dm_encode_kernel(DmArgs a) {
     *reinterpret_cast<u32x4*>(wlds + r * kEnc2Lds + cc * 8) = wreg[k];
   }
   reinterpret_cast<float*>(wlds + 128 * kEnc2Lds)[threadIdx.x] = bias_in;      // (twice: no branch between the gathers
-                                                                                 //  and their use, see perm16)
+                                                                                 //  and their use)
   __syncthreads();
   DM_STAMP(2);
 
@@ -666,30 +688,37 @@ __global__ __launch_bounds__(256, 2) void corr_dm_build_kernel(DmBuildArgs a) {
     }
     __syncthreads();
   }
-  // ---- emission: segment = (source row syh of the half tile, local target row r, displacement column dx) -> 8 lanes ----
+  // ---- emission: segment = (source row syh of the half tile, local target row r, displacement-column PAIR dx2) -> the 32
+  // bytes of 8 lanes x 2 columns (the inverse of dx = (tx - sxl + cx) mod wp; a displacement that names the padding column
+  // of an odd width stores a zero)
   auto emit = [&](const _Float16* src, int stride, int Wp, int lvl, int rows, int hl, int wl) {
     const int cy = hl >> 1, cx = wl >> 1;
+    const int wp = (wl + 1) & ~1, wp2 = wp >> 1;
     const int y0 = (8 * grp) >> lvl;
-    _Float16* dst = a.lvl[lvl] + (sl * ntiles + tile) * ((size_t)hl * wl * 64);
-    const int nseg = 4 * rows * wl;
+    _Float16* dst = a.lvl[lvl] + (sl * ntiles + tile) * ((size_t)hl * wp * 64);
+    const int nseg = 4 * rows * wp2;
     for (int idx = tid; idx < nseg; idx += 256) {
-      const int dx = idx % wl, t = idx / wl, r = t % rows, syh = t / rows;
+      const int dx2 = idx % wp2, t = idx / wp2, r = t % rows, syh = t / rows;
       const int tyl = y0 + r, sy = tyi * 8 + half * 4 + syh;
       if (tyl >= hl || sy >= h) continue;
       int dy = tyl - (sy >> lvl) + cy;
       dy = dy < 0 ? dy + hl : (dy >= hl ? dy - hl : dy);
-      _Float16 v[8];
+      u32x4 o[2];
 #pragma unroll
       for (int lx = 0; lx < 8; ++lx) {
         const int sxl = min(txi * 8 + lx, w - 1) >> lvl;
-        int txl = dx - cx + sxl;
-        txl = txl < 0 ? txl + wl : (txl >= wl ? txl - wl : txl);
-        v[lx] = src[(syh * 8 + lx) * stride + r * Wp + txl];
-      }
-      u32x4 o;
+        _Float16 v[2];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) o[k] = pk2h(v[2 * k], v[2 * k + 1]);
-      *reinterpret_cast<u32x4*>(dst + ((size_t)dy * wl + dx) * 64 + (half * 4 + syh) * 8) = o;
+        for (int sub = 0; sub < 2; ++sub) {
+          int txl = 2 * dx2 + sub - cx + sxl;
+          txl = txl < 0 ? txl + wp : (txl >= wp ? txl - wp : txl);
+          v[sub] = txl < wl ? src[(syh * 8 + lx) * stride + r * Wp + txl] : (_Float16)0.0f;
+        }
+        o[lx >> 2][lx & 3] = pk2h(v[0], v[1]);
+      }
+      u32x4* out = reinterpret_cast<u32x4*>(dst + (((size_t)dy * wp2 + dx2) * 64 + (half * 4 + syh) * 8) * 2);
+      out[0] = o[0];
+      out[1] = o[1];
     }
   };
   emit(R, RS, W8, 0, 8, h, w);
@@ -705,7 +734,7 @@ using namespace glorie;
 extern "C" long glorie_corr_dm_level_halfs(int h, int w, int level) {
   if (h <= 0 || w <= 0 || level < 0 || level > 3) return -1;
   const long ntiles = (long)((h + 7) / 8) * ((w + 7) / 8);
-  return ntiles * (long)(h >> level) * (long)(w >> level) * 64;
+  return ntiles * (long)(h >> level) * (long)(((w >> level) + 1) & ~1) * 64;
 }
 
 extern "C" int glorie_corr_dm_build(const void* fmaps_cl, const int64_t* ii, const int64_t* jj, const int* slots,

@@ -127,44 +127,49 @@ def corr_lookup_tiled_cl(pyramid, coords, h2, w2, slots=None, interleaved=False)
 
 # ---- displacement-major, source-tiled pyramid (csrc/corr_dm.hip) ---------------------------------------------
 def dm_shape(h, w, l):
-    """(ntiles, h>>l, w>>l) of level l: levels are [slots][ntiles][(h>>l)*(w>>l)][64] fp16"""
-    return ((h + 7) // 8) * ((w + 7) // 8), h >> l, w >> l
+    """(ntiles, h>>l, Wp) of level l, Wp = (w>>l) rounded up to even: levels are [slots][ntiles][(h>>l) * Wp][64] fp16 -
+    per (tile, dy) the line of displacement-column PAIR dx2 holds, per lane, the two halfs dx = 2 dx2 and 2 dx2 + 1"""
+    return ((h + 7) // 8) * ((w + 7) // 8), h >> l, ((w >> l) + 1) & ~1
 
 
-def _dm_index(n_src, n_dst, l, device):
+def _dm_index(n_src, n_dst, l, device, n_mod=None):
     """[source coordinate s][displacement index d] -> target coordinate t, i.e. the inverse of
-    d = (t - (s >> l) + (n_dst >> 1)) mod n_dst (include/glorie_hip.h: glorie_corr_dm_build)"""
+    d = (t - (s >> l) + (n_dst >> 1)) mod n_mod (include/glorie_hip.h: glorie_corr_dm_build); n_mod = n_dst for rows, the even
+    padded width for columns (t >= n_dst then names the padding column)"""
+    n_mod = n_dst if n_mod is None else n_mod
     s = torch.arange(n_src, device=device)[:, None] >> l
-    d = torch.arange(n_dst, device=device)[None, :]
-    return (d - (n_dst >> 1) + s) % n_dst
+    d = torch.arange(n_mod, device=device)[None, :]
+    return (d - (n_dst >> 1) + s) % n_mod
 
 
 def dm_corr_level(vol, l):
-    """row-major level [N, h, w, h>>l, w>>l] -> displacement-major [N, ntiles * (h>>l) * (w>>l) * 64] (a torch
+    """row-major level [N, h, w, h>>l, w>>l] -> displacement-major [N, ntiles * (h>>l) * Wp * 64] (a torch
     restatement of the layout for tests and for CorrBlock pyramids built with torch; the product path builds the
     layout directly with glorie_corr_dm_build)"""
     N, h, w, hl, wl = vol.shape
+    wp = (wl + 1) & ~1
     nty, ntx = (h + 7) // 8, (w + 7) // 8
     H8, W8 = nty * 8, ntx * 8
-    vp = torch.zeros((N, H8, W8, hl, wl), dtype=vol.dtype, device=vol.device)
-    vp[:, :h, :w] = vol
+    vp = torch.zeros((N, H8, W8, hl, wp), dtype=vol.dtype, device=vol.device)      # column wl (odd widths): zeros
+    vp[:, :h, :w, :, :wl] = vol
     ty = _dm_index(H8, hl, l, vol.device)            # [sy][dy] -> ty
-    tx = _dm_index(W8, wl, l, vol.device)            # [sx][dx] -> tx
+    tx = _dm_index(W8, wl, l, vol.device, wp)        # [sx][dx] -> tx (possibly the padding column)
     sy = torch.arange(H8, device=vol.device)[:, None, None, None]
     sx = torch.arange(W8, device=vol.device)[None, :, None, None]
     d = vp[:, sy, sx, ty[:, None, :, None], tx[None, :, None, :]]              # [N, sy, sx, dy, dx]
-    d = d.view(N, nty, 8, ntx, 8, hl, wl).permute(0, 1, 3, 5, 6, 2, 4)         # [N, ty, tx, dy, dx, ly, lx]
+    d = d.view(N, nty, 8, ntx, 8, hl, wp // 2, 2).permute(0, 1, 3, 5, 6, 2, 4, 7)   # [N, ty, tx, dy, dx2, ly, lx, dx & 1]
     return d.reshape(N, -1).contiguous()
 
 
 def dm_to_rowmajor(dm, h, w, l):
-    """inverse of dm_corr_level: [N, ntiles*(h>>l)*(w>>l)*64] -> [N, h, w, h>>l, w>>l]"""
+    """inverse of dm_corr_level: [N, ntiles*(h>>l)*Wp*64] -> [N, h, w, h>>l, w>>l]"""
     N = dm.shape[0]
     hl, wl = h >> l, w >> l
+    wp = (wl + 1) & ~1
     nty, ntx = (h + 7) // 8, (w + 7) // 8
-    d = dm.view(N, nty, ntx, hl, wl, 8, 8).permute(0, 1, 5, 2, 6, 3, 4).reshape(N, nty * 8, ntx * 8, hl, wl)[:, :h, :w]
+    d = dm.view(N, nty, ntx, hl, wp // 2, 8, 8, 2).permute(0, 1, 5, 2, 6, 3, 4, 7).reshape(N, nty * 8, ntx * 8, hl, wp)[:, :h, :w]
     dy = (torch.arange(hl, device=dm.device)[None, :] - (torch.arange(h, device=dm.device)[:, None] >> l) + (hl >> 1)) % hl
-    dx = (torch.arange(wl, device=dm.device)[None, :] - (torch.arange(w, device=dm.device)[:, None] >> l) + (wl >> 1)) % wl
+    dx = (torch.arange(wl, device=dm.device)[None, :] - (torch.arange(w, device=dm.device)[:, None] >> l) + (wl >> 1)) % wp
     sy = torch.arange(h, device=dm.device)[:, None, None, None]
     sx = torch.arange(w, device=dm.device)[None, :, None, None]
     return d[:, sy, sx, dy[:, None, :, None], dx[None, :, None, :]].contiguous()

@@ -118,9 +118,12 @@ int glorie_corr_lookup_tiled_cl(const void* const* levels, int num_levels, const
 /* The pyramid in the DISPLACEMENT-MAJOR, source-tiled layout (round 3; csrc/corr_dm.hip) - the same fp16 values as the
  * reference's per-pixel planes [N,h,w,h>>l,w>>l] (corr.py:26-41), stored so that neighbouring source pixels that look at the
  * same displacement share a 128-byte line:
- *   levels[l] = [capacity][ntiles][(h>>l)*(w>>l)][64] fp16,  ntiles = ceil(h/8)*ceil(w/8)  (8 x 8 source tiles, row-major),
- *   element [slot][tile][dy*(w>>l) + dx][(sy&7)*8 + (sx&7)] = volume_l[slot][sy][sx][ty][tx] with
- *   dy = (ty - (sy>>l) + ((h>>l)>>1)) mod (h>>l), dx = (tx - (sx>>l) + ((w>>l)>>1)) mod (w>>l).
+ *   levels[l] = [capacity][ntiles][(h>>l) * Wp][64] fp16,  ntiles = ceil(h/8)*ceil(w/8)  (8 x 8 source tiles, row-major),
+ *   Wp = (w>>l) rounded up to even;  element [slot][tile][dy][dx >> 1][(sy&7)*8 + (sx&7)][dx & 1] =
+ *   volume_l[slot][sy][sx][ty][tx] with  dy = (ty - (sy>>l) + ((h>>l)>>1)) mod (h>>l),
+ *   dx = (tx - (sx>>l) + ((w>>l)>>1)) mod Wp  (round 4: a lane's two neighbouring displacement columns are one dword, so a
+ *   window row is five dword gathers instead of eight 2-byte ones; for odd w>>l the displacement that would name target
+ *   column w>>l holds a zero).
  * glorie_corr_dm_level_halfs: halfs per slot of level l (-1 for bad arguments).
  * glorie_corr_dm_build: CorrBlock.__init__ for a batch of new edges into arena slots; arguments as glorie_corr_build (any
  *   width whose staging fits LDS, w <= ~112; C must be 128); lanes of padding source pixels (sy >= h or sx >= w) are

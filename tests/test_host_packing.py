@@ -100,7 +100,7 @@ def test_se3_inverse_helper():
 
 def test_dm_layout_definition_and_roundtrip():
     """droid_backends.dm_corr_level / dm_to_rowmajor against the layout's definition (include/glorie_hip.h:
-    glorie_corr_dm_build), element by element, on CPU"""
+    glorie_corr_dm_build), element by element, on CPU - incl. odd level widths (a zero padding column)"""
     import numpy as np
     import torch
     from glorie_slam_amd import droid_backends as db
@@ -108,14 +108,20 @@ def test_dm_layout_definition_and_roundtrip():
     N, h, w = 2, 11, 18
     for l in range(4):
         hl, wl = h >> l, w >> l
+        wp = (wl + 1) & ~1
         vol = torch.from_numpy(rng.standard_normal((N, h, w, hl, wl)).astype(np.float16))
         dm = db.dm_corr_level(vol, l)
-        nt, _, _ = db.dm_shape(h, w, l)
-        assert dm.shape == (N, nt * hl * wl * 64)
+        nt, hh, ww = db.dm_shape(h, w, l)
+        assert (hh, ww) == (hl, wp) and dm.shape == (N, nt * hl * wp * 64)
         assert torch.equal(db.dm_to_rowmajor(dm, h, w, l), vol)
-        d = dm.view(N, (h + 7) // 8, (w + 7) // 8, hl, wl, 64)
+        d = dm.view(N, (h + 7) // 8, (w + 7) // 8, hl, wp // 2, 64, 2)
         for _ in range(200):
             n, sy, sx, ty, tx = (int(rng.integers(0, k)) for k in (N, h, w, hl, wl))
             dy = (ty - (sy >> l) + (hl >> 1)) % hl
-            dx = (tx - (sx >> l) + (wl >> 1)) % wl
-            assert d[n, sy // 8, sx // 8, dy, dx, (sy & 7) * 8 + (sx & 7)] == vol[n, sy, sx, ty, tx]
+            dx = (tx - (sx >> l) + (wl >> 1)) % wp
+            assert d[n, sy // 8, sx // 8, dy, dx >> 1, (sy & 7) * 8 + (sx & 7), dx & 1] == vol[n, sy, sx, ty, tx]
+        if wl & 1:      # the displacement that would name target column wl holds a zero for every live source pixel
+            for _ in range(50):
+                n, sy, sx, dy = (int(rng.integers(0, k)) for k in (N, h, w, hl))
+                dx = (wl - (sx >> l) + (wl >> 1)) % wp
+                assert d[n, sy // 8, sx // 8, dy, dx >> 1, (sy & 7) * 8 + (sx & 7), dx & 1] == 0
