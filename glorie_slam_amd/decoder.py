@@ -249,11 +249,20 @@ class POINT(nn.Module):
 
     def _packed(self):
         """parameter buffer of the fused kernels, rebuilt when any parameter was modified"""
-        ver = tuple(p._version for p in self.parameters()) + (str(next(self.parameters()).device),)
+        plist = getattr(self, "_plist", None)
+        if plist is None:
+            # (walking the module tree costs 0.16 ms per call - more than the neighbour search it is enqueued behind takes
+            # on a 1/8 frame shard; the tree does not change after construction, conversions are caught by `_apply`)
+            plist = self._plist = list(self.parameters())
+        ver = tuple((p._version, p.data_ptr()) for p in plist)
         if getattr(self, "_pack_ver", None) != ver:
             self._pack = point_ops.pack_decoders(self)
             self._pack_ver = ver
         return self._pack
+
+    def _apply(self, fn, *args, **kwargs):
+        self._plist = None                      # .to() / .half() / ... may replace the parameter objects
+        return super()._apply(fn, *args, **kwargs)
 
     def range_guard(self, device):
         """point_ops.RangeGuard of the fused kernels on `device` (include/glorie_hip.h: glorie_render_mlp range_flag)"""

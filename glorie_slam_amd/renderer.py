@@ -132,16 +132,20 @@ class Renderer(object):
 
     def render_batch_ray(self, npc, decoders, rays_d, rays_o, device, stage, gt_depth=None,
                          npc_geo_feats=None, npc_col_feats=None, is_tracker=False, cloud_pos=None,
-                         dynamic_r_query=None, image_w=None):
+                         dynamic_r_query=None, image_w=None, defer_guard=False):
         """Renderer.py:80-219 -> depth, uncertainty, color, valid_ray_mask, valid_ray_counts
         image_w (not in the reference): the rays are consecutive row-major pixels of an image of that width, starting
-        at a row start - lets the neighbour search walk the image in patches; the result does not depend on it."""
+        at a row start - lets the neighbour search walk the image in patches; the result does not depend on it.
+        defer_guard (not in the reference): do not read the decoders' range guard behind this batch (a host synchronisation:
+        the device then idles while the next batch is enqueued, ~0.1 ms per batch) - the caller reads
+        `decoders.range_guard(device).tripped()` once behind its last batch and, if it is set, renders again without this flag
+        (what render_img does for its strips)."""
         S = self.N_surface
         R = rays_o.shape[0]
         if self._fast_ok(decoders, rays_o, R, gt_depth, stage, npc_geo_feats, npc_col_feats, is_tracker, dynamic_r_query):
             out = self._render_fast(npc, decoders, rays_d, rays_o, stage, gt_depth, npc_geo_feats,
                                     npc_col_feats, cloud_pos, dynamic_r_query, image_w=image_w)
-            if out is not None and decoders.range_guard(rays_o.device).tripped():
+            if out is not None and not defer_guard and decoders.range_guard(rays_o.device).tripped():
                 # an activation, feature or weight outside the fp16 range: the split kernels' result is void
                 out = self._render_fast(npc, decoders, rays_d, rays_o, stage, gt_depth, npc_geo_feats,
                                         npc_col_feats, cloud_pos, dynamic_r_query, image_w=image_w, precise=True)

@@ -361,6 +361,47 @@ def test_render_batch_ray_end_to_end(gpu):
     assert (c.cpu().numpy() >= 0).all() and (c.cpu().numpy() <= 1).all()
 
 
+def test_render_batch_ray_deferred_range_guard(gpu):
+    """defer_guard=True: same values, no guard read behind the batch - a trip stays raised for the caller, who renders again
+    without the flag and gets the exact-fp32 kernels' values (what bench.render_pass and Renderer.render_img do per frame)"""
+    import glorie_slam_amd.synth as synth
+    from glorie_slam_amd.decoder import POINT
+    from glorie_slam_amd.neural_point import NeuralPointCloud
+    from glorie_slam_amd.renderer import Renderer
+    cfg = _cfg(gpu)
+    pts, geo, col = synth.box_cloud(n_hits=40000)
+    H, W = 24, 32
+    ro, rd, depth, radius, c2w = synth.box_rays(H, W, fx=16.0, fy=16.0, cx=15.5, cy=11.5)
+    t = lambda x: torch.from_numpy(x).to(gpu)
+
+    class Cam:
+        pass
+    cam = Cam()
+    cam.H, cam.W, cam.fx, cam.fy, cam.cx, cam.cy = H, W, 16.0, 16.0, 15.5, 11.5
+    ren = Renderer(cfg, cam)
+    for feat_scale, expect_trip in ((1.0, False), (1e6, True)):
+        npc = NeuralPointCloud(cfg)
+        npc.add_points(t(pts), t(geo) * feat_scale, t(col) * feat_scale)
+        torch.manual_seed(43)
+        dec = POINT(cfg, use_view_direction=True).eval().to(gpu)
+        run = lambda **k: ren.render_batch_ray(npc, dec, t(rd), t(ro), gpu, "color", gt_depth=t(depth),
+                                               npc_geo_feats=npc.geo_feats, npc_col_feats=npc.col_feats,
+                                               cloud_pos=npc.cloud_pos(), dynamic_r_query=t(radius * 2.5), **k)
+        with torch.no_grad():
+            checked = run()
+            assert not dec.range_guard(gpu).tripped()                # consumed by the per-batch check
+            deferred = run(defer_guard=True)
+            assert dec.range_guard(gpu).tripped() == expect_trip     # left for the caller
+            if not expect_trip:
+                for a, b in zip(checked, deferred):
+                    assert torch.equal(a, b)
+            else:
+                again = run()                                        # the caller's answer to a trip
+                for a, b in zip(checked, again):
+                    assert torch.equal(a, b)
+                assert all(bool(torch.isfinite(a.float()).all()) for a in again)
+
+
 def _reference_render_setup(gpu, ray_batch_size=65536):
     """scene, decoders and renderer of fixture F11 (tests/golden/render.npz, minted from the reference's
     Renderer by tests/golden/make_golden.py::make_render)"""
