@@ -46,9 +46,9 @@ for n in [int(v) for v in sys.argv[1:]] or (8, 24, 36):
     life = st[:, 7] - st[:, 0]                  # (stamps of different XCDs are not comparable: only differences within a wave)
     print(f"== {n} edges, {st.shape[0]} waves; wave lifetime in shader clocks: median {int(np.median(life))}  p90 "
           f"{int(np.percentile(life, 90))}")
-    print("   first phase: kernel arguments + unit + slot %d | coordinates fetched %d | level-0 state %d | 64 gathers issued %d"
+    print("   first phase: kernel arguments + unit + slot %d | coordinates fetched %d | level-0 state %d | first window's gathers issued %d"
           % tuple(int(v) for v in np.median(pre, 0)))
-    print(f"   latency of the first 64 gathers (issue done -> all landed): median {int(np.median(lat))}  p10 "
+    print(f"   latency of the first window's gathers (issue done -> all landed): median {int(np.median(lat))}  p10 "
           f"{int(np.percentile(lat, 10))}  p90 {int(np.percentile(lat, 90))}")
     print(f"   of the last phase, waiting for the stores to land: median {int(np.median(drain))}  p90 {int(np.percentile(drain, 90))}")
     for k, nm in enumerate(names):
