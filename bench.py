@@ -133,12 +133,15 @@ def render_pass(npc, dec, ren, rays, device):
     with torch.no_grad():
         # the decoders' range guard is read once per frame, behind the last batch (as Renderer.render_img does for its
         # strips); a frame that tripped it is rendered again with the per-batch check and its exact-fp32 fallback
+        # ... and the batches of the frame alternate between the renderer's two batch streams (Renderer.batch_stream)
         for defer in (True, False):
-            for i in range(0, n, bs):
-                ren.render_batch_ray(npc, dec, rays["d"][i:i + bs], rays["o"][i:i + bs], device, "color",
-                                     gt_depth=rays["depth"][i:i + bs], npc_geo_feats=npc.geo_feats,
-                                     npc_col_feats=npc.col_feats, cloud_pos=npc.cloud_pos(),
-                                     dynamic_r_query=rays["radius"][i:i + bs], image_w=image_w, defer_guard=defer)
+            for k, i in enumerate(range(0, n, bs)):
+                with torch.cuda.stream(ren.batch_stream(k, device) if (defer and n > bs) else torch.cuda.current_stream()):
+                    ren.render_batch_ray(npc, dec, rays["d"][i:i + bs], rays["o"][i:i + bs], device, "color",
+                                         gt_depth=rays["depth"][i:i + bs], npc_geo_feats=npc.geo_feats,
+                                         npc_col_feats=npc.col_feats, cloud_pos=npc.cloud_pos(),
+                                         dynamic_r_query=rays["radius"][i:i + bs], image_w=image_w, defer_guard=defer)
+            ren.join_batches(device)
             if not (defer and dec.range_guard(torch.device(device)).tripped()):
                 break
     return n

@@ -482,6 +482,47 @@ def test_render_img_matches_reference_renderer(gpu):
     _check_render(out, f, "img")
 
 
+def test_render_img_strips_on_two_streams_equal_one_batch(gpu):
+    """Renderer.render_img with strips of 16 image rows on the renderer's two batch streams (four strips in flight two at a
+    time) against the same frame rendered as one batch: bit-identical, the zero-depth fallback of a strip included"""
+    import glorie_slam_amd.synth as synth
+    from glorie_slam_amd.decoder import POINT
+    from glorie_slam_amd.neural_point import NeuralPointCloud
+    from glorie_slam_amd.renderer import Renderer
+    cfg = _cfg(gpu)
+    pts, geo, col = synth.box_cloud(n_hits=40000)
+    H, W = 64, 32
+    ro, rd, depth, radius, c2w = synth.box_rays(H, W, fx=16.0, fy=16.0, cx=15.5, cy=31.5)
+    t = lambda x: torch.from_numpy(x).to(gpu)
+    npc = NeuralPointCloud(cfg)
+    npc.add_points(t(pts), t(geo), t(col))
+    torch.manual_seed(43)
+    dec = POINT(cfg, use_view_direction=True).eval().to(gpu)
+
+    class Cam:
+        pass
+    cam = Cam()
+    cam.H, cam.W, cam.fx, cam.fy, cam.cx, cam.cy = H, W, 16.0, 16.0, 15.5, 31.5
+    strips, whole = Renderer(cfg, cam, ray_batch_size=16 * W), Renderer(cfg, cam, ray_batch_size=H * W)
+    for zero_at in (None, 16 * W * 2 + 7):
+        gt = t(depth).clone()
+        if zero_at is not None:
+            gt[zero_at] = 0.0                                   # the third strip takes the general path
+        kw = dict(gt_depth=gt.reshape(H, W), npc_geo_feats=npc.geo_feats, npc_col_feats=npc.col_feats,
+                  dynamic_r_query=t(radius * 2.5).reshape(H, W), cloud_pos=npc.cloud_pos())
+        with torch.no_grad():
+            a = strips.render_img(npc, dec, t(c2w), gpu, "color", **kw)
+            b = whole.render_img(npc, dec, t(c2w), gpu, "color", **kw)
+        if zero_at is None:
+            assert strips._streams is not None                  # the strips did go through the batch streams
+            for x, y in zip(a, b):
+                assert torch.equal(x, y)
+        else:
+            # (a whole frame with one zero-depth ray takes the general path everywhere: torch arithmetic, 1e-5)
+            for x, y in zip(a, b):
+                torch.testing.assert_close(x.float(), y.float(), atol=2e-4, rtol=1e-4)
+
+
 def test_ray_samples_camera_equals_get_rays_plus_ray_samples(gpu):
     """get_rays fused into the sample placement (row R7 + R4): the rays of a pixel strip formed in the kernel give the bits of
     get_rays followed by ray_samples, for a rotated camera and a strip that starts and ends inside image rows"""
