@@ -1161,7 +1161,11 @@ __global__ __launch_bounds__(512, 4) void mlp_nb_v4_kernel(NbParams P, const flo
 // 816 clocks of MFMA on its four SIMDs.  Keeping the 16 high fragments in 64 VGPRs (a third of the reads, 198 VGPRs, 2
 // waves per SIMD, a wave walking 16-sample blocks with the next neighbour's row prefetched; bit-identical) measured 432 us:
 // what the reads save, the lost occupancy costs (4 -> 2 waves per SIMD hide the gather and interleave MFMA with VALU
-// worse).  Not kept.
+// worse).  Not kept.  The untried middle followed at the end of the round: two 16-sample blocks per wave with the 128 output
+// features walked in two halves (2 x 4 accumulator tiles + 2 x 8 sum tiles: 162 VGPRs, no spill, 3 waves per SIMD, 4-wave
+// workgroups; every fragment read feeds six MFMAs; bit-identical) - and a 640x480 frame takes 5.42-5.51 ms with it against
+// 5.42-5.56 ms without, the single-batch 1/8 share 0.894-0.902 against 0.891-0.918 ms (interleaved builds, same box): halving
+// the fragment reads buys exactly what the fourth wave per SIMD was worth.  Not kept either.
 }  // namespace glorie
 
 using namespace glorie;
