@@ -122,7 +122,7 @@ def build_renderer(device, rank=0, world=1):
     return npc, dec, ren, rays
 
 
-def render_pass(npc, dec, ren, rays, device):
+def render_pass(npc, dec, ren, rays, device, two_streams=True):
     # the batching of Renderer.render_img: whole 16-row strips, so the neighbour search can walk image patches
     bs = ren.ray_batch_size
     W = rays["W"]
@@ -136,7 +136,7 @@ def render_pass(npc, dec, ren, rays, device):
         # ... and the batches of the frame alternate between the renderer's two batch streams (Renderer.batch_stream)
         for defer in (True, False):
             for k, i in enumerate(range(0, n, bs)):
-                with torch.cuda.stream(ren.batch_stream(k, device) if (defer and n > bs) else torch.cuda.current_stream()):
+                with torch.cuda.stream(ren.batch_stream(k, device) if (two_streams and defer and n > bs) else torch.cuda.current_stream()):
                     ren.render_batch_ray(npc, dec, rays["d"][i:i + bs], rays["o"][i:i + bs], device, "color",
                                          gt_depth=rays["depth"][i:i + bs], npc_geo_feats=npc.geo_feats,
                                          npc_col_feats=npc.col_feats, cloud_pos=npc.cloud_pos(),

@@ -36,7 +36,7 @@ for _ in range(3):
     point_ops.idw_gather2(D, I, nn, npc.geo_feats, npc.col_feats, radius_per_query=rq)
 # one full-frame render pass: the decoder kernels (the product's R2 gathers happen inside mlp_geo_v4 / mlp_nb_v4)
 for _ in range(2):
-    bench.render_pass(npc, dec, ren, rays, dev)
+    bench.render_pass(npc, dec, ren, rays, dev, two_streams=False)      # per-kernel figures: nothing beside them
 # calibration: a 1 GiB float4 streaming copy (reads 1 GiB, writes 1 GiB)
 src = torch.empty(1 << 28, dtype=torch.float32, device=dev).normal_()
 for _ in range(3):

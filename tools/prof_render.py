@@ -13,5 +13,5 @@ if __name__ == "__main__":
     torch.cuda.set_device(0)
     npc, dec, ren, rays = bench.build_renderer(dev)
     for _ in range(4):
-        bench.render_pass(npc, dec, ren, rays, dev)
+        bench.render_pass(npc, dec, ren, rays, dev, two_streams=False)      # per-kernel figures: nothing beside them
     torch.cuda.synchronize()
