@@ -344,18 +344,29 @@ class FactorGraph:
         self.net, self.target, self.weight = s_net, s_target, s_weight
         self.video.deferred_fallback = False
         try:
+            # capture_begin / capture_end on a side stream instead of the `torch.cuda.graph` context manager: that one also
+            # runs gc.collect() and torch.cuda.empty_cache() on entry - 3.5 ms of a 5.9 ms capture here, and every cached
+            # block handed back to the driver has to be hipMalloc'ed again by the next eager step; the tracking loop records
+            # ~2 graphs per keyframe and replays each ~4 times (tools/prof_sequence.py).
             # thread_local: calls of other threads (e.g. the RCCL watchdog of torch.distributed) must not
             # invalidate the capture
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                self._update_eager(*args)
-                if self.net.data_ptr() != s_net.data_ptr():     # FusedUpdate(inplace) already wrote s_net
-                    s_net.copy_(self.net)
-                # the BA arguments alias the recurrent state: keep them pointing at the static copies
-                ba_args = tuple(s_target if a is self.target else (s_weight if a is self.weight else a)
-                                for a in self._ba_args)
-                if self.target is not s_target:                 # (the eager step adds in place when it can)
-                    s_target.copy_(self.target)
-                s_weight.copy_(self.weight)
+            cap = getattr(self, "_capture_stream", None)
+            if cap is None:
+                cap = self._capture_stream = torch.cuda.Stream(self.net.device)
+            with torch.cuda.stream(cap):
+                graph.capture_begin(capture_error_mode="thread_local")
+                try:
+                    self._update_eager(*args)
+                    if self.net.data_ptr() != s_net.data_ptr():     # FusedUpdate(inplace) already wrote s_net
+                        s_net.copy_(self.net)
+                    # the BA arguments alias the recurrent state: keep them pointing at the static copies
+                    ba_args = tuple(s_target if a is self.target else (s_weight if a is self.weight else a)
+                                    for a in self._ba_args)
+                    if self.target is not s_target:                 # (the eager step adds in place when it can)
+                        s_target.copy_(self.target)
+                    s_weight.copy_(self.weight)
+                finally:
+                    graph.capture_end()
         finally:
             # the capture did not execute anything: restore the state the caller had
             self.net, self.target, self.weight = keep

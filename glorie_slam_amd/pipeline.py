@@ -87,24 +87,35 @@ class SequenceRunner:
         return kept
 
     # ---- mapper.py:517-684 (one keyframe) ---------------------------------------------------------------------------
-    def _keyframe_rays(self, k, stride=1, count=None):
-        """pixels of keyframe k with a valid depth -> rays, depth, colour, pixel ids (common.py:39-54 ray convention)"""
+    def _keyframe_view(self, k):
+        """depth map and camera-to-world matrix of keyframe k (constant while the keyframe is mapped)"""
+        v = self.video
+        depth = torch.where(v.disps_up[k] > 0, 1.0 / v.disps_up[k].clamp_min(1e-6), torch.zeros_like(v.disps_up[k]))
+        c2w = pose_matrix(se3_inv(v.poses[k]))
+        # the neural point cloud lives in the OpenGL camera convention of the renderer (common.py:302-322)
+        c2w = c2w.clone()
+        c2w[:3, 1] *= -1
+        c2w[:3, 2] *= -1
+        return depth, c2w
+
+    def _keyframe_rays(self, k, stride=1, count=None, view=None, pix=None):
+        """pixels of keyframe k with a valid depth -> rays, depth, colour, pixel ids (common.py:39-54 ray convention).
+        view: `_keyframe_view(k)` computed by the caller; pix: the (ii, jj) pixel draw of this call, already on the device
+        (the mapping loop draws all its iterations at once: a per-iteration host-to-device copy from pageable memory blocks
+        the host until the stream has drained)"""
         v = self.video
         H, W = v.ht, v.wd
         cam = self.renderer
-        depth = torch.where(v.disps_up[k] > 0, 1.0 / v.disps_up[k].clamp_min(1e-6), torch.zeros_like(v.disps_up[k]))
-        if count is None:
+        depth, c2w = view if view is not None else self._keyframe_view(k)
+        if pix is not None:
+            ii, jj = pix
+        elif count is None:
             jj, ii = torch.meshgrid(torch.arange(stride // 2, H, stride, device=self.device),
                                     torch.arange(stride // 2, W, stride, device=self.device), indexing="ij")
             ii, jj = ii.reshape(-1), jj.reshape(-1)
         else:
             ii = torch.randint(0, W, (count,), generator=self.gen).to(self.device)
             jj = torch.randint(0, H, (count,), generator=self.gen).to(self.device)
-        c2w = pose_matrix(se3_inv(v.poses[k]))
-        # the neural point cloud lives in the OpenGL camera convention of the renderer (common.py:302-322)
-        c2w = c2w.clone()
-        c2w[:3, 1] *= -1
-        c2w[:3, 2] *= -1
         ro, rd = get_rays_from_uv(ii.float(), jj.float(), c2w, cam.fx, cam.fy, cam.cx, cam.cy, self.device)
         d = depth[jj, ii]
         col = self.images[k][:, jj, ii].t().contiguous()
@@ -130,17 +141,25 @@ class SequenceRunner:
         opt = FeatureAdam([{"params": list(dec.parameters()), "lr": 0.005}, {"params": [geo], "lr": 0.005},
                            {"params": [col_f], "lr": 0.005}])
         first = last = None
+        with torch.no_grad():
+            view = self._keyframe_view(k)
+            # every iteration's pixel draw in one transfer ([iteration][ii | jj][ray], the generator's order per iteration)
+            draws = torch.stack([torch.stack([torch.randint(0, self.video.wd, (self.map_rays,), generator=self.gen),
+                                              torch.randint(0, self.video.ht, (self.map_rays,), generator=self.gen)])
+                                 for _ in range(self.map_iters)]).to(self.device) if self.map_iters else None
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for it in range(self.map_iters):
             with torch.no_grad():
-                ro, rd, d, gt_col, _, _, radius = self._keyframe_rays(k, count=self.map_rays)
+                ro, rd, d, gt_col, _, _, radius = self._keyframe_rays(k, view=view, pix=(draws[it, 0], draws[it, 1]))
             opt.zero_grad()
             depth, _, colour, _, counts = ren.render_batch_ray(npc, dec, rd, ro, self.device, "color", gt_depth=d,
                                                                npc_geo_feats=geo, npc_col_feats=col_f,
                                                                cloud_pos=npc.cloud_pos(), dynamic_r_query=radius)
-            seen = (counts > 0) & (d > 0)
-            loss = torch.abs(d - depth)[seen].sum() + 0.5 * torch.abs(gt_col - colour)[seen].sum()
+            # (masked sums instead of `x[seen].sum()`: boolean indexing sizes its result on the host - one device round trip
+            # in the forward and one in the backward pass of every iteration)
+            seen = ((counts > 0) & (d > 0)).to(depth.dtype)
+            loss = (torch.abs(d - depth) * seen).sum() + 0.5 * (torch.abs(gt_col - colour) * seen[:, None]).sum()
             loss = loss / seen.sum().clamp_min(1)
             loss.backward()
             opt.step()
