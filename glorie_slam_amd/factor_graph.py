@@ -350,9 +350,16 @@ class FactorGraph:
             # ~2 graphs per keyframe and replays each ~4 times (tools/prof_sequence.py).
             # thread_local: calls of other threads (e.g. the RCCL watchdog of torch.distributed) must not
             # invalidate the capture
+            # The private pools of the graphs an edge-set change dropped only return to the driver through empty_cache
+            # (100 GB reserved after 100 frames without it): trimmed when the cached-but-unused memory passes
+            # `capture_trim_bytes`, i.e. every ~10 captures instead of every one.  (One pool shared by all graphs of this
+            # object would be the cleaner fix; torch asserts when a pool handle outlives its last graph.)
             cap = getattr(self, "_capture_stream", None)
             if cap is None:
                 cap = self._capture_stream = torch.cuda.Stream(self.net.device)
+            dev = self.net.device
+            if torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev) > getattr(self, "capture_trim_bytes", 32 << 30):
+                torch.cuda.empty_cache()
             with torch.cuda.stream(cap):
                 graph.capture_begin(capture_error_mode="thread_local")
                 try:

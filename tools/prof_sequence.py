@@ -14,6 +14,8 @@ from glorie_slam_amd.pipeline import synthetic_long_runner  # noqa: E402
 dev = torch.device("cuda", 0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 run, lc, frames = synthetic_long_runner(dev, n_frames=n, map_iters=20)
+if os.environ.get("TRIM_GB"):
+    run.frontend.graph.capture_trim_bytes = int(float(os.environ["TRIM_GB"]) * 2 ** 30)
 intr = lc["intrinsics"]
 it = iter(frames())
 pr = cProfile.Profile()
@@ -31,7 +33,9 @@ t2 = time.perf_counter()
 print(f"frames 30..{n}: {(t2 - t1) / (n - 30) * 1e3:.1f} ms per frame (host wall incl. device waits)")
 import numpy as np
 tr, kp = np.array(run.timing["track_ms"]), np.array(run.timing["kept"])
-print(f"track ms per kept keyframe p50 {np.percentile(tr[kp][8:], 50):.1f}; mapping iteration {np.mean(run.timing['map_iter_ms'][2:]):.2f} ms")
+print(f"track ms per kept keyframe p50 {np.percentile(tr[kp][8:], 50):.1f} mean {tr[kp][8:].mean():.1f} p95 {np.percentile(tr[kp][8:], 95):.1f}; "
+      f"mapping iteration {np.mean(run.timing['map_iter_ms'][2:]):.2f} ms; allocator: {torch.cuda.memory_stats()['num_device_alloc']} device allocs, "
+      f"{torch.cuda.memory_reserved() / 2**30:.1f} GB reserved")
 st = pstats.Stats(pr).sort_stats("cumulative")
 st.print_stats(45)
 st.print_callers("method 'to' of")
