@@ -350,18 +350,27 @@ class FactorGraph:
             # ~2 graphs per keyframe and replays each ~4 times (tools/prof_sequence.py).
             # thread_local: calls of other threads (e.g. the RCCL watchdog of torch.distributed) must not
             # invalidate the capture
-            # The private pools of the graphs an edge-set change dropped only return to the driver through empty_cache
-            # (100 GB reserved after 100 frames without it): trimmed when the cached-but-unused memory passes
-            # `capture_trim_bytes`, i.e. every ~10 captures instead of every one.  (One pool shared by all graphs of this
-            # object would be the cleaner fix; torch asserts when a pool handle outlives its last graph.)
+            # ONE memory pool for every graph of this object: the blocks of the graphs an edge-set change drops go back to it
+            # and the next capture takes them.  With a private pool per graph every buffer of every capture is a hipMalloc
+            # (0.5 ms each, ~35 per keyframe: the largest single item of the tracking loop's host profile) and the dropped
+            # pools only return to the driver through empty_cache (100 GB reserved after 100 frames without it).  A
+            # one-node keeper graph holds the pool open (torch asserts when a pool handle outlives its last graph).
+            # Sharing is safe here: the graphs never run concurrently, and what a replay leaves behind for the host (ba_args)
+            # is read before any other graph of the pool is replayed or captured.
+            dev = self.net.device
             cap = getattr(self, "_capture_stream", None)
             if cap is None:
-                cap = self._capture_stream = torch.cuda.Stream(self.net.device)
-            dev = self.net.device
+                cap = self._capture_stream = torch.cuda.Stream(dev)
+                self._graph_pool = torch.cuda.graph_pool_handle()
+                self._pool_keeper = torch.cuda.CUDAGraph()
+                with torch.cuda.stream(cap):
+                    self._pool_keeper.capture_begin(pool=self._graph_pool, capture_error_mode="thread_local")
+                    self._pool_keeper_buf = torch.zeros(1, device=dev)
+                    self._pool_keeper.capture_end()
             if torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev) > getattr(self, "capture_trim_bytes", 32 << 30):
-                torch.cuda.empty_cache()
+                torch.cuda.empty_cache()                     # (other objects' dropped pools, eager-step leftovers)
             with torch.cuda.stream(cap):
-                graph.capture_begin(capture_error_mode="thread_local")
+                graph.capture_begin(pool=self._graph_pool, capture_error_mode="thread_local")
                 try:
                     self._update_eager(*args)
                     if self.net.data_ptr() != s_net.data_ptr():     # FusedUpdate(inplace) already wrote s_net
