@@ -60,20 +60,18 @@ def supported(decoders):
     return all(tuple(t.shape) == s for t, s in zip(decoder_tensors(decoders), _SHAPES))
 
 
-_DEV_CACHE = {}
-
-
 def _on_device(t, dev):
     """t on `dev`.  Tensors that live elsewhere - the fixed Fourier matrices of the colour decoder are plain attributes, not
     buffers, and stay on the host when the module is moved - are copied once per version: a pageable host-to-device copy in
     every forward pass stalls the host until the stream has drained (2.7 ms per mapping iteration)."""
     if t.device == dev:
         return t
-    key = (t.data_ptr(), tuple(t.shape), str(dev))
-    hit = _DEV_CACHE.get(key)
-    if hit is None or hit[0] != t._version:
+    # the copy rides on the tensor object itself: a table keyed by (address, shape) hands the copy of a freed tensor to the
+    # next one the host allocator places at the same address - another decoder's Fourier matrix
+    hit = getattr(t, "_glorie_on_device", None)
+    if hit is None or hit[0] != t._version or hit[1].device != dev:
         hit = (t._version, t.to(dev))
-        _DEV_CACHE[key] = hit
+        t._glorie_on_device = hit
     return hit[1]
 
 
