@@ -835,7 +835,10 @@ extern "C" int glorie_render_train_bwd(const glorie_decoder_params* P, const glo
       // one launch serves both; a NULL target is replaced by a scratch sink
       float* sinkB = G->n_B ? G->n_B : W.t_q4;          // 30 floats
       if (!d_col_feats) return GLORIE_EINVAL;
-      const long rpb = 1024;
+      // rows per workgroup: ~2048 workgroups (fixed 1024 rows left the chip a quarter full at the mapper's 5000 rays and gave
+      // 78 workgroups at 1000), at least 64 rows each so that the 30 atomics per workgroup on dB_rel stay rare
+      long rpb = ((Q * 8 + 2047) / 2048 + 3) & ~3L;
+      rpb = rpb < 64 ? 64 : (rpb > 1024 ? 1024 : rpb);
       hipLaunchKernelGGL(nb_rows_bwd_kernel, dim3((unsigned)((Q * 8 + rpb - 1) / rpb)), dim3(256), 0, st, W.t_n52, NB_IN, pts,
                          cloud_pos, I, P->n_B, Q, d_col_feats, sinkB, rpb);
       GLORIE_TRY(check_launch());
