@@ -65,12 +65,13 @@ def _on_device(t, dev):
     buffers, and stay on the host when the module is moved - are copied once per version: a pageable host-to-device copy in
     every forward pass stalls the host until the stream has drained (2.7 ms per mapping iteration)."""
     if t.device == dev:
-        return t
-    # the copy rides on the tensor object itself: a table keyed by (address, shape) hands the copy of a freed tensor to the
-    # next one the host allocator places at the same address - another decoder's Fourier matrix
+        return t.detach().contiguous().float()
+    # the copy rides on the tensor OBJECT the decoder holds (callers pass that object, not a detach()ed view of it): a table
+    # keyed by (address, shape) hands the copy of a freed tensor to the next one the host allocator places at the same
+    # address - another decoder's Fourier matrix
     hit = getattr(t, "_glorie_on_device", None)
     if hit is None or hit[0] != t._version or hit[1].device != dev:
-        hit = (t._version, t.to(dev))
+        hit = (t._version, t.detach().contiguous().float().to(dev))
         t._glorie_on_device = hit
     return hit[1]
 
@@ -87,7 +88,7 @@ class RenderTrain(torch.autograd.Function):
         lib = L.load()
         f32c = lambda t: t.detach().contiguous().float()
         geo_feats_c, col_feats_c = f32c(geo_feats), f32c(col_feats)
-        pcs = [_on_device(f32c(p), dev) for p in params]
+        pcs = [_on_device(p, dev) for p in params]
         ws = torch.empty(int(lib.glorie_render_train_workspace(Q)) // 4, dtype=torch.float32, device=dev)
         raw = torch.empty(Q, 4, dtype=torch.float32, device=dev)
         P = _ptr_struct(pcs)
