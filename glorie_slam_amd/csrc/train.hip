@@ -657,6 +657,44 @@ Ws carve(float* base, long Q) {
   return w;
 }
 inline unsigned blocks(long n) { return (unsigned)((n + 255) / 256); }
+
+// The weight gradients of the backward pass run on a SECOND stream.  A layer's backward is  dW += dY^T X  (a reduction over all
+// rows with fp32 atomics: 45-70 us at the sequence's 1000 rays) and  dX = dY W  (20 us) - both read dY, neither waits for the
+// other, and at these sizes one of them does not fill the chip.  Every dY of a section gets its own buffer (no ping-pong), so
+// the second stream only has to start behind the kernel that produced its dY (an event) and the first one only waits for it
+// where a section's scratch is handed on (side_join).  One process drives one GPU: the stream and the events are process-wide.
+struct Side {
+  hipStream_t s = nullptr;
+  hipEvent_t fork[32];
+  hipEvent_t join;
+  unsigned used = 0;
+};
+int side_get(Side** out) {
+  static Side sd;
+  if (!sd.s) {
+    GLORIE_TRY(check_hip(hipStreamCreateWithFlags(&sd.s, hipStreamNonBlocking)));
+    for (auto& e : sd.fork) GLORIE_TRY(check_hip(hipEventCreateWithFlags(&e, hipEventDisableTiming)));
+    GLORIE_TRY(check_hip(hipEventCreateWithFlags(&sd.join, hipEventDisableTiming)));
+  }
+  *out = &sd;
+  return GLORIE_OK;
+}
+// the second stream, ordered behind everything `st` holds so far
+int side_fork(hipStream_t st, hipStream_t* side) {
+  Side* sd;
+  GLORIE_TRY(side_get(&sd));
+  hipEvent_t e = sd->fork[sd->used++ % 32];
+  GLORIE_TRY(check_hip(hipEventRecord(e, st)));
+  GLORIE_TRY(check_hip(hipStreamWaitEvent(sd->s, e, 0)));
+  *side = sd->s;
+  return GLORIE_OK;
+}
+int side_join(hipStream_t st) {
+  Side* sd;
+  GLORIE_TRY(side_get(&sd));
+  GLORIE_TRY(check_hip(hipEventRecord(sd->join, sd->s)));
+  return check_hip(hipStreamWaitEvent(st, sd->join, 0));
+}
 }  // namespace
 
 extern "C" size_t glorie_render_train_workspace(long Q) { return carve(nullptr, Q < 0 ? 0 : Q).total * sizeof(float); }
@@ -688,20 +726,24 @@ static int trunk_fwd(hipStream_t st, long Q, int hid, int emb_w, int act, const 
   return GLORIE_OK;
 }
 
-// backward of the trunk: dH_4 ([Q,hid] contiguous, destroyed) -> parameter gradients (accumulated), dc [Q,32]
-// (overwritten) and, if demb != NULL, the gradient of the embedding [Q,emb_w] (overwritten).
-// scratch: p0, p1, dz [Q,hid]; dcat [Q,emb_w + hid]
+// backward of the trunk: dH_4 ([Q,hid] contiguous) -> parameter gradients (accumulated, on the second stream: the caller joins),
+// dc [Q,32] (overwritten) and, if demb != NULL, the gradient of the embedding [Q,emb_w] (overwritten).
+// scratch: 8 buffers [Q,hid] (every dH / dZ of the five layers keeps its own: the weight gradients read them later);
+// dcat [Q,emb_w + hid]
 static int trunk_bwd(hipStream_t st, long Q, int hid, int emb_w, int act, const float* emb, const float* c,
                      const float* const* Wl, const float* const* Ul, float* const* dWl, float* const* dbl,
                      float* const* dUl, float* const* dul, float* const* A, float* const* H, const float* cat,
-                     float* dH4, float* p0, float* p1, float* dz, float* dcat, float* dc, float* demb) {
+                     float* dH4, float* scratch8, float* dcat, float* dc, float* demb) {
   const int catw = emb_w + hid;
   GLORIE_TRY(check_hip(hipMemsetAsync(dc, 0, sizeof(float) * (size_t)Q * 32, st)));
   const float* dh = dH4;
   int ldd = hid;
+  hipStream_t sd;
   for (int i = 4; i >= 0; --i) {
+    float* dz = scratch8 + (size_t)i * Q * hid;                    // dZ_i
     // H_i = A_i + c U_i^T + u_i
-    GLORIE_TRY(wgrad(st, dh, ldd, c, 32, Q, hid, 32, dUl[i], 32, dul[i]));
+    GLORIE_TRY(side_fork(st, &sd));
+    GLORIE_TRY(wgrad(sd, dh, ldd, c, 32, Q, hid, 32, dUl[i], 32, dul[i]));
     GLORIE_TRY(mm(st, false, dh, ldd, Ul[i], 32, nullptr, (int)Q, hid, 32, TACT_NONE, dc, 32, nullptr, 0, nullptr, 0, 0, 1));
     // A_i = act(Z_i):  dZ_i = dH_i * act'(A_i)
     GLORIE_TRY(dact(st, dh, ldd, A[i], hid, act, Q, hid, dz, hid));
@@ -711,7 +753,8 @@ static int trunk_bwd(hipStream_t st, long Q, int hid, int emb_w, int act, const 
     else if (i == 3) { hin = cat; hw = catw; ldh = catw; }
     else if (i == 4) { hin = H[3]; hw = hid; ldh = hid; }
     else { hin = H[i - 1]; hw = hid; ldh = hid; }              // i = 1, 2: H_0, H_1
-    GLORIE_TRY(wgrad(st, dz, hid, hin, ldh, Q, hid, hw, dWl[i], hw, dbl[i]));
+    GLORIE_TRY(side_fork(st, &sd));
+    GLORIE_TRY(wgrad(sd, dz, hid, hin, ldh, Q, hid, hw, dWl[i], hw, dbl[i]));
     if (i == 0) {
       if (demb) GLORIE_TRY(mm(st, false, dz, hid, Wl[0], emb_w, nullptr, (int)Q, hid, emb_w, TACT_NONE, demb, emb_w,
                               nullptr, 0, nullptr, 0, 0, /*accumulate=*/1));
@@ -722,7 +765,7 @@ static int trunk_bwd(hipStream_t st, long Q, int hid, int emb_w, int act, const 
                                               sizeof(float) * emb_w, (size_t)Q, hipMemcpyDeviceToDevice, st)));
       dh = dcat + emb_w; ldd = catw;
     } else {
-      float* nxt = (i == 4 || i == 2) ? p0 : p1;
+      float* nxt = scratch8 + (size_t)(5 + (i == 4 ? 0 : (i == 2 ? 1 : 2))) * Q * hid;      // dH_3, dH_1, dH_0
       GLORIE_TRY(mm(st, false, dz, hid, Wl[i], hid, nullptr, (int)Q, hid, hid, TACT_NONE, nxt, hid));
       dh = nxt; ldd = hid;
     }
@@ -795,13 +838,15 @@ extern "C" int glorie_render_train_bwd(const glorie_decoder_params* P, const glo
   // ---- geometry decoder ----
   {
     // occ = H_4 Wo^T + bo
-    GLORIE_TRY(wgrad(st, docc, 4, W.g_H[4], G_HID, Q, 1, G_HID, G->g_Wo, G_HID, G->g_bo));
+    hipStream_t sd;
+    GLORIE_TRY(side_fork(st, &sd));
+    GLORIE_TRY(wgrad(sd, docc, 4, W.g_H[4], G_HID, Q, 1, G_HID, G->g_Wo, G_HID, G->g_bo));
     float* dH4 = W.t_a;
     GLORIE_TRY(mm(st, false, docc, 4, P->g_Wo, G_HID, nullptr, (int)Q, 1, G_HID, TACT_NONE, dH4, G_HID));
     float* gH[5] = {W.g_H[0], W.g_H[1], W.g_cat + G_EMB, W.g_H[3], W.g_H[4]};
-    float* p0 = W.t_b, *p1 = W.t_b + (size_t)Q * G_HID, *dz = W.t_b + (size_t)Q * 2 * G_HID;
+    // scratch: the eight [Q,32] buffers of the trunk live in the (still unused) neighbour temporaries
     GLORIE_TRY(trunk_bwd(st, Q, G_HID, G_EMB, TACT_RELU, W.g_emb, W.g_c, P->g_W, P->g_U, G->g_W, G->g_b, G->g_U, G->g_u,
-                         W.g_A, gH, W.g_cat, dH4, p0, p1, dz, W.t_cat, W.t_c32, G->g_B ? W.t_emb : nullptr));
+                         W.g_A, gH, W.g_cat, dH4, W.t_n128, W.t_cat, W.t_c32, G->g_B ? W.t_emb : nullptr));
     if (G->g_B) {
       const int rpb = 256;
       hipLaunchKernelGGL(fourier_bwd_kernel, dim3((unsigned)((Q + rpb - 1) / rpb)), dim3(256), 0, st, pts, 3, P->g_B, G_EMB, 0, Q,
@@ -810,26 +855,31 @@ extern "C" int glorie_render_train_bwd(const glorie_decoder_params* P, const glo
     if (d_geo_feats)
       hipLaunchKernelGGL(idw_bwd_kernel, dim3(blocks(Q * 32)), dim3(256), 0, st, W.t_c32, 32, I, w, has, Q, d_geo_feats);
     GLORIE_TRY(check_launch());
+    GLORIE_TRY(side_join(st));             // the colour decoder reuses t_a, t_q4 stays, t_n128 is handed on
   }
   if (!stage_color) return GLORIE_OK;
   // ---- colour decoder ----
   {
     // rgb = sigmoid(H_4 Wo^T + bo): t_q4[:, 0:3] already holds dZ
-    GLORIE_TRY(wgrad(st, W.t_q4, 4, W.c_H[4], C_HID, Q, 3, C_HID, G->c_Wo, C_HID, G->c_bo));
+    hipStream_t sd;
+    GLORIE_TRY(side_fork(st, &sd));
+    GLORIE_TRY(wgrad(sd, W.t_q4, 4, W.c_H[4], C_HID, Q, 3, C_HID, G->c_Wo, C_HID, G->c_bo));
     float* dH4 = W.t_a;
     GLORIE_TRY(mm(st, false, W.t_q4, 4, P->c_Wo, C_HID, nullptr, (int)Q, 3, C_HID, TACT_NONE, dH4, C_HID));
     float* cH[5] = {W.c_H[0], W.c_H[1], W.c_cat + C_EMB, W.c_H[3], W.c_H[4]};
-    // scratch: t_b holds only C_CAT floats per sample -> p0 there, p1 / dz in the (now free) neighbour temporaries
-    float* p0 = W.t_b, *p1 = W.t_n128, *dz = W.t_n128 + (size_t)Q * C_HID;
+    // scratch: the eight [Q,128] buffers of the trunk are exactly the [8Q,128] neighbour temporary
     GLORIE_TRY(trunk_bwd(st, Q, C_HID, C_EMB, TACT_SOFTPLUS, W.c_emb, W.c_c, P->c_W, P->c_U, G->c_W, G->c_b, G->c_U, G->c_u,
-                         W.c_A, cH, W.c_cat, dH4, p0, p1, dz, W.t_cat, W.t_c32, nullptr));
+                         W.c_A, cH, W.c_cat, dH4, W.t_n128, W.t_cat, W.t_c32, nullptr));
     // c = has ? sum_k w F : 0;  F = Z L2^T + b2;  Z = softplus(X L1^T + b1)
     hipLaunchKernelGGL(wsum_bwd_kernel, dim3(blocks(Q * 32)), dim3(256), 0, st, W.t_c32, 32, w, has, Q, W.t_n32, 32);
     GLORIE_TRY(check_launch());
-    GLORIE_TRY(wgrad(st, W.t_n32, 32, W.n_Z, C_HID, Q * 8, 32, C_HID, G->n_W2, C_HID, G->n_b2));
+    GLORIE_TRY(side_join(st));             // the trunk's weight gradients read t_n128, which the next launch overwrites
+    GLORIE_TRY(side_fork(st, &sd));
+    GLORIE_TRY(wgrad(sd, W.t_n32, 32, W.n_Z, C_HID, Q * 8, 32, C_HID, G->n_W2, C_HID, G->n_b2));
     GLORIE_TRY(mm(st, false, W.t_n32, 32, P->n_W2, C_HID, nullptr, (int)(Q * 8), 32, C_HID, TACT_NONE, W.t_n128, C_HID, nullptr, 0,
                   W.n_Z, C_HID, TACT_SOFTPLUS));
-    GLORIE_TRY(wgrad(st, W.t_n128, C_HID, W.n_X, NB_IN, Q * 8, C_HID, NB_IN, G->n_W1, NB_IN, G->n_b1));
+    GLORIE_TRY(side_fork(st, &sd));
+    GLORIE_TRY(wgrad(sd, W.t_n128, C_HID, W.n_X, NB_IN, Q * 8, C_HID, NB_IN, G->n_W1, NB_IN, G->n_b1));
     GLORIE_TRY(mm(st, false, W.t_n128, C_HID, P->n_W1, NB_IN, nullptr, (int)(Q * 8), C_HID, NB_IN, TACT_NONE, W.t_n52, NB_IN));
     if (d_col_feats || G->n_B) {
       // one launch serves both; a NULL target is replaced by a scratch sink
@@ -844,7 +894,7 @@ extern "C" int glorie_render_train_bwd(const glorie_decoder_params* P, const glo
       GLORIE_TRY(check_launch());
     }
   }
-  return GLORIE_OK;
+  return side_join(st);                    // the gradients (and the workspace) belong to the caller's stream again
 }
 
 extern "C" int glorie_composite_bwd(const float* raw, const float* z_vals, int R, int S, float coef, const float* g_depth,
