@@ -548,8 +548,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 // changes from step to step, so the host re-sends it only when a pointer moved;
 // block (x, y) updates elements [1024 x, 1024 x + 1024) of tensor y.
 struct AdamEntry { float* p; const float* g; float* m; float* v; long n; float lr, b1, b2, eps; long pad[3]; };
-__global__ __launch_bounds__(256) void adam_multi_kernel(const AdamEntry* __restrict__ table, int step) {
-  const AdamEntry e = table[blockIdx.y];
+__global__ __launch_bounds__(256) void adam_multi_kernel(const AdamEntry* __restrict__ table, int step, const char* grad_base) {
+  AdamEntry e = table[blockIdx.y];
+  if (grad_base) e.g = reinterpret_cast<const float*>(grad_base + reinterpret_cast<size_t>(e.g));   // g = byte offset
   const long base = (long)blockIdx.x * 1024;
   if (base >= e.n) return;
   const float bc1 = 1.0f - powf(e.b1, (float)step);          // as glorie_adam_step forms them on the host
@@ -920,12 +921,14 @@ extern "C" int glorie_adam_step(float* param, const float* grad, float* exp_avg,
   return check_launch();
 }
 
-extern "C" int glorie_adam_multi(const void* table, int n_tensors, long max_numel, int step, void* stream) {
+extern "C" int glorie_adam_multi(const void* table, int n_tensors, long max_numel, int step, const void* grad_base,
+                                 void* stream) {
   if (n_tensors < 0 || max_numel < 0 || step < 1) return GLORIE_EINVAL;
   if (n_tensors == 0 || max_numel == 0) return GLORIE_OK;
   if (!table) return GLORIE_EINVAL;
   static_assert(sizeof(AdamEntry) == 80, "table layout");
   const dim3 grid((unsigned)((max_numel + 1023) / 1024), (unsigned)n_tensors);
-  hipLaunchKernelGGL(adam_multi_kernel, grid, dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const AdamEntry*>(table), step);
+  hipLaunchKernelGGL(adam_multi_kernel, grid, dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const AdamEntry*>(table), step,
+                     reinterpret_cast<const char*>(grad_base));
   return check_launch();
 }

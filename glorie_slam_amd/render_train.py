@@ -244,19 +244,24 @@ class FeatureAdam:
                                              float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
                                              int(st["step"]), None, 1, L.stream_ptr(p.device)), "glorie_adam_step")
         elif small:
-            # glorie_adam_multi: one 80-byte table entry per tensor; re-packed and re-sent only when a pointer moved (the
-            # caching allocator hands the gradient buffer of the previous iteration back most of the time)
-            # the key covers EVERYTHING an entry holds: the mapper rewrites param_groups[i]['lr'] between its stages
-            # (mapper.py:412-414) while the allocator keeps handing back the same gradient buffers
-            key = tuple((p.data_ptr(), p.grad.data_ptr(), st["m"].data_ptr(), st["v"].data_ptr(), p.numel(), float(g["lr"]),
-                         float(g["betas"][0]), float(g["betas"][1]), float(g["eps"])) for p, st, g in small)
+            # glorie_adam_multi: one 80-byte table entry per tensor, re-packed and re-sent only when something it holds changed.
+            # The gradients of a backward pass are views of ONE buffer (RenderTrain.backward) that the caching allocator places
+            # somewhere else almost every iteration: the table then holds their byte offsets and the buffer's address travels
+            # as a kernel argument - with absolute pointers the table was rebuilt and uploaded on 1206 of 1240 steps.
+            # The key covers EVERYTHING an entry holds: the mapper rewrites param_groups[i]['lr'] between its stages
+            # (mapper.py:412-414).
             dev = small[0][0].device
+            gbase = small[0][0].grad.untyped_storage().data_ptr()
+            shared = all(p.grad.untyped_storage().data_ptr() == gbase for p, _, _ in small)
+            goff = (lambda p: p.grad.data_ptr() - gbase) if shared else (lambda p: p.grad.data_ptr())
+            key = tuple((p.data_ptr(), goff(p), st["m"].data_ptr(), st["v"].data_ptr(), p.numel(), float(g["lr"]),
+                         float(g["betas"][0]), float(g["betas"][1]), float(g["eps"])) for p, st, g in small) + (shared,)
             if getattr(self, "_table_key", None) != key:
-                buf = b"".join(struct.pack("<qqqqqffffqqq", p.data_ptr(), p.grad.data_ptr(), st["m"].data_ptr(),
+                buf = b"".join(struct.pack("<qqqqqffffqqq", p.data_ptr(), goff(p), st["m"].data_ptr(),
                                            st["v"].data_ptr(), p.numel(), float(g["lr"]), float(g["betas"][0]),
                                            float(g["betas"][1]), float(g["eps"]), 0, 0, 0) for p, st, g in small)
                 self._table = self._upload(buf, dev)
                 self._table_key = key
                 self._table_max = max(p.numel() for p, _, _ in small)
             L.check(lib.glorie_adam_multi(L.ptr(self._table), len(small), self._table_max, int(small[0][1]["step"]),
-                                          L.stream_ptr(dev)), "glorie_adam_multi")
+                                          gbase if shared else None, L.stream_ptr(dev)), "glorie_adam_multi")

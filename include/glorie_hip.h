@@ -714,8 +714,10 @@ int glorie_adam_step(float* param, const float* grad, float* exp_avg, float* exp
 
 /* glorie_adam_step for many small tensors that are at the same step, in one launch.  table: n_tensors entries of 80 bytes on
  * the device - { float* param; const float* grad; float* exp_avg; float* exp_avg_sq; int64 numel; float lr, beta1, beta2, eps;
- * 24 bytes padding } (nothing step-dependent: it is re-sent only when a pointer moved); max_numel = the largest numel. */
-int glorie_adam_multi(const void* table, int n_tensors, long max_numel, int step, void* stream);
+ * 24 bytes padding } (nothing step-dependent: it is re-sent only when a pointer moved); max_numel = the largest numel.
+ * grad_base != NULL: the `grad` field of every entry is a BYTE OFFSET from grad_base instead of a pointer - the gradients of a
+ * backward pass are views of one buffer that the allocator places anew every iteration; with offsets the table stays valid. */
+int glorie_adam_multi(const void* table, int n_tensors, long max_numel, int step, const void* grad_base, void* stream);
 
 #ifdef __cplusplus
 }
