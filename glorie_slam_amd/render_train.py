@@ -226,6 +226,9 @@ class FeatureAdam:
                 if st is None:               # (setdefault would build - and zero-fill - the default on every call)
                     st = self.state[id(p)] = {"step": 0, "m": torch.zeros_like(p), "v": torch.zeros_like(p)}
                 st["step"] += 1
+                # the kernels write through raw pointers: tell autograd (and every cache keyed on `_version`, e.g. the packed
+                # parameter buffer of the inference kernels, POINT._packed) that the tensor changed
+                torch.autograd.graph.increment_version(p)
                 mask = row_masks.get(id(p)) if row_masks else None
                 if not (p.is_contiguous() and p.grad.is_contiguous() and p.dtype == torch.float32):
                     raise RuntimeError("FeatureAdam: contiguous float32 parameters expected")

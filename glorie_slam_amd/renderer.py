@@ -130,6 +130,8 @@ class Renderer(object):
         a 640x480 frame, same values).  Usage (render_img, bench.render_pass): `with torch.cuda.stream(ren.batch_stream(k, dev)):
         render_batch_ray(...)` for every batch, then `ren.join_batches(dev)` before the results are read."""
         dev = torch.device(device)
+        if dev.index is None:                  # 'cuda' names the current device
+            dev = torch.device("cuda", torch.cuda.current_device())
         st = getattr(self, "_streams", None)
         if st is None or st[0].device != dev:
             st = self._streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]

@@ -103,6 +103,23 @@ def test_train_path_matches_reference_gradient_fixture(gpu):
     assert n >= 40
 
 
+def test_adam_step_invalidates_the_packed_inference_parameters(gpu):
+    """FeatureAdam updates the parameters through raw pointers; the inference kernels read a packed copy that POINT._packed
+    caches by tensor version: a step must make it stale (the mapper trains the decoders, render_img then reads them)"""
+    from glorie_slam_amd import point_ops
+    from glorie_slam_amd.render_train import FeatureAdam
+    _, npc, dec, ren, ro, rd, depth, radius, _, _ = _scene(gpu)
+    before = dec._packed().clone()
+    params = list(dec.parameters())
+    opt = FeatureAdam([{"params": params, "lr": 1e-2}])
+    for p in params:
+        p.grad = torch.ones_like(p)
+    opt.step()
+    after = dec._packed()
+    assert not torch.equal(before, after)
+    assert torch.equal(after, point_ops.pack_decoders(dec))
+
+
 def test_feature_adam_matches_torch_adam(gpu):
     from glorie_slam_amd.render_train import FeatureAdam
     g = torch.Generator().manual_seed(0)
