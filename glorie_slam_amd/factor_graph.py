@@ -27,9 +27,11 @@ def coords_grid(ht, wd, device):
 
 class FactorGraph:
     def __init__(self, video, update_op, device="cuda:0", corr_impl="volume", max_factors=-1,
-                 use_graphs=False):
+                 use_graphs=False, capture_after=1):
         """use_graphs: replay `update()` as a hipGraph while the edge set is unchanged (a BA-update
-        iteration is ~100 short launches; issuing them from Python costs as much as running them)"""
+        iteration is ~100 short launches; issuing them from Python costs as much as running them).
+        capture_after: eager sightings of a call before it is recorded (1: the second sighting records; the tracking
+        frontend, whose edge set changes with every keyframe, passes 6 - see update())"""
         self.video = video
         self.update_op = update_op
         self.device = device
@@ -49,6 +51,7 @@ class FactorGraph:
         self.target_inac, self.weight_inac = zero_tw(), zero_tw()
         self._uniq_cache = None
         self.use_graphs = bool(use_graphs) and str(device).startswith("cuda")
+        self.capture_after = max(int(capture_after), 1)   # eager sightings of a call before it is recorded (see update())
         self.stats = {"captures": 0, "replays": 0, "eager": 0}     # hipGraph bookkeeping of update() (pipeline / bench)
         self._topo = 0                      # bumped whenever the edge set changes
         self._graphs = {}                   # (topology, arguments) -> captured update
@@ -281,8 +284,14 @@ class FactorGraph:
         # the all-reduced fallback decision) and the row exchange are issued eagerly behind it
         key = (self._topo, t0, t1, itrs, bool(use_inactive), float(EP), bool(motion_only), opt_type, sharded)
         ent = self._graphs.get(key)
-        if ent is None:                     # first sighting: run eagerly (packs weights, sizes scratch buffers)
-            self._graphs[key] = "seen"
+        if ent is None or isinstance(ent, int):
+            # the first `capture_after` sightings of a call for this edge set run eagerly (the first one also packs weights
+            # and sizes scratch buffers): a capture keeps the device idle for ~2.7 ms and a replay saves ~0.5 ms over an
+            # eager call that is enqueued almost as fast as it executes - in the tracking loop, where every keyframe changes
+            # the edge set and a call is seen ~5 times, capturing on the second sighting cost 10 % (tools/prof_sequence.py);
+            # the BA-update loop of the bench and a backend that keeps its graph replay thousands of times
+            n = (ent or 0) + 1
+            self._graphs[key] = n if n < self.capture_after else "seen"
             return self._update_eager(t0, t1, itrs, use_inactive, EP, motion_only, opt_type)
         if ent == "seen":
             try:

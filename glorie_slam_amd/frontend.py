@@ -30,8 +30,11 @@ class Frontend:
         self.frontend_radius, self.frontend_max_factors = fe['radius'], fe['max_factors']
         self.enable_loop = fe['enable_loop']
         self.loop_closing = LoopClosing(net, video, cfg)
+        # capture_after=6: a keyframe changes the edge set and each of the two alternating calls is then seen ~6 times - not
+        # enough replays to pay for a capture (FactorGraph.update); a graph that survives longer (no new keyframe: a camera
+        # standing still) is still recorded
         self.graph = FactorGraph(video, net.update, device=cfg['device'], corr_impl='volume',
-                                 max_factors=self.frontend_max_factors, use_graphs=use_graphs)
+                                 max_factors=self.frontend_max_factors, use_graphs=use_graphs, capture_after=6)
 
     def _refine(self, iterations):
         """DSPO: even iterations optimise poses + disparities, odd ones disparities + scale/shift"""

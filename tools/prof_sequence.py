@@ -14,6 +14,8 @@ from glorie_slam_amd.pipeline import synthetic_long_runner  # noqa: E402
 dev = torch.device("cuda", 0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 run, lc, frames = synthetic_long_runner(dev, n_frames=n, map_iters=20)
+if os.environ.get("TRACK_GRAPHS") == "0":          # A/B: the frontend's updates always eager
+    run.frontend.graph.use_graphs = False
 if os.environ.get("TRIM_GB"):
     run.frontend.graph.capture_trim_bytes = int(float(os.environ["TRIM_GB"]) * 2 ** 30)
 intr = lc["intrinsics"]
