@@ -40,6 +40,7 @@ print(f"track ms per kept keyframe p50 {np.percentile(tr[kp][8:], 50):.1f} mean 
       f"{torch.cuda.memory_reserved() / 2**30:.1f} GB reserved")
 st = pstats.Stats(pr).sort_stats("cumulative")
 st.print_stats(45)
+pstats.Stats(pr).sort_stats("tottime").print_stats(30)
 st.print_callers("method 'to' of")
 st.print_callees("render_train.py:195")
 st.print_callees("pipeline.py:116")
