@@ -246,6 +246,40 @@ def test_graph_replay_matches_eager(gpu, stage2):
     graph.update(t0=1, t1=6, itrs=2)
 
 
+def test_capture_policy_and_shared_graph_pool(gpu):
+    """capture_after = n: a call runs eagerly n times, is recorded on sighting n + 1 and replayed from then on (the frontend
+    passes 6: its edge sets rarely live that long); every graph of a FactorGraph is recorded into ONE memory pool, so dropping
+    and re-recording graphs (edge-set changes) does not grow the allocator's reservation"""
+    from glorie_slam_amd.factor_graph import FactorGraph
+    from glorie_slam_amd.droid_net import UpdateModule
+    g, video = make_video(gpu, 6, 24, 32)
+    torch.manual_seed(43)
+    net = UpdateModule().to(gpu).eval()
+    graph = FactorGraph(video, net, device=str(gpu), use_graphs=True, capture_after=3)
+    ii, jj = torch.as_tensor(g["ii"], device=gpu), torch.as_tensor(g["jj"], device=gpu)
+    graph.add_factors(ii, jj)
+    seen = []
+    for i in range(7):
+        graph.update(t0=1, t1=6, itrs=2)
+        seen.append((graph.stats["eager"], graph.stats["captures"], graph.stats["replays"]))
+    # (a capture runs the eager code under stream capture: it counts as one eager pass and one replay of what it recorded)
+    assert [s[1] for s in seen] == [0, 0, 0, 1, 1, 1, 1], seen
+    assert seen[2][0] == 3 and seen[-1][2] >= 3, seen
+    # edge-set changes: the graphs are dropped and recorded again, the pool's blocks are reused
+    torch.cuda.synchronize()
+    reserved = []
+    for rep in range(6):
+        graph.rm_factors(torch.ones_like(graph.ii, dtype=torch.bool), store=False)
+        graph.add_factors(ii, jj)
+        for i in range(5):
+            graph.update(t0=1, t1=6, itrs=2)
+        torch.cuda.synchronize()
+        reserved.append(torch.cuda.memory_reserved())
+    assert graph.stats["captures"] == 7
+    assert reserved[-1] <= reserved[1] + (64 << 20), [r >> 20 for r in reserved]
+    assert torch.isfinite(video.poses[:6]).all() and video.ctx().ba_status()[0] == 0
+
+
 def test_full_resolution_valid_mask_and_video_npz(gpu, tmp_path):
     """update_valid_depth_mask(up=True) through glorie_valid_depth_mask == the
     reference's op-by-op formulation (global-memory radix-select median), and the video.npz format"""
