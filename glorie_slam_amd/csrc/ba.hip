@@ -17,8 +17,8 @@
 //   gram      (chunks x M)  prologue: C_k, w_k = sum of the frame's edge shares in CSR order (no atomics),
 //                           Q_k = 1 / (C_k + damping); then G_k = F diag(Q) F^T on the matrix cores
 //                           (v_mfma_f32_16x16x4_f32, exact fp32), F = the E_ij rows of frame
-//                           k plus the w row; scattered into the dense reduced system with
-//                           fp64 atomics.  The pose-pose blocks from H_jj / v_j (edge i of a frame by the
+//                           k plus the w row; scattered into the dense reduced system through
+//                           exact integer accumulators (acc_add: order-independent, bit-reproducible).  The pose-pose blocks from H_jj / v_j (edge i of a frame by the
 //                           workgroup of chunk i mod nchunks; a launch of its own, `assemble`, in motion-only mode).
 //   solve     (1 WG)        fp64 damping + Cholesky + triangular solves (zero update on
 //                           failure, like Eigen's LLT info != Success branch).
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(kBaThreads) void ba_jacobian_kernel(
   // one memset node less per iteration)
   {
     const long nthreads = (long)gridDim.x * gridDim.y * kBaThreads;
-    for (long i = ((long)n * gridDim.x + chunk) * kBaThreads + tid; i < hd_doubles; i += nthreads) wk.Hd[i] = 0.0;
+    for (long i = ((long)n * gridDim.x + chunk) * kBaThreads + tid; i < 2 * hd_doubles; i += nthreads) wk.Hacc[i] = 0ull;
   }
   if (wk.status[0] & BA_ST_M_MISMATCH) return;
   const int k = (int)ii[n];
@@ -282,9 +282,31 @@ __global__ __launch_bounds__(kBaThreads) void ba_jacobian_kernel(
 }
 
 // ------------------------------------------------------------------------------------
-// gram pass: G = F diag(Q) F^T with MFMA, then scatter into the dense system (fp64 atomics)
+// gram pass: G = F diag(Q) F^T with MFMA, then scatter into the dense system (exact accumulators)
 // ------------------------------------------------------------------------------------
-__device__ __forceinline__ void atomic_add_f64(double* p, double v) { unsafeAtomicAdd(p, v); }
+// Exact accumulation of the reduced system.  Many workgroups (pixel chunks x depth frames, and the edges' pose-pose
+// blocks) add into the same entry of [H | v]; with fp64 atomics the ORDER of those additions, and with it the last
+// bit of the sum, changed from run to run (measured in round 5: 999 of 1000 builds differed in some entry by one
+// ulp).  The reference sums in a fixed order (sorted-edge accum, droid_kernels.cu:948-998; Eigen triplets,
+// :1117-1219).  Here every term is rounded ONCE to a multiple of 2^-40 and added to a two-limb integer accumulator
+// (value = (hi 2^32 + lo) 2^-40): integer addition is associative, so the sum does not depend on the order, and the
+// limbs need no carry between them (lo takes < 2^32 per term: room for 2^31 terms; hi covers |sum| < 2^54).  The
+// 9e-13 absolute rounding per term is far below the fp32 rounding of the terms themselves.
+__device__ __forceinline__ void acc_add(const BaWork& wk, size_t idx, double v) {
+  if (!(fabs(v) < 0x1p50)) {                     // also NaN
+    atomicOr(&wk.status[0], BA_ST_NONFINITE);
+    return;
+  }
+  const double t = v * 256.0;                    // in units of 2^-40 2^32
+  const double fh = floor(t);
+  const unsigned long long lo = (unsigned long long)rint((t - fh) * 4294967296.0);   // t - fh is exact, in [0, 1)
+  atomicAdd(&wk.Hacc[2 * idx], (unsigned long long)(long long)fh);
+  atomicAdd(&wk.Hacc[2 * idx + 1], lo);
+}
+__device__ __forceinline__ double acc_value(const unsigned long long* acc, size_t idx) {
+  const long long hi = (long long)acc[2 * idx];
+  return ((double)hi * 4294967296.0 + (double)acc[2 * idx + 1]) * 0x1p-40;
+}
 
 __device__ __forceinline__ void assemble_edge(const BaWork& wk, const int64_t* __restrict__ ii,
                                               const int64_t* __restrict__ jj, int n, int nchunks, int t0, int t1,
@@ -460,15 +482,14 @@ __global__ __launch_bounds__(kBaThreads) void ba_gram_kernel(
         const int pa = (int)jj[wk.csr_edge[ea + a]] - t0;
         const int pb = (int)jj[wk.csr_edge[eb + b]] - t0;
         if (pa >= 0 && pa < P && pb >= 0 && pb < P && pa >= pb)
-          atomic_add_f64(&wk.Hd[(size_t)(6 * pa + r) * n6 + 6 * pb + c],
-                         -(double)Gs[(6 * a + r) * GL + 6 * b + c]);
+          acc_add(wk, (size_t)(6 * pa + r) * n6 + 6 * pb + c, -(double)Gs[(6 * a + r) * GL + 6 * b + c]);
       }
       if (Bg == 0) {
         for (int idx = tid; idx < degA * 6; idx += kBaThreads) {
           const int r = idx % 6, a = idx / 6;
           const int pa = (int)jj[wk.csr_edge[ea + a]] - t0;
           if (pa >= 0 && pa < P)
-            atomic_add_f64(&wk.vd[6 * pa + r], -(double)Gs[(6 * a + r) * GL + wcol]);
+            acc_add(wk, (size_t)n6 * n6 + 6 * pa + r, -(double)Gs[(6 * a + r) * GL + wcol]);
         }
       }
       if (self) {
@@ -489,8 +510,8 @@ __global__ __launch_bounds__(kBaThreads) void ba_gram_kernel(
           const int pb = (int)jj[wk.csr_edge[eb + b]] - t0;
           if (pb >= 0 && pb < P) {
             const double val = -(double)Xs[idx];
-            if (pk >= pb) atomic_add_f64(&wk.Hd[(size_t)(6 * pk + r) * n6 + 6 * pb + c], val);
-            else          atomic_add_f64(&wk.Hd[(size_t)(6 * pb + c) * n6 + 6 * pk + r], val);
+            if (pk >= pb) acc_add(wk, (size_t)(6 * pk + r) * n6 + 6 * pb + c, val);
+            else          acc_add(wk, (size_t)(6 * pb + c) * n6 + 6 * pk + r, val);
           }
         }
         if (tid < 36) {  // S_kk = -sum_b X_b L_b^T ;  H -= S_kk
@@ -501,7 +522,7 @@ __global__ __launch_bounds__(kBaThreads) void ba_gram_kernel(
 #pragma unroll
             for (int m = 0; m < 6; ++m) sum += Xs[b * 36 + r * 6 + m] * L[c * 6 + m];
           }
-          atomic_add_f64(&wk.Hd[(size_t)(6 * pk + r) * n6 + 6 * pk + c], (double)sum);
+          acc_add(wk, (size_t)(6 * pk + r) * n6 + 6 * pk + c, (double)sum);
         } else if (Bg == 0 && tid >= 64 && tid < 70) {  // v_S[k] = -sum_a L_a g_a ; v -= v_S
           const int r = tid - 64;
           float sum = 0.0f;
@@ -510,7 +531,7 @@ __global__ __launch_bounds__(kBaThreads) void ba_gram_kernel(
 #pragma unroll
             for (int m = 0; m < 6; ++m) sum += L[r * 6 + m] * Gs[(6 * a + m) * GL + wcol];
           }
-          atomic_add_f64(&wk.vd[6 * pk + r], (double)sum);
+          acc_add(wk, (size_t)n6 * n6 + 6 * pk + r, (double)sum);
         }
       }
     }
@@ -573,16 +594,16 @@ __device__ __forceinline__ void assemble_edge(const BaWork& wk, const int64_t* _
   const int n6 = 6 * P;
   if (tid < 36) {
     const int r = tid / 6, c = tid % 6;
-    if (ai) atomic_add_f64(&wk.Hd[(size_t)(6 * pi + r) * n6 + 6 * pi + c], Hii[tid]);
-    if (aj) atomic_add_f64(&wk.Hd[(size_t)(6 * pj + r) * n6 + 6 * pj + c], Hjj[tid]);
+    if (ai) acc_add(wk, (size_t)(6 * pi + r) * n6 + 6 * pi + c, Hii[tid]);
+    if (aj) acc_add(wk, (size_t)(6 * pj + r) * n6 + 6 * pj + c, Hjj[tid]);
     if (ai && aj) {
-      if (pi >= pj) atomic_add_f64(&wk.Hd[(size_t)(6 * pi + r) * n6 + 6 * pj + c], Hij[tid]);
-      else          atomic_add_f64(&wk.Hd[(size_t)(6 * pj + c) * n6 + 6 * pi + r], Hij[tid]);
+      if (pi >= pj) acc_add(wk, (size_t)(6 * pi + r) * n6 + 6 * pj + c, Hij[tid]);
+      else          acc_add(wk, (size_t)(6 * pj + c) * n6 + 6 * pi + r, Hij[tid]);
     }
   }
   if (tid < 6) {
-    if (ai) atomic_add_f64(&wk.vd[6 * pi + tid], vi[tid]);
-    if (aj) atomic_add_f64(&wk.vd[6 * pj + tid], vj[tid]);
+    if (ai) acc_add(wk, (size_t)n6 * n6 + 6 * pi + tid, vi[tid]);
+    if (aj) acc_add(wk, (size_t)n6 * n6 + 6 * pj + tid, vj[tid]);
   }
 }
 
@@ -594,6 +615,13 @@ __global__ __launch_bounds__(64) void ba_assemble_kernel(BaWork wk, const int64_
   __shared__ double sm[192];
   if (wk.status[0] & BA_ST_M_MISMATCH) return;
   assemble_edge(wk, ii, jj, blockIdx.x, nchunks, t0, t1, sm);
+}
+
+// accumulators -> the fp64 system [H | v] the solvers (and a multi-GPU all-reduce) work on
+__global__ __launch_bounds__(256) void ba_system_f64_kernel(BaWork wk, long total) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  // a dropped non-finite term poisons H[0][0]: after a multi-GPU all-reduce EVERY rank then sees the failure
+  if (i < total) wk.Hd[i] = (i == 0 && (wk.status[0] & BA_ST_NONFINITE)) ? __builtin_nan("") : acc_value(wk.Hacc, (size_t)i);
 }
 
 // ------------------------------------------------------------------------------------
@@ -656,7 +684,14 @@ __global__ __launch_bounds__(256) void chol_trail_kernel(BaWork wk, int n, int j
 
 __global__ __launch_bounds__(256) void chol_damp_kernel(BaWork wk, int n, float lm, float ep) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i == 0) atomicAnd(&wk.status[0], ~BA_ST_SOLVE_ABORT);     // first launch of a large-system solve
+  if (i == 0) {                                                   // first launch of a large-system solve
+    if (wk.status[0] & BA_ST_NONFINITE) {
+      atomicOr(&wk.status[0], BA_ST_CHOL_FAILED | BA_ST_SOLVE_ABORT);
+      atomicAdd(&wk.status[2], 1);
+    } else {
+      atomicAnd(&wk.status[0], ~BA_ST_SOLVE_ABORT);
+    }
+  }
   if (i < n) {
     double v = wk.Hd[(size_t)i * n + i];
     wk.Hd[(size_t)i * n + i] = v + (double)ep + (double)lm * v;
@@ -716,6 +751,14 @@ __device__ __forceinline__ double rcp_f64(double d) {
 // Each thread forms the b's it needs itself (two more LDS reads per entry), so the dependent chain
 // read -> 1/d0 -> d1 -> 1/d1 -> update -> write -> barrier is paid once per TWO columns; entries of column
 // j + 1 itself (dc == 0) only take the first term, which is exactly b.
+// Hazard (found in round 5, the cause of run-to-run differences of ~1e-6 .. 1e-3 in the poses whenever the waves
+// of this workgroup did not run in lock step): column j + 1 is READ by every thread of the step (hr, hc, h11)
+// and its new value b is WRITTEN by the owners of the dc == 0 entries in the same step - a wave that got through
+// its two rcp chains before another wave had issued its loads made that wave read b instead of H[.][j + 1].  With
+// one barrier per step the reads and writes of a step must not alias: the b column is therefore kept in registers
+// and written one step LATE (step j + 2 reads columns j + 2, j + 3 and the window right of them, never column
+// j + 1; the back substitution runs after the final barrier).  Everything else a step writes (dc > 0: columns
+// >= j + 2) is read by nobody in that step.
 template <int NQ>
 __device__ __forceinline__ void band_eliminate(double* B, double* u, double* rinv, int* fail, int n, int bw) {
   const int tid = threadIdx.x;
@@ -742,6 +785,10 @@ __device__ __forceinline__ void band_eliminate(double* B, double* u, double* rin
   }
   const int rhs_dc = tid <= bw ? tid : (1 << 20);
   const int o_rc = (1 + rhs_dc) * S + rhs_dc + 1;
+  double pend[NQ];
+  bool pend_on[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) { pend[q] = 0.0; pend_on[q] = false; }
   __syncthreads();
   int j = 0;
   for (; j + 1 < n; j += 2) {
@@ -776,13 +823,19 @@ __device__ __forceinline__ void band_eliminate(double* B, double* u, double* rin
     if (tid == 0) { rinv[j] = ri0; rinv[j + 1] = ri1; }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
+      // column j - 1 of the previous step (nobody reads it any more); the slot is rewritten below iff ok[q]
+      if (pend_on[q]) B[(j - 2) * S + o_w[q]] = pend[q];
+      pend_on[q] = false;
       if (!ok[q]) continue;
       double v = cur[q] - ar[q] * ri0 * ac[q];
       if (e_dc[q] > 0) {
         const double br = hr[q] - ar[q] * ri0 * a1, bc = hc[q] - ac[q] * ri0 * a1;
         v -= br * ri1 * bc;
+        B[j * S + o_w[q]] = v;
+      } else {
+        pend[q] = v;              // column j + 1: read by other waves in THIS step, stored in the next one
+        pend_on[q] = true;
       }
-      B[j * S + o_w[q]] = v;
     }
     if (rok) {
       double v = ru - u0 * ri0 * ra;
@@ -794,23 +847,31 @@ __device__ __forceinline__ void band_eliminate(double* B, double* u, double* rin
     }
     __syncthreads();
   }
+  // the b column of the last step (the barrier that closed it is behind us; the back substitution reads it)
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+    if (pend_on[q]) B[(j - 2) * S + o_w[q]] = pend[q];
   if (j < n) {                       // odd n: the last column has nothing below it
     const double d = B[j * S];
     if (!(d > 0.0) && tid == 0) *fail = 1;
     if (tid == 0) rinv[j] = rcp_f64(d);
-    __syncthreads();
   }
+  __syncthreads();
 }
 
+// from_acc: the system is read straight from the accumulators (single-GPU solve of a small system: no conversion launch)
 __global__ __launch_bounds__(kBandThreads) void ba_solve_band_kernel(BaWork wk, int n, float lm, float ep,
-                                                                    int lds_doubles, int force_bw) {
+                                                                    int lds_doubles, int force_bw, int from_acc) {
   extern __shared__ double bsm[];
   __shared__ int fail, bw_s;
   const int tid = threadIdx.x;
   const double* A = wk.Hd;          // (n + 1) x n row-major, lower triangle; row n = right-hand side
   // force_bw >= 0: small dense systems (n <= 64) come here directly as a band of width n - 1, without the
   // bandwidth kernel and without the status[3] handshake
-  if (tid == 0) { fail = (wk.status[0] & BA_ST_M_MISMATCH) ? 1 : 0; bw_s = force_bw >= 0 ? force_bw : wk.status[3] >> 1; }
+  if (tid == 0) {
+    fail = (wk.status[0] & (BA_ST_M_MISMATCH | BA_ST_NONFINITE)) ? 1 : 0;
+    bw_s = force_bw >= 0 ? force_bw : wk.status[3] >> 1;
+  }
   __syncthreads();
   const int bw = bw_s;
   const int S = bw + 1;             // band row: B[r][k] = H[r][r - k], k = 0 .. bw
@@ -828,7 +889,7 @@ __global__ __launch_bounds__(kBandThreads) void ba_solve_band_kernel(BaWork wk, 
       const int idx = base + q * kBandThreads;
       const int r = idx / S, k = S - 1 - (idx - r * S);       // consecutive threads -> consecutive columns
       rr[q] = r; kk[q] = k;
-      v[q] = (idx < n * S && k <= r) ? A[(size_t)r * n + r - k] : 0.0;
+      v[q] = (idx < n * S && k <= r) ? (from_acc ? acc_value(wk.Hacc, (size_t)r * n + r - k) : A[(size_t)r * n + r - k]) : 0.0;
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
@@ -838,7 +899,8 @@ __global__ __launch_bounds__(kBandThreads) void ba_solve_band_kernel(BaWork wk, 
       B[rr[q] * S + kk[q]] = x;
     }
   }
-  for (int i = tid; i < n; i += kBandThreads) u[i] = A[(size_t)n * n + i];
+  for (int i = tid; i < n; i += kBandThreads)
+    u[i] = from_acc ? acc_value(wk.Hacc, (size_t)n * n + i) : A[(size_t)n * n + i];
   if ((bw + 1) * (bw + 2) / 2 <= 4 * kBandThreads) band_eliminate<4>(B, u, rinv, &fail, n, bw);
   else band_eliminate<9>(B, u, rinv, &fail, n, bw);      // bw <= 63: 2080 window entries at most
   if (fail) {
@@ -908,7 +970,7 @@ __global__ __launch_bounds__(1024) void ba_solve_fused_kernel(BaWork wk, int n, 
   const int tid = threadIdx.x;
   double* A = wk.Hd;                // (n + 1) x n row-major; row n = right-hand side (wk.vd)
   // status[3] = (half bandwidth << 1) | solved, left by ba_solve_band_kernel which always runs first
-  if (tid == 0) { fail = (wk.status[0] & BA_ST_M_MISMATCH) ? 1 : 0; bw_s = wk.status[3]; }
+  if (tid == 0) { fail = (wk.status[0] & (BA_ST_M_MISMATCH | BA_ST_NONFINITE)) ? 1 : 0; bw_s = wk.status[3]; }
   __syncthreads();
   if (tid == 0) wk.status[3] = 0;      // consumed (everybody has read it above)
   if (bw_s & 1) return;
@@ -1288,6 +1350,7 @@ namespace glorie {
 struct BaPlan {
   BaWork wk;
   int B, N, M, h, w, HW, t0, t1, P, n6, ppt, chunk_px, nchunks;
+  size_t scratch_used;
 };
 
 // validates sizes, carves the scratch arena (identical layout for identical sizes, so a
@@ -1319,8 +1382,10 @@ static int ba_plan(glorie_ctx* ctx, int B, int N, int M, int h, int w, int t0, i
   const size_t o_W = carve(sizeof(float) * (size_t)M * HW);
   const size_t o_CW = carve(sizeof(float) * 2 * (size_t)N * HW);
   const size_t o_Hd = carve(sizeof(double) * (n6 * n6 + n6));
+  const size_t o_acc = carve(2 * sizeof(unsigned long long) * (n6 * n6 + n6));
   const size_t o_dx = carve(sizeof(float) * n6);
   GLORIE_TRY(ctx_reserve(ctx, off));
+  pl.scratch_used = off;
   char* base = reinterpret_cast<char*>(ctx->scratch);
   BaWork& wk = pl.wk;
   wk.slot_of_frame = reinterpret_cast<int*>(base + o_slot);
@@ -1338,6 +1403,7 @@ static int ba_plan(glorie_ctx* ctx, int B, int N, int M, int h, int w, int t0, i
   // multi-GPU caller can all-reduce it in a single collective
   wk.Hd = hv_ext ? hv_ext : reinterpret_cast<double*>(base + o_Hd);
   wk.vd = wk.Hd + n6 * n6;
+  wk.Hacc = reinterpret_cast<unsigned long long*>(base + o_acc);
   wk.dx = reinterpret_cast<float*>(base + o_dx);
   static bool attr_set = false;
   if (!attr_set) {
@@ -1354,7 +1420,7 @@ static int ba_plan(glorie_ctx* ctx, int B, int N, int M, int h, int w, int t0, i
 static int ba_build_system(const BaPlan& pl, const float* poses, const float* disps,
                            const float* intrinsics, const float* disps_sens, const float* targets,
                            const float* weights, const float* eta, const int64_t* ii,
-                           const int64_t* jj, int flags, hipStream_t st) {
+                           const int64_t* jj, int flags, bool to_f64, hipStream_t st) {
   const BaWork& wk = pl.wk;
   const int motion_only = flags & 1, hwc = (flags & GLORIE_BA_TARGETS_HWC) ? 1 : 0;
   hipLaunchKernelGGL(ba_jacobian_kernel, dim3(pl.nchunks, pl.N), dim3(kBaThreads), 0, st, wk, poses,
@@ -1365,27 +1431,31 @@ static int ba_build_system(const BaPlan& pl, const float* poses, const float* di
                        pl.chunk_px, pl.t0, pl.t1, pl.nchunks, eta, disps, disps_sens);
   else
     hipLaunchKernelGGL(ba_assemble_kernel, dim3(pl.N), dim3(64), 0, st, wk, ii, jj, pl.nchunks, pl.t0, pl.t1);
+  if (to_f64) {
+    const long total = (long)pl.n6 * pl.n6 + pl.n6;
+    hipLaunchKernelGGL(ba_system_f64_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, wk, total);
+  }
   return check_launch();
 }
 
 // fp64 solve of the (all-reduced) system, then back-substitution + retraction
 static int ba_solve_update(const BaPlan& pl, float* poses, float* disps, const int64_t* ii,
                            const int64_t* jj, float lm, float ep, int motion_only, int depth_only,
-                           float* dx_out, float* dz_out, hipStream_t st) {
+                           float* dx_out, float* dz_out, bool from_acc, hipStream_t st) {
   const BaWork& wk = pl.wk;
   const int n6 = pl.n6;
   if (n6 <= kSolveMaxN) {
     const int bwf = n6 > 1 ? n6 - 1 : 1;
     const int need = n6 * (bwf + 1) + 2 * n6;
     hipLaunchKernelGGL(ba_solve_band_kernel, dim3(1), dim3(kBandThreads), sizeof(double) * (size_t)need, st, wk, n6,
-                       lm, ep, need, bwf);
+                       lm, ep, need, bwf, from_acc ? 1 : 0);
   } else if (n6 <= kFusedMaxN) {
     const size_t rows = (size_t)(n6 + 1 > kCB ? n6 + 1 - kCB : 1);
     const size_t lds = sizeof(double) * (2 * kCB * kCBP + (rows * kCBP > (size_t)n6 ? rows * kCBP : (size_t)n6));
     const int band_doubles = (160 * 1024 - 256) / (int)sizeof(double);
     hipLaunchKernelGGL(ba_bandwidth_kernel, dim3(n6), dim3(64), 0, st, wk, n6);
     hipLaunchKernelGGL(ba_solve_band_kernel, dim3(1), dim3(kBandThreads), sizeof(double) * (size_t)band_doubles, st,
-                       wk, n6, lm, ep, band_doubles, -1);
+                       wk, n6, lm, ep, band_doubles, -1, 0);
     hipLaunchKernelGGL(ba_solve_fused_kernel, dim3(1), dim3(1024), lds, st, wk, n6, lm, ep);
   } else {
     hipLaunchKernelGGL(chol_damp_kernel, dim3((n6 + 255) / 256), dim3(256), 0, st, wk, n6, lm, ep);
@@ -1428,12 +1498,15 @@ extern "C" int glorie_ba(glorie_ctx* ctx, float* poses, float* disps, const floa
   if (!poses || !disps || !intrinsics || !targets || !weights || !ii || !jj) return GLORIE_EINVAL;
   if (!motion_only && !eta) return GLORIE_EINVAL;
   hipStream_t st = (hipStream_t)stream;
+  GLORIE_TRY(ctx_poison(ctx, pl.scratch_used, st));
   GLORIE_TRY(ba_prepare(pl.wk, ii, B, N, M, t0, t1, st));
+  // small systems are read by the band solver straight from the accumulators (no conversion launch)
+  const bool direct = pl.n6 <= kSolveMaxN;
   for (int it = 0; it < iterations; ++it) {
     GLORIE_TRY(ba_build_system(pl, poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj,
-                               flags, st));
+                               flags, !direct, st));
     GLORIE_TRY(ba_solve_update(pl, poses, disps, ii, jj, lm, ep, motion_only, depth_only, dx_out,
-                               dz_out, st));
+                               dz_out, direct, st));
   }
   return GLORIE_OK;
 }
@@ -1454,9 +1527,10 @@ extern "C" int glorie_ba_build_system(glorie_ctx* ctx, const float* poses, const
   }
   if (!poses || !disps || !intrinsics || !targets || !weights || !ii || !jj) return GLORIE_EINVAL;
   if (!(motion_only & 1) && !eta) return GLORIE_EINVAL;
+  GLORIE_TRY(ctx_poison(ctx, pl.scratch_used, st));
   GLORIE_TRY(ba_prepare(pl.wk, ii, B, N, M, t0, t1, st));
   return ba_build_system(pl, poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj,
-                         motion_only, st);
+                         motion_only, /*to_f64=*/true, st);
 }
 
 extern "C" int glorie_ba_solve_update(glorie_ctx* ctx, float* poses, float* disps,
@@ -1473,9 +1547,10 @@ extern "C" int glorie_ba_solve_update(glorie_ctx* ctx, float* poses, float* disp
     // no local edges: still solve and retract the (replicated) poses; no depth frames to update
     pl.M = 1;
     return ba_solve_update(pl, poses, disps, ii, jj, lm, ep, /*motion_only=*/1, depth_only, dx_out,
-                           nullptr, st);
+                           nullptr, /*from_acc=*/false, st);
   }
-  return ba_solve_update(pl, poses, disps, ii, jj, lm, ep, motion_only, depth_only, dx_out, dz_out, st);
+  return ba_solve_update(pl, poses, disps, ii, jj, lm, ep, motion_only, depth_only, dx_out, dz_out,
+                         /*from_acc=*/false, st);
 }
 
 // ---- exchange format of the reduced system: lower triangle (row r: columns 0..r) followed by v ----

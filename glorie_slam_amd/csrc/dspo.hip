@@ -290,6 +290,7 @@ extern "C" int glorie_dspo_scale_shift(glorie_ctx* ctx, const float* poses, floa
   const size_t o_W = carve(sizeof(float) * (size_t)M * HW);
   const size_t o_dx = carve(sizeof(float) * 2 * (size_t)M);
   GLORIE_TRY(ctx_reserve(ctx, off));
+  GLORIE_TRY(ctx_poison(ctx, off, st));
   char* base = reinterpret_cast<char*>(ctx->scratch);
   BaWork wk{};
   wk.slot_of_frame = reinterpret_cast<int*>(base + o_slot);

@@ -526,6 +526,7 @@ extern "C" int glorie_knn_build(glorie_ctx* ctx, const float* points, int np, fl
   const size_t o_bsum = o_fill + ((sizeof(int) * (size_t)(max_cells + 1) + 255) & ~(size_t)255);
   const size_t total = o_bsum + sizeof(int) * 1024;
   GLORIE_TRY(ctx_reserve(ctx, total));
+  GLORIE_TRY(ctx_poison(ctx, total, st));
   char* base = reinterpret_cast<char*>(ctx->scratch);
   unsigned* bb = reinterpret_cast<unsigned*>(base + o_bb);
   int* keys = reinterpret_cast<int*>(base + o_keys);

@@ -1,6 +1,7 @@
 // Context, scratch arena and library identification for libglorie_hip.so
 #include <hip/hip_runtime.h>
 #include <new>
+#include <stdlib.h>
 #include "common.hiph"
 
 namespace glorie {
@@ -31,6 +32,15 @@ int ctx_reserve(Ctx* ctx, size_t bytes) {
   ctx->scratch_bytes = want;
   ctx->generation += 1;
   return GLORIE_OK;
+}
+
+int ctx_poison(Ctx* ctx, size_t bytes, hipStream_t st) {
+  static const bool on = [] {
+    const char* e = getenv("GLORIE_POISON_SCRATCH");
+    return e && e[0] && e[0] != '0';
+  }();
+  if (!on || !ctx->scratch || bytes == 0) return GLORIE_OK;
+  return check_hip(hipMemsetAsync(ctx->scratch, 0xFF, bytes < ctx->scratch_bytes ? bytes : ctx->scratch_bytes, st));
 }
 
 }  // namespace glorie

@@ -82,6 +82,23 @@ def test_ba_hwc_target_layout_is_bit_identical(gpu):
         assert torch.equal(a, b)
 
 
+# one problem per solver class (tools/ba_repeat.py:SIZES): n6 = 30 / 42 dense band <4>, 60 dense band <9>, 66 / 174 sliding
+# window band, 84 band <9>, 78 dense fused (bw >= 64), 474 fused (band does not fit LDS), 594 multi-kernel
+@pytest.mark.parametrize("K", [6, 8, 11, 12, 14, 15, 30, 80, 100])
+def test_ba_is_bitwise_reproducible(gpu, K):
+    """Contract: identical inputs -> identical bits, for the reduced system (exact integer accumulators
+    instead of fp64 atomics), for the solvers on a fixed system, and for glorie_ba as a whole - also while a second
+    stream keeps the chip busy (which is what exposed the read/write hazard of band_eliminate in round 4: 157 of
+    18000 repetitions differed by up to 9e-4 in a pose, profiles/r05_ba_repeat_before.txt).  The reference is
+    deterministic by construction (droid_kernels.cu:948-998 sorted-edge accum, :1117-1219 Eigen LLT on the host)."""
+    from tools import ba_repeat
+    h, w, radius = ba_repeat.SIZES[K]
+    p = ba_repeat.make_problem(K, h, w, radius)
+    for busy in (False, True):
+        bad, worst = ba_repeat.repeat_phases(p, 150, busy=busy)
+        assert bad == dict(build=0, solve=0, full=0), (busy, bad, worst)
+
+
 def test_ba_window_inside_graph(gpu):
     """t0 > 1: frames below t0 are fixed but still own depth maps (kx = unique(cat(ts, ii)))"""
     K = 7
@@ -149,6 +166,18 @@ def test_ba_cholesky_failure_gives_zero_update(gpu):
     g = make_problem(K, 12, 16)
     p, d, dx, dz, st = run_gpu(g, gpu, 1, K, 1, lm=-3.0, ep=-1.0)
     assert st[0] & 4 and st[2] == 1
+    assert np.all(dx == 0)
+    assert np.array_equal(p, g["poses"])
+
+
+@pytest.mark.parametrize("K", [4, 12, 92])                  # dense band / band + fused / multi-kernel solver
+def test_ba_nonfinite_term_gives_zero_update(gpu, K):
+    """a NaN target poisons the reduced system: zero pose update and the failure bit, as a NaN matrix does to the
+    reference's LLT (droid_kernels.cu:1192-1213); the exact accumulators must not silently drop the term"""
+    g = make_problem(K, 8, 12, radius=3 if K > 4 else 2)
+    g["target"][1, 0, 3, 4] = np.nan
+    p, d, dx, dz, st = run_gpu(g, gpu, 1, K, 1)
+    assert st[0] & 4 and st[0] & 32 and st[2] == 1
     assert np.all(dx == 0)
     assert np.array_equal(p, g["poses"])
 
