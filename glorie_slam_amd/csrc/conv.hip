@@ -980,6 +980,7 @@ static size_t halo_lds_bytes(int W, int MB) {
 template <int MB>
 static int launch_conv_halo(const ConvArgs& a, int epilogue, hipStream_t st) {
   constexpr int PT = 128, TN = 32 * MB;
+  if (a.pair && (MB % 2)) return GLORIE_EINVAL;        // paired weight rows need pairs of 16-row blocks (conv_epilogue_pair)
   const long ptiles = (a.P - a.pbeg + PT - 1) / PT;
   if (ptiles <= 0) return GLORIE_OK;
   const long nwg = ptiles * ((a.nout + TN - 1) / TN);
@@ -1005,6 +1006,7 @@ static int launch_conv_halo(const ConvArgs& a, int epilogue, hipStream_t st) {
 template <int NB, int BK, int NW, int ST, int MB = 4>
 static int launch_conv(const ConvArgs& a, int epilogue, hipStream_t st, long max_ptiles = -1) {
   constexpr int PT = (NW / 2) * 16 * NB;
+  if (a.pair && (MB % 2)) return GLORIE_EINVAL;        // paired weight rows need pairs of 16-row blocks (conv_epilogue_pair)
   long ptiles = (a.P - a.pbeg + PT - 1) / PT;
   if (epilogue == EPI_GLO) ptiles = (a.P / a.HW) * ((a.HW + PT - 1) / PT);      // tiles laid per map
   if (max_ptiles >= 0) ptiles = ptiles < max_ptiles ? ptiles : max_ptiles;

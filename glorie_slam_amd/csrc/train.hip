@@ -21,6 +21,8 @@
 #include <stdint.h>
 #include <math.h>
 #include <stdlib.h>
+#include <atomic>
+#include <mutex>
 #include "common.hiph"
 
 namespace glorie {
@@ -663,19 +665,29 @@ inline unsigned blocks(long n) { return (unsigned)((n + 255) / 256); }
 // rows with fp32 atomics: 45-70 us at the sequence's 1000 rays) and  dX = dY W  (20 us) - both read dY, neither waits for the
 // other, and at these sizes one of them does not fill the chip.  Every dY of a section gets its own buffer (no ping-pong), so
 // the second stream only has to start behind the kernel that produced its dY (an event) and the first one only waits for it
-// where a section's scratch is handed on (side_join).  One process drives one GPU: the stream and the events are process-wide.
+// where a section's scratch is handed on (side_join).  The stream and the events are per device.
 struct Side {
   hipStream_t s = nullptr;
   hipEvent_t fork[32];
   hipEvent_t join;
-  unsigned used = 0;
+  std::atomic<unsigned> used{0};
 };
+// one Side per device (created on first use under a mutex): a process that drives a second GPU must not launch its
+// weight gradients on a stream of the first one
 int side_get(Side** out) {
-  static Side sd;
+  static Side table[16];
+  static std::mutex mu;
+  int dev = 0;
+  GLORIE_TRY(check_hip(hipGetDevice(&dev)));
+  if (dev < 0 || dev >= 16) return GLORIE_EUNSUPPORTED;
+  Side& sd = table[dev];
+  std::lock_guard<std::mutex> lock(mu);
   if (!sd.s) {
-    GLORIE_TRY(check_hip(hipStreamCreateWithFlags(&sd.s, hipStreamNonBlocking)));
+    hipStream_t s;
+    GLORIE_TRY(check_hip(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)));
     for (auto& e : sd.fork) GLORIE_TRY(check_hip(hipEventCreateWithFlags(&e, hipEventDisableTiming)));
     GLORIE_TRY(check_hip(hipEventCreateWithFlags(&sd.join, hipEventDisableTiming)));
+    sd.s = s;
   }
   *out = &sd;
   return GLORIE_OK;
@@ -684,7 +696,7 @@ int side_get(Side** out) {
 int side_fork(hipStream_t st, hipStream_t* side) {
   Side* sd;
   GLORIE_TRY(side_get(&sd));
-  hipEvent_t e = sd->fork[sd->used++ % 32];
+  hipEvent_t e = sd->fork[sd->used.fetch_add(1) % 32];
   GLORIE_TRY(check_hip(hipEventRecord(e, st)));
   GLORIE_TRY(check_hip(hipStreamWaitEvent(sd->s, e, 0)));
   *side = sd->s;

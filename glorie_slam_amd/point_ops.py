@@ -142,6 +142,15 @@ def idw_gather2(D, I, nn, feats_a, feats_b, radius=0.0, radius_per_query=None, m
 _T_LIN = {}
 
 
+def t_lin(dev, S):
+    """the [S] sample fractions of a ray, one per (device, S); created on the CALLER's stream - Renderer.prepare_frame
+    calls this before the frame's batches fork onto their own streams"""
+    key = (str(dev), int(S))
+    if key not in _T_LIN:
+        _T_LIN[key] = torch.linspace(0.0, 1.0, steps=S, device=dev)
+    return _T_LIN[key]
+
+
 def ray_samples(rays_o, rays_d, depth, radius, S, near_s, far_s):
     """Renderer.py:106-125,177-184 for rays with a depth prior -> z_vals [R,S], pts [R*S,3],
     views [R*S,3], radius per sample [R*S] (None without `radius`), n_zero (device int32 [1]: rays with
@@ -149,9 +158,7 @@ def ray_samples(rays_o, rays_d, depth, radius, S, near_s, far_s):
     L.need_cuda(rays_o, rays_d, depth)
     dev = rays_o.device
     R = rays_o.shape[0]
-    key = (str(dev), int(S))
-    if key not in _T_LIN:
-        _T_LIN[key] = torch.linspace(0.0, 1.0, steps=S, device=dev)
+    tl = t_lin(dev, S)
     f = lambda t: t.detach().reshape(-1).contiguous().float()
     z = torch.empty(R, S, device=dev)
     pts = torch.empty(R * S, 3, device=dev)
@@ -162,7 +169,7 @@ def ray_samples(rays_o, rays_d, depth, radius, S, near_s, far_s):
     r = f(radius) if radius is not None else None
     if g.shape[0] != R or (r is not None and r.shape[0] != R):
         raise RuntimeError("ray_samples: depth / radius must have one entry per ray")
-    L.check(L.load().glorie_ray_samples(L.ptr(o), L.ptr(d), L.ptr(g), L.ptr(r), L.ptr(_T_LIN[key]), R, int(S),
+    L.check(L.load().glorie_ray_samples(L.ptr(o), L.ptr(d), L.ptr(g), L.ptr(r), L.ptr(tl), R, int(S),
                                         float(near_s), float(far_s), L.ptr(z), L.ptr(pts), L.ptr(views),
                                         L.ptr(rs), L.ptr(nz), L.stream_ptr()), "glorie_ray_samples")
     return z, pts, views, rs, nz
@@ -185,9 +192,7 @@ def ray_samples_camera(cam, image_w, first_pixel, depth, radius, S, near_s, far_
     f = lambda t: t.detach().reshape(-1).contiguous().float()
     g = f(depth)
     R = g.shape[0]
-    key = (str(dev), int(S))
-    if key not in _T_LIN:
-        _T_LIN[key] = torch.linspace(0.0, 1.0, steps=S, device=dev)
+    tl = t_lin(dev, S)
     z = torch.empty(R, S, device=dev)
     pts = torch.empty(R * S, 3, device=dev)
     views = torch.empty(R * S, 3, device=dev)
@@ -197,7 +202,7 @@ def ray_samples_camera(cam, image_w, first_pixel, depth, radius, S, near_s, far_
     if r is not None and r.shape[0] != R:
         raise RuntimeError("ray_samples_camera: radius must have one entry per ray")
     L.check(L.load().glorie_ray_samples_camera(L.ptr(cam), int(image_w), int(first_pixel), L.ptr(g), L.ptr(r),
-                                               L.ptr(_T_LIN[key]), R, int(S), float(near_s), float(far_s), L.ptr(z),
+                                               L.ptr(tl), R, int(S), float(near_s), float(far_s), L.ptr(z),
                                                L.ptr(pts), L.ptr(views), L.ptr(rs), L.ptr(nz), L.stream_ptr()),
             "glorie_ray_samples_camera")
     return z, pts, views, rs, nz

@@ -140,6 +140,21 @@ class Renderer(object):
         self._flag_slot = k & 1
         return st[k & 1]
 
+    def prepare_frame(self, npc, decoders, device):
+        """Everything the batches of a frame SHARE and build lazily is materialised here, on the caller's stream, before the
+        first `batch_stream` fork: the decoders' packed parameters (`pack_decoders`: dozens of asynchronous cat / copy kernels,
+        again after every FeatureAdam.step), their range-guard word, the sample fractions and the cloud's position table.
+        Otherwise batch 0 builds them on stream 0 while batch 1 - a cache hit on stream 1, ordered only against the caller's
+        stream - may launch `render_mlp` on a half-written pack or an unzeroed flag."""
+        dev = torch.device(device)
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        decoders._packed()
+        decoders.range_guard(dev)
+        point_ops.t_lin(dev, self.N_surface)
+        if npc is not None:
+            npc.cloud_pos()
+
     def join_batches(self, device):
         st = getattr(self, "_streams", None)
         if st is not None:
@@ -230,6 +245,8 @@ class Renderer(object):
         rays = None
         bad_any = False
         two = cam is not None and n_rays > bs and not torch.is_grad_enabled()
+        if two:
+            self.prepare_frame(npc, decoders, device)
         for k, i in enumerate(range(0, n_rays, bs)):
             g_i = gt[i:i + bs] if gt is not None else None
             r_i = dynamic_r_query[i:i + bs] if self.use_dynamic_radius else None

@@ -228,13 +228,16 @@ CONV_POLICY = {None: 0, "auto": 0, "128": 1, "64": 2, "split": 3, "wide": 4, "no
 
 
 def conv_igemm(xa, xb, w_packed, taps, nout, out, epilogue=EPI_BIAS_ACT, terms=None, act=ACT_NONE,
-               net=None, z=None, out2=None, pre=None, pre_map=None, policy=None):
+               net=None, z=None, out2=None, pre=None, pre_map=None, policy=None, pair=None):
     """Implicit-GEMM convolution with fused epilogue (csrc/conv.hip, include/glorie_hip.h).
     xa / xb: channels-last fp16 maps [N,Ca,h,w] / [N,Cb,h,w] (either may be None); writes `out`
     (and `out2` for the GRU gates) and returns `out`.  pre: fp16 channels-last [N,nout,h,w] added before the
     gate non-linearity (the hoisted convolution over the context features); with pre_map (int32 [N]) map e reads map
     pre_map[e] of `pre`, which then holds one map per distinct context (source keyframe) instead of one per edge.
-    policy: tile choice forced by the caller (CONV_POLICY; tests and tools/bench_conv.py - the product passes None = auto)."""
+    policy: tile choice forced by the caller (CONV_POLICY; tests and tools/bench_conv.py - the product passes None = auto).
+    pair: the row layout of `w_packed` (pack_conv_igemm(pair=...)).  None reads the flag pack_conv_igemm left on the tensor
+    object and RAISES when it is gone: a copy (.to / .clone / state_dict round trip) drops Python attributes, and the
+    unpaired epilogue on paired rows would permute the output channels without any error."""
     ref = xa if xa is not None else xb
     L.need_cuda(ref, w_packed, out)
     n, _, h, w = ref.shape
@@ -263,7 +266,12 @@ def conv_igemm(xa, xb, w_packed, taps, nout, out, epilogue=EPI_BIAS_ACT, terms=N
         raise RuntimeError("conv_igemm: pre_map must be a contiguous int32 [N] on the device, next to pre")
     if out.shape[1] != (128 if (epilogue & 0xff) != EPI_BIAS_ACT else nout) or out.shape[0] != n:
         raise RuntimeError("conv_igemm: bad output shape")
-    if getattr(w_packed, "_glorie_pair", False):
+    if pair is None:
+        pair = getattr(w_packed, "_glorie_pair", None)
+        if pair is None:
+            raise RuntimeError("conv_igemm: w_packed carries no row-layout flag (a copy of a pack_conv_igemm result loses "
+                               "it): pack again or pass pair=True/False")
+    if pair:
         epilogue |= EPI_PAIR16
     epilogue |= CONV_POLICY[policy] << 12
     L.check(L.load().glorie_conv_igemm(pa, sa, ca, pb, sb, cb, L.ptr(w_packed), taps, nout, epilogue,

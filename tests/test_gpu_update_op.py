@@ -419,6 +419,14 @@ def test_conv_igemm_gru_epilogues(gpu):
     q = torch.tanh(_conv_ref([rnet, hx], wq) + terms[:, 256:].reshape(n, 128, 1, 1))
     ref = (1 - z.float()) * net.float() + z.float() * q
     torch.testing.assert_close(new.float(), ref, atol=4e-3, rtol=4e-3)
+    # a COPY of packed weights has lost the row-layout flag pack_conv_igemm left on the tensor object: the call must fail
+    # loudly (the unpaired epilogue on paired rows would permute the channels silently) unless the caller states the layout
+    wq_copy = U.pack_conv_igemm(wq, pair=True).clone()
+    with pytest.raises(RuntimeError, match="row-layout flag"):
+        U.conv_igemm(rnet, hx, wq_copy, 9, 128, new, epilogue=U.EPI_GRU_Q, terms=terms[:, 256:], net=net, z=z)
+    new2 = torch.empty_like(net)
+    U.conv_igemm(rnet, hx, wq_copy, 9, 128, new2, epilogue=U.EPI_GRU_Q, terms=terms[:, 256:], net=net, z=z, pair=True)
+    assert torch.equal(new2, new)
 
 
 @pytest.mark.parametrize("mode", ["128", "64", "split", "wide", "nohalo"])
