@@ -115,31 +115,64 @@ class DepthVideo:
         jj = jj.to(device=device, dtype=torch.long).reshape(-1)
         return ii, jj
 
-    def enable_sharding(self, owner, rank, world, group=None):
+    def enable_sharding(self, owner, rank, world, group=None, force=False):
         """edges of this process' graphs are a source-keyframe shard (dist.shard_frames).
-        GLORIE_NATIVE_COMM=1: the context gets its own RCCL communicator (dist.init_ctx_comm) and the BA's exchange step
-        runs as glorie_allreduce_normal_eq on the stream instead of a torch.distributed collective (opt-in: only its
-        one-rank form can be exercised on the single-GPU test box)."""
-        self.shard = dict(owner=owner, rank=rank, world=world, group=group)
-        if os.environ.get("GLORIE_NATIVE_COMM") == "1" and self.poses.is_cuda and world > 1:
-            from . import dist as gdist
-            gdist.init_ctx_comm(self.ctx(), group)
+        On the GPU with RCCL as the process group's backend the context gets its OWN communicator (dist.init_ctx_comm), and
+        every exchange of a BA-update - the all-reduce of the reduced normal equations, the fallback flag of a depth_scale
+        stage, the owned rows - is a C-ABI call on the stream (glorie_allreduce_normal_eq / glorie_allgather_rows): the whole
+        sharded step is then ONE hipGraph (FactorGraph.update).  GLORIE_NATIVE_COMM=0 opts out (torch.distributed
+        collectives, the BA issued eagerly behind the replayed part); =1 asks for it whatever the backend says.  A
+        communicator that cannot be created (or does not sum a probe correctly) leaves the torch.distributed path in place.
+        force (tests): treat a world of one as sharded, so the exchange path runs on the single GPU of the test box."""
+        self.shard = dict(owner=owner, rank=rank, world=world, group=group, force=bool(force))
+        want = os.environ.get("GLORIE_NATIVE_COMM")
+        if want == "0" or not self.poses.is_cuda or not (world > 1 or force):
+            return
+        import torch.distributed as tdist
+        from . import dist as gdist
+        active = tdist.is_available() and tdist.is_initialized()
+        if want != "1" and world > 1 and not (active and tdist.get_backend(group) == "nccl"):
+            return            # (gloo test runs with several ranks on one device: RCCL refuses duplicate devices)
+        try:
+            gdist.init_ctx_comm(self.ctx(), group, rank=rank if not active else None, world=world if not active else None)
+            probe = torch.ones(1, dtype=torch.float64, device=self.poses.device)
+            L.check(L.load().glorie_allreduce_normal_eq(self.ctx().handle, L.ptr(probe), 1, L.stream_ptr()),
+                    "glorie_allreduce_normal_eq")
+            if float(probe.item()) != float(world):
+                raise RuntimeError(f"probe all-reduce summed to {float(probe.item())} over {world} ranks")
+        except Exception as exc:
+            import warnings
+            warnings.warn(f"context-owned RCCL communicator unavailable ({exc!r}): exchange through torch.distributed")
+            try:
+                L.load().glorie_comm_destroy(self.ctx().handle)
+            except Exception:
+                pass
+
+    def is_sharded(self):
+        return self.shard is not None and (self.shard["world"] > 1 or self.shard.get("force", False))
+
+    def native_exchange(self):
+        """the exchange steps run on the context's own communicator (capturable)"""
+        if not self.is_sharded():
+            return False
+        from . import dist as gdist
+        return self.poses.is_cuda and gdist.native_comm(self._ctx, self.shard["group"], want_world=self.shard["world"])
 
     def sync_owned(self, *names):
         """all-gather the rows owned by each rank of the named per-keyframe buffers"""
-        if self.shard is None or self.shard["world"] <= 1:
+        if not self.is_sharded():
             return
         from . import dist as gdist
         for nme in names:
             gdist.allgather_owned_rows(getattr(self, nme), self.shard["owner"], self.shard["rank"],
-                                       self.shard["world"], self.shard["group"])
+                                       self.shard["world"], self.shard["group"], force=self.shard["force"], ctx=self._ctx)
             if nme == "disps_up":
                 self.shard["stale_up"] = False
 
     def sync_owned_state(self):
         """disps, depth_scale and depth_shift of every rank's frames in ONE collective (three small
         exchanges per BA-update are three collective latencies)"""
-        if self.shard is None or self.shard["world"] <= 1:
+        if not self.is_sharded():
             return
         from . import dist as gdist
         nf = min(len(self.shard["owner"]), self.disps.shape[0])
@@ -149,7 +182,7 @@ class DepthVideo:
         pack[:, hw] = self.depth_scale[:nf]
         pack[:, hw + 1] = self.depth_shift[:nf]
         gdist.allgather_owned_rows(pack, self.shard["owner"], self.shard["rank"], self.shard["world"],
-                                   self.shard["group"])
+                                   self.shard["group"], force=self.shard["force"], ctx=self._ctx)
         self.disps[:nf] = pack[:, :hw].reshape(nf, *self.disps.shape[1:])
         self.depth_scale[:nf] = pack[:, hw]
         self.depth_shift[:nf] = pack[:, hw + 1]
@@ -159,7 +192,7 @@ class DepthVideo:
         inside the update loop reads another rank's disps_up (61 MB at 50 keyframes), so their exchange is
         left to the consumers - the valid-depth mask, the mapper's accessors, save_video - via
         `fresh_disps_up()`; a COLLECTIVE call: every rank has to reach the same consumer."""
-        if self.shard is not None and self.shard["world"] > 1:
+        if self.is_sharded():
             self.shard["stale_up"] = True
 
     def fresh_disps_up(self):
@@ -281,11 +314,12 @@ class DepthVideo:
                 # (depth_video.py:215-216 of the reference)
                 target = target.reshape(-1, h, w, 2).contiguous()
                 weight = weight.reshape(-1, h, w, 2).contiguous()
-                if self.shard is not None and self.shard["world"] > 1:
+                if self.is_sharded():
                     from . import dist as gdist
                     gdist.ba_sharded(self.ctx(), self.poses, self.disps, self.intrinsics[0].contiguous(),
                                      target, weight, eta.contiguous(), ii, jj, t0, t1, itrs, lm, ep,
-                                     motion_only, False, group=self.shard["group"], targets_hwc=True)
+                                     motion_only, False, group=self.shard["group"], targets_hwc=True,
+                                     force_collective=self.shard["force"])
                 else:
                     droid_backends.ba(self.poses, self.disps, self.intrinsics[0].contiguous(), None,
                                       target, weight, eta, ii, jj, t0, t1, itrs, lm, ep, motion_only,

@@ -79,20 +79,40 @@ def ctx_comm_world(ctx):
     return int(L.load().glorie_comm_world(ctx.handle)) if ctx is not None else 0
 
 
+def native_comm(ctx, group=None, want_world=None):
+    """True when `ctx` owns an RCCL communicator built for exactly the ranks of `group` (init_ctx_comm): the exchange steps
+    are then C-ABI calls on the stream (capturable).  A caller that names another group - or a process group that appeared
+    after a world-of-one communicator was made - goes through torch.distributed instead."""
+    if ctx is None or ctx_comm_world(ctx) <= 0:
+        return False
+    made = getattr(ctx, "_comm_group", None)
+    if want_world is None:
+        want_world = dist.get_world_size(group) if _active(group) else 1
+    return not (made is None or made[2] != want_world or (made[0] is not group and not (made[0] is None and group is None)))
+
+
+def allreduce_flag_any(flag, group=None, ctx=None, force=False):
+    """`flag` (int32 [1] on the device, 0 / 1) becomes 1 on every rank if it is 1 on any (the stage-1 fallback decision of
+    a depth_scale stage selects a collective path: it has to be identical everywhere).  Native communicator: the flag
+    rides as one double through glorie_allreduce_normal_eq - stream work, recorded into the step's hipGraph like the
+    launches around it; otherwise a torch.distributed MAX."""
+    if flag.is_cuda and native_comm(ctx, group):
+        one = flag.to(torch.float64)
+        L.check(L.load().glorie_allreduce_normal_eq(ctx.handle, L.ptr(one), 1, L.stream_ptr()), "glorie_allreduce_normal_eq")
+        flag.copy_(one > 0)
+        return flag
+    if _active(group) and (dist.get_world_size(group) > 1 or force):
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+    return flag
+
+
 def allreduce_system(hv, group=None, n6=None, force=False, ctx=None):
     """sum the reduced system [H | v] over ranks (RCCL all-reduce; gloo in the CPU tests).  hv: n6*n6 + n6
     doubles.  On the device and for n6 >= PACK_MIN_N6 only the lower triangle + v travel
     (glorie_ba_pack_system): xGMI rings are per-link bound, half the bytes is half the time.
     ctx with its own communicator (init_ctx_comm): the sum is glorie_allreduce_normal_eq on the current stream.
     force: run the collective even with one rank (exercises the RCCL path on a single GPU)."""
-    native = hv.is_cuda and ctx_comm_world(ctx) > 0
-    if native:
-        # the communicator sums over the ranks it was built for: a caller that names another group (or a process group
-        # that appeared after a world-of-one communicator was made) goes through torch.distributed instead
-        made = getattr(ctx, "_comm_group", None)
-        want_world = dist.get_world_size(group) if _active(group) else 1
-        if made is None or made[2] != want_world or (made[0] is not group and not (made[0] is None and group is None)):
-            native = False
+    native = hv.is_cuda and native_comm(ctx, group)
     if not native and (not _active(group) or (dist.get_world_size(group) <= 1 and not force)):
         return hv
     lib = L.load()
@@ -152,19 +172,27 @@ def _owner_blocks(owner, nf, world):
     return starts, counts
 
 
-def allgather_owned_rows(buf, owner, rank, world, group=None, force=False):
+def allgather_owned_rows(buf, owner, rank, world, group=None, force=False, ctx=None):
     """make `buf[f]` consistent on all ranks: row f is taken from owner[f] (disps / depth_scale / disps_up
     after a sharded BA-update).  shard_frames hands every rank one contiguous block of frames, so this is an
     all-gather of the blocks (padded to the largest one): each row crosses a link once, where the masked
-    all-reduce of full buffers it replaces moved every row twice and summed zeros."""
+    all-reduce of full buffers it replaces moved every row twice and summed zeros.
+    ctx with its own communicator for these ranks (init_ctx_comm): glorie_allgather_rows on the current stream."""
     if world <= 1 and not force:
         return buf
+    native = buf.is_cuda and native_comm(ctx, group, want_world=world)
     nf = min(len(owner), buf.shape[0])
     blocks = _owner_blocks(owner, nf, world)
     if blocks is None:                      # non-contiguous ownership: masked all-reduce(sum)
         mine = torch.as_tensor(np.asarray(owner[:nf]) == rank, device=buf.device)
         contrib = torch.where(mine.view(-1, *([1] * (buf.dim() - 1))), buf[:nf], torch.zeros_like(buf[:nf]))
-        dist.all_reduce(contrib, op=dist.ReduceOp.SUM, group=group)
+        if native:
+            c64 = contrib.to(torch.float64).contiguous()
+            L.check(L.load().glorie_allreduce_normal_eq(ctx.handle, L.ptr(c64), int(c64.numel()), L.stream_ptr()),
+                    "glorie_allreduce_normal_eq")
+            contrib = c64.to(buf.dtype)
+        else:
+            dist.all_reduce(contrib, op=dist.ReduceOp.SUM, group=group)
         buf[:nf] = contrib
         return buf
     starts, counts = blocks
@@ -172,7 +200,11 @@ def allgather_owned_rows(buf, owner, rank, world, group=None, force=False):
     send = torch.zeros((width,) + tuple(buf.shape[1:]), dtype=buf.dtype, device=buf.device)
     send[:counts[rank]] = buf[starts[rank]:starts[rank] + counts[rank]]
     recv = torch.empty((world * width,) + tuple(buf.shape[1:]), dtype=buf.dtype, device=buf.device)
-    dist.all_gather_into_tensor(recv, send, group=group)
+    if native:
+        L.check(L.load().glorie_allgather_rows(ctx.handle, L.ptr(send), L.ptr(recv), int(send.numel() * send.element_size()),
+                                               L.stream_ptr()), "glorie_allgather_rows")
+    else:
+        dist.all_gather_into_tensor(recv, send, group=group)
     for r in range(world):
         if r != rank and counts[r]:
             buf[starts[r]:starts[r] + counts[r]] = recv[r * width:r * width + counts[r]]

@@ -61,7 +61,7 @@ def depth_scale_stage(video, target, weight, eta, ii, jj, itrs, lm, ep, fused=Tr
         # under hipGraph capture the stage-1 decision is left to the owner of the graph: the preparation's last launch
         # publishes the flag itself (a sharded run all-reduces it first and publishes below)
         self_publish = bool(video.mono_thres and torch.cuda.is_current_stream_capturing()
-                            and not (shard_ is not None and shard_["world"] > 1))
+                            and not video.is_sharded())
         edge_on, any_on = droid_backends.dspo_prepare(
             video.poses, video.disps, video.intrinsics[0].contiguous(), video.mono_disps, n, mv['thresh'],
             mv['visible_num'], video.mono_thres, ii.contiguous(), jj.contiguous(), video.valid_depth_mask_small,
@@ -71,11 +71,11 @@ def depth_scale_stage(video, target, weight, eta, ii, jj, itrs, lm, ep, fused=Tr
     else:
         edge_on, any_on = _prepare_torch(video, n, ii, jj)
     if edge_on is not None:
-        shard = getattr(video, "shard", None)
-        if shard is not None and shard["world"] > 1:
-            # the fallback decision must be identical on every rank (it selects a collective path)
-            import torch.distributed as dist
-            dist.all_reduce(any_on, op=dist.ReduceOp.MAX, group=shard["group"])
+        if video.is_sharded():
+            # the fallback decision must be identical on every rank (it selects a collective path); with the context's own
+            # communicator the flag's all-reduce is stream work and the stage stays capturable
+            from . import dist as gdist
+            gdist.allreduce_flag_any(any_on, video.shard["group"], ctx=video._ctx, force=video.shard["force"])
         if any_on.is_cuda and torch.cuda.is_current_stream_capturing():
             # hipGraph capture: no host decision is possible here.  With every edge off the stage-2
             # launch below leaves all frames untouched, so it is recorded unconditionally; the flag

@@ -274,15 +274,18 @@ class FactorGraph:
                opt_type="pose_depth"):
         """factor_graph.py:212-256.  With use_graphs the launch sequence of one call is captured
         the second time it is seen for the current edge set and replayed afterwards."""
-        sharded = getattr(self.video, "shard", None) is not None and self.video.shard["world"] > 1
+        sharded = self.video.is_sharded()
+        # with the context's own RCCL communicator (DepthVideo.enable_sharding) every exchange of the step is stream work:
+        # the WHOLE sharded step - update operator, build -> all-reduce -> solve per GN iteration, the all-reduced fallback
+        # flag, upsampling, the exchange of the owned rows - is one hipGraph, like the single-GPU step.  Through
+        # torch.distributed (gloo, or GLORIE_NATIVE_COMM=0) the replay stops before the BA, which is issued eagerly
+        whole = not sharded or self.video.native_exchange()
         if self.ii.numel() == 0:
             return self._update_eager(t0, t1, itrs, use_inactive, EP, motion_only, opt_type)
         t0, t1 = self._window(t0, t1, use_inactive)
         if not self.use_graphs:
             return self._update_eager(t0, t1, itrs, use_inactive, EP, motion_only, opt_type)
-        # sharded graphs: everything up to the BA is replayed, the BA (all-reduce of the normal equations,
-        # the all-reduced fallback decision) and the row exchange are issued eagerly behind it
-        key = (self._topo, t0, t1, itrs, bool(use_inactive), float(EP), bool(motion_only), opt_type, sharded)
+        key = (self._topo, t0, t1, itrs, bool(use_inactive), float(EP), bool(motion_only), opt_type, sharded, whole)
         ent = self._graphs.get(key)
         if ent is None or isinstance(ent, int):
             # the first `capture_after` sightings of a call for this edge set run eagerly (the first one also packs weights
@@ -295,7 +298,7 @@ class FactorGraph:
             return self._update_eager(t0, t1, itrs, use_inactive, EP, motion_only, opt_type)
         if ent == "seen":
             try:
-                ent = self._capture(key, (t0, t1, itrs, use_inactive, EP, motion_only, opt_type, not sharded))
+                ent = self._capture(key, (t0, t1, itrs, use_inactive, EP, motion_only, opt_type, whole))
                 self.stats["captures"] += 1
             except Exception as exc:        # a failed capture must not take the step down: stay eager
                 import warnings
@@ -320,18 +323,23 @@ class FactorGraph:
         self.net, self.target, self.weight = s_net, s_target, s_weight
         self._ba_args = ba_args
         self._eta_fb = eta_fb
-        if sharded:
+        if not whole:
             return self._update_finish(itrs, motion_only, opt_type)
         if deferred:
             # the recorded depth_scale stage could not take its stage-1 fallback decision on the host
             # (dspo.depth_scale_stage): read the flag it leaves in pinned memory (no stream synchronisation:
-            # DepthVideo.await_any_on polls for this replay's launch count) and redo it here
+            # DepthVideo.await_any_on polls for this replay's launch count) and redo it here.  Sharded: the flag was
+            # all-reduced inside the replay, so every rank takes this (collective) branch together; the fallback BA of a
+            # shard spans the whole window and has its own damping rows (eta_fb)
             if self.video.await_any_on() == 0:
                 self.video.stage2_fallbacks += 1
                 target, weight, damping, ii, jj, uniq, upmask, t0_, t1_ = ba_args
-                self.video.dspo(target, weight, damping, ii, jj, t0_, t1_, itrs, 1e-4, 0.1, motion_only,
-                                "pose_depth")
+                self.video.dspo(target, weight, damping if eta_fb is None else eta_fb, ii, jj, t0_, t1_, itrs, 1e-4, 0.1,
+                                motion_only, "pose_depth")
                 self.video.upsample(uniq, upmask)
+                if sharded:
+                    self.video.sync_owned_state()
+                    self.video.mark_upsampled()
 
     def _capture(self, key, args):
         """capture one update() on static copies of the recurrent state (net, target, weight);
@@ -447,7 +455,7 @@ class FactorGraph:
                     self.update_op(self.net, self.inp, corr, motn, self.ii, self.jj)
         if t0 is None or t1 is None:
             t0, t1 = self._window(t0, t1, use_inactive)
-        sharded = getattr(self.video, "shard", None) is not None and self.video.shard["world"] > 1
+        sharded = self.video.is_sharded()
         # target = coords1 + delta, damping[uniq] = eta, the BA's damping 0.2 * eta + EP and age += 1 in ONE launch
         # (glorie_update_bookkeeping) when the tensors are the plain fp32 ones of the fused operator
         fused_book = (self.fast_update is not None and not use_inactive and not sharded and coords1.is_cuda
@@ -537,7 +545,7 @@ class FactorGraph:
         self.video.ba(target, weight, damping, ii, jj, t0, t1, iters=itrs, lm=1e-4, ep=0.1,
                       motion_only=motion_only, opt_type=opt_type, eta_fallback=getattr(self, "_eta_fb", None))
         self.video.upsample(uniq, upmask)
-        if getattr(self.video, "shard", None) is not None and self.video.shard["world"] > 1:
+        if self.video.is_sharded():
             self.video.sync_owned_state()
             self.video.mark_upsampled()
         if getattr(self, "_age_done", False):

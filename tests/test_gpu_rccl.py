@@ -142,3 +142,58 @@ def test_context_owned_communicator_and_graph_capture(gpu, tmp_path):
         gp, gd = res[tag + "_graph"]
         assert gp == 0.0 and gd == 0.0, (tag, res[tag + "_graph"])
     assert res["rows"]
+
+
+def _worker_whole_step(rank, out_path, thresh):
+    """a FactorGraph whose video is sharded over a (forced) world of ONE with the context's own communicator: every exchange
+    of the step - normal equations, fallback flag, owned rows - goes through RCCL on the stream, and with use_graphs the
+    whole step is one hipGraph"""
+    sys.path.insert(0, ROOT)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    import bench
+    from glorie_slam_amd import dist as gdist
+    K = 9
+    res = {}
+    for tag, sharded, graphs in (("ref", False, False), ("eager", True, False), ("graph", True, True)):
+        g, video, graph = bench.build_graph(dev, K=K, h=24, w=32, use_graphs=graphs)
+        if thresh is not None:
+            video.cfg["tracking"]["multiview_filter"]["thresh"] = thresh
+        if sharded:
+            owner = gdist.shard_frames(g["ii"], 1)
+            video.enable_sharding(owner, 0, 1, force=True)
+            res[tag + "_native"] = bool(video.native_exchange()) and gdist.ctx_comm_world(video.ctx()) == 1
+        for i in range(8):
+            graph.update(t0=1, t1=K, itrs=2, use_inactive=False, opt_type="pose_depth" if i % 2 == 0 else "depth_scale")
+        video.fresh_disps_up()
+        torch.cuda.synchronize()
+        res[tag] = {"poses": video.poses[:K].cpu(), "disps": video.disps[:K].cpu(), "disps_up": video.disps_up[:K].cpu(),
+                    "scale": video.depth_scale[:K].cpu(), "status": video.ctx().ba_status()[0],
+                    "fallbacks": int(video.stage2_fallbacks), "stats": dict(graph.stats),
+                    "whole_keys": sum(1 for k, v in graph._graphs.items()
+                                      if isinstance(k, tuple) and len(k) == 10 and k[-2] and k[-1] and isinstance(v, tuple))}
+    torch.save(res, out_path)
+
+
+@pytest.mark.parametrize("thresh", [None, 1e-4])          # 1e-4: every depth_scale stage takes the stage-1 fallback
+def test_whole_sharded_step_replays_from_one_graph(gpu, tmp_path, thresh):
+    """with the context-owned communicator (the default whenever the process group runs on RCCL) the sharded
+    step has no torch.distributed collective left in it: build -> all-reduce -> solve, the all-reduced fallback flag and the
+    exchange of the owned rows are recorded with the update operator into ONE hipGraph per (edge set, stage).  One rank
+    here (two RCCL ranks cannot share a device): the values must equal the unsharded step's, eagerly and replayed."""
+    out = str(tmp_path / "whole.pt")
+    mp.spawn(_worker_whole_step, args=(out, thresh), nprocs=1, join=True)
+    res = torch.load(out)
+    assert res["eager_native"] and res["graph_native"]
+    ref = res["ref"]
+    for tag in ("eager", "graph"):
+        got = res[tag]
+        assert got["status"] == 0 and got["fallbacks"] == ref["fallbacks"], (tag, got["fallbacks"], ref["fallbacks"])
+        for name in ("poses", "disps", "disps_up", "scale"):
+            torch.testing.assert_close(got[name], ref[name], atol=1e-4, rtol=1e-4, equal_nan=True, msg=lambda m, n=name, t=tag: f"{t} {n}: {m}")
+    assert ref["fallbacks"] == (4 if thresh is not None else 0)
+    st = res["graph"]["stats"]
+    assert st["captures"] == 2 and st["replays"] >= 4 and res["graph"]["whole_keys"] == 2, (st, res["graph"]["whole_keys"])
+    for name in ("poses", "disps"):                            # a replayed step = the eager sharded step, bit for bit
+        assert torch.equal(res["graph"][name], res["eager"][name]), name
