@@ -62,6 +62,7 @@ struct ConvArgs {
   long pbeg;                                    // first pixel of this launch (a layer may be split into two launches)
   int pair;                                     // weight rows packed so that a lane owns 8 consecutive channels (conv_epilogue_tile)
   unsigned long long* stamps;                   // EXP_CONV_STAMPS builds: s_memtime checkpoints (tools/conv_timeline.py)
+  int pp_full, pp_nbr;                          // conv_pp_kernel: workgroups with full (256-pixel) tiles, 16-pixel blocks per wave of the rest
   // EPI_HEADS: the first tap_groups 128-channel tiles feed the tap GEMM of a 3x3 head instead of being stored
   const f16x8* tap_w; float* tap_out; int tap_groups, tap_ncols;
   // EPI_UPSAMPLE: convex upsampling of the disparity maps with the tile's logits as the mask
@@ -946,6 +947,293 @@ __global__ __launch_bounds__(256, MB <= 4 ? 3 : 2) void conv_halo_kernel(ConvArg
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// conv_pp_kernel: 256 channels x 256 pixels per workgroup, EIGHT waves in two groups that run HALF A K-TILE APART
+// ("ping-pong", round 5).  conv_igemm_kernel leaves the overlap of one workgroup's fragment reads / DMA issue with the
+// other resident workgroup's MFMAs to chance (tools/conv_timeline.sh: a K-tile of the z|r launch takes 3852 cycles per
+// workgroup, two resident, for 2 x 1024 cycles of MFMA per SIMD - the DMA issue alone 980 cycles, because all four waves
+// push their 12 pieces into the CU's one address unit at the same moment).  Here the overlap is built in:
+//   * wave w and wave w + 4 share a SIMD and belong to different groups; group 1 executes ONE extra barrier before its
+//     loop, so between any two workgroup barriers one group is in its MEM phase (24 ds_read_b128 of tile t, lgkmcnt(0))
+//     and the other in its MFMA phase (64 MFMAs at raised priority) - the matrix pipe of every SIMD always has a wave
+//     whose operands are already in registers;
+//   * per-wave tile 128 channels x 64 pixels (MB = 8, NB = 4: the fragment reads per MFMA of the 256 x 128 tile) but
+//     half the DMA bytes per MFMA (64 KB per K-tile for 256 x 256 outputs); two LDS stages (128 KB), one workgroup per CU;
+//   * the CU's one address unit takes ~17 cycles per 1 KB piece: the 64 pieces of a K-tile are half of its MFMA time and must
+//     not bunch up in one phase.  LDS = two pixel stages + THREE weight stages (160 KB): a pixel stage frees at an even
+//     barrier - group 0 refills it first thing in its MEM phase (8 pieces per wave); a weight stage has a period more of
+//     slack - group 1 refills it behind the fragment reads of ITS MEM phase (8 pieces per wave, waited for with vmcnt(8) one
+//     K-tile later): 32 pieces per period, none beside MFMAs.  (Measured on the way, tools/conv_pp_timeline.sh: half of the
+//     pieces between group 1's MFMAs - every piece stalls that wave's MFMA issue ~90 cycles, 1930 instead of 1204 cycles for
+//     the phase, 3760 per K-tile; all 64 pieces by group 0 with two full stages - its MEM phase 1792 cycles, 3392 per K-tile.)
+//   * the DMA pieces are inline asm (m0 written in the same statement): hipcc drains every LDS-DMA it KNOWS of with
+//     vmcnt(0) before the next ds_read that might alias it, which would pin group 1's pieces to one phase of flight.
+// K order, MFMA sequence per accumulator, zero padding (bit 31 of the lane's offset) and the epilogues are those of
+// conv_igemm_kernel<EPI, 4, 64, 4, 1, 8>: the outputs are bit-identical (tests/test_gpu_update_op.py).
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void dma16_asm(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, unsigned lds) {
+  // every SGPR operand is SALU-produced at the call sites (checked in the ISA: no v_readfirstlane feeds them, which would need
+  // five wait states in front of the VMEM instruction); s_nop 0: the M0 write -> LDS-DMA hazard
+  asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+               :: "v"(voff), "s"(r), "s"(soff), "s"(lds) : "memory");
+}
+#define PP_BARRIER() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_barrier" ::: "memory");        \
+                          __builtin_amdgcn_sched_barrier(0); } while (0)
+#define PP_WAIT_LGKM_BARRIER() do { __builtin_amdgcn_sched_barrier(0);                                        \
+                                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");           \
+                                    __builtin_amdgcn_sched_barrier(0); } while (0)
+#define PP_WAIT_VM_BARRIER() do { __builtin_amdgcn_sched_barrier(0);                                          \
+                                  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");               \
+                                  __builtin_amdgcn_sched_barrier(0); } while (0)
+#define PP_WAIT_ALL_BARRIER() do { __builtin_amdgcn_sched_barrier(0);                                         \
+                                   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   \
+                                   __builtin_amdgcn_sched_barrier(0); } while (0)
+
+template <int EPI, int NB>
+__device__ __forceinline__ void conv_pp_tile(const ConvArgs& a, const long p0, const int n0, const int lid, char* smem) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int MB = 8, NW = 8, NWS = 4, TN = 256, PT = 64 * NB, RB = 128, SL = 8, RPI = 8, KK = 2;
+  constexpr int XI = PT / RPI / NWS, WI = TN / RPI / NWS;      // 8 pixel pieces per wave of group 0, 8 weight pieces per wave of group 1
+  constexpr int XBYTES = PT * RB, WBYTES = TN * RB;
+  constexpr int WBASE = 2 * 256 * RB;                           // LDS: pixel tiles 0 1 | weight tiles 0 1 2  (160 KB)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int w4 = wv & 3;                                        // staging slot inside the group
+  const int col = lane & 15, kg = lane >> 4;
+  const int wm = wv & 1, wn = wv >> 1;
+  const int grp = wv >> 2;                                      // waves w and w + 4 share a SIMD
+
+  const int nchunks = a.cha + a.chb;
+  const int C = nchunks * 64;
+  const int T = a.taps * nchunks;
+
+  f32x4 acc[MB][NB];
+#pragma unroll
+  for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NB; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int foff[KK];
+#pragma unroll
+  for (int kk = 0; kk < KK; ++kk) foff[kk] = col * RB + (((kk * 4 + kg) ^ (col & 7)) << 4);
+  const int wfrag = WBASE + wm * (16 * MB) * RB, xfrag = wn * (16 * NB) * RB;
+  f16x8 wf[KK][MB], xf[KK][NB];
+
+  // MEM phase = the wave's 24 fragment reads and its 8 DMA pieces.  Inside one wave the two do not mix: a piece between
+  // reads stalls the in-order issue on the address unit's queue and the reads behind it (own work 1568 / 1722 cycles per MEM
+  // phase against 1404 with the pieces first and 1164 with the reads first, tools/conv_pp_timeline.sh).  Across waves they
+  // do: staging slots 0 / 1 read first, slots 2 / 3 issue their pieces first, so the LDS pipe and the address unit both have
+  // work during the whole phase.
+  auto read_frags = [&](int xb, int wb) {
+    const char* bx = smem + xb * (256 * RB) + xfrag;
+    const char* bw = smem + wb * WBYTES + wfrag;
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+#pragma unroll
+      for (int mi = 0; mi < MB; ++mi) wf[kk][mi] = *reinterpret_cast<const f16x8*>(bw + mi * 16 * RB + foff[kk]);
+#pragma unroll
+      for (int ni = 0; ni < NB; ++ni) xf[kk][ni] = *reinterpret_cast<const f16x8*>(bx + ni * 16 * RB + foff[kk]);
+    }
+  };
+  const bool pieces_first = w4 >= 2;
+  auto mfmas = [&]() {
+    __builtin_amdgcn_s_setprio(1);      // (no measurable effect here: 225.5 us with, 227.4 without, 225.8 with the MEM phase raised instead)
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+      for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NB; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kk][mi], xf[kk][ni], acc[mi][ni], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+#ifdef EXP_CONV_STAMPS
+  // experiment (tools/conv_pp_timeline.py): shader-clock stamps of K-tiles 10-13 of every 41st workgroup, [16][8][4][4]
+  const int swg = lid / 41;
+#define PP_STAMP(k) do { if (a.stamps && lane == 0 && lid >= 0 && lid % 41 == 0 && swg < 16 && t >= 10 && t < 14) { unsigned long long ts_; \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_) : : "memory");                                              \
+    a.stamps[((swg * NW + wv) * 4 + (t - 10)) * 4 + (k)] = ts_; } } while (0)
+#else
+#define PP_STAMP(k)
+#endif
+  const int srow = lane / SL, slot = lane % SL;
+  const int row0 = w4 * RPI + srow;                             // piece i of staging slot w4: rows (i * NWS + w4) * RPI .. + RPI - 1
+  const int sw0 = (slot ^ (row0 & 7)) << 3;
+  const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem) + (unsigned)(w4 * RPI * RB);
+  // K-tile t: 64-channel chunk t / taps (outermost), tap t % taps - the K order of conv_igemm_kernel
+
+  // barrier k = the k-th workgroup barrier; group 0: MEM(t) between barriers 2t and 2t + 1, MFMA(t) between 2t + 1 and
+  // 2t + 2; group 1 one barrier later (MEM(t) in the odd period 2t + 1).
+  //   pixel tile t + 1 -> stage (t + 1) % 2, free behind barrier 2t (group 1 read tile t - 1 in period 2t - 1), due at barrier
+  //     2t + 2: group 0, first thing in its MEM(t) phase, vmcnt(0) at the end of its MFMA(t) phase;
+  //   weight tile t + 2 -> stage (t + 2) % 3, free behind barrier 2t (ditto), due at barrier 2t + 4: group 1 in its MEM(t)
+  //     phase (period 2t + 1) behind its fragment reads; it waits for tile t + 1 there with vmcnt(8) - three periods of flight.
+  if (grp == 0) {
+    const int back = a.taps == 9 ? a.W + 1 : 0;
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.xa - (long)back * a.xa_stride), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.xb - (long)back * a.xb_stride), 0, 0x7fffffff, 0x00020000);
+    const unsigned voffA0 = (unsigned)(((p0 + row0) * a.xa_stride + sw0) * 2);
+    const unsigned voffB0 = (unsigned)(((p0 + row0) * a.xb_stride + sw0) * 2);
+    unsigned vmask[(XI + 2) / 3];                        // 9 tap bits per piece, three pieces per register
+#pragma unroll
+    for (int i = 0; i < (XI + 2) / 3; ++i) vmask[i] = 0;
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      const long p = p0 + (i * NWS + w4) * RPI + srow;
+      unsigned m = 0;
+      if (p < a.P) {
+        const int pi_ = (int)p, xw = pi_ % a.W, yh = (pi_ / a.W) % a.H;
+        if (a.taps == 9) {
+#pragma unroll
+          for (int d = 0; d < 9; ++d) {
+            const int dy = d / 3 - 1, dx = d % 3 - 1;
+            if ((unsigned)(yh + dy) < (unsigned)a.H && (unsigned)(xw + dx) < (unsigned)a.W) m |= 1u << d;
+          }
+        } else {
+          m = 1;
+        }
+      }
+      vmask[i / 3] |= m << (9 * (i % 3));
+    }
+    struct PixTile { unsigned xsoff, xstep, l0, d; bool segA; };
+    auto pix_tile = [&](int t, int buf) {
+      PixTile pt_;
+      const int ch = t / a.taps, d = t - ch * a.taps;
+      const int shift = (a.taps == 9 ? (d / 3 - 1) * a.W + (d % 3 - 1) : 0) + back;
+      pt_.segA = ch < a.cha;
+      const int xs = pt_.segA ? a.xa_stride : a.xb_stride;
+      pt_.xsoff = (unsigned)((shift * xs + (pt_.segA ? ch : ch - a.cha) * 64) * 2);
+      pt_.xstep = (unsigned)(NWS * RPI * xs * 2);
+      pt_.l0 = lds0 + buf * (256 * RB);
+      pt_.d = (unsigned)d;
+      return pt_;
+    };
+    auto pix_piece = [&](const PixTile& pt_, int i) {
+      const unsigned inv = ~(vmask[i / 3] >> (pt_.d + 9 * (i % 3)));
+      const unsigned vo = (inv << 31) | (pt_.segA ? voffA0 : voffB0);
+      dma16_asm(pt_.segA ? rA : rB, vo, pt_.xsoff + i * pt_.xstep, pt_.l0 + i * (NWS * RPI * RB));
+    };
+    {
+      const PixTile p0_ = pix_tile(0, 0);
+#pragma unroll
+      for (int i = 0; i < XI; ++i) pix_piece(p0_, i);
+    }
+    for (int t = 0; t < T; ++t) {
+      PP_WAIT_VM_BARRIER();                               // barrier 2t: pixel tile t landed (own pieces), weight tile t: group 1
+      PP_STAMP(0);
+#ifdef EXP_PP_NO_PIECES
+      const bool more = false;                            // ablation (wrong results): no DMA in the K loop
+#else
+      const bool more = t + 1 < T;
+#endif
+      const PixTile nx = pix_tile(more ? t + 1 : 0, (t + 1) & 1);
+      if (pieces_first) {
+        if (more) {
+#pragma unroll
+          for (int i = 0; i < XI; ++i) pix_piece(nx, i);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(t & 1, t % 3);
+      } else {
+        read_frags(t & 1, t % 3);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) {
+#pragma unroll
+          for (int i = 0; i < XI; ++i) pix_piece(nx, i);
+        }
+      }
+      PP_STAMP(3);
+      PP_WAIT_LGKM_BARRIER();                             // barrier 2t + 1
+      PP_STAMP(1);
+      mfmas();
+      PP_STAMP(2);
+    }
+    PP_BARRIER();                                         // barrier 2T (group 1's last one)
+  } else {
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, 0x7fffffff, 0x00020000);
+    const unsigned woff0 = (unsigned)(((size_t)row0 * C + sw0) * 2);
+    const unsigned wstep = (unsigned)(NWS * RPI * C * 2);
+    auto w_piece = [&](int t, int buf, int i) {
+      const int ch = t / a.taps, d = t - ch * a.taps;
+      const unsigned wsoff = (unsigned)((((size_t)d * a.npad + n0) * C + ch * 64) * 2);
+      dma16_asm(rW, woff0, wsoff + i * wstep, lds0 + WBASE + buf * WBYTES + i * (NWS * RPI * RB));
+    };
+#pragma unroll
+    for (int i = 0; i < WI; ++i) w_piece(0, 0, i);
+    if (1 < T) {
+#pragma unroll
+      for (int i = 0; i < WI; ++i) w_piece(1, 1, i);
+    }
+    PP_WAIT_VM_BARRIER();                                 // barrier 0: weight tiles 0 and 1 landed
+    int wb = 0;                                           // t % 3
+    for (int t = 0; t < T; ++t) {
+      PP_BARRIER();                                       // barrier 2t + 1
+      PP_STAMP(0);
+#ifdef EXP_PP_NO_PIECES
+      const bool more = false;
+#else
+      const bool more = t + 2 < T;
+#endif
+      const int wnext = wb == 0 ? 2 : wb - 1;             // (t + 2) % 3
+      if (pieces_first) {
+        if (more) {
+#pragma unroll
+          for (int i = 0; i < WI; ++i) w_piece(t + 2, wnext, i);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(t & 1, wb);
+      } else {
+        read_frags(t & 1, wb);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) {
+#pragma unroll
+          for (int i = 0; i < WI; ++i) w_piece(t + 2, wnext, i);
+        }
+      }
+      PP_STAMP(3);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // barrier 2t + 2: weight tile t + 1 landed
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      PP_STAMP(1);
+      mfmas();
+      PP_STAMP(2);
+      wb = wb == 2 ? 0 : wb + 1;
+    }
+  }
+  conv_epilogue_tile<EPI, MB, NB>(a, acc, p0 + wn * (16 * NB) + col, n0 + wm * (16 * MB) + kg * 4);
+#endif
+}
+
+// Tiles: `pp_full` workgroups with 256-pixel tiles (a whole number of rounds over the chip's CUs), then the rest of the map in
+// tiles of 64 * pp_nbr pixels - one partial round of SMALLER tiles instead of a mostly empty round of full ones (G8: 675
+// tiles on 256 CUs = 3 rounds of which the last is 64 % full; 512 full tiles + 218 tiles of 192 pixels = 2.75 rounds).
+// Both ranges are spread over the XCDs by the same bijective remap (pp_full is a multiple of 8).
+template <int EPI>
+__global__ __launch_bounds__(512, 1) void conv_pp_kernel(ConvArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int ntn = a.nout / 256;
+  const int bid = blockIdx.x, nfull = a.pp_full;
+  const bool full = bid < nfull;
+  const int base = full ? 0 : nfull, nwg = full ? nfull : (int)gridDim.x - nfull, j = bid - base;
+  const int xcd = j & 7, q = nwg >> 3, r = nwg & 7;
+  const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (j >> 3);
+  const int pt = lid / ntn, nt = lid - pt * ntn;
+  const int n0 = nt * 256;
+  if (full) {
+    conv_pp_tile<EPI, 4>(a, (long)pt * 256, n0, lid, smem);
+  } else {
+    const long p0 = (long)(nfull / ntn) * 256 + (long)pt * (64 * a.pp_nbr);
+    if (a.pp_nbr == 3) conv_pp_tile<EPI, 3>(a, p0, n0, -1, smem);
+    else if (a.pp_nbr == 2) conv_pp_tile<EPI, 2>(a, p0, n0, -1, smem);
+    else conv_pp_tile<EPI, 1>(a, p0, n0, -1, smem);
+  }
+#endif
+}
+
 template <int EPI, int NB, int BK, int NW, int ST, int MB>
 static void launch_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
   constexpr int RB = BK * 2, PT = (NW / 2) * 16 * NB;
@@ -977,6 +1265,64 @@ static size_t halo_lds_bytes(int W, int MB) {
   const size_t seed = (size_t)128 * 32 * MB * 2;
   return need > seed ? need : seed;
 }
+template <int EPI>
+static void launch_pp_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
+  constexpr size_t lds = 5 * 256 * 128;                     // two pixel stages + three weight stages
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pp_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    attr = true;
+  }
+  hipLaunchKernelGGL((conv_pp_kernel<EPI>), grid, dim3(512), lds, st, a);
+}
+// 256-channel x 256-pixel ping-pong tiles (conv_pp_kernel): layers whose output channels are a multiple of 256
+static bool pp_enabled() {                        // A/B switch of the round-5 experiments (tools/ab_bench.sh "GLORIE_CONV_PP=0" ...)
+  static const bool on = !(getenv("GLORIE_CONV_PP") && getenv("GLORIE_CONV_PP")[0] == '0');
+  return on;
+}
+static int launch_conv_pp(const ConvArgs& a_, int epilogue, hipStream_t st) {
+  if ((a_.nout & 255) || a_.pbeg != 0) return GLORIE_EUNSUPPORTED;
+  ConvArgs a = a_;
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return GLORIE_EHIP;
+    ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  const long ntn = a.nout / 256;
+  const long pt_all = (a.P + 255) / 256;
+  // whole rounds of full tiles (one workgroup per CU, `ntn` channel tiles per pixel tile); what is left goes into one partial
+  // round of smaller tiles when that makes the round shorter
+  long full_pt = pt_all * ntn / ncu * ncu / ntn;
+  full_pt -= full_pt % 8;                                   // (the XCD remap of both ranges wants multiples of 8)
+  if (full_pt < 0) full_pt = 0;
+  long rest_px = a.P - full_pt * 256;
+  int nbr = 4;
+  long rest_pt = 0;
+  if (rest_px > 0) {
+    const long per_cu = (rest_px * ntn + ncu - 1) / ncu;    // pixels per CU if the rest is spread evenly
+    nbr = (int)((per_cu + 63) / 64);
+    if (nbr > 4 || full_pt == 0) nbr = 4;
+    if (nbr < 1) nbr = 1;
+    rest_pt = (rest_px + 64 * nbr - 1) / (64 * nbr);
+  }
+  if (nbr == 4) { full_pt = pt_all; rest_pt = 0; }
+  const long nwg = (full_pt + rest_pt) * ntn;
+  if (nwg <= 0) return GLORIE_OK;
+  if (nwg > 0x7fffffffL) return GLORIE_EINVAL;
+  a.pp_full = (int)(full_pt * ntn);
+  a.pp_nbr = nbr;
+  const dim3 grid((unsigned)nwg);
+  switch (epilogue) {
+    case EPI_BIAS_ACT: launch_pp_one<EPI_BIAS_ACT>(a, grid, st); break;
+    case EPI_GRU_ZR: launch_pp_one<EPI_GRU_ZR>(a, grid, st); break;
+    default: return GLORIE_EUNSUPPORTED;
+  }
+  return check_launch();
+}
+
 template <int MB>
 static int launch_conv_halo(const ConvArgs& a, int epilogue, hipStream_t st) {
   constexpr int PT = 128, TN = 32 * MB;
@@ -1051,7 +1397,7 @@ static int conv_igemm_impl(const void* xa, int xa_stride, int ca, const void* xb
   const int pair = (epilogue >> 8) & 1;                 // GLORIE_CONV_PAIR16: the weights come from a paired packing
   const int policy = (epilogue >> 12) & 15;             // GLORIE_CONV_POLICY_*: tile choice forced by the caller (tests, bench_conv)
   epilogue &= 0xff;
-  if (policy > 5) return GLORIE_EINVAL;
+  if (policy > 6) return GLORIE_EINVAL;
   if (epilogue < 0 || epilogue > 5) return GLORIE_EINVAL;
   if (pair && (epilogue > EPI_GRU_Q || (nout & 31))) return GLORIE_EINVAL;
   if (epilogue == EPI_UPSAMPLE && (!up_disps || !up_ix || !up_out || !terms || nout != 1024 || taps != 1 || pre))
@@ -1085,6 +1431,7 @@ static int conv_igemm_impl(const void* xa, int xa_stride, int ca, const void* xb
   // the context term joins in the epilogue (16-byte pieces with paired weights; rounds 2-3 seeded the accumulators with it
   // through an LDS image of the [pixel][channel] tile, which the paired channel order made obsolete)
   a.pair = pair;
+  a.pp_full = 0; a.pp_nbr = 4;
 #ifdef EXP_CONV_STAMPS
   a.stamps = getenv("GLORIE_CONV_STAMPS") ? (unsigned long long*)strtoull(getenv("GLORIE_CONV_STAMPS"), nullptr, 0) : nullptr;
 #else
@@ -1106,6 +1453,7 @@ static int conv_igemm_impl(const void* xa, int xa_stride, int ca, const void* xb
   // 3x3 layers on the 128-channel tile: the pixel tile is shared by the nine taps of a chunk (conv_halo_kernel) while its haloed
   // tile leaves three workgroups per CU (image width <= 83); small launches keep their 64-pixel tiles, the 256- and 64-channel
   // tiles their per-tap staging (measured slower with the shared tile).  Policy 5 (nohalo): per-tap staging everywhere.
+  if (policy == 6) return launch_conv_pp(a, epilogue, st);     // GLORIE_CONV_POLICY_PP: forced by the caller
   {
     if (policy == 0 && taps == 9 && a.pbeg == 0) {
       const long tiles128 = (a.P + 127) / 128 * ((nout + 127) / 128);
@@ -1136,6 +1484,10 @@ static int conv_igemm_impl(const void* xa, int xa_stride, int ca, const void* xb
   // policy (bits 12-15 of `epilogue`, include/glorie_hip.h): 0 auto, 1 = 128 x 128, 2 = 64-pixel tiles, 3 = whole rounds +
   // remainder, 4 = 128 x 256, 5 = auto without the haloed tile
   const char t0c = policy == 1 ? '1' : policy == 2 ? '6' : policy == 3 ? 's' : policy == 4 ? 'w' : 0;
+  // z|r gates and other 3x3 layers with a multiple of 256 output channels, once the map fills the chip at least once with
+  // 256-pixel tiles: the ping-pong kernel (z|r gate launch at G8 251 -> 234 us in an interleaved A/B, tools/bench_conv.py)
+  if (policy == 0 && (nout & 255) == 0 && taps == 9 && epilogue <= EPI_GRU_ZR && a.P >= 256L * 256 && pp_enabled())
+    return launch_conv_pp(a, epilogue, st);
   if (t0c == 0 && (nout & 255) == 0) return launch_conv<4, 64, 4, 1, 8>(a, epilogue, st);
   // small launches (GraphAgg's convolutions run on the 8 keyframe maps, 300 pixel tiles): 128-pixel tiles would leave most
   // of the 768 workgroup slots empty and every CU with one latency-bound workgroup - 64-pixel tiles double the workgroups

@@ -462,6 +462,44 @@ def test_conv_tile_variants_are_bit_identical(gpu, mode):
     assert torch.equal(run(mode, True), ref) and torch.equal(run(None, True), ref)
 
 
+# 390 px (ragged second tile) ... G8; on 256 CUs the last three end in a partial round of 64- / 128- / 192-pixel tiles
+@pytest.mark.parametrize("n,h,w", [(3, 10, 13), (13, 24, 32), (27, 50, 50), (38, 48, 50), (36, 60, 80)])
+def test_conv_pingpong_tiles_are_bit_identical(gpu, n, h, w):
+    """conv_pp_kernel (256 channels x 256 pixels, eight waves in two groups half a K-tile apart, DMA pieces as inline asm
+    with counted waits) sums the same products in the same order as the default kernel: same bits for the z|r gate launch
+    (paired and unpaired weights, with and without the context term) and the plain 320 -> 256 convolution - and the same bits
+    again on every repetition (its LDS stages are guarded by barrier counts, not by luck)"""
+    from glorie_slam_amd import update_ops as U
+    net = _cl_half(n, 128, h, w, gpu, 61)
+    wide_t = _cl_half(n, 256, h, w, gpu, 62)
+    xb = wide_t[:, 64:256]
+    g = torch.Generator(device="cpu").manual_seed(63)
+    wzr_t = (torch.randn(256, 320, 3, 3, generator=g) / 54).to(gpu)
+    w11_t = (torch.randn(256, 320, 1, 1, generator=g) / 18).to(gpu)
+    terms = torch.randn(n, 256, generator=g).to(gpu)
+    bias = torch.randn(256, generator=g).to(gpu)
+    pre = _cl_half(n, 256, h, w, gpu, 64)
+    cl = lambda c: torch.empty((n, c, h, w), dtype=torch.float16, device=gpu, memory_format=torch.channels_last)
+
+    def run(policy, pair, with_pre):
+        wzr = U.pack_conv_igemm(wzr_t, pair=pair)
+        z, rnet, plain, one = cl(128), cl(128), cl(256), cl(256)
+        U.conv_igemm(net, xb, wzr, 9, 256, z, epilogue=U.EPI_GRU_ZR, terms=terms, net=net, out2=rnet,
+                     pre=pre if with_pre else None, policy=policy)
+        U.conv_igemm(net, xb, wzr, 9, 256, plain, terms=bias, act=U.ACT_RELU, policy=policy)
+        U.conv_igemm(net, xb, U.pack_conv_igemm(w11_t, pair=pair), 1, 256, one, terms=bias, policy=policy)
+        return torch.cat([z, rnet, plain, one], 1).clone()
+
+    for with_pre in (True, False):
+        ref = run("nohalo", False, with_pre)            # conv_igemm_kernel (auto takes the ping-pong tile itself on large maps)
+        for rep in range(3):
+            assert torch.equal(run("pp", False, with_pre), ref), (with_pre, rep)
+        assert torch.equal(run("pp", True, with_pre), ref)
+    # layers the tile does not fit are refused, not mangled
+    with pytest.raises(Exception):
+        U.conv_igemm(net, xb, U.pack_conv_igemm(wzr_t[:128]), 9, 128, cl(128), policy="pp")
+
+
 def test_flow_conv7_matches_conv2d(gpu):
     from glorie_slam_amd import update_ops as U
     n, h, w = 3, 9, 11                                              # 297 pixels: ragged last tile, maps < 7 wide halo

@@ -94,11 +94,40 @@ def tile_modes():
     }
     for name, fn in cases.items():
         res = []
-        for mode in ("128", "wide", "64", "split", "nohalo", None):
+        for mode in ("128", "wide", "64", "split", "nohalo", None) + (("pp",) if "z|r" in name else ()):
             res.append(f"{mode or 'auto'} {timed(lambda: fn(mode)):6.1f} us")
         print(f"{name:20s} " + "   ".join(res), flush=True)
+
+
+def pp_ab(rounds=6):
+    """interleaved A/B of the z|r gate launch and the plain 448 -> 256 layer: default tile against the ping-pong tile"""
+    dev = torch.device("cuda:0")
+    n, h, w = 36, 60, 80
+    torch.manual_seed(3)
+    cl = lambda c: torch.randn(n, c, h, w, device=dev).half().contiguous(memory_format=torch.channels_last)
+    net, wide, pre = cl(128), cl(320), cl(256)
+    dynx = wide[:, 128:320]
+    wzr = U.pack_conv_igemm(torch.randn(256, 320, 3, 3, device=dev) / 54, pair=True)
+    w448 = U.pack_conv_igemm(torch.randn(256, 448, 3, 3, device=dev) / 63)
+    x448 = cl(448)
+    terms = torch.randn(n, 256, device=dev)
+    z, rnet, out = cl(128), cl(128), cl(256)
+    gate = lambda pol: U.conv_igemm(net, dynx, wzr, 9, 256, z, epilogue=U.EPI_GRU_ZR, terms=terms, net=net, out2=rnet, pre=pre,
+                                    policy=pol)
+    plain = lambda pol: U.conv_igemm(x448, None, w448, 9, 256, out, policy=pol)
+    for name, fn, fl in (("z|r gate 320->256 (paired)", gate, 2.0 * n * h * w * 320 * 9 * 256),
+                         ("plain 448->256", plain, 2.0 * n * h * w * 448 * 9 * 256)):
+        ts = {"nohalo": [], "pp": []}                  # "nohalo" = the 256-channel x 128-pixel tile of conv_igemm_kernel for these layers
+        for _ in range(rounds):
+            for pol in ("nohalo", "pp"):
+                ts[pol].append(timed(lambda: fn(pol), iters=20))
+        med = {k: sorted(v)[len(v) // 2] for k, v in ts.items()}
+        print(f"{name:28s} 256x128 {med['nohalo']:6.1f} us ({fl / med['nohalo'] / 1e6:5.0f} TF/s)   ping-pong {med['pp']:6.1f} us "
+              f"({fl / med['pp'] / 1e6:5.0f} TF/s)   all 256x128 {[round(x, 1) for x in ts['nohalo']]} pp {[round(x, 1) for x in ts['pp']]}",
+              flush=True)
 
 
 if __name__ == "__main__" and os.environ.get("BENCH_CONV_GATE", "1") == "1":
     gate_case()
     tile_modes()
+    pp_ab()
