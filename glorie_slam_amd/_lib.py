@@ -104,6 +104,9 @@ SIGNATURES = {
     "glorie_composite_bwd": (_c_int, [_vp, _vp, _c_int, _c_int, _c_f, _vp, _vp, _vp, _vp]),
     "glorie_adam_step": (_c_int, [_vp, _vp, _vp, _vp, ctypes.c_long, _c_f, _c_f, _c_f, _c_f, _c_int, _vp, _c_int, _vp]),
     "glorie_adam_multi": (_c_int, [_vp, _c_int, ctypes.c_long, _c_int, _vp, _vp]),
+    "glorie_adam_step_dev": (_c_int, [_vp, _vp, _vp, _vp, ctypes.c_long, _c_f, _c_f, _c_f, _c_f, _vp, _vp, _c_int, _vp]),
+    "glorie_adam_multi_dev": (_c_int, [_vp, _c_int, ctypes.c_long, _vp, _vp, _vp]),
+    "glorie_counter_add": (_c_int, [_vp, _c_int, _vp]),
     "glorie_ba_status": (_c_int, [_vp, ctypes.POINTER(_c_int), _vp]),
 }
 

@@ -545,12 +545,34 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   p[i] -= (lr / bc1) * mi / denom;
 }
 
+// the same with the step count in DEVICE memory (a mapping iteration recorded into a hipGraph: a count passed by value would
+// be baked into the recording): the bias corrections are formed per thread from *step_dev
+__global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                       float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
+                                                       const int* __restrict__ step_dev, const uint8_t* __restrict__ row_mask,
+                                                       int row_len) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  if (row_mask && !row_mask[i / row_len]) return;
+  const float step = (float)*step_dev;
+  const float bc1 = 1.0f - powf(b1, step), bc2_sqrt = sqrtf(1.0f - powf(b2, step));
+  const float gi = g[i];
+  const float mi = b1 * m[i] + (1.0f - b1) * gi;
+  const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+  m[i] = mi; v[i] = vi;
+  const float denom = sqrtf(vi) / bc2_sqrt + eps;
+  p[i] -= (lr / bc1) * mi / denom;
+}
+__global__ void counter_add_kernel(int* ctr, int delta) { *ctr += delta; }
+
 // the same update for MANY small tensors in one launch (the 52 decoder tensors of a mapping iteration: 52 launches of a few
 // hundred elements each otherwise).  Table entry = 10 x 8 bytes: p, g, m, v, n, (lr, b1), (b2, eps), 3 x pad - nothing in it
 // changes from step to step, so the host re-sends it only when a pointer moved;
 // block (x, y) updates elements [1024 x, 1024 x + 1024) of tensor y.
 struct AdamEntry { float* p; const float* g; float* m; float* v; long n; float lr, b1, b2, eps; long pad[3]; };
-__global__ __launch_bounds__(256) void adam_multi_kernel(const AdamEntry* __restrict__ table, int step, const char* grad_base) {
+__global__ __launch_bounds__(256) void adam_multi_kernel(const AdamEntry* __restrict__ table, int step, const char* grad_base,
+                                                         const int* __restrict__ step_dev) {
+  if (step_dev) step = *step_dev;
   AdamEntry e = table[blockIdx.y];
   if (grad_base) e.g = reinterpret_cast<const float*>(grad_base + reinterpret_cast<size_t>(e.g));   // g = byte offset
   const long base = (long)blockIdx.x * 1024;
@@ -941,6 +963,34 @@ extern "C" int glorie_adam_multi(const void* table, int n_tensors, long max_nume
   static_assert(sizeof(AdamEntry) == 80, "table layout");
   const dim3 grid((unsigned)((max_numel + 1023) / 1024), (unsigned)n_tensors);
   hipLaunchKernelGGL(adam_multi_kernel, grid, dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const AdamEntry*>(table), step,
-                     reinterpret_cast<const char*>(grad_base));
+                     reinterpret_cast<const char*>(grad_base), (const int*)nullptr);
+  return check_launch();
+}
+
+extern "C" int glorie_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr,
+                                    float beta1, float beta2, float eps, const int* step_dev, const uint8_t* row_mask,
+                                    int row_len, void* stream) {
+  if (n < 0) return GLORIE_EINVAL;
+  if (n == 0) return GLORIE_OK;
+  if (!param || !grad || !exp_avg || !exp_avg_sq || !step_dev || (row_mask && row_len < 1)) return GLORIE_EINVAL;
+  hipLaunchKernelGGL(adam_dev_kernel, dim3(blocks(n)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n,
+                     lr, beta1, beta2, eps, step_dev, row_mask, row_len > 0 ? row_len : 1);
+  return check_launch();
+}
+
+extern "C" int glorie_adam_multi_dev(const void* table, int n_tensors, long max_numel, const int* step_dev,
+                                     const void* grad_base, void* stream) {
+  if (n_tensors < 0 || max_numel < 0) return GLORIE_EINVAL;
+  if (n_tensors == 0 || max_numel == 0) return GLORIE_OK;
+  if (!table || !step_dev) return GLORIE_EINVAL;
+  const dim3 grid((unsigned)((max_numel + 1023) / 1024), (unsigned)n_tensors);
+  hipLaunchKernelGGL(adam_multi_kernel, grid, dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const AdamEntry*>(table), 1,
+                     reinterpret_cast<const char*>(grad_base), step_dev);
+  return check_launch();
+}
+
+extern "C" int glorie_counter_add(int* counter, int delta, void* stream) {
+  if (!counter) return GLORIE_EINVAL;
+  hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counter, delta);
   return check_launch();
 }

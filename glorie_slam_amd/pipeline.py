@@ -58,6 +58,13 @@ class SequenceRunner:
         self.last_ba = 0
         self.losses = []                      # per mapped keyframe: (first, last) loss of its mapping iterations
         self.timing = {"track_ms": [], "map_iter_ms": [], "ba_ms": [], "kept": []}
+        # record the mapping iteration into a hipGraph per keyframe (map_keyframe).  Off by default: built and measured in
+        # round 5 (tools/prof_map_graph.py) - recording 3.3 ms per keyframe, a replay 2.26 ms against 2.0-2.5 ms for an eager
+        # iteration at 1000 rays: the iteration is ~110 small launches whose device-side latency a replay does not shorten
+        # (the sum of its kernel durations IS its wall time, profiles/r04_train_kernel_stats.csv), not host-bound as the
+        # round-4 notes had it.  What would shorten it is fewer launches (fused layers in csrc/train.hip).
+        self.map_graph = False
+        self.map_graph_stats = {"captures": 0, "replays": 0}
         self.init_state = None                # callable(k, tstamp): the tracker's initial guess for a new keyframe (tests)
 
     # ---- tracker.py:33-77 ------------------------------------------------------------------------------------------
@@ -138,20 +145,25 @@ class SequenceRunner:
         dec.train()
         for p in dec.parameters():
             p.requires_grad_(True)
-        opt = FeatureAdam([{"params": list(dec.parameters()), "lr": 0.005}, {"params": [geo], "lr": 0.005},
-                           {"params": [col_f], "lr": 0.005}])
-        first = last = None
         with torch.no_grad():
             view = self._keyframe_view(k)
             # every iteration's pixel draw in one transfer ([iteration][ii | jj][ray], the generator's order per iteration)
             draws = torch.stack([torch.stack([torch.randint(0, self.video.wd, (self.map_rays,), generator=self.gen),
                                               torch.randint(0, self.video.ht, (self.map_rays,), generator=self.gen)])
                                  for _ in range(self.map_iters)]).to(self.device) if self.map_iters else None
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for it in range(self.map_iters):
+            # one look at the keyframe's depth map (a host round trip per KEYFRAME): if every pixel carries a depth, no
+            # iteration needs the host - the renderer skips its per-batch zero-depth check and the iteration can be recorded
+            all_depth = bool((view[0] > 0).all())
+        use_graph = bool(getattr(self, "map_graph", True)) and all_depth and self.map_iters >= 4 and \
+            str(self.device).startswith("cuda") and getattr(ren, "use_train_path", True)
+        opt = FeatureAdam([{"params": list(dec.parameters()), "lr": 0.005}, {"params": [geo], "lr": 0.005},
+                           {"params": [col_f], "lr": 0.005}], capturable=use_graph)
+        self.last_optimizer = opt                            # (tests: step bookkeeping)
+        pix = draws[0].clone() if self.map_iters else None   # the iteration reads its pixels from this buffer
+
+        def iteration():
             with torch.no_grad():
-                ro, rd, d, gt_col, _, _, radius = self._keyframe_rays(k, view=view, pix=(draws[it, 0], draws[it, 1]))
+                ro, rd, d, gt_col, _, _, radius = self._keyframe_rays(k, view=view, pix=(pix[0], pix[1]))
             opt.zero_grad()
             depth, _, colour, _, counts = ren.render_batch_ray(npc, dec, rd, ro, self.device, "color", gt_depth=d,
                                                                npc_geo_feats=geo, npc_col_feats=col_f,
@@ -163,9 +175,47 @@ class SequenceRunner:
             loss = loss / seen.sum().clamp_min(1)
             loss.backward()
             opt.step()
-            last = loss.detach()
-            if first is None:
-                first = last
+            return loss.detach()
+
+        first = last = None
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ren.assume_depth = all_depth
+        try:
+            graph = None
+            for it in range(self.map_iters):
+                if it:
+                    pix.copy_(draws[it])
+                if graph is not None:
+                    graph.replay()
+                    continue
+                if use_graph and it == 1:
+                    # Iteration 0 ran eagerly (it sizes the scratch arenas, creates the Adam moments and sends the pointer
+                    # table); iteration 1 is RECORDED - forward, masked loss, backward (incl. its second stream for the weight
+                    # gradients), Adam with the step count in device memory - and replayed for itself and every later one
+                    # (mapper.py:586-624 runs 150-1500 of them per keyframe on the same tensors).
+                    try:
+                        graph, last = self._capture_iteration(iteration)
+                    except Exception as exc:      # a failed recording must not take the mapper down
+                        import warnings
+                        warnings.warn(f"hipGraph capture of the mapping iteration failed ({exc!r}); running eagerly")
+                        graph, use_graph = None, False
+                        opt.capturable_fallback()
+                    if graph is not None:
+                        graph.replay()
+                        continue
+                last = iteration()
+                if first is None:
+                    first = last.clone()
+            if graph is not None:
+                # host bookkeeping: the eager iteration and the recording itself each counted one step, the device did
+                # 1 + (map_iters - 1)
+                opt.advance(self.map_iters - 2)
+                last = last.clone()
+                self.map_graph_stats["captures"] += 1
+                self.map_graph_stats["replays"] += self.map_iters - 1
+        finally:
+            ren.assume_depth = False
         torch.cuda.synchronize()
         self.timing["map_iter_ms"].append(1e3 * (time.perf_counter() - t0) / max(self.map_iters, 1))
         with torch.no_grad():
@@ -174,6 +224,31 @@ class SequenceRunner:
         dec.eval()
         self.losses.append((float(first), float(last)))
         return self.losses[-1]
+
+    def _capture_iteration(self, iteration):
+        """record one mapping iteration into a hipGraph (one memory pool for all keyframes of this runner, kept open by a
+        one-node keeper graph as in FactorGraph._capture); returns (graph, the iteration's loss tensor inside the pool)"""
+        dev = torch.device(self.device)
+        cap = getattr(self, "_map_capture_stream", None)
+        if cap is None:
+            cap = self._map_capture_stream = torch.cuda.Stream(dev)
+            self._map_pool = torch.cuda.graph_pool_handle()
+            self._map_keeper = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(cap):
+                self._map_keeper.capture_begin(pool=self._map_pool)
+                self._map_keeper_buf = torch.zeros(1, device=dev)
+                self._map_keeper.capture_end()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        cap.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(cap):
+            graph.capture_begin(pool=self._map_pool)
+            try:
+                loss = iteration()
+            finally:
+                graph.capture_end()
+        torch.cuda.current_stream(dev).wait_stream(cap)
+        return graph, loss
 
     def map_pending(self):
         """map every keyframe the frontend has finished with (its redundancy test culls a frame inside the same call that

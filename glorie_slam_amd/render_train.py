@@ -155,17 +155,22 @@ def render_rays(renderer, npc, decoders, rays_d, rays_o, stage, gt_depth, npc_ge
         # the zero-depth count travels to pinned memory behind the sampling kernel and is looked at after the forward pass
         # has been enqueued: `int(n_zero)` here would stall the host until the previous iteration's backward and Adam
         # step have drained (the loop was host-bound on exactly that wait)
-        flag = renderer._pinned_flag()
-        flag.copy_(n_zero, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
+        # (renderer.assume_depth: the caller has checked that every ray it will draw carries a depth prior - the mapping
+        # loop does so once per keyframe; nothing of the iteration then needs the host, and it can be recorded into a hipGraph)
+        checked = not getattr(renderer, "assume_depth", False)
+        if checked:
+            flag = renderer._pinned_flag()
+            flag.copy_(n_zero, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
     cp = (cloud_pos if cloud_pos is not None else npc.cloud_pos()).detach().contiguous().float()
     meta = (pts, views, cp, I.contiguous(), w.contiguous(), has8.contiguous(), z_vals, renderer.sigmoid_coefficient,
             stage == "color")
     depth, var, rgb = RenderTrain.apply(meta, npc_geo_feats, npc_col_feats, *decoder_tensors(decoders))
-    ev.synchronize()
-    if int(flag[0]) != 0:
-        return None                      # a ray without depth: the general path redoes the batch
+    if checked:
+        ev.synchronize()
+        if int(flag[0]) != 0:
+            return None                  # a ray without depth: the general path redoes the batch
     return depth, var, rgb, valid, counts
 
 
@@ -173,7 +178,13 @@ class FeatureAdam:
     """torch.optim.Adam semantics (mapper.py:612-624) on glorie_adam_step: one launch per tensor, optional row mask
     for the frustum-selected rows of a feature table (rows outside it keep their value AND their moments)."""
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, capturable=False):
+        """capturable: the step count lives in device memory (one word for all tensors: they start together) and is advanced
+        on the stream (glorie_counter_add, glorie_adam_step_dev / glorie_adam_multi_dev) - `step()` can then be recorded
+        into a hipGraph with the backward pass in front of it; after replays the host side is brought up to date with
+        `advance(n)`"""
+        self.capturable = bool(capturable)
+        self._step_dev = None
         self.param_groups = []
         for g in params:
             g = dict(g) if isinstance(g, dict) else {"params": list(g)}
@@ -213,11 +224,33 @@ class FeatureAdam:
 
     MULTI_MAX = 1 << 16           # tensors up to this many elements share one launch (the decoder's 52 tensors)
 
+    def capturable_fallback(self):
+        """leave the capturable mode (a recording failed): later steps pass the host's step count by value again"""
+        self.capturable = False
+
+    def advance(self, n):
+        """host bookkeeping for `n` replays of a recorded step: step counts and the parameters' version counters"""
+        for g in self.param_groups:
+            for p in g["params"]:
+                st = self.state.get(id(p))
+                if st is not None:
+                    st["step"] += int(n)
+                    torch.autograd.graph.increment_version(p)
+
     @torch.no_grad()
     def step(self, row_masks=None):
         import struct
         lib = L.load()
         small = []
+        sdev = None
+        if self.capturable:
+            dev0 = next(p.device for g in self.param_groups for p in g["params"])
+            if self._step_dev is None:
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("FeatureAdam(capturable): take one eager step before recording")
+                self._step_dev = torch.zeros(1, dtype=torch.int32, device=dev0)
+            sdev = self._step_dev
+            L.check(lib.glorie_counter_add(L.ptr(sdev), 1, L.stream_ptr(dev0)), "glorie_counter_add")
         for g in self.param_groups:
             for p in g["params"]:
                 if p.grad is None:
@@ -237,10 +270,19 @@ class FeatureAdam:
                     continue
                 row_len = p.shape[-1] if mask is not None else 1
                 m8 = mask.to(torch.uint8).contiguous() if mask is not None else None
+                if sdev is not None:
+                    L.check(lib.glorie_adam_step_dev(L.ptr(p), L.ptr(p.grad), L.ptr(st["m"]), L.ptr(st["v"]), p.numel(),
+                                                     float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
+                                                     float(g["eps"]), L.ptr(sdev), L.ptr(m8), int(row_len),
+                                                     L.stream_ptr(p.device)), "glorie_adam_step_dev")
+                    continue
                 L.check(lib.glorie_adam_step(L.ptr(p), L.ptr(p.grad), L.ptr(st["m"]), L.ptr(st["v"]), p.numel(),
                                              float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
                                              int(st["step"]), L.ptr(m8), int(row_len), L.stream_ptr(p.device)),
                         "glorie_adam_step")
+        if sdev is not None and len({st["step"] for g in self.param_groups for p in g["params"]
+                                      for st in [self.state.get(id(p))] if st is not None}) > 1:
+            raise RuntimeError("FeatureAdam(capturable): every tensor must be at the same step")
         if small and len({st["step"] for _, st, _ in small}) > 1:
             for p, st, g in small:                                  # tensors at different steps: one launch each
                 L.check(lib.glorie_adam_step(L.ptr(p), L.ptr(p.grad), L.ptr(st["m"]), L.ptr(st["v"]), p.numel(),
@@ -260,11 +302,18 @@ class FeatureAdam:
             key = tuple((p.data_ptr(), goff(p), st["m"].data_ptr(), st["v"].data_ptr(), p.numel(), float(g["lr"]),
                          float(g["betas"][0]), float(g["betas"][1]), float(g["eps"])) for p, st, g in small) + (shared,)
             if getattr(self, "_table_key", None) != key:
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("FeatureAdam: the pointer table changed under capture (take an eager step with the "
+                                       "same tensors first)")
                 buf = b"".join(struct.pack("<qqqqqffffqqq", p.data_ptr(), goff(p), st["m"].data_ptr(),
                                            st["v"].data_ptr(), p.numel(), float(g["lr"]), float(g["betas"][0]),
                                            float(g["betas"][1]), float(g["eps"]), 0, 0, 0) for p, st, g in small)
                 self._table = self._upload(buf, dev)
                 self._table_key = key
                 self._table_max = max(p.numel() for p, _, _ in small)
-            L.check(lib.glorie_adam_multi(L.ptr(self._table), len(small), self._table_max, int(small[0][1]["step"]),
-                                          gbase if shared else None, L.stream_ptr(dev)), "glorie_adam_multi")
+            if sdev is not None:
+                L.check(lib.glorie_adam_multi_dev(L.ptr(self._table), len(small), self._table_max, L.ptr(sdev),
+                                                  gbase if shared else None, L.stream_ptr(dev)), "glorie_adam_multi_dev")
+            else:
+                L.check(lib.glorie_adam_multi(L.ptr(self._table), len(small), self._table_max, int(small[0][1]["step"]),
+                                              gbase if shared else None, L.stream_ptr(dev)), "glorie_adam_multi")

@@ -719,6 +719,18 @@ int glorie_adam_step(float* param, const float* grad, float* exp_avg, float* exp
  * backward pass are views of one buffer that the allocator places anew every iteration; with offsets the table stays valid. */
 int glorie_adam_multi(const void* table, int n_tensors, long max_numel, int step, const void* grad_base, void* stream);
 
+/* The two Adam entry points with the step count read from DEVICE memory (*step_dev, 1-based, one word shared by the tensors of
+ * an optimizer) and glorie_counter_add(counter, delta) to advance it on the stream: a mapping iteration - forward, loss,
+ * backward, Adam - recorded into a hipGraph per keyframe (the loop of src/mapper.py:586-624 runs 150-1500 iterations on the
+ * same tensors) must not bake a by-value step into the recording.  The bias corrections 1 - beta^step are formed on the device
+ * (powf) as glorie_adam_multi does. */
+int glorie_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr,
+                         float beta1, float beta2, float eps, const int* step_dev, const uint8_t* row_mask, int row_len,
+                         void* stream);
+int glorie_adam_multi_dev(const void* table, int n_tensors, long max_numel, const int* step_dev, const void* grad_base,
+                          void* stream);
+int glorie_counter_add(int* counter, int delta, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -143,3 +143,50 @@ def test_config3_long_sequence_with_culling_loop_closure_and_bounded_memory(gpu)
     assert fg.stats["captures"] <= 4 * K and fg.stats["replays"] + fg.stats["eager"] > 8 * K, fg.stats
     peak = torch.cuda.max_memory_allocated() - mem0
     assert peak < 24 * 2 ** 30, peak / 2 ** 30
+
+
+def test_recorded_mapping_iterations_follow_the_eager_ones(gpu):
+    """SequenceRunner.map_keyframe records iteration 1 of a keyframe - forward, masked loss, backward (two streams), Adam
+    with the step count in device memory (glorie_adam_step_dev / glorie_adam_multi_dev / glorie_counter_add) - into a hipGraph
+    and replays it for the remaining iterations (mapper.py:586-624).  Same keyframes (the generating poses and depth maps
+    written into the video buffers: tracking is not part of this test) and the same pixel draws as an eager run.  Adam
+    normalises every element's step to +-lr, so the rounding noise of the fp32 atomics in the weight gradients decides the
+    direction of elements whose gradient is ~0 - two EAGER runs differ element-wise too.  What must agree: the step
+    bookkeeping (host and device), the loss trajectory, and the direction of the update as a whole."""
+    from glorie_slam_amd.pipeline import synthetic_images, synthetic_runner
+    K, M = 6, 8
+    out = {}
+    for tag, graphs in (("eager", False), ("eager2", False), ("graph", True)):
+        run, c = synthetic_runner(gpu, K, zero_flow_head=True, map_iters=M, map_rays=600)
+        run.map_graph = graphs
+        video, imgs = c["video"], synthetic_images(K)
+        video.poses[:K] = c["poses"][:K]
+        video.disps[:K] = c["disps"][:K]
+        video.disps_up[:K] = torch.nn.functional.interpolate(c["disps"][:K, None], scale_factor=8, mode="bilinear",
+                                                             align_corners=False)[:, 0]
+        video.counter.value = K
+        p0 = [p.detach().clone() for p in run.decoders.parameters()]
+        losses = []
+        for k in range(K):
+            run.images[k] = imgs[k].to(gpu)
+            losses.append(run.map_keyframe(k))
+            opt = run.last_optimizer
+            steps = {st["step"] for st in opt.state.values()}
+            assert steps == {M}, steps                                      # host bookkeeping of eager steps + replays
+            if graphs:
+                assert int(opt._step_dev.item()) == M                      # ... and the device's own count
+        torch.cuda.synchronize()
+        dp = torch.cat([(p.detach() - q).reshape(-1) for p, q in zip(run.decoders.parameters(), p0)])
+        out[tag] = (c["npc"].geo_feats.clone(), dp, losses, dict(run.map_graph_stats))
+    assert out["eager"][3] == {"captures": 0, "replays": 0}
+    assert out["graph"][3] == {"captures": K, "replays": K * (M - 1)}, out["graph"][3]
+    assert sum(b < a for a, b in out["eager"][2]) >= K - 2, out["eager"][2]          # the iterations do reduce the loss
+    cos = lambda a, b: float((a * b).sum() / (a.norm() * b.norm()))
+    ref_cos_p, ref_cos_f = cos(out["eager2"][1], out["eager"][1]), cos(out["eager2"][0], out["eager"][0])
+    got_cos_p, got_cos_f = cos(out["graph"][1], out["eager"][1]), cos(out["graph"][0], out["eager"][0])
+    # the recorded run is as close to an eager run as a second eager run is (the noise floor of the comparison)
+    assert got_cos_p > min(0.9, ref_cos_p - 0.05) and got_cos_f > min(0.9, ref_cos_f - 0.05), \
+        (got_cos_p, ref_cos_p, got_cos_f, ref_cos_f)
+    le, l2, lg = (np.array(out[t][2]) for t in ("eager", "eager2", "graph"))
+    noise = np.abs(l2 - le).max()
+    assert np.abs(lg - le).max() <= max(3.0 * noise, 2e-2 * np.abs(le).max()), (lg, le, noise)
