@@ -108,6 +108,7 @@ SIGNATURES = {
     "glorie_adam_multi_dev": (_c_int, [_vp, _c_int, ctypes.c_long, _vp, _vp, _vp]),
     "glorie_counter_add": (_c_int, [_vp, _c_int, _vp]),
     "glorie_ba_status": (_c_int, [_vp, ctypes.POINTER(_c_int), _vp]),
+    "glorie_ba_set_gate": (_c_int, [_vp, _vp, _vp]),
 }
 
 _lib = None

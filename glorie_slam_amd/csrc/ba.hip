@@ -69,12 +69,14 @@ __device__ __forceinline__ void block_inclusive_scan(int* a, int n) {
 
 __global__ __launch_bounds__(1024) void ba_prepare_kernel(BaWork wk, const int64_t* __restrict__ ii,
                                                           int B, int N, int M, int t0, int t1) {
+  if (ba_skipped(wk)) return;        // glorie_ba_set_gate
   extern __shared__ int sm[];
   int* cnt = sm;             // [B] edges per frame
   int* scan = sm + B;        // [B] scan workspace
   int* slot = sm + 2 * B;    // [B] frame -> slot
   int* eii = sm + 3 * B;     // [N] source frame per edge
   const int tid = threadIdx.x;
+  if (tid == 0 && wk.gate_hits) atomicAdd(wk.gate_hits, 1);
   for (int f = tid; f < B; f += 1024) cnt[f] = 0;
   if (tid < 4) wk.status[tid] = 0;
   __syncthreads();
@@ -181,6 +183,7 @@ __global__ __launch_bounds__(kBaThreads) void ba_jacobian_kernel(
     const float* __restrict__ targets, const float* __restrict__ weights,
     const float* __restrict__ eta, const int64_t* __restrict__ ii,
     const int64_t* __restrict__ jj, int HW, int w, int nchunks, int ppt, int motion_only, int hwc, long hd_doubles) {
+  if (ba_skipped(wk)) return;        // glorie_ba_set_gate
   __shared__ float red[4][28];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wv = tid >> 6;
@@ -325,6 +328,7 @@ constexpr int kRowsA = 48, kRowsB = 64;  // B side carries the extra w row (+pad
 __global__ __launch_bounds__(kBaThreads) void ba_gram_kernel(
     BaWork wk, const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, int HW, int chunk_px, int t0, int t1,
     int nchunks, const float* __restrict__ eta, const float* __restrict__ disps, const float* __restrict__ disps_sens) {
+  if (ba_skipped(wk)) return;        // glorie_ba_set_gate
   __shared__ __attribute__((aligned(16))) float lds[(kRowsA + kRowsB) * kGramLd];
   __shared__ float Xs[kGS * 36];
   __shared__ int eA[kGS], eB[kGS];          // edge ids of the two row groups being multiplied
@@ -612,6 +616,7 @@ __device__ __forceinline__ void assemble_edge(const BaWork& wk, const int64_t* _
 __global__ __launch_bounds__(64) void ba_assemble_kernel(BaWork wk, const int64_t* __restrict__ ii,
                                                          const int64_t* __restrict__ jj,
                                                          int nchunks, int t0, int t1) {
+  if (ba_skipped(wk)) return;        // glorie_ba_set_gate
   __shared__ double sm[192];
   if (wk.status[0] & BA_ST_M_MISMATCH) return;
   assemble_edge(wk, ii, jj, blockIdx.x, nchunks, t0, t1, sm);
@@ -619,6 +624,7 @@ __global__ __launch_bounds__(64) void ba_assemble_kernel(BaWork wk, const int64_
 
 // accumulators -> the fp64 system [H | v] the solvers (and a multi-GPU all-reduce) work on
 __global__ __launch_bounds__(256) void ba_system_f64_kernel(BaWork wk, long total) {
+  if (ba_skipped(wk)) return;        // glorie_ba_set_gate
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   // a dropped non-finite term poisons H[0][0]: after a multi-GPU all-reduce EVERY rank then sees the failure
   if (i < total) wk.Hd[i] = (i == 0 && (wk.status[0] & BA_ST_NONFINITE)) ? __builtin_nan("") : acc_value(wk.Hacc, (size_t)i);
@@ -637,6 +643,7 @@ constexpr int kNB = 32;
 // updates); row index t of the (rem + 1)-row panel: t < rem -> matrix row j0 + nb + t, t == rem -> row n
 constexpr int kTrailTile = 64;
 __global__ __launch_bounds__(256) void chol_trail_kernel(BaWork wk, int n, int j0, int nb) {
+  if (ba_skipped(wk)) return;        // glorie_ba_set_gate
   __shared__ double Ar[kTrailTile][kNB + 1], Ac[kTrailTile][kNB + 1];
   if (wk.status[0] & (BA_ST_SOLVE_ABORT | BA_ST_M_MISMATCH)) return;
   const int base = j0 + nb, rem = n - base;
@@ -683,6 +690,7 @@ __global__ __launch_bounds__(256) void chol_trail_kernel(BaWork wk, int n, int j
 }
 
 __global__ __launch_bounds__(256) void chol_damp_kernel(BaWork wk, int n, float lm, float ep) {
+  if (ba_skipped(wk)) return;        // glorie_ba_set_gate
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i == 0) {                                                   // first launch of a large-system solve
     if (wk.status[0] & BA_ST_NONFINITE) {
@@ -718,6 +726,7 @@ constexpr int kBandThreads = 256;
 // half bandwidth of the system: one wave per row looks for its first non-zero; result in status[3] = bw << 1
 // (status[3] is 0 between solves: ba_solve_fused_kernel resets it)
 __global__ __launch_bounds__(64) void ba_bandwidth_kernel(BaWork wk, int n) {
+  if (ba_skipped(wk)) return;        // glorie_ba_set_gate
   const int r = blockIdx.x, lane = threadIdx.x;
   const double* row = wk.Hd + (size_t)r * n;
   int first = r;
@@ -862,6 +871,7 @@ __device__ __forceinline__ void band_eliminate(double* B, double* u, double* rin
 // from_acc: the system is read straight from the accumulators (single-GPU solve of a small system: no conversion launch)
 __global__ __launch_bounds__(kBandThreads) void ba_solve_band_kernel(BaWork wk, int n, float lm, float ep,
                                                                     int lds_doubles, int force_bw, int from_acc) {
+  if (ba_skipped(wk)) return;        // glorie_ba_set_gate
   extern __shared__ double bsm[];
   __shared__ int fail, bw_s;
   const int tid = threadIdx.x;
@@ -962,6 +972,7 @@ constexpr int kCBP = kCB + 1;     // padded row of the LDS copies
 constexpr int kFusedMaxN = 540;   // panel (n + 1 - 32 rows) x 33 doubles must fit into LDS next to the blocks
 
 __global__ __launch_bounds__(1024) void ba_solve_fused_kernel(BaWork wk, int n, float lm, float ep) {
+  if (ba_skipped(wk)) return;        // glorie_ba_set_gate
   extern __shared__ double fsm[];
   double* Dl = fsm;                 // [32][33] diagonal block (unscaled columns), then L11
   double* Wl = Dl + kCB * kCBP;     // [32][33] row operations applied to I, then L11^-1
@@ -1139,6 +1150,7 @@ __global__ __launch_bounds__(1024) void ba_solve_fused_kernel(BaWork wk, int n, 
 // diagonal phase of ba_solve_fused_kernel; L11 goes back into the lower triangle, L11^-1 (strictly lower
 // part, transposed) into the unused upper triangle of the block
 __global__ __launch_bounds__(1024) void chol_diag_inv_kernel(BaWork wk, int n, int j0, int nb) {
+  if (ba_skipped(wk)) return;        // glorie_ba_set_gate
   __shared__ double Dl[kCB * kCBP], Wl[kCB * kCBP];
   __shared__ int fail;
   const int tid = threadIdx.x, br = tid >> 5, bc = tid & 31;
@@ -1178,6 +1190,7 @@ __global__ __launch_bounds__(1024) void chol_diag_inv_kernel(BaWork wk, int n, i
 // thread = (row, residue g of its 4 columns 8 q + g): wave-uniform columns -> the L11^-1 reads are broadcasts
 constexpr int kPanelRows = 128;
 __global__ __launch_bounds__(1024) void chol_panel_gemm_kernel(BaWork wk, int n, int j0, int nb) {
+  if (ba_skipped(wk)) return;        // glorie_ba_set_gate
   __shared__ double Wl[kCB * kCBP], P[kPanelRows * kCBP];
   if (wk.status[0] & (BA_ST_SOLVE_ABORT | BA_ST_M_MISMATCH)) return;
   const int tid = threadIdx.x, br = tid >> 5, bc = tid & 31;
@@ -1222,6 +1235,7 @@ __global__ __launch_bounds__(1024) void chol_panel_gemm_kernel(BaWork wk, int n,
 // subtracts L[blk rows][r] x_blk from its slice of y (rows of L: coalesced in r) - the O(n^2) part of the sweep
 // spread over the chip instead of one workgroup; workgroup 0 also stores x_blk (and zeros after a failure).
 __global__ __launch_bounds__(256) void chol_backsub_block_kernel(BaWork wk, int n, int j0, int nb) {
+  if (ba_skipped(wk)) return;        // glorie_ba_set_gate
   __shared__ double Wl[kCB * kCBP], yb[kCB], xb[kCB];
   const int tid = threadIdx.x;
   double* A = wk.Hd;
@@ -1263,6 +1277,7 @@ __global__ __launch_bounds__(kBaThreads) void ba_update_kernel(
     BaWork wk, float* __restrict__ poses, float* __restrict__ disps,
     const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, int HW, int t0, int t1,
     int motion_only, int depth_only, float* __restrict__ dx_out, float* __restrict__ dz_out) {
+  if (ba_skipped(wk)) return;        // glorie_ba_set_gate
   constexpr int EB = 128;  // edges per batch
   __shared__ float ys[EB * 6];
   const int tid = threadIdx.x;
@@ -1405,6 +1420,8 @@ static int ba_plan(glorie_ctx* ctx, int B, int N, int M, int h, int w, int t0, i
   wk.vd = wk.Hd + n6 * n6;
   wk.Hacc = reinterpret_cast<unsigned long long*>(base + o_acc);
   wk.dx = reinterpret_cast<float*>(base + o_dx);
+  wk.gate = ctx->ba_gate;
+  wk.gate_hits = nullptr;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ba_solve_fused_kernel),
@@ -1499,7 +1516,11 @@ extern "C" int glorie_ba(glorie_ctx* ctx, float* poses, float* disps, const floa
   if (!motion_only && !eta) return GLORIE_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   GLORIE_TRY(ctx_poison(ctx, pl.scratch_used, st));
-  GLORIE_TRY(ba_prepare(pl.wk, ii, B, N, M, t0, t1, st));
+  {
+    BaWork w0 = pl.wk;                          // the first launch of a gated call counts itself (if it runs)
+    if (ctx->ba_gate && ctx->ba_gate_count) { w0.gate_hits = ctx->ba_gate_hits; ctx->ba_gate_count = false; }
+    GLORIE_TRY(ba_prepare(w0, ii, B, N, M, t0, t1, st));
+  }
   // small systems are read by the band solver straight from the accumulators (no conversion launch)
   const bool direct = pl.n6 <= kSolveMaxN;
   for (int it = 0; it < iterations; ++it) {
@@ -1528,7 +1549,11 @@ extern "C" int glorie_ba_build_system(glorie_ctx* ctx, const float* poses, const
   if (!poses || !disps || !intrinsics || !targets || !weights || !ii || !jj) return GLORIE_EINVAL;
   if (!(motion_only & 1) && !eta) return GLORIE_EINVAL;
   GLORIE_TRY(ctx_poison(ctx, pl.scratch_used, st));
-  GLORIE_TRY(ba_prepare(pl.wk, ii, B, N, M, t0, t1, st));
+  {
+    BaWork w0 = pl.wk;                          // the first launch of a gated call counts itself (if it runs)
+    if (ctx->ba_gate && ctx->ba_gate_count) { w0.gate_hits = ctx->ba_gate_hits; ctx->ba_gate_count = false; }
+    GLORIE_TRY(ba_prepare(w0, ii, B, N, M, t0, t1, st));
+  }
   return ba_build_system(pl, poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj,
                          motion_only, /*to_f64=*/true, st);
 }
@@ -1551,6 +1576,20 @@ extern "C" int glorie_ba_solve_update(glorie_ctx* ctx, float* poses, float* disp
   }
   return ba_solve_update(pl, poses, disps, ii, jj, lm, ep, motion_only, depth_only, dx_out, dz_out,
                          /*from_acc=*/false, st);
+}
+
+// Device-side gate for the BA entry points called next on this context (until cleared with run_if_zero = NULL): every kernel
+// of glorie_ba / glorie_ba_build_system / glorie_ba_solve_update returns at once unless *run_if_zero == 0 - poses, disparities
+// and the status word stay untouched.  The stage-1 fallback of a depth_scale stage (depth_video.py:290-294: "if not success:
+// run pose_depth") is enqueued behind the stage unconditionally, gated on the stage's own `any edge left` word: no host
+// decision, no stream drain per step, and the whole step stays one hipGraph.  hits (may be NULL): incremented once per gated
+// call that did run.
+extern "C" int glorie_ba_set_gate(glorie_ctx* ctx, const int* run_if_zero, int* hits) {
+  if (!ctx) return GLORIE_EINVAL;
+  ctx->ba_gate = run_if_zero;
+  ctx->ba_gate_hits = run_if_zero ? hits : nullptr;
+  ctx->ba_gate_count = run_if_zero && hits;
+  return GLORIE_OK;
 }
 
 // ---- exchange format of the reduced system: lower triangle (row r: columns 0..r) followed by v ----

@@ -57,11 +57,23 @@ class DepthVideo:
         self.poses[:] = torch.as_tensor([0, 0, 0, 0, 0, 0, 1], **f32)
         self.printer = printer
         self._ctx = None
-        self.stage2_fallbacks = 0      # depth_scale stages that fell back to pose_depth (depth_video.py:290-294)
+        # depth_scale stages that fell back to pose_depth (depth_video.py:290-294): decided on the host (CPU tensors, sharded
+        # runs) or on the device (glorie_ba_set_gate; counted there, read lazily by the `stage2_fallbacks` property)
+        self._fb_host = 0
+        self._fb_hits = None
         # multi-GPU state (glorie_slam_amd.dist): None = single GPU
         self.shard = None
 
     # ---- bookkeeping -----------------------------------------------------------------
+    @property
+    def stage2_fallbacks(self):
+        """host-decided fallbacks + the device's count of gated stage-1 BAs that ran (reading it synchronises)"""
+        return self._fb_host + (int(self._fb_hits.item()) if self._fb_hits is not None else 0)
+
+    @stage2_fallbacks.setter
+    def stage2_fallbacks(self, value):
+        self._fb_host = int(value) - (int(self._fb_hits.item()) if self._fb_hits is not None else 0)
+
     def get_lock(self):
         return self.counter.get_lock()
 
@@ -304,7 +316,7 @@ class DepthVideo:
                 return word & 1
 
     def dspo(self, target, weight, eta, ii, jj, t0=1, t1=None, itrs=2, lm=1e-4, ep=0.1,
-             motion_only=False, opt_type="pose_depth"):
+             motion_only=False, opt_type="pose_depth", gate=None):
         with self.get_lock():
             if t1 is None:
                 t1 = max(ii.max().item(), jj.max().item()) + 1
@@ -323,7 +335,7 @@ class DepthVideo:
                 else:
                     droid_backends.ba(self.poses, self.disps, self.intrinsics[0].contiguous(), None,
                                       target, weight, eta, ii, jj, t0, t1, itrs, lm, ep, motion_only,
-                                      False, ctx=self.ctx(), want_updates=False, targets_hwc=True)
+                                      False, ctx=self.ctx(), want_updates=False, targets_hwc=True, gate=gate)
                 self.disps.clamp_(min=1e-5)
                 return True
             elif opt_type == "depth_scale":
@@ -338,6 +350,16 @@ class DepthVideo:
         edges, its pose_depth BA the whole window: dist.ba_sharded)"""
         if self.BA_type == "DSPO":
             ok = self.dspo(target, weight, eta, ii, jj, t0, t1, iters, lm, ep, motion_only, opt_type)
+            if isinstance(ok, torch.Tensor):
+                # the stage left its decision on the device (dspo.depth_scale_stage): the reference's `if not success:
+                # pose_depth` (depth_video.py:290-294) is enqueued behind it with every kernel gated on that word
+                if self._fb_hits is None:
+                    if torch.cuda.is_current_stream_capturing():
+                        raise RuntimeError("the fallback counter must exist before a capture (run one eager step first)")
+                    self._fb_hits = torch.zeros(1, dtype=torch.int32, device=ok.device)
+                self.dspo(target, weight, eta if eta_fallback is None else eta_fallback, ii, jj, t0, t1, iters, lm, ep,
+                          motion_only, "pose_depth", gate=(ok, self._fb_hits))
+                return
             if not ok:
                 self.stage2_fallbacks += 1
                 self.dspo(target, weight, eta if eta_fallback is None else eta_fallback, ii, jj, t0, t1, iters, lm, ep,

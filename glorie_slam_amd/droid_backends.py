@@ -427,11 +427,12 @@ def cvx_upsample(disps, ix, mask, disps_up, softmax_f32=False):
 # bundle adjustment
 # --------------------------------------------------------------------------------------
 def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, t1,
-       iterations, lm, ep, motion_only, depth_only=False, ctx=None, want_updates=True, targets_hwc=False):
+       iterations, lm, ep, motion_only, depth_only=False, ctx=None, want_updates=True, targets_hwc=False, gate=None):
     """reference: droid.cpp:89-119, droid_kernels.cu:1314-1437.  Returns [dx, dz] of the last
     iteration (the reference's return value, unused by its caller).  poses/disps updated in
     place.  targets_hwc=True: targets / weights are [N,h,w,2] (FactorGraph's own layout) instead of the
-    binding's [N,2,h,w]."""
+    binding's [N,2,h,w].  gate = (flag, hits): int32 device words - the call's kernels run only if flag == 0 (decided on the
+    device when they execute, glorie_ba_set_gate) and a call that ran increments hits."""
     L.need_cuda(poses, disps, intrinsics, targets, weights, ii, jj)
     L.need_contiguous(targets=targets, weights=weights, poses=poses, disps=disps,
                       intrinsics=intrinsics, disps_sens=disps_sens, ii=ii, jj=jj)
@@ -454,14 +455,21 @@ def ba(poses, disps, intrinsics, disps_sens, targets, weights, eta, ii, jj, t0, 
     if motion_only and M == 0:
         # the device still needs the slot count to carve its tables
         M = int(torch.unique(torch.cat([torch.arange(t0, t1, device=ii.device), ii])).numel())
-    L.check(L.load().glorie_ba(ctx.handle, L.ptr(poses), L.ptr(disps), L.ptr(intrinsics),
-                               L.ptr(disps_sens), L.ptr(targets), L.ptr(weights), L.ptr(eta),
-                               L.ptr(ii), L.ptr(jj), B, N, M, h, w, int(t0), int(t1),
-                               int(iterations), float(lm), float(ep),
-                               int(bool(motion_only)) | (L.BA_TARGETS_HWC if targets_hwc else 0),
-                               int(bool(depth_only)), L.ptr(dx),
-                               L.ptr(dz) if (dz is not None and dz.numel()) else None,
-                               L.stream_ptr()), "glorie_ba")
+    lib = L.load()
+    if gate is not None:
+        L.check(lib.glorie_ba_set_gate(ctx.handle, L.ptr(gate[0]), L.ptr(gate[1])), "glorie_ba_set_gate")
+    try:
+        L.check(lib.glorie_ba(ctx.handle, L.ptr(poses), L.ptr(disps), L.ptr(intrinsics),
+                              L.ptr(disps_sens), L.ptr(targets), L.ptr(weights), L.ptr(eta),
+                              L.ptr(ii), L.ptr(jj), B, N, M, h, w, int(t0), int(t1),
+                              int(iterations), float(lm), float(ep),
+                              int(bool(motion_only)) | (L.BA_TARGETS_HWC if targets_hwc else 0),
+                              int(bool(depth_only)), L.ptr(dx),
+                              L.ptr(dz) if (dz is not None and dz.numel()) else None,
+                              L.stream_ptr()), "glorie_ba")
+    finally:
+        if gate is not None:
+            lib.glorie_ba_set_gate(ctx.handle, None, None)
     if _CHECK_STATUS:
         # opt-in (GLORIE_CHECK_STATUS=1): surface what the reference raises on the host - a shape mismatch of
         # eta (droid_kernels.cu:1339-1352) - and report Cholesky failures; costs a device synchronisation

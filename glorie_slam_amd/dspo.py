@@ -51,7 +51,10 @@ def _prepare_torch(video, n, ii, jj):
 
 
 def depth_scale_stage(video, target, weight, eta, ii, jj, itrs, lm, ep, fused=True):
-    """returns `success` like DepthVideo.dspo(opt_type='depth_scale')"""
+    """returns `success` like DepthVideo.dspo(opt_type='depth_scale') - or, for an eagerly issued step of an unsharded video on
+    the GPU, the stage's device word `any edge left` (int32 [1]): the stage has then been enqueued in full (with every edge off it leaves
+    all frames untouched) and the caller gates the stage-1 fallback on that word ON THE DEVICE (DepthVideo.ba,
+    glorie_ba_set_gate) - no host decision, no stream drain per step"""
     n = video.counter.value
     self_publish = False
     if fused and video.disps.is_cuda and n > 0:
@@ -76,6 +79,18 @@ def depth_scale_stage(video, target, weight, eta, ii, jj, itrs, lm, ep, fused=Tr
             # communicator the flag's all-reduce is stream work and the stage stays capturable
             from . import dist as gdist
             gdist.allreduce_flag_any(any_on, video.shard["group"], ctx=video._ctx, force=video.shard["force"])
+        if any_on.is_cuda and not video.is_sharded() and not torch.cuda.is_current_stream_capturing():
+            # EAGER steps (the tracking loop, whose edge set changes every keyframe): the decision stays on the device -
+            # stage 2 is enqueued unconditionally (a no-op with every edge off) and the caller enqueues the stage-1 fallback
+            # behind it, gated on this word.  No `.item()`, i.e. no stream drain per depth_scale stage: kept keyframe
+            # 28.4 -> 27.5 ms (tools/prof_sequence.py, interleaved).  A RECORDED step keeps the pinned-word poll below: its
+            # host wait overlaps the tail of the replay, while the ~12 gated no-op launches would cost the replay 3 %
+            # (1068 -> 1040 it/s, tools/ab_bench.sh).
+            if n <= 0:
+                return False
+            scale_shift_step(video, target, weight, eta, ii, jj, edge_on, itrs, lm, ep, alpha=0.01)
+            video.disps.clamp_(min=1e-5)
+            return any_on
         if any_on.is_cuda and torch.cuda.is_current_stream_capturing():
             # hipGraph capture: no host decision is possible here.  With every edge off the stage-2
             # launch below leaves all frames untouched, so it is recorded unconditionally; the flag

@@ -436,6 +436,14 @@ int glorie_ba_solve_update(glorie_ctx* ctx, float* poses, float* disps, const in
                            float lm, float ep, int motion_only, int depth_only, const double* hv,
                            float* dx_out, float* dz_out, void* stream);
 
+/* Device-side gate for the bundle-adjustment entry points called next on `ctx` (sticky until cleared with run_if_zero = NULL):
+ * every kernel of glorie_ba / glorie_ba_build_system / glorie_ba_solve_update returns at once unless *run_if_zero == 0 - poses,
+ * disparities and the status word stay untouched.  It carries the reference's host decision `if not success: run pose_depth`
+ * (src/depth_video.py:290-294) onto the device: the stage-1 fallback of a depth_scale stage is enqueued behind the stage,
+ * gated on the stage's own "any edge left" word (glorie_dspo_prepare's any_on), so a BA-update step needs no host round trip
+ * and replays as one hipGraph.  hits (may be NULL) is incremented once per gated call that did run. */
+int glorie_ba_set_gate(glorie_ctx* ctx, const int* run_if_zero, int* hits);
+
 /* The exchange step itself (glorie_allreduce_normal_eq(ctx, S_v_buf, n)).  The context owns an RCCL
  * communicator: rank 0 draws an id (glorie_comm_unique_id, GLORIE_COMM_ID_BYTES bytes), hands it to every rank by whatever
  * channel the host has (the Python side broadcasts it through torch.distributed's store), and every rank calls

@@ -99,6 +99,40 @@ def test_ba_is_bitwise_reproducible(gpu, K):
         assert bad == dict(build=0, solve=0, full=0), (busy, bad, worst)
 
 
+@pytest.mark.parametrize("K", [6, 14, 100])               # band solver / fused solver / multi-kernel solver
+def test_ba_device_gate(gpu, K):
+    """glorie_ba_set_gate: with the gate word != 0 a BA call leaves poses, disparities and the status word untouched (every
+    kernel returns at once) and does not count itself; with the word == 0 it is the ungated call, bit for bit, and counts
+    once.  This is how the stage-1 fallback of a depth_scale stage (depth_video.py:290-294) is decided on the device."""
+    from glorie_slam_amd import droid_backends as db, _lib
+    from tools import ba_repeat
+    h, w, radius = ba_repeat.SIZES[K]
+    g = make_problem(K, h, w, radius=radius)
+    args = lambda: (_t(g["intrinsics"][0], gpu), None, _t(g["target"], gpu), _t(g["weight"], gpu), _t(g["eta"], gpu),
+                    _t(g["ii"], gpu), _t(g["jj"], gpu), 1, K, 2, 1e-4, 0.1, False, False)
+    ref_p, ref_d = _t(g["poses"], gpu), _t(g["disps"], gpu)
+    db.ba(ref_p, ref_d, *args(), want_updates=False)
+    torch.cuda.synchronize()
+    st_ref = _lib.default_context().ba_status()
+    hits = torch.zeros(1, dtype=torch.int32, device=gpu)
+    for flag_value in (1, 0, 7):
+        flag = torch.full((1,), flag_value, dtype=torch.int32, device=gpu)
+        p, d = _t(g["poses"], gpu), _t(g["disps"], gpu)
+        before = int(hits.item())
+        db.ba(p, d, *args(), want_updates=False, gate=(flag, hits))
+        torch.cuda.synchronize()
+        if flag_value == 0:
+            assert torch.equal(p, ref_p) and torch.equal(d, ref_d) and int(hits.item()) == before + 1
+        else:
+            assert torch.equal(p, _t(g["poses"], gpu)) and torch.equal(d, _t(g["disps"], gpu))
+            assert int(hits.item()) == before
+        assert _lib.default_context().ba_status() == st_ref
+    # the gate does not outlive the call
+    p, d = _t(g["poses"], gpu), _t(g["disps"], gpu)
+    db.ba(p, d, *args(), want_updates=False)
+    assert torch.equal(p, ref_p)
+
+
 def test_ba_window_inside_graph(gpu):
     """t0 > 1: frames below t0 are fixed but still own depth maps (kx = unique(cat(ts, ii)))"""
     K = 7
