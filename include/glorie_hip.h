@@ -276,7 +276,10 @@ int glorie_conv3x3_small(const void* x, int x_stride, const float* in_bias, int 
  *          products and sums: the output is bit-identical to the unpaired packing's.
  *   bits 12-15: tile policy forced by the caller, 0 = automatic (what every product call passes); 1 = 128 x 128 tiles,
  *          2 = 64-pixel tiles, 3 = whole rounds of 128-pixel tiles + the remainder as 64-pixel tiles, 4 = 128 x 256,
- *          5 = automatic without the haloed pixel tile.  Tests (bit-identity of the variants) and tools/bench_conv.py. */
+ *          5 = conv_igemm_kernel's own choice (no haloed pixel tile, no ping-pong tile), 6 = the 256-channel x 256-pixel
+ *          ping-pong tile of round 5 (conv_pp_kernel: 3x3 / 1x1 layers with nout % 256 == 0, epilogues 0 and 1; the automatic
+ *          policy takes it for such 3x3 layers on maps of >= 65,536 pixels).  Tests (bit-identity of the variants) and
+ *          tools/bench_conv.py. */
 #define GLORIE_CONV_PAIR16 0x100
 int glorie_conv_igemm(const void* xa, int xa_stride, int ca, const void* xb, int xb_stride, int cb,
                       const void* w_packed, int taps, int nout, int epilogue, const float* terms,
