@@ -970,6 +970,13 @@ __global__ __launch_bounds__(256, MB <= 4 ? 3 : 2) void conv_halo_kernel(ConvArg
 //     vmcnt(0) before the next ds_read that might alias it, which would pin group 1's pieces to one phase of flight.
 // K order, MFMA sequence per accumulator, zero padding (bit 31 of the lane's offset) and the epilogues are those of
 // conv_igemm_kernel<EPI, 4, 64, 4, 1, 8>: the outputs are bit-identical (tests/test_gpu_update_op.py).
+// The 128-CHANNEL layers (q gate, heads) were given the same schedule over a haloed pixel tile in two LDS buffers + three
+// weight stages (128 x 256 tile, wave tile 64 x 64, 157 KB; bit-identical on four shapes) and LOST to the haloed 128 x 128
+// tile at three workgroups per CU: q gate 151 vs 144 us, 128 -> 384 182 vs 157 us.  A phase then holds 32 MFMAs (~750-860
+// cycles to issue) against the same two barriers, the 16 fragment reads + zero-padding selects + pieces of the MEM phase take as
+// long (810-850), and a K-tile costs 2440 cycles for half the MACs of the 3144-cycle tile above
+// (profiles/r05_conv_pph_timeline.txt); 64-MFMA phases need 512-pixel tiles or two taps per K-tile, neither fits 160 KB of LDS
+// with a double-buffered halo.  Removed.
 // ------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void dma16_asm(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, unsigned lds) {
   // every SGPR operand is SALU-produced at the call sites (checked in the ISA: no v_readfirstlane feeds them, which would need
