@@ -25,9 +25,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
-PMC_SUMMARY = "r04_pmc_kernels.json"   # refreshed per round by tools/pmc_passes.sh
-PMC_CORR_SUMMARY = "r04_pmc_corr.json"  # tools/pmc_corr.sh
-KNN_GATHER_PHASE = "r04_knn_gather_phase.json"   # tools/knn_gather_phase.sh
+PMC_SUMMARY = "r05_pmc_kernels.json"   # refreshed per round by tools/pmc_passes.sh
+PMC_CORR_SUMMARY = "r05_pmc_corr.json"  # tools/pmc_corr.sh
+KNN_GATHER_PHASE = "r05_knn_gather_phase.json"   # tools/knn_gather_phase.sh
 KNN_LAYOUT = "image"                             # --knn-layout
 MFMA_F16_PEAK_TF = 2500.0  # same guide: ~2.5 PFLOP/s dense f16/bf16 (not the 2:1-sparsity figure)
 
@@ -289,9 +289,14 @@ def main():
     ap.add_argument("--strong-k", type=int, default=128, help="keyframes of the strong-scaling graph (512 = long end of config 4)")
     ap.add_argument("--corr-impl", default="volume", choices=["volume", "otf"], help="correlation operator of the timed graph")
     ap.add_argument("--knn-layout", default="image", choices=["image", "linear"], help="query order of the renderer's search")
+    ap.add_argument("--g8-only", action="store_true",
+                    help="only the G8 / 640x480 workloads (no 40x80 graph, no frontend configuration, no sequences, no strong-scaling "
+                         "graph): what tools/final_profile.sh profiles, so that a kernel's average in the stats is a G8 figure")
     args = ap.parse_args()
     global KNN_LAYOUT
     KNN_LAYOUT = args.knn_layout
+    if args.g8_only:
+        args.no_sequence = args.no_strong = True
 
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
@@ -435,7 +440,7 @@ def main():
     # ---- the same graph at the size of the SHIPPED Replica config (configs/Replica/replica.yaml:55-56: 320 x 640 output ->
     # 40 x 80 maps, HW = 3200; SURVEY 8: "report both"), same schedule, soak + 100 timed steps
     replica_yaml = None
-    if world == 1:
+    if world == 1 and not args.g8_only:
         gR, videoR, graphR = build_graph(device, K=8, h=40, w=80, use_graphs=os.environ.get("GLORIE_NO_GRAPHS") is None)
         stepR = make_step(graphR, videoR, 8, [0])
         for _ in range(4 + 150):
@@ -556,7 +561,7 @@ def main():
         # ---- the configuration the tracking driver calls (frontend.py:50-53): use_inactive=True, t0 = t1 = None,
         # on a graph whose oldest edges have retired to the inactive set; eager launches and hipGraph replay
         fe = {}
-        for tag, ug in (("eager", False), ("replay", True)):
+        for tag, ug in (() if args.g8_only else (("eager", False), ("replay", True))):
             _, v2, g2 = build_graph(device, K=K_graph, use_graphs=ug)
             g2.rm_factors((g2.ii == 0) | (g2.jj == 0), store=True)
             for i in range(6):
@@ -570,7 +575,7 @@ def main():
             fe["edges_active"], fe["edges_inactive"] = int(g2.ii.numel()), int(g2.ii_inac.numel())
             assert v2.ctx().ba_status()[0] == 0 and bool(torch.isfinite(v2.poses).all())
             del g2, v2
-        frontend_cfg = fe
+        frontend_cfg = fe or None
         torch.cuda.empty_cache()
 
     # ---- roofline of the dominant kernel of a step (GRU gate convolution, 23 % of it): HIP events on
@@ -936,7 +941,7 @@ def main():
                    "parallelism": ("single GPU" if world == 1 else
                                    f"edges sharded by source keyframe over {world} GPUs + RCCL all-reduce of the "
                                    f"reduced normal equations; rays of the one frame sharded {world} ways")},
-        "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel<EPI_GRU_ZR,4,64> (ConvGRU convz|convr over [net|corr|flow], 320->256, 3x3, + hoisted context term)",
+        "roofline": {"bound": "mfma", "kernel": "conv_pp_kernel<EPI_GRU_ZR> (ConvGRU convz|convr over [net|corr|flow], 320->256, 3x3, + hoisted context term; 256 x 256 ping-pong tile)",
                      "achieved": conv_tf, "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s",
                      "frac": conv_tf / MFMA_F16_PEAK_TF, "traffic": conv_traffic if full else None,
                      "traffic_source": "profiles/" + PMC_SUMMARY + " (rocprofv3 --pmc passes on the builder's box, not this run)",

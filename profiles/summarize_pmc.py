@@ -33,7 +33,8 @@ def main(fetch_dir, write_dir):
     write_corr = GiB_KiB / cal_w     # ~1.0
     out = {"calibration": {"copy_bytes": 1 << 30, "FETCH_SIZE_KiB": cal_f, "WRITE_SIZE_KiB": cal_w,
                            "fetch_correction": fetch_corr, "write_correction": write_corr}}
-    for key, pred in (("conv_igemm_gru_zr", lambda n: "conv_igemm_kernel<1" in n or "conv_igemm_kernelILi1" in n),
+    for key, pred in (("conv_igemm_gru_zr", lambda n: "conv_igemm_kernel<1" in n or "conv_igemm_kernelILi1" in n or "conv_pp_kernel<1" in n
+                       or "conv_pp_kernelILi1" in n),
                       ("corr_lookup", lambda n: "corr_lookup" in n), ("knn_query", lambda n: "knn_query" in n),
                       ("idw_gather", lambda n: "idw_gather" in n), ("mlp_geo", lambda n: "mlp_geo" in n),
                       ("mlp_nb", lambda n: "mlp_nb" in n), ("mlp_col", lambda n: "mlp_col" in n),

@@ -5,7 +5,7 @@
 R=$PWD; O=$R/gpurun_out/final; mkdir -p $O
 python bench.py --steps 20 --warmup 3 > $O/bench.json 2> $O/bench.err
 cd /tmp; export TMPDIR=/tmp
-rm -rf /tmp/fb; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/fb -o b -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-sequence --no-strong > $O/bench_prof.json 2> $O/bench_prof.err
+rm -rf /tmp/fb; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/fb -o b -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --g8-only > $O/bench_prof.json 2> $O/bench_prof.err
 cp $(find /tmp/fb -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats.csv
 python $R/tools/trace_step.py $(find /tmp/fb -name "*kernel_trace.csv" | head -1) corr_dm_encode 20 > $O/step_trace.txt 2>&1
 rm -rf /tmp/fr; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/fr -o r -- python $R/tools/prof_render.py > /dev/null 2>&1
@@ -24,4 +24,7 @@ bash tools/pmc_corr.sh > $O/pmc_corr.log 2>&1; cp gpurun_out/pmc_corr/summary.js
 bash tools/pmc_mfma.sh > /dev/null 2>&1; cp gpurun_out/pmc_mfma.txt $O/pmc_mfma.txt
 bash tools/pmc_kernel.sh mlp_ tools/prof_render.py > $O/pmc_render.txt 2>&1
 bash tools/pmc_kernel.sh knn_query tools/prof_render.py >> $O/pmc_render.txt 2>&1
+bash tools/pmc_passes.sh > $O/pmc_passes.log 2>&1; cp gpurun_out/pmc_kernels.json $O/pmc_kernels.json 2>/dev/null
+bash tools/knn_gather_phase.sh > $O/knn_gather_phase.log 2>&1; cp gpurun_out/knn_gather_phase.json $O/knn_gather_phase.json 2>/dev/null
+bash tools/conv_pp_timeline.sh > /dev/null 2>&1
 tail -c 600 $O/bench.json

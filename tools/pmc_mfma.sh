@@ -12,7 +12,7 @@ import csv, sys, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(sys.argv[1])):
     n = r["Kernel_Name"]
-    if "conv_igemm_kernel<1" in n or "conv_igemm_kernelILi1" in n or "mlp_" in n:
+    if "conv_igemm_kernel<1" in n or "conv_igemm_kernelILi1" in n or "conv_pp_kernel<1" in n or "conv_pp_kernelILi1" in n or "mlp_" in n:
         short = n.split("(")[0].replace("void ", "").replace("glorie::", "")[:34]
         acc[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for n, d in sorted(acc.items()):
