@@ -1284,10 +1284,6 @@ static void launch_pp_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
   hipLaunchKernelGGL((conv_pp_kernel<EPI>), grid, dim3(512), lds, st, a);
 }
 // 256-channel x 256-pixel ping-pong tiles (conv_pp_kernel): layers whose output channels are a multiple of 256
-static bool pp_enabled() {                        // A/B switch of the round-5 experiments (tools/ab_bench.sh "GLORIE_CONV_PP=0" ...)
-  static const bool on = !(getenv("GLORIE_CONV_PP") && getenv("GLORIE_CONV_PP")[0] == '0');
-  return on;
-}
 static int launch_conv_pp(const ConvArgs& a_, int epilogue, hipStream_t st) {
   if ((a_.nout & 255) || a_.pbeg != 0) return GLORIE_EUNSUPPORTED;
   ConvArgs a = a_;
@@ -1493,7 +1489,7 @@ static int conv_igemm_impl(const void* xa, int xa_stride, int ca, const void* xb
   const char t0c = policy == 1 ? '1' : policy == 2 ? '6' : policy == 3 ? 's' : policy == 4 ? 'w' : 0;
   // z|r gates and other 3x3 layers with a multiple of 256 output channels, once the map fills the chip at least once with
   // 256-pixel tiles: the ping-pong kernel (z|r gate launch at G8 251 -> 234 us in an interleaved A/B, tools/bench_conv.py)
-  if (policy == 0 && (nout & 255) == 0 && taps == 9 && epilogue <= EPI_GRU_ZR && a.P >= 256L * 256 && pp_enabled())
+  if (policy == 0 && (nout & 255) == 0 && taps == 9 && epilogue <= EPI_GRU_ZR && a.P >= 256L * 256)
     return launch_conv_pp(a, epilogue, st);
   if (t0c == 0 && (nout & 255) == 0) return launch_conv<4, 64, 4, 1, 8>(a, epilogue, st);
   // small launches (GraphAgg's convolutions run on the 8 keyframe maps, 300 pixel tiles): 128-pixel tiles would leave most
