@@ -29,6 +29,7 @@ PMC_SUMMARY = "r05_pmc_kernels.json"   # refreshed per round by tools/pmc_passes
 PMC_CORR_SUMMARY = "r05_pmc_corr.json"  # tools/pmc_corr.sh
 KNN_GATHER_PHASE = "r05_knn_gather_phase.json"   # tools/knn_gather_phase.sh
 KNN_LAYOUT = "image"                             # --knn-layout
+KNN_PRODUCT_TRAFFIC = None
 MFMA_F16_PEAK_TF = 2500.0  # same guide: ~2.5 PFLOP/s dense f16/bf16 (not the 2:1-sparsity figure)
 
 
@@ -159,13 +160,13 @@ def _pmc_traffic():
     except Exception:
         return None, None, None
     get = lambda k: d[k]["hbm_bytes"] if k in d and d[k].get("hbm_bytes") is not None else None
-    knn = None
-    if get("knn_query") is not None and get("mlp_geo") is not None and get("mlp_nb") is not None:
-        # round 4: the product's R1 + R2 = the search launch + the two decoder kernels that pull the feature rows (their
-        # counters include the kernels' other traffic: positions, masks, the 32-float colour feature they hand on)
-        knn = get("knn_query") + get("mlp_geo") + get("mlp_nb")
-    elif get("knn_query") is not None and get("idw_gather") is not None:
-        knn = get("knn_query") + get("idw_gather")
+    # (search, stand-alone two-table gather): the launches `roofline_knn` times live; (search, mlp_geo, mlp_nb): the product's
+    # R1 + R2 launches (the decoder kernels' counters include their other traffic: positions, masks, the 32-float colour
+    # feature they hand on) for the `product_gather_from_profile` side field
+    knn = (get("knn_query") + get("idw_gather")) if (get("knn_query") is not None and get("idw_gather") is not None) else None
+    global KNN_PRODUCT_TRAFFIC
+    KNN_PRODUCT_TRAFFIC = (get("knn_query") + get("mlp_geo") + get("mlp_nb")) \
+        if all(get(k) is not None for k in ("knn_query", "mlp_geo", "mlp_nb")) else None
     return get("conv_igemm_gru_zr"), get("corr_lookup"), knn
 
 
@@ -997,6 +998,7 @@ def main():
                              "gather_ms": product_gather_ms,
                              "parts_ms": {"mlp_geo_v4": gp["geo_gather_ms"] * scale, "mlp_nb_v4": gp["nb_gather_ms"] * scale},
                              "ms_with_this_runs_search": product_knn_ms,
+                             "traffic_search_plus_decoder_kernels": KNN_PRODUCT_TRAFFIC,
                              "frac": knn_bytes / (product_knn_ms * 1e-3) / 1e9 / HBM_PEAK_GBS} if gp else None)},
         # decoders: fp32-accurate matmuls as hi*hi + hi*lo + lo*hi on the fp16 matrix cores (per-neighbour and colour
         # all three kernels; the narrow output layers stay fp32).  `achieved` counts ALGORITHMIC (fp32) FLOPs; the
