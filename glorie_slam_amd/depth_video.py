@@ -152,6 +152,24 @@ class DepthVideo:
                     "glorie_allreduce_normal_eq")
             if float(probe.item()) != float(world):
                 raise RuntimeError(f"probe all-reduce summed to {float(probe.item())} over {world} ranks")
+            # ... and the same collective RECORDED into a hipGraph and replayed (what FactorGraph.update will do with the
+            # whole sharded step): a communicator that cannot be captured must not be discovered in the middle of a run
+            probe.fill_(1.0)
+            side = torch.cuda.Stream(self.poses.device)
+            side.wait_stream(torch.cuda.current_stream(self.poses.device))
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                g.capture_begin(capture_error_mode="thread_local")
+                try:
+                    L.check(L.load().glorie_allreduce_normal_eq(self.ctx().handle, L.ptr(probe), 1, L.stream_ptr()),
+                            "glorie_allreduce_normal_eq")
+                finally:
+                    g.capture_end()
+            g.replay()
+            torch.cuda.synchronize(self.poses.device)
+            if float(probe.item()) != float(world):
+                raise RuntimeError(f"replayed probe all-reduce summed to {float(probe.item())} over {world} ranks")
+            del g
         except Exception as exc:
             import warnings
             warnings.warn(f"context-owned RCCL communicator unavailable ({exc!r}): exchange through torch.distributed")
