@@ -1379,7 +1379,7 @@ static int ba_plan(glorie_ctx* ctx, int B, int N, int M, int h, int w, int t0, i
   // pixel chunking: enough workgroups to fill 256 CUs, at most 4 pixels per thread
   int ppt = 1;
   const int per1 = (pl.HW + kBaThreads - 1) / kBaThreads;
-  while (ppt < 4 && (long)M * ((per1 + ppt - 1) / ppt) > 1024) ++ppt;
+  while (ppt < 4 && (long)M * ((per1 + ppt - 1) / ppt) > 256) ++ppt;       // (round 5: 1024 -> 256 - every (frame, chunk) workgroup scatters its block with two integer atomics per entry)
   pl.ppt = ppt;
   pl.chunk_px = kBaThreads * ppt;
   pl.nchunks = (pl.HW + pl.chunk_px - 1) / pl.chunk_px;
