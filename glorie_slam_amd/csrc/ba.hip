@@ -1376,10 +1376,15 @@ static int ba_plan(glorie_ctx* ctx, int B, int N, int M, int h, int w, int t0, i
   if (B > kMaxFramesLds || N > kMaxEdgesLds || t1 > B) return GLORIE_EUNSUPPORTED;
   pl.B = B; pl.N = N; pl.M = M; pl.h = h; pl.w = w; pl.HW = h * w; pl.t0 = t0; pl.t1 = t1;
   pl.P = t1 - t0; pl.n6 = 6 * pl.P;
+#ifdef EXP_BA_CHUNK_WGS
+  constexpr long kChunkWgs = EXP_BA_CHUNK_WGS;
+#else
+  constexpr long kChunkWgs = 256;
+#endif
   // pixel chunking: enough workgroups to fill 256 CUs, at most 4 pixels per thread
   int ppt = 1;
   const int per1 = (pl.HW + kBaThreads - 1) / kBaThreads;
-  while (ppt < 4 && (long)M * ((per1 + ppt - 1) / ppt) > 256) ++ppt;       // (round 5: 1024 -> 256 - every (frame, chunk) workgroup scatters its block with two integer atomics per entry)
+  while (ppt < 4 && (long)M * ((per1 + ppt - 1) / ppt) > kChunkWgs) ++ppt;       // (round 5: 1024 -> 256 - every (frame, chunk) workgroup scatters its block with two integer atomics per entry)
   pl.ppt = ppt;
   pl.chunk_px = kBaThreads * ppt;
   pl.nchunks = (pl.HW + pl.chunk_px - 1) / pl.chunk_px;
