@@ -405,3 +405,62 @@ def test_oracle_frame_distance_equals_reference_induced_flow():
     want = np.sqrt((flow.astype(np.float64) ** 2).sum(-1)).reshape(N, -1).mean(1)
     d = ogeom.frame_distance(POPS["poses"], POPS["disps"], POPS["intr"][0], POPS["ii"][keep], POPS["jj"][keep], 1.0)
     np.testing.assert_allclose(d, want[keep], rtol=2e-5)
+
+
+# ---- the lietorch stand-in of the minting script against an INDEPENDENT SE3 (scipy) ------------------------------------------
+def test_lietorch_stand_in_matches_scipy():
+    """`pops.npz`, `ba_scale_shift.npz` and `ba_python.npz` were minted by running the reference's Python geometry with
+    `make_pins.MatSE3` in place of the absent lietorch.  That stand-in is builder-written, so it is pinned here against code
+    that shares nothing with it: rotations through scipy's `Rotation`, the exponential map through `scipy.linalg.expm` of the
+    4 x 4 twist matrix (lietorch's tangent order [translation, rotation], data order [t, q_xyzw]), the adjoint through the
+    defining identity  T exp(a) T^-1 = exp(Ad_T a)."""
+    from scipy.linalg import expm
+    from scipy.spatial.transform import Rotation
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    from make_pins import MatSE3
+
+    rng = np.random.default_rng(7)
+
+    def mat(data):                                         # [t, q_xyzw] -> 4 x 4, by scipy
+        T = np.eye(4)
+        T[:3, :3] = Rotation.from_quat(np.asarray(data[3:], np.float64)).as_matrix()
+        T[:3, 3] = np.asarray(data[:3], np.float64)
+        return T
+
+    def hat(xi):                                           # twist [tau, phi] -> 4 x 4
+        tau, phi = xi[:3], xi[3:]
+        X = np.zeros((4, 4))
+        X[:3, :3] = [[0, -phi[2], phi[1]], [phi[2], 0, -phi[0]], [-phi[1], phi[0], 0]]
+        X[:3, 3] = tau
+        return X
+
+    for _ in range(20):
+        xi = np.concatenate([rng.normal(0, 0.5, 3), rng.normal(0, 0.4, 3)])
+        xj = np.concatenate([rng.normal(0, 0.5, 3), rng.normal(0, 0.4, 3)])
+        A = MatSE3.exp(torch.tensor(xi, dtype=torch.float32))
+        B = MatSE3.exp(torch.tensor(xj, dtype=torch.float32))
+        TA, TB = expm(hat(xi)), expm(hat(xj))
+        # exp: closed form of the stand-in against the matrix exponential
+        np.testing.assert_allclose(mat(A.data.numpy()), TA, atol=2e-6)
+        # inverse and composition
+        np.testing.assert_allclose(mat(A.inv().data.numpy()), np.linalg.inv(TA), atol=3e-6)
+        np.testing.assert_allclose(mat((A * B).data.numpy()), TA @ TB, atol=5e-6)
+        # action on homogeneous points [X, Y, Z, d]
+        pts = rng.normal(0, 1, (5, 4)).astype(np.float32)
+        got = (MatSE3(A.data[None].expand(5, 7)) * torch.from_numpy(pts)).numpy()
+        np.testing.assert_allclose(got, (TA @ pts.T.astype(np.float64)).T, atol=5e-6)
+        # adjT(a) = Ad_T^T a, with Ad_T defined by  T exp(b) T^-1 = exp(Ad_T b)  (checked column by column on small b)
+        Ad = np.zeros((6, 6))
+        eps = 1e-6
+        for c in range(6):
+            b = np.zeros(6)
+            b[c] = eps
+            M = TA @ expm(hat(b)) @ np.linalg.inv(TA)
+            L = (M - np.eye(4)) / eps                      # first order: hat(Ad e_c)
+            Ad[:, c] = [L[0, 3], L[1, 3], L[2, 3], L[2, 1], L[0, 2], L[1, 0]]
+        a = rng.normal(0, 1, 6)
+        got = A.adjT(torch.tensor(a, dtype=torch.float32)).numpy()
+        np.testing.assert_allclose(got, Ad.T @ a, atol=2e-4, rtol=2e-4)
+        # retraction: exp(a) * T
+        r = A.retr(torch.tensor(xj, dtype=torch.float32))
+        np.testing.assert_allclose(mat(r.data.numpy()), TB @ TA, atol=5e-6)
