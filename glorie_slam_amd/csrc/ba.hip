@@ -1346,11 +1346,10 @@ int ba_prepare(const BaWork& wk, const int64_t* ii, int B, int N, int M, int t0,
                hipStream_t st) {
   const size_t prep_lds = sizeof(int) * ((size_t)3 * B + (size_t)N);
   if (prep_lds > 150 * 1024) return GLORIE_EUNSUPPORTED;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_set;
+  if (attr_set.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ba_prepare_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    attr_set = true;
   }
   hipLaunchKernelGGL(ba_prepare_kernel, dim3(1), dim3(1024), prep_lds, st, wk, ii, B, N, M, t0, t1);
   return check_launch();
@@ -1427,13 +1426,12 @@ static int ba_plan(glorie_ctx* ctx, int B, int N, int M, int h, int w, int t0, i
   wk.dx = reinterpret_cast<float*>(base + o_dx);
   wk.gate = ctx->ba_gate;
   wk.gate_hits = nullptr;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_set;
+  if (attr_set.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ba_solve_fused_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ba_solve_band_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-    attr_set = true;
   }
   return GLORIE_OK;
 }
@@ -1503,6 +1501,15 @@ static int ba_solve_update(const BaPlan& pl, float* poses, float* disps, const i
   return check_launch();
 }
 
+// the zero system of a rank without edges, behind the device gate of glorie_ba_set_gate
+__global__ __launch_bounds__(256) void ba_zero_gated_kernel(const int* __restrict__ gate, int* __restrict__ dstatus,
+                                                            double* __restrict__ hv, size_t n) {
+  if (*gate != 0) return;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < 4) dstatus[i] = 0;
+  if (i < n) hv[i] = 0.0;
+}
+
 }  // namespace glorie
 
 extern "C" int glorie_ba(glorie_ctx* ctx, float* poses, float* disps, const float* intrinsics,
@@ -1548,8 +1555,15 @@ extern "C" int glorie_ba_build_system(glorie_ctx* ctx, const float* poses, const
   if (!hv_out || pl.P == 0) return GLORIE_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   if (N == 0 || pl.HW == 0) {  // a rank without edges contributes a zero system
+    const size_t nhv = (size_t)pl.n6 * pl.n6 + pl.n6;
+    if (ctx->ba_gate) {
+      // gated call (glorie_ba_set_gate): the status word and hv_out stay untouched unless the gate is open
+      hipLaunchKernelGGL(ba_zero_gated_kernel, dim3((unsigned)((nhv + 255) / 256)), dim3(256), 0, st, ctx->ba_gate,
+                         ctx->dstatus, hv_out, nhv);
+      return check_launch();
+    }
     GLORIE_TRY(check_hip(hipMemsetAsync(ctx->dstatus, 0, 4 * sizeof(int), st)));
-    return check_hip(hipMemsetAsync(hv_out, 0, sizeof(double) * ((size_t)pl.n6 * pl.n6 + pl.n6), st));
+    return check_hip(hipMemsetAsync(hv_out, 0, sizeof(double) * nhv, st));
   }
   if (!poses || !disps || !intrinsics || !targets || !weights || !ii || !jj) return GLORIE_EINVAL;
   if (!(motion_only & 1) && !eta) return GLORIE_EINVAL;

@@ -1246,22 +1246,22 @@ static void launch_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
   constexpr int RB = BK * 2, PT = (NW / 2) * 16 * NB;
   constexpr size_t stage_bytes = (size_t)ST * (PT * RB + 32 * MB * RB);
   constexpr size_t lds = stage_bytes;
-  static bool attr = false;            // > 64 KB of dynamic LDS needs the opt-in once per kernel
-  if (!attr) {
+  static PerDeviceOnce attr;            // > 64 KB of dynamic LDS needs the opt-in once per kernel
+  if (attr.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<EPI, NB, BK, NW, ST, MB>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr = true;
   }
   hipLaunchKernelGGL((conv_igemm_kernel<EPI, NB, BK, NW, ST, MB>), grid, dim3(64 * NW), lds, st, a);
 }
 
 template <int EPI, int MB>
 static void launch_halo_one(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t st) {
-  static size_t granted = 64 * 1024;          // more dynamic LDS than 64 KB needs the opt-in (once per kernel and size)
-  if (lds > granted) {
+  static size_t granted[kMaxDevices] = {};    // more dynamic LDS than 64 KB needs the opt-in (per kernel, device and size)
+  size_t& g = granted[current_device()];
+  if (lds > 64 * 1024 && lds > g) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<EPI, MB>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    granted = lds;
+    g = lds;
   }
   hipLaunchKernelGGL((conv_halo_kernel<EPI, MB>), grid, dim3(256), lds, st, a);
 }
@@ -1275,11 +1275,10 @@ static size_t halo_lds_bytes(int W, int MB) {
 template <int EPI>
 static void launch_pp_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
   constexpr size_t lds = 5 * 256 * 128;                     // two pixel stages + three weight stages
-  static bool attr = false;
-  if (!attr) {
+  static PerDeviceOnce attr;
+  if (attr.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pp_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
-    attr = true;
   }
   hipLaunchKernelGGL((conv_pp_kernel<EPI>), grid, dim3(512), lds, st, a);
 }
@@ -1287,13 +1286,7 @@ static void launch_pp_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
 static int launch_conv_pp(const ConvArgs& a_, int epilogue, hipStream_t st) {
   if ((a_.nout & 255) || a_.pbeg != 0) return GLORIE_EUNSUPPORTED;
   ConvArgs a = a_;
-  static int ncu = 0;
-  if (!ncu) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return GLORIE_EHIP;
-    ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  }
+  const int ncu = device_cus();
   const long ntn = a.nout / 256;
   const long pt_all = (a.P + 255) / 256;
   // whole rounds of full tiles (one workgroup per CU, `ntn` channel tiles per pixel tile); what is left goes into one partial

@@ -155,11 +155,10 @@ extern "C" int glorie_corr_build(const void* fmaps_cl, const int64_t* ii, const 
   auto pad8 = [](int v) { return ((v + 7) >> 3) << 3; };
   const size_t lds = sizeof(_Float16) * 32 * (size_t)(8 * pad8(w) + 4 * pad8(w >> 1) + 2 * pad8(w >> 2) + pad8(w >> 3));
   if (lds > 80 * 1024) return GLORIE_EUNSUPPORTED;
-  static bool attr = false;
-  if (!attr) {
+  static PerDeviceOnce attr;
+  if (attr.first()) {
     GLORIE_TRY(check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(corr_build_kernel),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)));
-    attr = true;
   }
   const dim3 grid((h * w + 31) / 32, (h + 7) / 8, n_new);
   hipLaunchKernelGGL(corr_build_kernel, grid, dim3(256), lds, (hipStream_t)stream, a);

@@ -755,11 +755,10 @@ extern "C" int glorie_corr_dm_build(const void* fmaps_cl, const int64_t* ii, con
   const size_t lds = sizeof(_Float16) * 32 *
                      (size_t)((8 * pad8(w) + 4) + (4 * pad8(w >> 1) + 2) + (2 * pad8(w >> 2) + 2) + (pad8(w >> 3) + 2));
   if (lds > 80 * 1024) return GLORIE_EUNSUPPORTED;
-  static bool attr = false;
-  if (!attr) {
+  static PerDeviceOnce attr;
+  if (attr.first()) {
     GLORIE_TRY(check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(corr_dm_build_kernel),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)));
-    attr = true;
   }
   const dim3 grid(a.ntx * a.nty * 2, (h + 7) / 8, n_new);
   hipLaunchKernelGGL(corr_dm_build_kernel, grid, dim3(256), lds, (hipStream_t)stream, a);
@@ -797,13 +796,12 @@ extern "C" int glorie_corr_dm_lookup(const void* const* levels, const int* slots
     return check_launch();
   }
   const size_t lds = sizeof(_Float16) * 128 * kEnc2Lds + 256 * sizeof(float) + 4 * 4096;   // weights, bias, store stages
-  static int cus = 0;
-  if (!cus) {
+  static PerDeviceOnce enc_attr;
+  if (enc_attr.first()) {
     GLORIE_TRY(check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(corr_dm_encode_kernel<false>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)));
     GLORIE_TRY(check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(corr_dm_encode_kernel<true>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)));
-    cus = 1;
   }
   // the output rows are stored through a buffer descriptor (32-bit offsets, out-of-map lanes dropped by its range check):
   // a call whose rows span 2 GB or more is issued in runs of edges

@@ -455,11 +455,10 @@ constexpr size_t kOtf8Lds = sizeof(_Float16) * (64 * kLdR8 + 8 + 64 * kLdT8);
 template <bool WC, bool EN>
 static int launch_otf8(const void* fmap1, const OtfLevels& lv, int num_levels, const float* coords, const int64_t* ii,
                        const int64_t* jj, void* out, int N, int h, int w, const OtfEnc& enc, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_set;
+  if (attr_set.first()) {
     GLORIE_TRY(check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_otf8_kernel<WC, EN>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kOtf8Lds)));
-    attr_set = true;
   }
   dim3 grid(((w + 7) / 8) * ((h + 7) / 8), N);
   hipLaunchKernelGGL((corr_otf8_kernel<WC, EN>), grid, dim3(256), kOtf8Lds, st, reinterpret_cast<const _Float16*>(fmap1),

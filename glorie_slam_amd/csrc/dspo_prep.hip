@@ -310,11 +310,10 @@ extern "C" int glorie_dspo_prepare(const float* poses, const float* disps, const
   uint8_t* bad = reinterpret_cast<uint8_t*>(ix + n);
   hipLaunchKernelGGL(prep_stats_kernel, dim3(n), dim3(1024), 0, st, disps, HW, mv_thresh, thresh, avg, ix, any_on);
   GLORIE_TRY(glorie_depth_filter(poses, disps, intrinsics, ix, thresh, count, B, n, h, w, stream));
-  static bool attr = false;
-  if (!attr) {
+  static PerDeviceOnce attr;
+  if (attr.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(prep_align_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    attr = true;
   }
   hipLaunchKernelGGL(prep_align_kernel, dim3(n), dim3(1024), (size_t)HW * 4, st, disps, mono_disps, count, avg,
                      HW, (float)visible_num, mono_thres, valid_mask, scales, shifts, bad);

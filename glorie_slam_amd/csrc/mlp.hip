@@ -1222,20 +1222,18 @@ extern "C" int glorie_render_mlp(const float* packed, const float* pts, const fl
   const float* geo_frags = c.take((size_t)kGeoFrag);
   const int blocks2 = (Q + kTM2 - 1) / kTM2;
   const size_t geo_lds = sizeof(float) * kGeoImage;
-  static bool geo_attr = false;
-  if (!geo_attr) {
+  static PerDeviceOnce geo_attr;
+  if (geo_attr.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_geo_v3_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)geo_lds);
-    geo_attr = true;
   }
   const char* f32env = getenv("GLORIE_MLP_F32");
   const bool geo_f32 = force_f32 || (f32env && f32env[0] == '1');
   const size_t geo4_lds = sizeof(float) * (kGeoFrag + 32 * 16);
-  static bool geo4_attr = false;
-  if (!geo4_attr) {
+  static PerDeviceOnce geo4_attr;
+  if (geo4_attr.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_geo_v4_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)geo4_lds);
-    geo4_attr = true;
   }
   if (geo_f32)
     hipLaunchKernelGGL(mlp_geo_v3_kernel, dim3(blocks2), dim3(512), geo_lds, st, g, geo_image, pts, c_geo,
@@ -1247,23 +1245,21 @@ extern "C" int glorie_render_mlp(const float* packed, const float* pts, const fl
   if (stage_color) {
     const size_t nb_lds = sizeof(float) * (52 * kLdw3 + 128 + kTM2 * 8 + 80) + sizeof(int) * kTM2 * 8;
     const size_t col_lds = sizeof(float) * 2 * kChunkFloats3;
-    static bool attr = false;
-    if (!attr) {
+    static PerDeviceOnce attr;
+    if (attr.first()) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_nb_v3_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)nb_lds);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_col_v3_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)col_lds);
-      attr = true;
     }
     // per-neighbour and colour decoders: fp16 matrix cores with the 3-term split (fp32 accuracy); GLORIE_MLP_F32=1 keeps
     // the fp32 MFMA kernels
     const char* f32 = force_f32 ? "1" : getenv("GLORIE_MLP_F32");
     const size_t nb4_lds = sizeof(float) * (8192 + 128 + kTM2 * 8 + 80) + sizeof(int) * kTM2 * 8;
-    static bool attr4 = false;
-    if (!attr4) {
+    static PerDeviceOnce attr4;
+    if (attr4.first()) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_nb_v4_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)nb4_lds);
-      attr4 = true;
     }
     // colour decoder: 32 samples per wave, 4 waves per workgroup (measured per 614k-sample batch against 16 samples per wave
     // and against 8-wave workgroups: 427 vs 495 / 485 us; the other two forms were removed in round 4)

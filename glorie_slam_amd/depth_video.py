@@ -74,6 +74,10 @@ class DepthVideo:
     def stage2_fallbacks(self, value):
         self._fb_host = int(value) - (int(self._fb_hits.item()) if self._fb_hits is not None else 0)
 
+    def count_host_fallback(self, n=1):
+        """a stage-1 fallback decided on the host: no read of the device counter (the property drains the stream)"""
+        self._fb_host += int(n)
+
     def get_lock(self):
         return self.counter.get_lock()
 
@@ -145,6 +149,7 @@ class DepthVideo:
         active = tdist.is_available() and tdist.is_initialized()
         if want != "1" and world > 1 and not (active and tdist.get_backend(group) == "nccl"):
             return            # (gloo test runs with several ranks on one device: RCCL refuses duplicate devices)
+        ok = True
         try:
             gdist.init_ctx_comm(self.ctx(), group, rank=rank if not active else None, world=world if not active else None)
             probe = torch.ones(1, dtype=torch.float64, device=self.poses.device)
@@ -173,6 +178,18 @@ class DepthVideo:
         except Exception as exc:
             import warnings
             warnings.warn(f"context-owned RCCL communicator unavailable ({exc!r}): exchange through torch.distributed")
+            ok = False
+        if active and world > 1:
+            # the ranks must AGREE on the exchange path: one rank falling back alone would meet the others' native
+            # all-reduce with a torch.distributed collective and deadlock.  (A rank that failed before the id broadcast of
+            # init_ctx_comm leaves its peers inside that broadcast - bounded by torch.distributed's own timeout.)
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.poses.device)
+            tdist.all_reduce(flag, op=tdist.ReduceOp.MIN, group=group)
+            if ok and int(flag.item()) == 0:
+                import warnings
+                warnings.warn("another rank could not create its RCCL communicator: exchange through torch.distributed")
+                ok = False
+        if not ok:
             try:
                 L.load().glorie_comm_destroy(self.ctx().handle)
             except Exception:
@@ -379,7 +396,7 @@ class DepthVideo:
                           motion_only, "pose_depth", gate=(ok, self._fb_hits))
                 return
             if not ok:
-                self.stage2_fallbacks += 1
+                self.count_host_fallback()
                 self.dspo(target, weight, eta if eta_fallback is None else eta_fallback, ii, jj, t0, t1, iters, lm, ep,
                           motion_only, "pose_depth")
         elif self.BA_type == "DBA":

@@ -325,6 +325,10 @@ class FactorGraph:
         self._eta_fb = eta_fb
         if not whole:
             return self._update_finish(itrs, motion_only, opt_type)
+        if sharded:
+            # host-side bookkeeping of the recorded step: the replay rewrote this rank's disps_up rows, the graph cannot
+            # set the flag its consumers (valid-depth mask, mapper, save_video) look at
+            self.video.mark_upsampled()
         if deferred:
             # the recorded depth_scale stage could not take its stage-1 fallback decision on the host
             # (dspo.depth_scale_stage): read the flag it leaves in pinned memory (no stream synchronisation:
@@ -332,7 +336,7 @@ class FactorGraph:
             # all-reduced inside the replay, so every rank takes this (collective) branch together; the fallback BA of a
             # shard spans the whole window and has its own damping rows (eta_fb)
             if self.video.await_any_on() == 0:
-                self.video.stage2_fallbacks += 1
+                self.video.count_host_fallback()
                 target, weight, damping, ii, jj, uniq, upmask, t0_, t1_ = ba_args
                 self.video.dspo(target, weight, damping if eta_fb is None else eta_fb, ii, jj, t0_, t1_, itrs, 1e-4, 0.1,
                                 motion_only, "pose_depth")

@@ -444,7 +444,9 @@ int glorie_ba_solve_update(glorie_ctx* ctx, float* poses, float* disps, const in
  * disparities and the status word stay untouched.  It carries the reference's host decision `if not success: run pose_depth`
  * (src/depth_video.py:290-294) onto the device: the stage-1 fallback of a depth_scale stage is enqueued behind the stage,
  * gated on the stage's own "any edge left" word (glorie_dspo_prepare's any_on), so a BA-update step needs no host round trip
- * and replays as one hipGraph.  hits (may be NULL) is incremented once per gated call that did run. */
+ * and replays as one hipGraph.  hits (may be NULL) is incremented once per gated call that did run.
+ * The gate is state of the CONTEXT, not of a call: a context with a gate set must not be shared with another thread's BA calls
+ * between the set and the clear (use one glorie_ctx per thread of BA callers). */
 int glorie_ba_set_gate(glorie_ctx* ctx, const int* run_if_zero, int* hits);
 
 /* The exchange step itself (glorie_allreduce_normal_eq(ctx, S_v_buf, n)).  The context owns an RCCL

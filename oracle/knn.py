@@ -41,6 +41,25 @@ def knn_bruteforce(points, queries, k, chunk=2048):
     return D, I
 
 
+def build_kdtree(points):
+    """k-d tree over the cloud for knn_kdtree (scipy; the CPU baseline of bench.py - the parity checker stays
+    knn_bruteforce, whose (distance, index) tie order the k-d tree does not promise)"""
+    from scipy.spatial import cKDTree
+    return cKDTree(np.asarray(points, np.float64).reshape(-1, 3))
+
+
+def knn_kdtree(tree, queries, k, workers=-1):
+    """exact k nearest neighbours through a k-d tree, all cores (workers=-1) -> (squared distances float32, indices int64)
+    in the brute-force search's conventions (missing: FLT_MAX / -1)"""
+    q = np.asarray(queries, np.float64).reshape(-1, 3)
+    d, i = tree.query(q, k=k, workers=workers)
+    d, i = d.reshape(q.shape[0], k), i.reshape(q.shape[0], k).astype(np.int64)
+    miss = ~np.isfinite(d)
+    D = np.where(miss, FLT_MAX, (d * d)).astype(np.float32)
+    I = np.where(miss, -1, i)
+    return D, I
+
+
 def neighbor_count(D, radius):
     r = np.asarray(radius, np.float32)
     r2 = (r * r).reshape(-1, 1) if r.ndim else r * r

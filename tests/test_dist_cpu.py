@@ -30,16 +30,16 @@ def test_shard_frames_balanced_and_deterministic():
         assert all(blocks[r][1] == blocks[r + 1][0] for r in range(world - 1))
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, K=6):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        g = synth.keyframe_graph(K=6, h=10, w=12, radius=2, seed=11)
+        g = synth.keyframe_graph(K=K, h=10, w=12, radius=2, seed=11)
         coords, _ = ogeom.reproject(g["poses"], g["disps"], g["intrinsics"], g["ii"], g["jj"])
         target = (coords.transpose(0, 3, 1, 2) + g["noise"]).astype(np.float32)
-        t0, t1 = 1, 6
-        eta_by_frame = g["eta"].reshape(6, -1)
+        t0, t1 = 1, K
+        eta_by_frame = g["eta"].reshape(K, -1)
         owner = gdist.shard_frames(g["ii"], world)
         m = gdist.local_edges(g["ii"], owner, rank)
         A, b = oba.reduced_system(g["poses"], g["disps"], g["intrinsics"][0], target[m], g["weight"][m],
@@ -51,35 +51,53 @@ def _worker(rank, world, port, ret):
         full = np.concatenate([Af.reshape(-1), bf])
         err = float(np.abs(hv.numpy() - full).max() / np.abs(full).max())
         # owned-row all-gather
-        buf = torch.full((6, 3), float(rank + 1))
+        buf = torch.full((K, 3), float(rank + 1))
         gdist.allgather_owned_rows(buf, owner, rank, world)
-        expect = torch.as_tensor(owner[:6] + 1, dtype=torch.float32)[:, None].expand(6, 3)
+        expect = torch.as_tensor(owner[:K] + 1, dtype=torch.float32)[:, None].expand(K, 3)
         ok_rows = bool(torch.equal(buf, expect))
-        # uneven blocks (rank 0 owns one frame, rank 1 four) with trailing rows nobody owns, and a
-        # non-contiguous ownership pattern (falls back to the masked all-reduce)
-        for own in (np.array([0, 1, 1, 1, 1]), np.array([1, 0, 1, 0, 0])):
+        # uneven blocks (rank 0 owns one frame, the last rank the rest; ranks in between own nothing) with trailing rows
+        # nobody owns, and a non-contiguous ownership pattern (falls back to the masked all-reduce)
+        top = world - 1
+        for own in (np.array([0, top, top, top, top]), np.array([top, 0, top, 0, 0])):
             b2 = torch.arange(7 * 2, dtype=torch.float32).view(7, 2) + 100.0 * (rank + 1)
             gdist.allgather_owned_rows(b2, own, rank, world)
             want = torch.arange(7 * 2, dtype=torch.float32).view(7, 2)
             want[:5] += 100.0 * torch.as_tensor(own + 1, dtype=torch.float32)[:, None]
             want[5:] += 100.0 * (rank + 1)                       # rows beyond len(owner) stay local
             ok_rows = ok_rows and bool(torch.equal(b2, want))
-        ret[rank] = (err, ok_rows, int(m.sum()))
+        # ray split (dist.shard_range, the renderer's partition: no collective in the forward pass): every rank evaluates a
+        # per-ray function on its block only; gathered in rank order the blocks are the full frame, each ray exactly once
+        n_rays = 4099                                            # (not a multiple of any world size used here)
+        rays = torch.arange(n_rays, dtype=torch.float64)
+        lo, hi = gdist.shard_range(n_rays, rank, world)
+        mine = torch.sin(rays[lo:hi]) * 3.0 + rays[lo:hi]
+        sizes = [gdist.shard_range(n_rays, r, world) for r in range(world)]
+        width = max(b - a for a, b in sizes)                     # (gloo's all_gather wants equal shapes: pad the blocks)
+        send = torch.zeros(width, dtype=torch.float64)
+        send[:hi - lo] = mine
+        parts = [torch.empty(width, dtype=torch.float64) for _ in sizes]
+        dist.all_gather(parts, send)
+        got = torch.cat([p[:b - a] for p, (a, b) in zip(parts, sizes)])
+        ok_rays = bool(torch.equal(got, torch.sin(rays) * 3.0 + rays))
+        ret[rank] = (err, ok_rows, int(m.sum()), ok_rays)
     finally:
         dist.destroy_process_group()
 
 
-def test_sharded_normal_equations_sum_to_unsharded_gloo():
-    world = 2
-    port = 29500 + (os.getpid() % 500)
+# world 2: the BASELINE config-4 minimum; 4 and 8: the other shard counts north_star reports (shard-count
+# invariance at 1 / 2 / 4 / 8).  K = 12 at 4 and 8 ranks: with 8 ranks some own a single frame's edges
+@pytest.mark.parametrize("world,K", [(2, 6), (4, 12), (8, 12)])
+def test_sharded_normal_equations_sum_to_unsharded_gloo(world, K):
+    port = 29500 + ((os.getpid() * 7 + world) % 500)
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, ret, K), nprocs=world, join=True)
     assert len(ret) == world
     n_edges = 0
     for r in range(world):
-        err, ok_rows, n = ret[r]
+        err, ok_rows, n, ok_rays = ret[r]
         assert err < 1e-12, err
         assert ok_rows
+        assert ok_rays
         n_edges += n
-    assert n_edges == len(synth.keyframe_graph(K=6, h=10, w=12, radius=2, seed=11)["ii"])
+    assert n_edges == len(synth.keyframe_graph(K=K, h=10, w=12, radius=2, seed=11)["ii"])

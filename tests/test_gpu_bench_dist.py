@@ -21,22 +21,34 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def test_bench_main_with_two_ranks_over_gloo(gpu):
+# 2 ranks: the smallest split; 8 ranks: the node north_star names (50 keyframes = 288 edges, 6P = 294 pose unknowns: the packed
+# lower-triangle exchange; the frame split into eight 60-row blocks; every `exchange_step` key of the 8-way record)
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_main_with_several_ranks_over_gloo(gpu, world):
     env = dict(os.environ)
     env.update({"GLORIE_DIST_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "PYTHONPATH": ROOT})
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--no-cpu-baseline", "--no-sequence"]
-    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2",
+           "--warmup", "1", "--no-cpu-baseline", "--no-sequence"] + (["--soak", "20"] if world > 2 else [])
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]                       # rank 0 prints ONE line
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["n_gpus"] == world and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
     assert d["value"] > 0 and d["ms_per_step"] > 0
-    assert d["config"]["edges_total"] == 72 and 0 < d["config"]["edges_local"] < 72      # 36 N edges, sharded
+    assert d["config"]["edges_total"] == 36 * world and 0 < d["config"]["edges_local"] < 36 * world      # 36 N edges, sharded
+    assert d["config"]["keyframes"] == 6 * world + 2
     assert d["checks"]["ba_status"][0] == 0 and d["checks"]["state_finite"]
-    assert d["rays_per_sec"] > 0 and d["render"]["rays_local"] == 307200 // 2           # the frame is split over the ranks
+    assert d["rays_per_sec"] > 0 and d["render"]["rays_local"] == 307200 // world       # the frame is split over the ranks
+    ex = d["exchange_step"]
+    assert "error" not in ex, ex
+    assert ex["torch_distributed_world"] == world and ex["backend"] == "gloo" and ex["rccl_ranks_ctx_communicator"] == 0
+    assert len(ex["edges_local_by_rank"]) == world and sum(ex["edges_local_by_rank"]) == 36 * world
+    assert all(n > 0 for n in ex["edges_local_by_rank"])
+    n6 = 6 * (6 * world + 1)
+    assert ex["pose_unknowns"] == n6 and ex["packed_lower_triangle"] == (n6 >= 96)
+    assert ex["allreduce_bytes"] == 8 * ((n6 * (n6 + 1) // 2 + n6) if n6 >= 96 else (n6 * n6 + n6)) and ex["allreduce_ms"] > 0
     s = d["strong_scaling_graph"]
     assert "error" not in s, s
     assert s["edges_total"] == 756 and 0 < s["edges_local"] < 756 and s["state_ok"] and s["updates_per_sec"] > 0

@@ -62,6 +62,24 @@ def test_stage2_matches_dense_oracle(gpu, itrs):
     np.testing.assert_allclose(gd, d, rtol=1e-4, atol=2e-5)
 
 
+@pytest.mark.parametrize("K,h,w", [(40, 48, 64), (64, 30, 40)])
+def test_stage2_matches_dense_oracle_at_long_graph_shapes(gpu, K, h, w):
+    """the same comparison at the shapes of BASELINE config 5 (TUM 384x512 -> 48x64, M = 40 depth frames) and config 4
+    (ScanNet 240x320 -> 30x40, M = 64): BA_with_scale_shift (src/geom/ba.py:127-216) in the reference's dense M x M
+    formulation (oracle/dspo.py: E is M x M x 2 x HW, 39 MB at M = 40) against the block-diagonal HIP solve, two calls"""
+    g = problem(K=K, h=h, w=w, seed=5)
+    assert len(set(g["ii"].tolist())) == K
+    d, s, q = g["disps"], g["scales"], g["shifts"]
+    for _ in range(2):
+        d, s, q, _ = odspo.ba_with_scale_shift(g["target"], g["weight_hw2"], g["eta"], g["poses"], d,
+                                               g["intrinsics"], g["ii"], g["jj"], g["mono"], s, q, g["vmask"])
+    gd, gs, gq, st = run_gpu(g, gpu, 2)
+    assert st[0] == 0
+    np.testing.assert_allclose(gs, s, rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(gq, q, rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(gd, d, rtol=1e-4, atol=2e-5)
+
+
 def test_stage2_edge_mask_equals_filtered_graph(gpu):
     """edge_on mask == physically removing the edges (and the eta rows of emptied frames)"""
     g = problem(K=6)

@@ -166,9 +166,23 @@ def _worker_whole_step(rank, out_path, thresh):
             res[tag + "_native"] = bool(video.native_exchange()) and gdist.ctx_comm_world(video.ctx()) == 1
         for i in range(8):
             graph.update(t0=1, t1=K, itrs=2, use_inactive=False, opt_type="pose_depth" if i % 2 == 0 else "depth_scale")
+        stale_seq = None
+        if sharded:
+            # the host-side bookkeeping of a step must survive the replay: a consumer's fresh_disps_up() clears the flag, the
+            # next (replayed) step rewrites this rank's disps_up rows and has to set it again (the replay path
+            # returned before mark_upsampled, so the mapper / valid-depth mask / save_video read other ranks' stale rows)
+            video.fresh_disps_up()
+            a = bool(video.shard["stale_up"])
+            replays0 = graph.stats["replays"]
+            graph.update(t0=1, t1=K, itrs=2, use_inactive=False, opt_type="pose_depth")
+            b = bool(video.shard["stale_up"])
+            stale_seq = (a, b, graph.stats["replays"] - replays0)
+            # (undo nothing: the reference run gets the same ninth update below)
+        else:
+            graph.update(t0=1, t1=K, itrs=2, use_inactive=False, opt_type="pose_depth")
         video.fresh_disps_up()
         torch.cuda.synchronize()
-        res[tag] = {"poses": video.poses[:K].cpu(), "disps": video.disps[:K].cpu(), "disps_up": video.disps_up[:K].cpu(),
+        res[tag] = {"stale_seq": stale_seq, "poses": video.poses[:K].cpu(), "disps": video.disps[:K].cpu(), "disps_up": video.disps_up[:K].cpu(),
                     "scale": video.depth_scale[:K].cpu(), "status": video.ctx().ba_status()[0],
                     "fallbacks": int(video.stage2_fallbacks), "stats": dict(graph.stats),
                     "whole_keys": sum(1 for k, v in graph._graphs.items()
@@ -193,6 +207,8 @@ def test_whole_sharded_step_replays_from_one_graph(gpu, tmp_path, thresh):
         for name in ("poses", "disps", "disps_up", "scale"):
             torch.testing.assert_close(got[name], ref[name], atol=1e-4, rtol=1e-4, equal_nan=True, msg=lambda m, n=name, t=tag: f"{t} {n}: {m}")
     assert ref["fallbacks"] == (4 if thresh is not None else 0)
+    assert res["eager"]["stale_seq"] == (False, True, 0)
+    assert res["graph"]["stale_seq"] == (False, True, 1), res["graph"]["stale_seq"]     # set again by a REPLAYED step
     st = res["graph"]["stats"]
     assert st["captures"] == 2 and st["replays"] >= 4 and res["graph"]["whole_keys"] == 2, (st, res["graph"]["whole_keys"])
     for name in ("poses", "disps"):                            # a replayed step = the eager sharded step, bit for bit
