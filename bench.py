@@ -1003,6 +1003,8 @@ def main():
                                 if world == 1 else
                                 f"G8 topology over {K_graph} keyframes = {len(g['ii'])} edges (36 per GPU), 60x80, BA itrs=2, "
                                 f"DSPO stages alternating; value = G8-sized (36-edge) updates per second")
+                               + "; multiview_filter.thresh = 0.25 (reference ships 0.01, configs/mono_point_slam.yaml:75: with "
+                                 "untrained weights 0.01 rejects > 80 % of every frame and no depth_scale step would reach stage 2)"
                                + "; render: 524k-point cloud, one 640x480 view, 10 samples/ray",
                    "edges_local": int(N), "edges_total": int(len(g["ii"])), "hw": int(HW),
                    "keyframes": int(K_graph),
@@ -1013,10 +1015,7 @@ def main():
                      "achieved": conv_tf, "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s",
                      "frac": conv_tf / MFMA_F16_PEAK_TF, "traffic": conv_traffic if full else None,
                      "traffic_source": "profiles/" + PMC_SUMMARY + " (rocprofv3 --pmc passes on the builder's box, not this run)",
-                     "flops_per_launch": conv_flops, "ms_per_launch": conv_ms, "back_to_back_ms": conv_b2b_ms,
-                     # the reference evaluates all 448 input channels in every iteration (gru.py:20-24)
-                     "reference_formulation": {"flops_per_launch": conv_flops * 448.0 / 320.0,
-                                               "equiv_frac": conv_tf * 448.0 / 320.0 / MFMA_F16_PEAK_TF}},
+                     "flops_per_launch": conv_flops, "ms_per_launch": conv_ms, "back_to_back_ms": conv_b2b_ms},
         "roofline_q": {"bound": "mfma", "kernel": "conv_igemm_kernel<EPI_GRU_Q,4,64> (ConvGRU convq, 320->128, 3x3, GRU blend epilogue)",
                        "achieved": q_flops / (q_ms * 1e-3) / 1e12 if q_ms else None, "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s",
                        "frac": (q_flops / (q_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TF) if q_ms else None, "traffic": None,
