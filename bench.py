@@ -25,9 +25,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
-PMC_SUMMARY = "r05_pmc_kernels.json"   # refreshed per round by tools/pmc_passes.sh
-PMC_CORR_SUMMARY = "r05_pmc_corr.json"  # tools/pmc_corr.sh
-KNN_GATHER_PHASE = "r05_knn_gather_phase.json"   # tools/knn_gather_phase.sh
+PMC_SUMMARY = "r06_pmc_kernels.json"   # refreshed per round by tools/pmc_passes.sh
+PMC_CORR_SUMMARY = "r06_pmc_corr.json"  # tools/pmc_corr.sh
+KERNEL_STATS = "r06_final_bench_kernel_stats.csv"   # rocprofv3 --kernel-trace --stats of `bench.py --g8-only` (tools/final_profile.sh)
 KNN_LAYOUT = "image"                             # --knn-layout
 KNN_PRODUCT_TRAFFIC = None
 MFMA_F16_PEAK_TF = 2500.0  # same guide: ~2.5 PFLOP/s dense f16/bf16 (not the 2:1-sparsity figure)
@@ -168,6 +168,20 @@ def _pmc_traffic():
     KNN_PRODUCT_TRAFFIC = (get("knn_query") + get("mlp_geo") + get("mlp_nb")) \
         if all(get(k) is not None for k in ("knn_query", "mlp_geo", "mlp_nb")) else None
     return get("conv_igemm_gru_zr"), get("corr_lookup"), knn
+
+
+def _profile_mean_ms(substr):
+    """average duration (ms) of the kernel whose name contains `substr` in the round's committed rocprofv3 kernel stats
+    (profiles/<round>_final_bench_kernel_stats.csv: the whole profiled `bench.py --g8-only` run), or None"""
+    import csv
+    try:
+        with open(os.path.join(ROOT, "profiles", KERNEL_STATS)) as f:
+            for row in csv.DictReader(f):
+                if substr in row["Name"]:
+                    return float(row["AverageNs"]) * 1e-6, int(row["Calls"])
+    except Exception:
+        pass
+    return None, None
 
 
 def gru_gate_conv_workload(device, N, ht, wd, ii=None):
@@ -746,6 +760,8 @@ def main():
     corr_ms = corr_step_ms if (corr_step_ms and graph.corr_impl != "otf" and graph.fast_update is not None
                                and getattr(graph.corr, "layout", None) == "dm") else corr_b2b_ms
     achieved = alg_bytes / (corr_ms * 1e-3) / 1e9
+    corr_prof_ms, corr_prof_calls = _profile_mean_ms("corr_dm_encode_kernel" if corr_traffic_key == "dm_enc" else "corr_otf8"
+                                                     if graph.corr_impl == "otf" else "corr_lookup")
 
     # ---- M2: rendered rays/sec (full 640x480 frame, rays sharded over ranks) ----------
     npc, dec, ren, rays = build_renderer(device, rank, world)
@@ -940,25 +956,23 @@ def main():
     knn_search_ms = timed(knn_product)
     Dk, Ik, nnk, _, _ = knn_product()
     gather_ms = timed(lambda: point_ops.idw_gather2(Dk, Ik, nnk, npc.geo_feats, npc.col_feats, radius_per_query=rq))
-    # R2 as the product performs it: the feature rows are pulled inside mlp_geo_v4 / mlp_nb_v4.  Their gather phases were
-    # isolated with an instrumentation build that removes the networks (tools/knn_gather_phase.sh, -DEXP_GATHER_ONLY: ids,
-    # weights, rows, positions and the interpolation stay) and are read from the round's profile; the search is timed live
-    gp = None
-    try:
-        with open(os.path.join(ROOT, "profiles", KNN_GATHER_PHASE)) as f:
-            gp = json.load(f)
-    except Exception:
-        gp = None
-    scale = pq.shape[0] / 614400.0
-    product_gather_ms = (gp["geo_gather_ms"] + gp["nb_gather_ms"]) * scale if gp else None
-    # `roofline_knn` reports what THIS run timed: the search launch as the renderer issues it + the stand-alone two-table
-    # gather (R1 + R2 back to back).  The product pulls the rows inside the decoder kernels instead; that phase can only be
-    # isolated by an instrumentation build (profiles/<round>_knn_gather_phase.json, measured on the builder's box) and is
-    # carried as an annotated side field, priced with this run's search time
-    knn_ms = knn_search_ms + gather_ms
+    # R2 as the PRODUCT performs it: the feature rows are pulled inside mlp_geo_v4 / mlp_nb_v4, not by a stand-alone gather.
+    # Their gather phases are timed LIVE in this process through the measurement instantiations of the two kernels
+    # (glorie_render_mlp stage_flags & 4: ids, weights, the 8 neighbour rows of both tables, positions and the interpolation
+    # stay, the networks are removed) next to the live search launch: `roofline_knn.frac` is that composite - the
+    # stand-alone two-table gather (a launch the renderer never makes) is kept as a side field only
+    vq_k = rays["d"][:nq].repeat_interleave(S, dim=0).contiguous()
+    Dk, Ik, nnk, wk_, hask_ = knn_product()
+    packed_k = dec._packed()
+
+    def gather_phase():
+        return point_ops.render_mlp(packed_k, pq, vq_k, npc.cloud_pos(), npc.col_feats, None, Ik, wk_, hask_,
+                                    geo_feats=npc.geo_feats, gather_phase_only=True)
+    product_gather_ms = timed(gather_phase)
     knn_bytes = 2156.0 * pq.shape[0]
+    knn_ms = knn_search_ms + product_gather_ms
     knn_gbs = knn_bytes / (knn_ms * 1e-3) / 1e9
-    product_knn_ms = (knn_search_ms + product_gather_ms) if product_gather_ms is not None else None
+    standalone_ms = knn_search_ms + gather_ms
     # fused decoders alone: executed FLOPs (post-sum F_theta form, 358,848 FLOP per sample)
     D_, I_, nn_ = npc.index.search(pq, 8, radius_per_query=rq)
     cg_, has_, w_ = point_ops.idw_gather(D_, I_, nn_, npc.geo_feats, radius_per_query=rq, return_weights=True)
@@ -1029,8 +1043,14 @@ def main():
                           "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": achieved / HBM_PEAK_GBS, "traffic": corr_traffic if full else None,
                           "traffic_source": "profiles/" + (PMC_CORR_SUMMARY if corr_traffic_key else PMC_SUMMARY) + " (rocprofv3 --pmc passes on the builder's box, not this run)",
-                          "alg_bytes_per_launch": alg_bytes, "ms_per_launch": corr_ms, "back_to_back_ms": corr_b2b_ms,
-                          "back_to_back_frac": alg_bytes / (corr_b2b_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          "alg_bytes_per_launch": alg_bytes, "ms_per_launch": corr_ms,
+                          # `frac` above: the launch inside 30 live eager steps of THIS run (cold pyramid, the step's clocks).
+                          # The same launch averaged by rocprofv3 over every step of the round's profiled run:
+                          "profile_mean_ms": corr_prof_ms, "profile_calls": corr_prof_calls,
+                          "profile_frac": (alg_bytes / (corr_prof_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (corr_prof_ms and full) else None,
+                          "profile_source": "profiles/" + KERNEL_STATS,
+                          # 20 replays of the one launch re-read the same 92 MB from the 256 MB Infinity Cache: NOT HBM evidence
+                          "back_to_back_ms_l3_resident": corr_b2b_ms,
                           # bytes the hardware really moved (PMC) over the same time: the rocprof HBM GB/s
                           "measured_hbm_gbs": (corr_traffic / (corr_ms * 1e-3) / 1e9) if (full and corr_traffic) else None,
                           "measured_hbm_frac": (corr_traffic / (corr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
@@ -1049,23 +1069,20 @@ def main():
         "render": {"rays_local": int(n_r // render_reps), "samples_per_ray": int(S), "cloud_points": int(npc.pts_num()),
                    "ms_per_frame_shard": 1e3 * t_r / render_reps},
         "roofline_knn": {"bound": "hbm", "kernel": "knn_query_kernel<8> as the renderer launches it (image-patch order, bounded by the "
-                                                   "query radius, + IDW weights and mask) + idw_gather2 (both feature tables); both "
-                                                   "timed live in this run",
-                         "search_ms": knn_search_ms, "standalone_gather2_ms": gather_ms,
+                                                   "query radius, + IDW weights and mask) + the feature-pull phases of mlp_geo_v4 / "
+                                                   "mlp_nb_v4 (where the product gathers the 8 neighbour rows of both tables), all "
+                                                   "three timed live in this run (glorie_render_mlp stage_flags & 4)",
+                         "search_ms": knn_search_ms, "product_gather_ms": product_gather_ms,
                          "achieved": knn_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": knn_gbs / HBM_PEAK_GBS, "traffic": knn_traffic if world == 1 else None,
-                         "traffic_source": "profiles/" + PMC_SUMMARY + " (rocprofv3 --pmc passes on the builder's box, not this run)",
+                         "frac": knn_gbs / HBM_PEAK_GBS,
+                         "traffic": KNN_PRODUCT_TRAFFIC if world == 1 else None,
+                         "traffic_source": "profiles/" + PMC_SUMMARY + " (search + the two decoder kernels incl. their other "
+                                           "traffic; rocprofv3 --pmc passes on the builder's box, not this run)",
                          "alg_bytes_per_launch": knn_bytes, "ms_per_launch": knn_ms,
-                         "measured_hbm_gbs": (knn_traffic / (knn_ms * 1e-3) / 1e9) if (world == 1 and knn_traffic) else None,
-                         # R2 as the PRODUCT performs it (rows pulled inside mlp_geo_v4 / mlp_nb_v4): profile-derived, not live
-                         "product_gather_from_profile": ({
-                             "source": "profiles/" + KNN_GATHER_PHASE + " (-DEXP_GATHER_ONLY build of tools/knn_gather_phase.sh on the "
-                                       "builder's box, scaled by the sample count)",
-                             "gather_ms": product_gather_ms,
-                             "parts_ms": {"mlp_geo_v4": gp["geo_gather_ms"] * scale, "mlp_nb_v4": gp["nb_gather_ms"] * scale},
-                             "ms_with_this_runs_search": product_knn_ms,
-                             "traffic_search_plus_decoder_kernels": KNN_PRODUCT_TRAFFIC,
-                             "frac": knn_bytes / (product_knn_ms * 1e-3) / 1e9 / HBM_PEAK_GBS} if gp else None)},
+                         # a launch the product does NOT make (search + stand-alone two-table gather), for comparison only
+                         "standalone_gather2": {"gather_ms": gather_ms, "ms": standalone_ms,
+                                                "frac": knn_bytes / (standalone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                "traffic": knn_traffic if world == 1 else None}},
         # decoders: fp32-accurate matmuls as hi*hi + hi*lo + lo*hi on the fp16 matrix cores (per-neighbour and colour
         # all three kernels; the narrow output layers stay fp32).  `achieved` counts ALGORITHMIC (fp32) FLOPs; the
         # ceiling of a 3-product split is the dense fp16 peak / 3; the fp32 MFMA path it replaced peaks at 157.3.

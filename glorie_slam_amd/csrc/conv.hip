@@ -70,6 +70,7 @@ struct ConvArgs {
 };
 
 constexpr int kTileN = 128;       // output channels per workgroup
+constexpr long kConvPpwMinPixels = 512L * 512;   // conv_ppw_kernel is the automatic choice from two rounds of 512-pixel tiles on (below: equal or slower)
 
 // v_rcp_f32 (1 ulp) instead of the IEEE division sequence (v_div_scale / v_rcp / four FMAs / v_div_fmas / v_div_fixup per
 // element): the gates are rounded to fp16 right after, and the epilogues evaluate 128 of these per lane
@@ -984,6 +985,16 @@ __device__ __forceinline__ void dma16_asm(__amdgpu_buffer_rsrc_t r, unsigned vof
   asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
                :: "v"(voff), "s"(r), "s"(soff), "s"(lds) : "memory");
 }
+// a pixel piece with its zero-padding bit formed INSIDE the statement: offset = voff | (~(mask >> shift) << 31).  As separate
+// C++ expressions hipcc forms the offsets of all of a tile's pieces ahead of the first DMA (eight more live VGPRs in a loop
+// that sits at the 256-register limit; same speed in an interleaved A/B of two builds, 228-230 us for the z|r gate launch)
+__device__ __forceinline__ void dma16_masked_asm(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned mask, unsigned shift,
+                                                 unsigned soff, unsigned lds) {
+  unsigned tmp;
+  asm volatile("v_lshrrev_b32 %0, %5, %6\n\tv_not_b32 %0, %0\n\tv_lshl_or_b32 %0, %0, 31, %1\n\t"
+               "s_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds"
+               : "=&v"(tmp) : "v"(voff), "s"(r), "s"(soff), "s"(lds), "s"(shift), "v"(mask) : "memory");
+}
 #define PP_BARRIER() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_barrier" ::: "memory");        \
                           __builtin_amdgcn_sched_barrier(0); } while (0)
 #define PP_WAIT_LGKM_BARRIER() do { __builtin_amdgcn_sched_barrier(0);                                        \
@@ -996,10 +1007,13 @@ __device__ __forceinline__ void dma16_asm(__amdgpu_buffer_rsrc_t r, unsigned vof
                                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   \
                                    __builtin_amdgcn_sched_barrier(0); } while (0)
 
+// (Round 6: the same wave tile on v_mfma_f32_32x32x16_f16 - 32 MFMAs per K-tile, MFMA phase 5-7 % shorter - was built and
+// removed: the 32 x 32 result layout doubles the epilogue's address work and the launch is 7-12 % slower,
+// profiles/r06_conv_m32.txt.)
 template <int EPI, int NB>
 __device__ __forceinline__ void conv_pp_tile(const ConvArgs& a, const long p0, const int n0, const int lid, char* smem) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int MB = 8, NW = 8, NWS = 4, TN = 256, PT = 64 * NB, RB = 128, SL = 8, RPI = 8, KK = 2;
+  constexpr int MB = 8, NWS = 4, TN = 256, PT = 64 * NB, RB = 128, SL = 8, RPI = 8, KK = 2;
   constexpr int XI = PT / RPI / NWS, WI = TN / RPI / NWS;      // 8 pixel pieces per wave of group 0, 8 weight pieces per wave of group 1
   constexpr int XBYTES = PT * RB, WBYTES = TN * RB;
   constexpr int WBASE = 2 * 256 * RB;                           // LDS: pixel tiles 0 1 | weight tiles 0 1 2  (160 KB)
@@ -1118,9 +1132,8 @@ __device__ __forceinline__ void conv_pp_tile(const ConvArgs& a, const long p0, c
       return pt_;
     };
     auto pix_piece = [&](const PixTile& pt_, int i) {
-      const unsigned inv = ~(vmask[i / 3] >> (pt_.d + 9 * (i % 3)));
-      const unsigned vo = (inv << 31) | (pt_.segA ? voffA0 : voffB0);
-      dma16_asm(pt_.segA ? rA : rB, vo, pt_.xsoff + i * pt_.xstep, pt_.l0 + i * (NWS * RPI * RB));
+      dma16_masked_asm(pt_.segA ? rA : rB, pt_.segA ? voffA0 : voffB0, vmask[i / 3], pt_.d + 9 * (i % 3),
+                       pt_.xsoff + i * pt_.xstep, pt_.l0 + i * (NWS * RPI * RB));
     };
     {
       const PixTile p0_ = pix_tile(0, 0);
@@ -1241,6 +1254,268 @@ __global__ __launch_bounds__(512, 1) void conv_pp_kernel(ConvArgs a) {
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// conv_ppw_kernel (round 6): the ping-pong schedule of conv_pp_kernel for the 128-CHANNEL layers (q gate 320 -> 128, the heads'
+// 128 -> 384 as three channel tiles, corr_encoder[1] / flow layers 128 -> 128): 128 channels x 512 pixels per workgroup.
+// The round-5 attempt (a haloed 128 x 256 tile, wave tile 64 x 64) lost because a phase held only 32 MFMAs against the same
+// two barriers.  Here the WAVE tile stays 128 channels x 64 pixels (MB = 8, NB = 4: 64 MFMAs per phase, 24 fragment reads),
+// the eight waves sit side by side along the pixels, and - because group g (waves 4g .. 4g + 3) reads ONLY its own 256
+// pixel rows - the staging needs no cross-group hand-over for the pixels at all:
+//   LDS (160 KB exactly): pixel buffers [group][2] x 32 KB, two weight stages x 16 KB;
+//   group g, in its MEM phase of K-tile t: DMA of ITS pixel half of tile t + 1 into its other buffer (read last in its own
+//     MEM phase of tile t - 1; 8 pieces per wave), waited for with vmcnt(0) at the end of its MFMA phase - two periods of flight;
+//   group 0 additionally stages the weight tile t + 1 (4 pieces per wave) into stage (t + 1) & 1, whose last reader (group 1,
+//     tile t - 1, period 2t - 1) retired its reads in front of barrier 2t; group 1 reads it three barriers later.
+// K order, MFMA sequence per accumulator, zero padding and epilogues are those of conv_igemm_kernel<EPI, 4, 64, 4, 1, 4>:
+// bit-identical outputs (tests/test_gpu_update_op.py::test_conv_wide_pingpong_tiles_are_bit_identical).  The heads' tap GEMM
+// needs no LDS here: a wave holds all 128 hidden channels of its 64 pixels (the two 64-channel halves are summed in registers
+// in the order the 128 x 128 tile sums them through LDS).
+// ------------------------------------------------------------------------------------------------------------------
+template <int NB>
+__device__ __forceinline__ void conv_epilogue_heads_w(const ConvArgs& a, f32x4 (&acc)[8][NB], long pwave, int n0, int kg,
+                                                      int col, int lane) {
+  const int grp = n0 >> 7;
+  const f16x8* wp = a.tap_w + (size_t)grp * 2 * 4 * 64 + lane;                  // [group][half][chunk*2 + row block][64]
+  f16x8 wf[2][2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) wf[h][c][rb] = wp[((h * 2 + c) * 2 + rb) * 64];
+  float4 b[8];
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi) b[mi] = *reinterpret_cast<const float4*>(a.terms + n0 + mi * 16 + kg * 4);
+#pragma unroll
+  for (int ni = 0; ni < NB; ++ni) {
+    f16x8 hf[4];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+      const f32x4 v = acc[mi][ni];
+      const int h = (mi & 1) * 4;
+      hf[mi >> 1][h + 0] = (_Float16)fmaxf(v[0] + b[mi].x, 0.0f);
+      hf[mi >> 1][h + 1] = (_Float16)fmaxf(v[1] + b[mi].y, 0.0f);
+      hf[mi >> 1][h + 2] = (_Float16)fmaxf(v[2] + b[mi].z, 0.0f);
+      hf[mi >> 1][h + 3] = (_Float16)fmaxf(v[3] + b[mi].w, 0.0f);
+    }
+    const long p = pwave + ni * 16 + col;
+    float* dst = a.tap_out + (size_t)(grp * a.tap_ncols) * a.P + (p < a.P ? p : a.P - 1);
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[0][c][rb], hf[c], s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[1][c][rb], hf[2 + c], s1, 0, 0, 0);
+      }
+      const int n = rb * 16 + kg * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (p < a.P && n + r < a.tap_ncols) dst[(size_t)(n + r) * a.P] = s0[r] + s1[r];
+    }
+  }
+}
+
+template <int EPI, int NB>
+__device__ __forceinline__ void conv_ppw_tile(const ConvArgs& a, const long p0, const int n0, const int nt, char* smem) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int MB = 8, NWS = 4, RB = 128, SL = 8, RPI = 8, KK = 2;
+  constexpr int PG = 64 * NB;                                   // pixel rows of one group's half of the tile
+  constexpr int XI = PG / RPI / NWS, WI = 128 / RPI / NWS;      // 2 NB pixel pieces per wave; 4 weight pieces per wave of group 0
+  constexpr int XBUF = 256 * RB;                                // one pixel buffer, [group][buffer]
+  constexpr int WBASE = 4 * XBUF, WBYTES = 128 * RB;            // weight stages 0 1 behind the four pixel buffers (160 KB)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int w4 = wv & 3;                                        // staging slot inside the group = pixel quarter of its half
+  const int col = lane & 15, kg = lane >> 4;
+  const int grp = wv >> 2;                                      // waves w and w + 4 share a SIMD
+
+  const int nchunks = a.cha + a.chb;
+  const int C = nchunks * 64;
+  const int T = a.taps * nchunks;
+
+  f32x4 acc[MB][NB];
+#pragma unroll
+  for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NB; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int foff[KK];
+#pragma unroll
+  for (int kk = 0; kk < KK; ++kk) foff[kk] = col * RB + (((kk * 4 + kg) ^ (col & 7)) << 4);
+  const int xfrag = grp * 2 * XBUF + w4 * (16 * NB) * RB;
+  f16x8 wf[KK][MB], xf[KK][NB];
+
+  auto read_frags = [&](int buf) {                              // pixel buffer and weight stage of tile t: both t & 1
+    const char* bx = smem + xfrag + buf * XBUF;
+    const char* bw = smem + WBASE + buf * WBYTES;
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+#pragma unroll
+      for (int mi = 0; mi < MB; ++mi) wf[kk][mi] = *reinterpret_cast<const f16x8*>(bw + mi * 16 * RB + foff[kk]);
+#pragma unroll
+      for (int ni = 0; ni < NB; ++ni) xf[kk][ni] = *reinterpret_cast<const f16x8*>(bx + ni * 16 * RB + foff[kk]);
+    }
+  };
+  const bool pieces_first = w4 >= 2;                            // (conv_pp_tile: the LDS pipe and the address unit both stay busy)
+  auto mfmas = [&]() {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+      for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NB; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kk][mi], xf[kk][ni], acc[mi][ni], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  const int srow = lane / SL, slot = lane % SL;
+  const int row0 = w4 * RPI + srow;                             // piece i of staging slot w4: rows (i * NWS + w4) * RPI .. + RPI - 1
+  const int sw0 = (slot ^ (row0 & 7)) << 3;
+  const unsigned ldsb = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
+  const unsigned lds0 = ldsb + (unsigned)(grp * 2 * XBUF + w4 * RPI * RB);
+  const long ph = p0 + (long)grp * PG;                          // first pixel of this group's half
+
+  // ---- pixel staging of this wave's group (both groups) ----
+  const int back = a.taps == 9 ? a.W + 1 : 0;
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(a.xa - (long)back * a.xa_stride), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(a.xb - (long)back * a.xb_stride), 0, 0x7fffffff, 0x00020000);
+  const unsigned voffA0 = (unsigned)(((ph + row0) * a.xa_stride + sw0) * 2);
+  const unsigned voffB0 = (unsigned)(((ph + row0) * a.xb_stride + sw0) * 2);
+  unsigned vmask[(XI + 2) / 3];                                 // 9 tap bits per piece, three pieces per register
+#pragma unroll
+  for (int i = 0; i < (XI + 2) / 3; ++i) vmask[i] = 0;
+#pragma unroll
+  for (int i = 0; i < XI; ++i) {
+    const long p = ph + (i * NWS + w4) * RPI + srow;
+    unsigned m = 0;
+    if (p < a.P) {
+      const int pi_ = (int)p, xw = pi_ % a.W, yh = (pi_ / a.W) % a.H;
+      if (a.taps == 9) {
+#pragma unroll
+        for (int d = 0; d < 9; ++d) {
+          const int dy = d / 3 - 1, dx = d % 3 - 1;
+          if ((unsigned)(yh + dy) < (unsigned)a.H && (unsigned)(xw + dx) < (unsigned)a.W) m |= 1u << d;
+        }
+      } else {
+        m = 1;
+      }
+    }
+    vmask[i / 3] |= m << (9 * (i % 3));
+  }
+  struct PixTile { unsigned xsoff, xstep, l0, d; bool segA; };
+  auto pix_tile = [&](int t, int buf) {
+    PixTile pt_;
+    const int ch = t / a.taps, d = t - ch * a.taps;
+    const int shift = (a.taps == 9 ? (d / 3 - 1) * a.W + (d % 3 - 1) : 0) + back;
+    pt_.segA = ch < a.cha;
+    const int xs = pt_.segA ? a.xa_stride : a.xb_stride;
+    pt_.xsoff = (unsigned)((shift * xs + (pt_.segA ? ch : ch - a.cha) * 64) * 2);
+    pt_.xstep = (unsigned)(NWS * RPI * xs * 2);
+    pt_.l0 = lds0 + buf * XBUF;
+    pt_.d = (unsigned)d;
+    return pt_;
+  };
+  auto pix_piece = [&](const PixTile& pt_, int i) {
+    dma16_masked_asm(pt_.segA ? rA : rB, pt_.segA ? voffA0 : voffB0, vmask[i / 3], pt_.d + 9 * (i % 3),
+                     pt_.xsoff + i * pt_.xstep, pt_.l0 + i * (NWS * RPI * RB));
+  };
+  // ---- weight staging (group 0) ----
+  const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, 0x7fffffff, 0x00020000);
+  const unsigned woff0 = (unsigned)(((size_t)row0 * C + sw0) * 2);
+  const unsigned wstep = (unsigned)(NWS * RPI * C * 2);
+  const unsigned ldsw0 = ldsb + (unsigned)(WBASE + w4 * RPI * RB);
+  auto w_piece = [&](int t, int buf, int i) {
+    const int ch = t / a.taps, d = t - ch * a.taps;
+    const unsigned wsoff = (unsigned)((((size_t)d * a.npad + n0) * C + ch * 64) * 2);
+    dma16_asm(rW, woff0, wsoff + i * wstep, ldsw0 + buf * WBYTES + i * (NWS * RPI * RB));
+  };
+
+  // barrier k = the k-th workgroup barrier; group 0: MEM(t) between barriers 2t and 2t + 1, MFMA(t) between 2t + 1 and 2t + 2;
+  // group 1 one barrier later.  Every wave waits vmcnt(0) in front of the barrier that opens its MEM phase (its own pieces of
+  // the tile it is about to read - and, for group 0, the weight tile both groups are about to read - have landed).
+  {
+    const PixTile p0_ = pix_tile(0, 0);
+#pragma unroll
+    for (int i = 0; i < XI; ++i) pix_piece(p0_, i);
+  }
+  if (grp == 0) {
+#pragma unroll
+    for (int i = 0; i < WI; ++i) w_piece(0, 0, i);
+  } else {
+    PP_WAIT_VM_BARRIER();                                 // barrier 0
+  }
+  for (int t = 0; t < T; ++t) {
+    PP_WAIT_VM_BARRIER();                                 // group 0: barrier 2t; group 1: barrier 2t + 1
+    const bool more = t + 1 < T;
+    const PixTile nx = pix_tile(more ? t + 1 : 0, (t + 1) & 1);
+    if (pieces_first) {
+      if (more) {
+#pragma unroll
+        for (int i = 0; i < XI; ++i) pix_piece(nx, i);
+        if (grp == 0) {
+#pragma unroll
+          for (int i = 0; i < WI; ++i) w_piece(t + 1, (t + 1) & 1, i);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      read_frags(t & 1);
+    } else {
+      read_frags(t & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) {
+#pragma unroll
+        for (int i = 0; i < XI; ++i) pix_piece(nx, i);
+        if (grp == 0) {
+#pragma unroll
+          for (int i = 0; i < WI; ++i) w_piece(t + 1, (t + 1) & 1, i);
+        }
+      }
+    }
+    PP_WAIT_LGKM_BARRIER();                               // group 0: barrier 2t + 1; group 1: barrier 2t + 2
+    mfmas();
+  }
+  if (grp == 0) PP_BARRIER();                             // barrier 2T (group 1's last one)
+
+  const long pwave = p0 + (long)wv * (16 * NB);
+  if constexpr (EPI == EPI_HEADS) {
+    if (nt < a.tap_groups)                                                      // workgroup-uniform
+      conv_epilogue_heads_w<NB>(a, acc, pwave, n0, kg, col, lane);
+    else
+      conv_epilogue_tile<EPI_BIAS_ACT, MB, NB>(a, acc, pwave + col, n0 + kg * 4, a.tap_groups * 128);
+  } else {
+    conv_epilogue_tile<EPI, MB, NB>(a, acc, pwave + col, n0 + kg * 4);
+  }
+#endif
+}
+
+// Tiles as in conv_pp_kernel: `pp_full` workgroups with full (512-pixel) tiles, then the rest of the map in tiles of
+// 128 * pp_nbr pixels; both ranges spread over the XCDs by the same bijective remap.
+template <int EPI>
+__global__ __launch_bounds__(512, 1) void conv_ppw_kernel(ConvArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int ntn = a.nout / 128;
+  const int bid = blockIdx.x, nfull = a.pp_full;
+  const bool full = bid < nfull;
+  const int base = full ? 0 : nfull, nwg = full ? nfull : (int)gridDim.x - nfull, j = bid - base;
+  const int xcd = j & 7, q = nwg >> 3, r = nwg & 7;
+  const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (j >> 3);
+  const int pt = lid / ntn, nt = lid - pt * ntn;
+  const int n0 = nt * 128;
+  if (full) {
+    conv_ppw_tile<EPI, 4>(a, (long)pt * 512, n0, nt, smem);
+  } else {
+    const long p0 = (long)(nfull / ntn) * 512 + (long)pt * (128 * a.pp_nbr);
+    if (a.pp_nbr == 3) conv_ppw_tile<EPI, 3>(a, p0, n0, nt, smem);
+    else if (a.pp_nbr == 2) conv_ppw_tile<EPI, 2>(a, p0, n0, nt, smem);
+    else conv_ppw_tile<EPI, 1>(a, p0, n0, nt, smem);
+  }
+#endif
+}
+
 template <int EPI, int NB, int BK, int NW, int ST, int MB>
 static void launch_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
   constexpr int RB = BK * 2, PT = (NW / 2) * 16 * NB;
@@ -1314,6 +1589,53 @@ static int launch_conv_pp(const ConvArgs& a_, int epilogue, hipStream_t st) {
   switch (epilogue) {
     case EPI_BIAS_ACT: launch_pp_one<EPI_BIAS_ACT>(a, grid, st); break;
     case EPI_GRU_ZR: launch_pp_one<EPI_GRU_ZR>(a, grid, st); break;
+    default: return GLORIE_EUNSUPPORTED;
+  }
+  return check_launch();
+}
+
+template <int EPI>
+static void launch_ppw_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
+  constexpr size_t lds = 4 * 256 * 128 + 2 * 128 * 128;     // four pixel buffers + two weight stages = 160 KB
+  static PerDeviceOnce attr;
+  if (attr.first()) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_ppw_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+  }
+  hipLaunchKernelGGL((conv_ppw_kernel<EPI>), grid, dim3(512), lds, st, a);
+}
+// 128-channel x 512-pixel ping-pong tiles (conv_ppw_kernel): layers whose output channels are a multiple of 128
+static int launch_conv_ppw(const ConvArgs& a_, int epilogue, hipStream_t st) {
+  if ((a_.nout & 127) || a_.pbeg != 0) return GLORIE_EUNSUPPORTED;
+  ConvArgs a = a_;
+  const int ncu = device_cus();
+  const long ntn = a.nout / 128;
+  const long pt_all = (a.P + 511) / 512;
+  // whole rounds of full tiles, the rest in one partial round of smaller tiles when that makes the round shorter (launch_conv_pp)
+  long full_pt = pt_all * ntn / ncu * ncu / ntn;
+  full_pt -= full_pt % 8;
+  if (full_pt < 0) full_pt = 0;
+  long rest_px = a.P - full_pt * 512;
+  int nbr = 4;
+  long rest_pt = 0;
+  if (rest_px > 0) {
+    const long per_cu = (rest_px * ntn + ncu - 1) / ncu;
+    nbr = (int)((per_cu + 127) / 128);
+    if (nbr > 4 || full_pt == 0) nbr = 4;
+    if (nbr < 1) nbr = 1;
+    rest_pt = (rest_px + 128 * nbr - 1) / (128 * nbr);
+  }
+  if (nbr == 4) { full_pt = pt_all; rest_pt = 0; }
+  const long nwg = (full_pt + rest_pt) * ntn;
+  if (nwg <= 0) return GLORIE_OK;
+  if (nwg > 0x7fffffffL) return GLORIE_EINVAL;
+  a.pp_full = (int)(full_pt * ntn);
+  a.pp_nbr = nbr;
+  const dim3 grid((unsigned)nwg);
+  switch (epilogue) {
+    case EPI_BIAS_ACT: launch_ppw_one<EPI_BIAS_ACT>(a, grid, st); break;
+    case EPI_GRU_Q: launch_ppw_one<EPI_GRU_Q>(a, grid, st); break;
+    case EPI_HEADS: launch_ppw_one<EPI_HEADS>(a, grid, st); break;
     default: return GLORIE_EUNSUPPORTED;
   }
   return check_launch();
@@ -1393,7 +1715,7 @@ static int conv_igemm_impl(const void* xa, int xa_stride, int ca, const void* xb
   const int pair = (epilogue >> 8) & 1;                 // GLORIE_CONV_PAIR16: the weights come from a paired packing
   const int policy = (epilogue >> 12) & 15;             // GLORIE_CONV_POLICY_*: tile choice forced by the caller (tests, bench_conv)
   epilogue &= 0xff;
-  if (policy > 6) return GLORIE_EINVAL;
+  if (policy > 7) return GLORIE_EINVAL;
   if (epilogue < 0 || epilogue > 5) return GLORIE_EINVAL;
   if (pair && (epilogue > EPI_GRU_Q || (nout & 31))) return GLORIE_EINVAL;
   if (epilogue == EPI_UPSAMPLE && (!up_disps || !up_ix || !up_out || !terms || nout != 1024 || taps != 1 || pre))
@@ -1450,6 +1772,17 @@ static int conv_igemm_impl(const void* xa, int xa_stride, int ca, const void* xb
   // tile leaves three workgroups per CU (image width <= 83); small launches keep their 64-pixel tiles, the 256- and 64-channel
   // tiles their per-tap staging (measured slower with the shared tile).  Policy 5 (nohalo): per-tap staging everywhere.
   if (policy == 6) return launch_conv_pp(a, epilogue, st);     // GLORIE_CONV_POLICY_PP: forced by the caller
+  if (policy == 7) return launch_conv_ppw(a, epilogue, st);    // GLORIE_CONV_POLICY_PPW
+  {
+    // 128-channel layers on the 128 x 512 ping-pong tile (conv_ppw_kernel): 3x3 layers whose output channels are a multiple of
+    // 128 (but not of 256: those take conv_pp_kernel) once the map fills the chip with 512-pixel tiles.  GLORIE_CONV_PPW = 0 / 1
+    // switches it off / forces it wherever the kernel applies (A/B runs, tests of the heads entry point)
+    const char* ppw = getenv("GLORIE_CONV_PPW");
+    const bool fits = (nout & 127) == 0 && (epilogue == EPI_BIAS_ACT || epilogue == EPI_GRU_Q || epilogue == EPI_HEADS);
+    const bool want = ppw ? ppw[0] == '1' : (taps == 9 && (nout == 128 || epilogue == EPI_HEADS) && epilogue != EPI_BIAS_ACT &&
+                                             a.P >= kConvPpwMinPixels);
+    if (policy == 0 && fits && want && !(ppw && ppw[0] == '0')) return launch_conv_ppw(a, epilogue, st);
+  }
   {
     if (policy == 0 && taps == 9 && a.pbeg == 0) {
       const long tiles128 = (a.P + 127) / 128 * ((nout + 127) / 128);

@@ -822,6 +822,10 @@ __device__ __forceinline__ void mma_g3(f32x4 (&acc)[2], const h16x8 bhi, const h
   __builtin_amdgcn_sched_barrier(0);
 }
 
+// GO (gather only): the measurement instantiation behind stage_flags bit 2 of glorie_render_mlp - the kernel's R2 phase
+// alone (ids, weights, the 8 feature rows and their interpolation) with the decoder removed, so that bench.py can time the
+// feature pull AS THE PRODUCT PERFORMS IT (inside this kernel, not in a stand-alone gather launch) in its own process.
+template <bool GO>
 __global__ __launch_bounds__(512, 4) void mlp_geo_v4_kernel(GeoParams P, const float* __restrict__ frags,
                                                             const float* __restrict__ wout,
                                                             const float* __restrict__ pts,
@@ -907,13 +911,12 @@ __global__ __launch_bounds__(512, 4) void mlp_geo_v4_kernel(GeoParams P, const f
       }
     }
     split2(c[0], c[1], chi, clo);
-#ifdef EXP_GATHER_ONLY
-    // measurement build (tools/knn_gather_phase.sh): the kernel's R2 phase alone - ids, weights, the 8 feature rows and their
-    // interpolation - with the decoder removed; the interpolated feature's sum stands in for the occupancy
-    if (g == 0 && qs < Q) raw[(size_t)qs * 4 + 3] = (c[0][0] + c[0][1]) + (c[1][2] + c[1][3]);
-    cur = nxt;
-    continue;
-#endif
+    if constexpr (GO) {
+      // the interpolated feature's sum stands in for the occupancy
+      if (g == 0 && qs < Q) raw[(size_t)qs * 4 + 3] = (c[0][0] + c[0][1]) + (c[1][2] + c[1][3]);
+      cur = nxt;
+      continue;
+    }
   }
   auto act = [&](int li) {   // ReLU(acc + bias) + fc_c bias
 #pragma unroll
@@ -986,6 +989,7 @@ __global__ __launch_bounds__(512, 4) void mlp_geo_v4_kernel(GeoParams P, const f
 // zero), chunk 1 = the 32 colour-feature channels (slot s <-> channel 16 (s >> 2) + 4 g + (s & 3), the two 16-byte loads of
 // the feature row).  W1 is packed split, as A fragments [chunk][hi|lo][out block][lane][8] (point_ops.pack_decoders), and copied
 // to LDS once per workgroup.
+template <bool GO>
 __global__ __launch_bounds__(512, 4) void mlp_nb_v4_kernel(NbParams P, const float* __restrict__ W1frag,
                                                            const float* __restrict__ pts,
                                                            const float* __restrict__ cloud,
@@ -1040,13 +1044,13 @@ __global__ __launch_bounds__(512, 4) void mlp_nb_v4_kernel(NbParams P, const flo
     const float4 c1 = *reinterpret_cast<const float4*>(col_feats + (size_t)pt * 32 + 16 + 4 * g);
     const float rx = cloud[(size_t)pt * 3 + 0] - qx, ry = cloud[(size_t)pt * 3 + 1] - qy,
                 rz = cloud[(size_t)pt * 3 + 2] - qz;
-#ifdef EXP_GATHER_ONLY
-    // measurement build: the neighbour's feature row and position, weighted - no embedding, no layers
-    ysum[0][0] += w * (c0.x + c1.x + rx); ysum[0][1] += w * (c0.y + c1.y + ry);
-    ysum[0][2] += w * (c0.z + c1.z + rz); ysum[0][3] += w * (c0.w + c1.w);
-    sw += w;
-    continue;
-#endif
+    if constexpr (GO) {
+      // measurement instantiation: the neighbour's feature row and position, weighted - no embedding, no layers
+      ysum[0][0] += w * (c0.x + c1.x + rx); ysum[0][1] += w * (c0.y + c1.y + ry);
+      ysum[0][2] += w * (c0.z + c1.z + rz); ysum[0][3] += w * (c0.w + c1.w);
+      sw += w;
+      continue;
+    }
     f32x4 acc[8];
     zero<8>(acc);
     // chunk 0: embedding features 4s + g (sin for feature < 10), phases in revolutions
@@ -1194,6 +1198,7 @@ extern "C" int glorie_render_mlp(const float* packed, const float* pts, const fl
                                  float* raw, int stage_flags, int* range_flag, void* stream) {
   const int stage_color = stage_flags & 1;
   const bool force_f32 = (stage_flags & 2) != 0;
+  const bool gather_only = (stage_flags & 4) != 0;        // measurement: the R2 phases of the geometry / per-neighbour kernels alone
   if (Q < 0) return GLORIE_EINVAL;
   if (Q == 0) return GLORIE_OK;
   if (!packed || !pts || !has || !raw) return GLORIE_EINVAL;
@@ -1232,14 +1237,32 @@ extern "C" int glorie_render_mlp(const float* packed, const float* pts, const fl
   const size_t geo4_lds = sizeof(float) * (kGeoFrag + 32 * 16);
   static PerDeviceOnce geo4_attr;
   if (geo4_attr.first()) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_geo_v4_kernel),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_geo_v4_kernel<false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)geo4_lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_geo_v4_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)geo4_lds);
+  }
+  if (gather_only) {
+    if (force_f32 || !(geo_feats && I && weights)) return GLORIE_EINVAL;
+    hipLaunchKernelGGL(mlp_geo_v4_kernel<true>, dim3(blocks2 < 512 ? blocks2 : 512), dim3(512), geo4_lds, st, g, geo_frags,
+                       geo_image + kGeoRows * 32, pts, c_geo, geo_feats, I, weights, has, Q, raw, range_flag);
+    if (stage_color) {
+      const size_t nb4_lds = sizeof(float) * (8192 + 128 + kTM2 * 8 + 80) + sizeof(int) * kTM2 * 8;
+      static PerDeviceOnce attr_go;
+      if (attr_go.first()) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_nb_v4_kernel<true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)nb4_lds);
+      }
+      hipLaunchKernelGGL(mlp_nb_v4_kernel<true>, dim3(blocks2), dim3(512), nb4_lds, st, n, nb_frags, pts, cloud_pos, col_feats,
+                         I, weights, has, Q, c_col_scratch, range_flag);
+    }
+    return check_launch();
   }
   if (geo_f32)
     hipLaunchKernelGGL(mlp_geo_v3_kernel, dim3(blocks2), dim3(512), geo_lds, st, g, geo_image, pts, c_geo,
                        c_geo ? nullptr : geo_feats, I, weights, has, Q, raw);
   else
-    hipLaunchKernelGGL(mlp_geo_v4_kernel, dim3(blocks2 < 512 ? blocks2 : 512), dim3(512), geo4_lds, st, g, geo_frags,
+    hipLaunchKernelGGL(mlp_geo_v4_kernel<false>, dim3(blocks2 < 512 ? blocks2 : 512), dim3(512), geo4_lds, st, g, geo_frags,
                        geo_image + kGeoRows * 32, pts, c_geo, c_geo ? nullptr : geo_feats, I, weights, has, Q, raw,
                        range_flag);
   if (stage_color) {
@@ -1258,7 +1281,7 @@ extern "C" int glorie_render_mlp(const float* packed, const float* pts, const fl
     const size_t nb4_lds = sizeof(float) * (8192 + 128 + kTM2 * 8 + 80) + sizeof(int) * kTM2 * 8;
     static PerDeviceOnce attr4;
     if (attr4.first()) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_nb_v4_kernel),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_nb_v4_kernel<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)nb4_lds);
     }
     // colour decoder: 32 samples per wave, 4 waves per workgroup (measured per 614k-sample batch against 16 samples per wave
@@ -1267,7 +1290,7 @@ extern "C" int glorie_render_mlp(const float* packed, const float* pts, const fl
       hipLaunchKernelGGL(mlp_nb_v3_kernel, dim3(blocks2), dim3(512), nb_lds, st, n, pts, cloud_pos, col_feats,
                          I, weights, has, Q, c_col_scratch);
     else
-      hipLaunchKernelGGL(mlp_nb_v4_kernel, dim3(blocks2), dim3(512), nb4_lds, st, n, nb_frags, pts, cloud_pos, col_feats,
+      hipLaunchKernelGGL(mlp_nb_v4_kernel<false>, dim3(blocks2), dim3(512), nb4_lds, st, n, nb_frags, pts, cloud_pos, col_feats,
                          I, weights, has, Q, c_col_scratch, range_flag);
     const size_t col16_lds = sizeof(float) * 2 * kChunkFloats16;
     if (f32 && f32[0] == '1')

@@ -363,13 +363,15 @@ def pack_decoders(decoders):
 
 
 def render_mlp(packed, pts, views, cloud_pos, col_feats, c_geo, I, weights, has, stage="color", geo_feats=None,
-               precise=False, range_flag=None):
+               precise=False, range_flag=None, gather_phase_only=False):
     """raw [Q,4] = (rgb, occ) for samples `pts` given their neighbours; occ = -100 where
     has == False.  stage 'geometry' leaves rgb = 0.  c_geo: the interpolated geometry feature [Q,32], or None
     with geo_feats [Np,32]: the geometry kernel interpolates it itself from (I, weights).
     precise: exact-fp32 MFMA kernels instead of the 3-term fp16 split.  range_flag: device int32 [1] (zero): the split
     kernels set it when an operand left the fp16 range - the caller then repeats the call with precise=True
-    (`range_checked` does both)."""
+    (`range_checked` does both).  gather_phase_only (bench.py): the measurement instantiations of the geometry / per-neighbour
+    kernels that pull the neighbour rows and drop the networks (stage_flags & 4, include/glorie_hip.h); the result is NOT a
+    rendering."""
     L.need_cuda(packed, pts, c_geo if c_geo is not None else geo_feats)
     Q = pts.shape[0]
     dev = pts.device
@@ -387,7 +389,8 @@ def render_mlp(packed, pts, views, cloud_pos, col_feats, c_geo, I, weights, has,
         L.ptr(geo_feats.contiguous()) if c_geo is None else None,
         L.ptr(I.contiguous()) if (color or c_geo is None) else None,
         L.ptr(weights.contiguous()) if (color or c_geo is None) else None, L.ptr(has8), Q, L.ptr(scratch),
-        L.ptr(raw), int(color) | (2 if precise else 0), L.ptr(range_flag), L.stream_ptr()), "glorie_render_mlp")
+        L.ptr(raw), int(color) | (2 if precise else 0) | (4 if gather_phase_only else 0), L.ptr(range_flag),
+        L.stream_ptr()), "glorie_render_mlp")
     return raw
 
 

@@ -224,7 +224,7 @@ def pack_corr_encoder_dm(weight):
     return wp.reshape(128, 224).contiguous()
 
 
-CONV_POLICY = {None: 0, "auto": 0, "128": 1, "64": 2, "split": 3, "wide": 4, "nohalo": 5, "pp": 6}   # bits 12-15 of `epilogue`
+CONV_POLICY = {None: 0, "auto": 0, "128": 1, "64": 2, "split": 3, "wide": 4, "nohalo": 5, "pp": 6, "ppw": 7}   # bits 12-15 of `epilogue`
 
 
 def conv_igemm(xa, xb, w_packed, taps, nout, out, epilogue=EPI_BIAS_ACT, terms=None, act=ACT_NONE,

@@ -278,8 +278,11 @@ int glorie_conv3x3_small(const void* x, int x_stride, const float* in_bias, int 
  *          2 = 64-pixel tiles, 3 = whole rounds of 128-pixel tiles + the remainder as 64-pixel tiles, 4 = 128 x 256,
  *          5 = conv_igemm_kernel's own choice (no haloed pixel tile, no ping-pong tile), 6 = the 256-channel x 256-pixel
  *          ping-pong tile of round 5 (conv_pp_kernel: 3x3 / 1x1 layers with nout % 256 == 0, epilogues 0 and 1; the automatic
- *          policy takes it for such 3x3 layers on maps of >= 65,536 pixels).  Tests (bit-identity of the variants) and
- *          tools/bench_conv.py. */
+ *          policy takes it for such 3x3 layers on maps of >= 65,536 pixels), 7 = the 128-channel x 512-pixel ping-pong tile of
+ *          round 6 (conv_ppw_kernel: nout % 128 == 0, epilogues 0 and 2, and the heads entry point; the automatic policy takes
+ *          it for the q gate and the heads on maps of >= 262,144 pixels - a 55-edge graph at 60 x 80 - where it is 4-5 %
+ *          faster; on G8 it equals the shipped tiles; GLORIE_CONV_PPW = 0 / 1 overrides).  Tests (bit-identity of the
+ *          variants) and tools/bench_conv.py. */
 #define GLORIE_CONV_PAIR16 0x100
 int glorie_conv_igemm(const void* xa, int xa_stride, int ca, const void* xb, int xb_stride, int cb,
                       const void* w_packed, int taps, int nout, int epilogue, const float* terms,
@@ -601,6 +604,10 @@ int glorie_idw_gather2(const float* D, const int64_t* I, const int* nn, const fl
  * kernels.  The split needs every operand within the fp16 range: range_flag (NULL or a device int, zero-initialised by the
  * caller) gets bit 0 set when a kernel met |x| > 65504 or a NaN - the results of that call are then invalid and the caller
  * repeats it with stage_flags | 2 (glorie_slam_amd.renderer does).
+ * stage_flags & 4 (measurement, bench.py's roofline_knn): only the feature-pull phases of the geometry and per-neighbour
+ * kernels run - ids, weights, the 8 neighbour rows, positions and the interpolation, the networks removed - so the R2 traffic
+ * can be timed the way the product performs it (inside these kernels); needs geo_feats (c_geo = NULL), not combinable with
+ * bit 1; `raw` / c_col_scratch then hold sums of the gathered values, not decoder outputs.
  * c_geo [Q,32] is the IDW-interpolated geometry feature (glorie_idw_gather); pass NULL and the feature table
  * geo_feats [Np,32] instead to have the geometry kernel interpolate it itself from (I, weights) - then
  * glorie_idw_gather is only needed for the weights and the mask (c_out = NULL). */

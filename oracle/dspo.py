@@ -17,9 +17,11 @@ from . import se3
 F = np.float32
 
 
-def schur_solve(H, E, C, v, w, ep=0.1, lm=1e-4):
+def schur_solve(H, E, C, v, w, ep=0.1, lm=1e-4, dtype=np.float32):
     """H [P,P,D,D], E [P,M,D,HW], C [M,HW], v [P,D], w [M,HW] -> dx [P,D], dz [M,HW] (float32 math
-    like torch; Cholesky failure -> dx = 0, chol.py:10-17)"""
+    like torch; Cholesky failure -> dx = 0, chol.py:10-17).  dtype=np.float64: the same algebra evaluated in double
+    (the yardstick for how much of a difference is the fp32 evaluation's own rounding, tests/test_gpu_dspo.py)"""
+    F = dtype
     P, M, D, HW = E.shape
     Hm = np.asarray(H, F).transpose(0, 2, 1, 3).reshape(P * D, P * D)
     Em = np.asarray(E, F).transpose(0, 2, 1, 3).reshape(P * D, M * HW)
@@ -55,9 +57,11 @@ def block_solve(H, b, ep=0.1, lm=1e-4):
 
 
 def ba_with_scale_shift(target, weight, eta, poses, disps, intr, ii, jj, mono, scales, shifts,
-                        vmask, lm=1e-4, ep=0.1, alpha=0.01):
+                        vmask, lm=1e-4, ep=0.1, alpha=0.01, dtype=np.float32):
     """One call of BA_with_scale_shift.  target/weight [N,h,w,2]; eta [M,h,w]; returns
-    (disps, scales, shifts, dz) with the dense M x M system of the reference."""
+    (disps, scales, shifts, dz) with the dense M x M system of the reference.  dtype=np.float64 evaluates the same
+    formulation in double from the same fp32 inputs (the relative pose of an edge stays oracle/se3.py's float32)."""
+    F = dtype
     poses = np.asarray(poses, F)
     disps = np.array(disps, F)
     scales = np.array(scales, F)
@@ -124,7 +128,7 @@ def ba_with_scale_shift(target, weight, eta, poses, disps, intr, ii, jj, mono, s
     for k in range(M):
         Hd[k, k] = H_wq[k]
         Ed[k, k] = E_d[k]
-    dwq, dz = schur_solve(Hd, Ed, C, u, wv_, ep, lm)
+    dwq, dz = schur_solve(Hd, Ed, C, u, wv_, ep, lm, dtype=F)
     for k, f in enumerate(kx):
         disps[f] = disps[f] + dz[k].reshape(h, w)
         scales[f] += dwq[k, 0]

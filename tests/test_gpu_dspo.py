@@ -66,18 +66,31 @@ def test_stage2_matches_dense_oracle(gpu, itrs):
 def test_stage2_matches_dense_oracle_at_long_graph_shapes(gpu, K, h, w):
     """the same comparison at the shapes of BASELINE config 5 (TUM 384x512 -> 48x64, M = 40 depth frames) and config 4
     (ScanNet 240x320 -> 30x40, M = 64): BA_with_scale_shift (src/geom/ba.py:127-216) in the reference's dense M x M
-    formulation (oracle/dspo.py: E is M x M x 2 x HW, 39 MB at M = 40) against the block-diagonal HIP solve, two calls"""
+    formulation (oracle/dspo.py: E is M x M x 2 x HW, 39 MB at M = 40) against the block-diagonal HIP solve, two calls.
+    At these sizes the reduced 2 x 2 systems are a 1e-3 cancellation (H - E Q E^T over 3072 pixels) and the reference's OWN
+    fp32 evaluation is only good to ~1e-4 on the shifts (measured: the fp32 oracle against the same algebra in double,
+    1.2e-4 at 48x64 - and the first version of this test, which held the HIP path to 2e-5 against the fp32 oracle, failed by
+    exactly that much).  So the yardstick is the double evaluation: the HIP path (fp32 per pixel, fp64 across workgroups and
+    in the solve) must be at least as close to it as the reference's fp32 formulation is, and within the stated tolerance
+    of the fp32 oracle widened by that rounding."""
     g = problem(K=K, h=h, w=w, seed=5)
     assert len(set(g["ii"].tolist())) == K
-    d, s, q = g["disps"], g["scales"], g["shifts"]
-    for _ in range(2):
-        d, s, q, _ = odspo.ba_with_scale_shift(g["target"], g["weight_hw2"], g["eta"], g["poses"], d,
-                                               g["intrinsics"], g["ii"], g["jj"], g["mono"], s, q, g["vmask"])
+    res = {}
+    for tag, dt in (("f32", np.float32), ("f64", np.float64)):
+        d, s, q = g["disps"], g["scales"], g["shifts"]
+        for _ in range(2):
+            d, s, q, _ = odspo.ba_with_scale_shift(g["target"], g["weight_hw2"], g["eta"], g["poses"], d, g["intrinsics"],
+                                                   g["ii"], g["jj"], g["mono"], s, q, g["vmask"], dtype=dt)
+        res[tag] = [np.asarray(x, np.float64) for x in (d, s, q)]
     gd, gs, gq, st = run_gpu(g, gpu, 2)
     assert st[0] == 0
-    np.testing.assert_allclose(gs, s, rtol=2e-4, atol=2e-5)
-    np.testing.assert_allclose(gq, q, rtol=2e-4, atol=2e-5)
-    np.testing.assert_allclose(gd, d, rtol=1e-4, atol=2e-5)
+    for name, got, r32, r64, rtol, atol in (("scales", gs, res["f32"][1], res["f64"][1], 2e-4, 2e-5),
+                                            ("shifts", gq, res["f32"][2], res["f64"][2], 2e-4, 2e-5),
+                                            ("disps", gd, res["f32"][0], res["f64"][0], 1e-4, 2e-5)):
+        e_ref = float(np.abs(r32 - r64).max())            # rounding of the reference's fp32 formulation
+        e_hip = float(np.abs(got - r64).max())
+        assert e_hip <= max(1.5 * e_ref, atol), (name, e_hip, e_ref)
+        np.testing.assert_allclose(got, r32, rtol=rtol, atol=atol + 2.0 * e_ref, err_msg=name)
 
 
 def test_stage2_edge_mask_equals_filtered_graph(gpu):

@@ -500,6 +500,69 @@ def test_conv_pingpong_tiles_are_bit_identical(gpu, n, h, w):
         U.conv_igemm(net, xb, U.pack_conv_igemm(wzr_t[:128]), 9, 128, cl(128), policy="pp")
 
 
+# 390 px (one ragged 128-pixel-block tile) ... G8 (256 full 512-pixel tiles + a partial round of 256-pixel tiles on 256 CUs)
+# ... and a 56-edge graph (268,800 pixels): from 262,144 pixels on the AUTOMATIC policy takes this kernel for the q gate and the heads
+@pytest.mark.parametrize("n,h,w", [(3, 10, 13), (13, 24, 32), (27, 50, 50), (38, 48, 50), (36, 60, 80), (56, 60, 80)])
+def test_conv_wide_pingpong_tiles_are_bit_identical(gpu, n, h, w, monkeypatch):
+    """conv_ppw_kernel (128 channels x 512 pixels, the ping-pong schedule with each wave group staging its own pixel half)
+    against the default kernels: the q gate launch (paired and unpaired weights, with the context term), plain 3x3 layers
+    with 128 and 384 output channels over two input segments, a 1x1 layer, and the heads launch (tap GEMMs of two heads in
+    the epilogue + the stored GraphAgg third) - same bits, on every repetition"""
+    from glorie_slam_amd import update_ops as U
+    monkeypatch.delenv("GLORIE_CONV_PPW", raising=False)
+    net = _cl_half(n, 128, h, w, gpu, 91)
+    wide_t = _cl_half(n, 256, h, w, gpu, 92)
+    xb = wide_t[:, 64:256]
+    g = torch.Generator(device="cpu").manual_seed(93)
+    wq_t = (torch.randn(128, 320, 3, 3, generator=g) / 54).to(gpu)
+    w384_t = (torch.randn(384, 128, 3, 3, generator=g) / 34).to(gpu)
+    w11_t = (torch.randn(128, 320, 1, 1, generator=g) / 18).to(gpu)
+    terms = torch.randn(n, 128, generator=g).to(gpu)
+    bias = torch.randn(384, generator=g).to(gpu)
+    pre = _cl_half(n, 128, h, w, gpu, 94)
+    z0 = _cl_half(n, 128, h, w, gpu, 95).abs().clamp(max=1.0)
+    w2 = [(torch.randn(2, 128, 3, 3, generator=g) / 30).to(gpu) for _ in range(2)]
+    tapw = U.pack_head_taps(w2)
+    cl = lambda c: torch.empty((n, c, h, w), dtype=torch.float16, device=gpu, memory_format=torch.channels_last)
+
+    def run(policy, pair, with_pre):
+        wq = U.pack_conv_igemm(wq_t, pair=pair)
+        new, plain, wide3, one = cl(128), cl(128), cl(384), cl(128)
+        U.conv_igemm(net, xb, wq, 9, 128, new, epilogue=U.EPI_GRU_Q, terms=terms, net=net, z=z0,
+                     pre=pre if with_pre else None, policy=policy)
+        U.conv_igemm(net, xb, wq, 9, 128, plain, terms=bias[:128].contiguous(), act=U.ACT_RELU, policy=policy)
+        U.conv_igemm(net, None, U.pack_conv_igemm(w384_t, pair=pair), 9, 384, wide3, terms=bias, policy=policy)
+        U.conv_igemm(net, xb, U.pack_conv_igemm(w11_t, pair=pair), 1, 128, one, terms=bias[:128].contiguous(), policy=policy)
+        return torch.cat([new, plain, wide3, one], 1).clone()
+
+    def heads(env):
+        if env is None:
+            monkeypatch.delenv("GLORIE_CONV_PPW", raising=False)
+        else:
+            monkeypatch.setenv("GLORIE_CONV_PPW", env)
+        rest = cl(128)
+        rows = U.conv_igemm_heads(net, U.pack_conv_igemm(w384_t), 9, 384, bias, tapw, 2, out=rest)
+        monkeypatch.delenv("GLORIE_CONV_PPW", raising=False)
+        return rows.clone(), rest.clone()
+
+    for with_pre in (True, False):
+        ref = run("nohalo", False, with_pre)
+        for rep in range(3):
+            assert torch.equal(run("ppw", False, with_pre), ref), (with_pre, rep)
+        assert torch.equal(run("ppw", True, with_pre), ref)
+    rows0, rest0 = heads("0")
+    for rep in range(3):
+        rows1, rest1 = heads("1")
+        assert torch.equal(rest1, rest0), rep
+        assert torch.equal(rows1, rows0), rep
+    rows_a, rest_a = heads(None)                       # the automatic choice (this kernel from 262,144 pixels on)
+    assert torch.equal(rest_a, rest0) and torch.equal(rows_a, rows0)
+    assert torch.equal(run(None, True, True), run("nohalo", False, True))
+    # layers the tile does not fit are refused, not mangled
+    with pytest.raises(Exception):
+        U.conv_igemm(net, xb, U.pack_conv_igemm(wq_t[:64]), 9, 64, cl(64), policy="ppw")
+
+
 def test_flow_conv7_matches_conv2d(gpu):
     from glorie_slam_amd import update_ops as U
     n, h, w = 3, 9, 11                                              # 297 pixels: ragged last tile, maps < 7 wide halo

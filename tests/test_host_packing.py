@@ -61,7 +61,7 @@ def test_pack_conv_igemm_paired_rows():
             assert chans == list(range(32 * b + 8 * kg, 32 * b + 8 * kg + 8))
     with pytest.raises(RuntimeError):
         U.pack_conv_igemm(torch.randn(70, 64, 3, 3), pair=True)          # Nout % 32 != 0
-    assert U.CONV_POLICY[None] == 0 and sorted(U.CONV_POLICY.values())[-1] == 6 and U.EPI_PAIR16 == 0x100
+    assert U.CONV_POLICY[None] == 0 and sorted(U.CONV_POLICY.values())[-1] == 7 and U.EPI_PAIR16 == 0x100
 
 
 def test_pack_conv3x3_small_and_flow_layouts():

@@ -75,7 +75,7 @@ def gate_case():
 def tile_modes():
     """the z|r and q gate launches and the 128 -> 384 head convolution under the three tile policies of glorie_conv_igemm"""
     dev = torch.device("cuda:0")
-    n, h, w = 36, 60, 80
+    h, w = 60, 80
     torch.manual_seed(2)
     cl = lambda c: torch.randn(n, c, h, w, device=dev).half().contiguous(memory_format=torch.channels_last)
     net, wide, pre = cl(128), cl(320), cl(384)
@@ -131,3 +131,50 @@ if __name__ == "__main__" and os.environ.get("BENCH_CONV_GATE", "1") == "1":
     gate_case()
     tile_modes()
     pp_ab()
+
+
+def ppw_ab(rounds=6, n=36):
+    """interleaved A/B of conv_ppw_kernel (128 x 512 ping-pong tile) against the shipped kernels on the 128-channel layers of
+    the update operator at G8: q gate (320 -> 128, blend epilogue, context term), heads (128 -> 384 + tap GEMMs),
+    128 -> 128 3x3 (corr_encoder[1] / flow layers)"""
+    import statistics
+    dev = torch.device("cuda:0")
+    h, w = 60, 80
+    torch.manual_seed(2)
+    cl = lambda c: torch.randn(n, c, h, w, device=dev).half().contiguous(memory_format=torch.channels_last)
+    net, wide, pre = cl(128), cl(320), cl(128)
+    dynx = wide[:, 128:320]
+    z0 = cl(128).abs().clamp(max=1.0)
+    wq = U.pack_conv_igemm(torch.randn(128, 320, 3, 3, device=dev) / (320 * 9) ** 0.5, pair=True)
+    w384 = torch.randn(384, 128, 3, 3, device=dev) / (128 * 9) ** 0.5
+    wh = U.pack_conv_igemm(w384)
+    w128 = U.pack_conv_igemm(torch.randn(128, 128, 3, 3, device=dev) / (128 * 9) ** 0.5, pair=True)
+    tapw = U.pack_head_taps([torch.randn(2, 128, 3, 3, device=dev) / 30 for _ in range(2)])
+    terms = torch.randn(n, 128, device=dev)
+    bias = torch.randn(384, device=dev)
+    out = torch.empty_like(net)
+    rest = torch.empty_like(net)
+
+    def q_gate():
+        U.conv_igemm(net, dynx, wq, 9, 128, out, epilogue=U.EPI_GRU_Q, terms=terms, net=net, z=z0, pre=pre)
+
+    def heads():
+        U.conv_igemm_heads(net, wh, 9, 384, bias, tapw, 2, out=rest)
+
+    def c128():
+        U.conv_igemm(net, None, w128, 9, 128, out, terms=bias[:128].contiguous(), act=U.ACT_RELU)
+
+    cases = (("q gate 320->128", q_gate, 2.0 * n * h * w * 9 * 320 * 128), ("heads 128->384", heads, 2.0 * n * h * w * 9 * 128 * 384),
+             ("128->128 3x3", c128, 2.0 * n * h * w * 9 * 128 * 128))
+    res = {(c[0], e): [] for c in cases for e in ("0", "1")}
+    for _ in range(rounds):
+        for name, fn, _fl in cases:
+            for e in ("0", "1"):
+                os.environ["GLORIE_CONV_PPW"] = e
+                res[(name, e)].append(timed(fn, 10))
+    os.environ.pop("GLORIE_CONV_PPW", None)
+    for name, _fn, fl in cases:
+        a, b = statistics.median(res[(name, "0")]), statistics.median(res[(name, "1")])
+        print(f"N={n} {name:18s} shipped {a:7.1f} us ({fl / a / 1e6:5.0f} TF/s)   128x512 ping-pong {b:7.1f} us ({fl / b / 1e6:5.0f} TF/s)", flush=True)
+
+

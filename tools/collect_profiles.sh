@@ -14,5 +14,4 @@ cp $O/pmc_corr.json profiles/${P}_pmc_corr.json
 cp $O/pmc_mfma.txt profiles/${P}_pmc_mfma.txt
 cp $O/pmc_render.txt profiles/${P}_pmc_render.txt
 cp $O/pmc_kernels.json profiles/${P}_pmc_kernels.json 2>/dev/null
-cp $O/knn_gather_phase.json profiles/${P}_knn_gather_phase.json 2>/dev/null
 ls -la profiles/${P}_*

@@ -25,6 +25,5 @@ bash tools/pmc_mfma.sh > /dev/null 2>&1; cp gpurun_out/pmc_mfma.txt $O/pmc_mfma.
 bash tools/pmc_kernel.sh mlp_ tools/prof_render.py > $O/pmc_render.txt 2>&1
 bash tools/pmc_kernel.sh knn_query tools/prof_render.py >> $O/pmc_render.txt 2>&1
 bash tools/pmc_passes.sh > $O/pmc_passes.log 2>&1; cp gpurun_out/pmc_kernels.json $O/pmc_kernels.json 2>/dev/null
-bash tools/knn_gather_phase.sh > $O/knn_gather_phase.log 2>&1; cp gpurun_out/knn_gather_phase.json $O/knn_gather_phase.json 2>/dev/null
 bash tools/conv_pp_timeline.sh > /dev/null 2>&1
 tail -c 600 $O/bench.json
