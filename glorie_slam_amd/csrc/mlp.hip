@@ -519,6 +519,11 @@ __device__ __forceinline__ void mma_h3n(f32x4 (&acc)[NB][8], const h16x8 (&bhi)[
   }
 }
 
+// Round 6, measured and not kept: three waves per SIMD instead of two (236 -> 168 registers: the embedding formed where it is
+// consumed, the colour feature re-read before each use, the weight chunk L2 -> LDS by DMA instead of through 16 VGPRs, layer 3
+// with its hidden chunks first) - 0.858-0.860 ms for the three decoder kernels against 0.838-0.853 ms, frame 5.49 / 5.63 against
+// 5.47 / 5.61 ms in interleaved runs (tools/time_mlp.py): like every occupancy change tried on these kernels, no gain.  (The
+// first build also failed the fixture test - a wrong chunk order in the re-ordered layer - and was not debugged further.)
 template <int NB, int WAVES>
 __global__ __launch_bounds__(WAVES * 64, NB == 1 ? 4 : 2)
 void mlp_col_v5_kernel(ColParams P, const float* __restrict__ W16, const float* __restrict__ pts,
@@ -839,10 +844,12 @@ __global__ __launch_bounds__(512, 4) void mlp_geo_v4_kernel(GeoParams P, const f
   extern __shared__ float smem[];              // [15][1024] fragments | [32][16] output layer
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   const int r = lane & 15, g = lane >> 4;
+  if constexpr (!GO) {                        // (the weights are no part of the feature pull)
 #pragma unroll 2
-  for (int idx = tid; idx < kGeoFrag / 4; idx += 512)
-    reinterpret_cast<float4*>(smem)[idx] = reinterpret_cast<const float4*>(frags)[idx];
-  if (tid < 128) reinterpret_cast<float4*>(smem + kGeoFrag)[tid] = reinterpret_cast<const float4*>(wout)[tid];
+    for (int idx = tid; idx < kGeoFrag / 4; idx += 512)
+      reinterpret_cast<float4*>(smem)[idx] = reinterpret_cast<const float4*>(frags)[idx];
+    if (tid < 128) reinterpret_cast<float4*>(smem + kGeoFrag)[tid] = reinterpret_cast<const float4*>(wout)[tid];
+  }
   __syncthreads();
   // persistent over the sample blocks: the 61 KB of fragments are staged once per workgroup (a launch used to stage them
   // for every 128 samples, 4800 times per 614k-sample batch, with the first MFMA of a workgroup waiting behind it)
@@ -1012,9 +1019,11 @@ __global__ __launch_bounds__(512, 4) void mlp_nb_v4_kernel(NbParams P, const flo
     const int f = tid >> 2, d = tid & 3;
     bs[tid] = d < 3 ? P.B[d * 10 + (f < 10 ? f : f - 10)] : 0.0f;
   }
-  for (int idx = tid; idx < 8192 / 4; idx += 512)             // the split fragments as packed (point_ops.pack_decoders)
-    reinterpret_cast<float4*>(smem)[idx] = reinterpret_cast<const float4*>(W1frag)[idx];
-  if (tid < 128) b1s[tid] = P.b1[tid];
+  if constexpr (!GO) {                                        // (the weights are no part of the feature pull)
+    for (int idx = tid; idx < 8192 / 4; idx += 512)           // the split fragments as packed (point_ops.pack_decoders)
+      reinterpret_cast<float4*>(smem)[idx] = reinterpret_cast<const float4*>(W1frag)[idx];
+    if (tid < 128) b1s[tid] = P.b1[tid];
+  }
   for (int idx = tid; idx < kTM2 * 8; idx += 512) {
     const int row = idx >> 3;
     const int q = min(q0 + row, Q - 1);
