@@ -365,6 +365,7 @@ def main():
     ap.add_argument("--no-sequence", action="store_true", help="skip the 13-frame tracking + mapping sequence (config 3)")
     ap.add_argument("--no-strong", action="store_true", help="skip the fixed 128-keyframe graph (strong-scaling figure)")
     ap.add_argument("--soak", type=int, default=300, help="untimed steps between the burst figure and the timed steps")
+    ap.add_argument("--sustained-steps", type=int, default=400, help="steps of each of the two sustained figures (tests shorten it)")
     ap.add_argument("--strong-k", type=int, default=128, help="keyframes of the strong-scaling graph (512 = long end of config 4)")
     ap.add_argument("--corr-impl", default="volume", choices=["volume", "otf"], help="correlation operator of the timed graph")
     ap.add_argument("--knn-layout", default="image", choices=["image", "linear"], help="query order of the renderer's search")
@@ -493,7 +494,7 @@ def main():
     # (a) with the state put back every `reset_every` steps INSIDE the timed region (five device copies, 46 MB) so that
     #     stage 2 keeps solving - the metric's workload, sustained; (b) free-running, where the drifted state makes most
     #     depth_scale steps fall back (prep + host poll + eager stage-1 BA: a fallback step costs MORE than a stage-2 step)
-    sustained_steps = max(400, args.steps)
+    sustained_steps = max(int(args.sustained_steps), args.steps)
     reset_every = 48
 
     def sustained(periodic_reset):

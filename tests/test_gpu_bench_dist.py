@@ -29,7 +29,8 @@ def test_bench_main_with_several_ranks_over_gloo(gpu, world):
     env.update({"GLORIE_DIST_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "PYTHONPATH": ROOT})
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2",
-           "--warmup", "1", "--no-cpu-baseline", "--no-sequence"] + (["--soak", "20"] if world > 2 else [])
+           "--warmup", "1", "--no-cpu-baseline", "--no-sequence"] + \
+        (["--soak", "10", "--sustained-steps", "20"] if world > 2 else [])     # (gloo collectives on device tensors: ~10 ms each at 8 ranks)
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
