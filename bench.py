@@ -1031,11 +1031,11 @@ def main():
                      "frac": conv_tf / MFMA_F16_PEAK_TF, "traffic": conv_traffic if full else None,
                      "traffic_source": "profiles/" + PMC_SUMMARY + " (rocprofv3 --pmc passes on the builder's box, not this run)",
                      "flops_per_launch": conv_flops, "ms_per_launch": conv_ms, "back_to_back_ms": conv_b2b_ms},
-        "roofline_q": {"bound": "mfma", "kernel": "conv_igemm_kernel<EPI_GRU_Q,4,64> (ConvGRU convq, 320->128, 3x3, GRU blend epilogue)",
+        "roofline_q": {"bound": "mfma", "kernel": "conv_halo_kernel<EPI_GRU_Q,4> (ConvGRU convq, 320->128, 3x3, GRU blend epilogue; haloed 128 x 128 tile - from 262,144 pixels on conv_ppw_kernel)",
                        "achieved": q_flops / (q_ms * 1e-3) / 1e12 if q_ms else None, "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s",
                        "frac": (q_flops / (q_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TF) if q_ms else None, "traffic": None,
                        "flops_per_launch": q_flops, "ms_per_launch": q_ms},
-        "roofline_heads": {"bound": "mfma", "kernel": "conv_igemm_kernel<EPI_HEADS,4,64> (delta[0] | weight[0] | agg.conv1, 128->384, "
+        "roofline_heads": {"bound": "mfma", "kernel": "conv_halo_kernel<EPI_HEADS,4> (delta[0] | weight[0] | agg.conv1, 128->384, "
                                                       "3x3, tap GEMMs of the heads in the epilogue)",
                            "achieved": heads_flops / (heads_ms * 1e-3) / 1e12 if heads_ms else None, "peak": MFMA_F16_PEAK_TF,
                            "unit": "TFLOP/s", "frac": (heads_flops / (heads_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TF) if heads_ms else None,

@@ -9,9 +9,10 @@ from glorie_slam_amd.render_train import FeatureAdam
 
 dev = torch.device("cuda", 0)
 npc, dec, ren, rays = bench.build_renderer(dev)
-pick = torch.randperm(rays["o"].shape[0], generator=torch.Generator().manual_seed(5))[:5000].to(dev)
+NR = int(os.environ.get("TRAIN_RAYS", 5000))          # 5000: mapper.py's batch; 1000: the batch of pipeline.SequenceRunner
+pick = torch.randperm(rays["o"].shape[0], generator=torch.Generator().manual_seed(5))[:NR].to(dev)
 b5 = {k: v[pick].contiguous() for k, v in rays.items() if torch.is_tensor(v)}
-gt = torch.rand(5000, 3, device=dev)
+gt = torch.rand(NR, 3, device=dev)
 hip = os.environ.get("TRAIN_TORCH") is None
 geo = npc.geo_feats.detach().clone().requires_grad_(True)
 col = npc.col_feats.detach().clone().requires_grad_(True)
