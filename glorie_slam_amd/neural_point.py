@@ -218,8 +218,12 @@ class NeuralPointCloud(object):
         pts_gt = (batch_rays_o[..., None, :] + batch_rays_d[..., None, :] * batch_gt_depth[..., None, None]).reshape(-1, 3)
         mask = torch.ones(pts_gt.shape[0], device=self.device).bool()
         if self.index.ntotal > 0 and pts_gt.shape[0]:      # (reference: `index.is_trained`, i.e. a non-empty cloud)
-            _, _, neighbor_num_gt = self.find_neighbors_faiss(pts_gt, step='add', is_pts_grad=is_pts_grad,
-                                                              dynamic_radius=dynamic_radius)
+            # only the COUNT inside the radius is consumed: the search is bounded by the ball (weights = (.., ball_only)), which
+            # leaves that count exact.  The unbounded exact 8-NN search expands shells until eight neighbours are found - for
+            # the points of a newly seen surface, far from the cloud, that walked large parts of the grid: 2.5-5.4 ms per
+            # keyframe insertion on the long synthetic sequence (tools/exp_naive.py, round 6) against ~0.1 ms bounded
+            neighbor_num_gt = self.find_neighbors_faiss(pts_gt, step='add', is_pts_grad=is_pts_grad,
+                                                        dynamic_radius=dynamic_radius, weights=(1, False, True))[2]
             mask = (neighbor_num_gt == 0)
         new = dict(_input_pos=pts_gt[mask], _input_rgb=batch_gt_color[mask], _input_depth=batch_gt_depth[mask],
                    _input_video_idx=video_idx * torch.ones_like(i[mask], dtype=torch.long, device=self.device),
@@ -293,7 +297,7 @@ class NeuralPointCloud(object):
             far = far.item()
         z_probe = torch.linspace(near, far, steps=intervals, device=self.device)
         pts = (rays_o[..., None, :] + rays_d[..., None, :] * z_probe[..., :, None]).reshape(-1, 3)
-        _, _, nn_num = self.find_neighbors_faiss(pts, step='query')
+        nn_num = self.find_neighbors_faiss(pts, step='query', weights=(1, False, True))[2]     # (count only: bounded by the ball)
         occ = nn_num.reshape(n_rays, intervals) > 0
         invalid = occ.sum(-1) < 2
         # first and second occupied probe of every ray, then num samples between them - the reference walks the

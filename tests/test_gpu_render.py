@@ -51,6 +51,32 @@ def test_knn_surface_cloud_and_dynamic_radius(gpu):
     assert np.array_equal(nn.cpu().numpy(), oknn.neighbor_count(rD, rad))
 
 
+def test_ball_bounded_search_counts_like_the_exact_search(gpu):
+    """what add_neural_points / sample_near_pcl consume is only the number of neighbours inside the (per-query) radius
+    (neural_point.py:165-262, 315-375): the ball-bounded search (weights = (.., ball_only)) must return exactly the counts of
+    the unbounded exact search and of brute force - for queries on the surface, off it, and far outside the cloud, where the
+    unbounded search walks the grid until it has eight points"""
+    import glorie_slam_amd.synth as synth
+    pts, _, _ = synth.box_cloud(n_hits=6000)
+    rng = np.random.default_rng(4)
+    sel = rng.integers(0, len(pts), 4000)
+    q = (pts[sel] * rng.uniform(0.9, 1.1, (4000, 1))).astype(np.float32)
+    q[:400] = rng.uniform(-6, 6, (400, 3)).astype(np.float32)             # far from every point
+    q[400:500] += 0.5
+    rad = rng.uniform(0.01, 0.3, 4000).astype(np.float32)
+    idx = _index(gpu, pts, 0.1, 1 << 18)
+    qt, rt = torch.from_numpy(q).to(gpu), torch.from_numpy(rad).to(gpu)
+    nn_exact = idx.search(qt, 8, radius_per_query=rt)[2].cpu().numpy()
+    nn_ball = idx.search(qt, 8, radius_per_query=rt, weights=(1, False, True))[2].cpu().numpy()
+    rD, _ = oknn.knn_bruteforce(pts, q, 8)
+    assert np.array_equal(nn_exact, oknn.neighbor_count(rD, rad))
+    assert np.array_equal(nn_ball, nn_exact)
+    for r_fixed in (0.04, 0.08):                                          # radius_add / radius_query as scalars
+        a = idx.search(qt, 8, radius=r_fixed)[2].cpu().numpy()
+        b = idx.search(qt, 8, radius=r_fixed, weights=(1, False, True))[2].cpu().numpy()
+        assert np.array_equal(a, b) and np.array_equal(a, oknn.neighbor_count(rD, np.float32(r_fixed)))
+
+
 def test_knn_ties_duplicates_and_tiny_clouds(gpu):
     rng = np.random.default_rng(2)
     base = rng.uniform(0, 1, (40, 3)).astype(np.float32)
